@@ -1,0 +1,87 @@
+"""ctypes binding of the C ABI in include/emba_hip.h (libemba_hip.so, hand-written HIP for gfx950).
+
+The library is built IN-TREE by `__graft_entry__.build()` / `emba_amd.build.build_hip()`.  There is no
+fallback: if the shared object is missing or no GPU is visible, the product path raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemba_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY = range(7)
+STATUS_NAMES = ["EMBA_OK", "EMBA_ERR_INVALID_ARG", "EMBA_ERR_NO_DEVICE", "EMBA_ERR_HIP", "EMBA_ERR_TIME_RANGE",
+                "EMBA_ERR_STATE", "EMBA_ERR_CAPACITY"]
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_u16p = C.POINTER(C.c_uint16)
+_u8p = C.POINTER(C.c_uint8)
+_i64p = C.POINTER(C.c_int64)
+_szp = C.POINTER(C.c_size_t)
+_fp = C.POINTER(C.c_float)
+
+
+class EmbaCfg(C.Structure):
+    _fields_ = [("sensor_w", C.c_int32), ("sensor_h", C.c_int32), ("pano_w", C.c_int32), ("pano_h", C.c_int32),
+                ("bearing_lut", _dp), ("C_th", C.c_double), ("event_batch", C.c_int32), ("outlier_px", C.c_double),
+                ("device", C.c_int32), ("stream", C.c_void_p)]
+
+
+# symbol -> (restype, argtypes); exactly the entry points include/emba_hip.h declares
+SIGNATURES = {
+    "emba_abi_version": (C.c_int, []),
+    "emba_build_info": (C.c_char_p, []),
+    "emba_create": (C.c_int, [C.POINTER(EmbaCfg), C.POINTER(C.c_void_p)]),
+    "emba_destroy": (None, [C.c_void_p]),
+    "emba_last_error": (C.c_char_p, [C.c_void_p]),
+    "emba_set_events": (C.c_int, [C.c_void_p, _u16p, _u16p, _u8p, _i64p, C.c_size_t, _u16p, _u16p, _i64p, C.c_size_t]),
+    "emba_event_counts": (C.c_int, [C.c_void_p, _szp, _szp]),
+    "emba_eval_data_error": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, _dp, C.c_int32, _dp, _szp, _i32p]),
+    "emba_form_normal_eq": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp, _dp, _szp, _u32p,
+                                      C.c_size_t, _dp, _dp, _dp]),
+    "emba_get_A12_sparse": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _dp, _dp, _dp, _dp]),
+    "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
+    "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),
+    "emba_dump_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, _dp, _dp, _dp]),
+    "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "emba_eval_launch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64]),
+    "emba_eval_finish": (C.c_int, [C.c_void_p, _dp, _szp, _i32p]),
+    "emba_form_active": (C.c_int, [C.c_void_p, C.c_int32, _szp, _szp]),
+    "emba_form_accumulate": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_double]),
+    "emba_form_finish": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u32p, C.c_size_t, _dp, _dp, _dp]),
+    "emba_sync": (C.c_int, [C.c_void_p]),
+    "emba_timer_start": (C.c_int, [C.c_void_p, C.c_int32]),
+    "emba_timer_stop": (C.c_int, [C.c_void_p, C.c_int32]),
+    "emba_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int32, _fp]),
+    "emba_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "emba_last_kernel_ms": (C.c_int, [C.c_void_p, _fp, _fp]),
+}
+
+
+class EmbaError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"{STATUS_NAMES[status] if 0 <= status < len(STATUS_NAMES) else status}: {message}")
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libemba_hip.so (no GPU needed to load and resolve symbols). Raises if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). emba_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,800 @@
+// emba_amd/csrc/emba_hip.hip — context, HBM residency and the C ABI of include/emba_hip.h.
+// Host code is C++17; every per-event / per-pixel computation runs in the HIP kernels of kernels.h.
+// There is no CPU compute path in this file: the host only sorts indices once per window
+// (emba_set_events: pose-independent structure), launches kernels and moves bytes.
+#include "../../include/emba_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace emba;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct emba_ctx {
+    emba_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    int sw = 0, sh = 0, W = 0, H = 0;
+    size_t S = 0, npix = 0;
+    double fx = 0, fy = 0, cx = 0, cy = 0, C_th = 0, outlier_px = 10.0;
+
+    // persistent device buffers
+    double* d_lut = nullptr;
+    double* d_texel = nullptr;
+    double* d_Gx_own = nullptr; double* d_Gy_own = nullptr;
+    const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // current map planes (own or bound)
+    int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
+    int32_t* d_compact = nullptr;
+    uint32_t* d_active = nullptr;
+    uint32_t* d_ablk_cnt = nullptr; uint32_t* d_ablk_off = nullptr; size_t n_ablk = 0;
+    double* d_pack_own = nullptr; size_t pack_own_cap = 0;
+    double* d_pack = nullptr; size_t pack_cap = 0; bool pack_bound = false;
+    double* d_knots = nullptr; int knots_cap = 0;
+    int* d_err = nullptr;
+    uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
+    double* d_scalar = nullptr;     // cost reductions
+    int* h_pinned = nullptr;        // small pinned readback area (4 ints + 2 doubles)
+
+    // per-window (set_events) state
+    bool have_events = false, have_map = false;
+    size_t n_in = 0, n_used = 0, n_halo = 0, n_sorted = 0, n_batch = 0, n_cand = 0;
+    long nblk = 0;
+    std::vector<uint32_t> h_pix, h_batch, h_orig;   // pixel-major
+    std::vector<int64_t> h_batch_t;
+    uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;
+    int64_t* d_batch_t = nullptr; double* d_pose = nullptr;
+    double* d_rec = nullptr; uint32_t* d_slot_key = nullptr;
+    double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
+    uint32_t* d_blk_cnt = nullptr; uint32_t* d_blk_off = nullptr;
+    double* d_ep = nullptr;
+    // key order cache
+    bool keys_ready = false; int64_t key_t0 = 0, key_dt = 0; int key_K = 0;
+
+    // per-iteration state
+    int K = 0;
+    bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
+    size_t n_inliers = 0, P = 0, pack_len = 0;
+    int thres = 0, irls = 0; double eta = 0;
+
+    // timing
+    hipEvent_t ev_start[8]{}, ev_stop[8]{};
+    bool kernel_timing = false;
+    hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
+    bool kt_warp_valid = false, kt_accum_valid = false;
+};
+
+namespace {
+
+emba_status fail(emba_ctx* c, emba_status st, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return st;
+}
+
+#define HIP_TRY(c, call)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail((c), EMBA_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                     \
+    } while (0)
+
+template <typename T>
+emba_status dev_alloc(emba_ctx* c, T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return EMBA_OK;
+}
+
+template <typename T>
+void dev_free(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_window(emba_ctx* c)
+{
+    dev_free(c->d_ev_pix); dev_free(c->d_ev_batch); dev_free(c->d_ev_slot); dev_free(c->d_batch_t);
+    dev_free(c->d_pose); dev_free(c->d_rec); dev_free(c->d_slot_key); dev_free(c->d_e_sorted);
+    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_blk_cnt); dev_free(c->d_blk_off);
+    dev_free(c->d_ep);
+    c->have_events = false; c->keys_ready = false;
+    c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
+}
+
+// ros::Time/Duration midpoint of a batch (model.cpp:116-119; rostime semantics per SURVEY Appendix A):
+// integer nanoseconds plus one double scale-and-round.  Pose-independent, so it is computed once per window.
+int64_t batch_mid_ns(int64_t t_first, int64_t t_last)
+{
+    const int64_t d = t_last - t_first;
+    int64_t dsec = d / 1000000000LL, dnsec = d % 1000000000LL;
+    if (dnsec < 0) { dnsec += 1000000000LL; dsec -= 1; }
+    const double half = ((double)dsec + 1e-9 * (double)dnsec) * 0.5;   // Duration::toSec() * 0.5
+    int64_t hsec = (int64_t)std::floor(half);
+    int64_t hnsec = (int64_t)std::round((half - (double)hsec) * 1e9);  // Duration::fromSec
+    hsec += hnsec / 1000000000LL;
+    hnsec = hnsec % 1000000000LL;
+    return t_first + hsec * 1000000000LL + hnsec;
+}
+
+// Assign every measurement candidate a record slot, sorted by (cp_c, cp_p): the control-pose pair is a
+// function of the batch midpoint times and the spline's (t0, dt) only, i.e. pose-independent.
+emba_status prepare_keys(emba_ctx* c, int64_t t0, int64_t dt, int K)
+{
+    if (c->keys_ready && c->key_t0 == t0 && c->key_dt == dt && c->key_K == K) return EMBA_OK;
+    if (dt <= 0 || K < 2 || K > 65535) return fail(c, EMBA_ERR_INVALID_ARG, "bad spline: dt_ns=%lld K=%d", (long long)dt, K);
+    std::vector<uint16_t> cp(c->h_batch_t.size());
+    for (size_t b = 0; b < cp.size(); ++b) {
+        const int64_t st = c->h_batch_t[b] - t0;
+        const int64_t s = (st >= 0) ? st / dt : -1;
+        if (st < 0 || s + 2 > (int64_t)K)
+            return fail(c, EMBA_ERR_TIME_RANGE, "batch %zu midpoint %lld ns outside spline [%lld, %lld) (K=%d)", b,
+                        (long long)c->h_batch_t[b], (long long)t0, (long long)(t0 + dt * (K - 1)), K);
+        cp[b] = (uint16_t)s;
+    }
+    const size_t n = c->n_sorted, M = c->n_cand;
+    std::vector<uint32_t> cand(M), key(M);
+    {
+        size_t m = 0;
+        for (size_t i = 1; i < n; ++i)
+            if ((c->h_pix[i] & 0x7FFFFFFFu) == (c->h_pix[i - 1] & 0x7FFFFFFFu)) {
+                cand[m] = (uint32_t)i;
+                key[m] = ((uint32_t)cp[c->h_batch[i]] << 16) | (uint32_t)cp[c->h_batch[i - 1]];
+                ++m;
+            }
+        if (m != M) return fail(c, EMBA_ERR_STATE, "candidate recount mismatch %zu vs %zu", m, M);
+    }
+    // stable LSD counting sort on the two 16-bit halves of the key
+    std::vector<uint32_t> ord(M), tmp(M);
+    for (size_t m = 0; m < M; ++m) ord[m] = (uint32_t)m;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<size_t> cnt(65537, 0);
+        const int sh = pass * 16;
+        for (size_t m = 0; m < M; ++m) cnt[((key[ord[m]] >> sh) & 0xFFFFu) + 1]++;
+        for (size_t k = 0; k < 65536; ++k) cnt[k + 1] += cnt[k];
+        for (size_t m = 0; m < M; ++m) tmp[cnt[(key[ord[m]] >> sh) & 0xFFFFu]++] = ord[m];
+        ord.swap(tmp);
+    }
+    std::vector<uint32_t> slot(n ? n : 1, kNoSlot), slot_key(M ? M : 1, 0);
+    for (size_t s = 0; s < M; ++s) {
+        slot[cand[ord[s]]] = (uint32_t)s;
+        slot_key[s] = key[ord[s]];
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_ev_slot, slot.data(), std::max<size_t>(n, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_slot_key, slot_key.data(), std::max<size_t>(M, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    c->keys_ready = true; c->key_t0 = t0; c->key_dt = dt; c->key_K = K;
+    return EMBA_OK;
+}
+
+emba_status ensure_pack(emba_ctx* c, int K)
+{
+    const size_t need = (size_t)9 * K * K + (size_t)3 * K + 5 * c->npix;
+    if (c->pack_bound) {
+        if (c->pack_cap < (size_t)9 * K * K + (size_t)3 * K)
+            return fail(c, EMBA_ERR_CAPACITY, "bound pack buffer too small for K=%d", K);
+        return EMBA_OK;
+    }
+    if (c->pack_own_cap < need) {
+        dev_free(c->d_pack_own);
+        emba_status st = dev_alloc(c, &c->d_pack_own, need);
+        if (st) return st;
+        c->pack_own_cap = need;
+    }
+    c->d_pack = c->d_pack_own;
+    c->pack_cap = c->pack_own_cap;
+    return EMBA_OK;
+}
+
+inline double* pack_A11(emba_ctx* c) { return c->d_pack; }
+inline double* pack_b1(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c->K; }
+inline double* pack_A22b2(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c->K + (size_t)3 * c->K; }
+
+long grid8(long n) { return (n + 7) / 8 * 8; }
+
+}  // namespace
+
+extern "C" {
+
+int emba_abi_version(void) { return EMBA_ABI_VERSION; }
+
+const char* emba_build_info(void)
+{
+    return "emba_hip: HIP/gfx950 (CDNA4, wave64) kernels, fp64, built " __DATE__ " " __TIME__;
+}
+
+const char* emba_last_error(const emba_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
+{
+    if (!out) return fail(nullptr, EMBA_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!cfg || !cfg->bearing_lut) return fail(nullptr, EMBA_ERR_INVALID_ARG, "cfg or bearing_lut is NULL");
+    if (cfg->sensor_w <= 0 || cfg->sensor_h <= 0 || cfg->pano_w <= 0 || cfg->pano_h <= 0 ||
+        (size_t)cfg->sensor_w * cfg->sensor_h >= 0x7FFFFFFFull || (size_t)cfg->pano_w * cfg->pano_h >= 0x7FFFFFFFull)
+        return fail(nullptr, EMBA_ERR_INVALID_ARG, "bad sensor/pano size");
+    if (cfg->event_batch != 0 && cfg->event_batch != 100)
+        return fail(nullptr, EMBA_ERR_INVALID_ARG, "event_batch must be 100 (reference hard-codes it, model.cpp:78)");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, EMBA_ERR_NO_DEVICE, "no HIP device (%s); this library has no CPU path", hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, EMBA_ERR_NO_DEVICE, "device ordinal %d not present (%d devices)", cfg->device, ndev);
+
+    emba_ctx* c = new emba_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->sw = cfg->sensor_w; c->sh = cfg->sensor_h; c->W = cfg->pano_w; c->H = cfg->pano_h;
+    c->S = (size_t)c->sw * c->sh; c->npix = (size_t)c->W * c->H;
+    c->C_th = cfg->C_th;
+    c->outlier_px = cfg->outlier_px > 0 ? cfg->outlier_px : 10.0;
+    // focalFromFOV(imageSize, 360, 180), equirectangular_camera.h:64-67
+    c->fx = (double)((c->W / 360.0) * 180.0 / M_PI);
+    c->fy = (double)((c->H / 180.0) * 180.0 / M_PI);
+    c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
+
+#define CREATE_TRY(call)                                                                                  \
+    do {                                                                                                  \
+        hipError_t e2_ = (call);                                                                          \
+        if (e2_ != hipSuccess) {                                                                          \
+            fail(nullptr, EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e2_));                  \
+            emba_destroy(c);                                                                              \
+            return EMBA_ERR_HIP;                                                                          \
+        }                                                                                                 \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(c->device));
+    if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
+    else { CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    CREATE_TRY(hipMalloc((void**)&c->d_lut, c->S * 3 * sizeof(double)));
+    CREATE_TRY(hipMemcpy(c->d_lut, cfg->bearing_lut, c->S * 3 * sizeof(double), hipMemcpyHostToDevice));
+    c->cfg.bearing_lut = nullptr;  // not retained
+    CREATE_TRY(hipMalloc((void**)&c->d_texel, c->npix * kTexelStride * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&c->d_count_own, c->npix * sizeof(int32_t)));
+    c->d_count = c->d_count_own;
+    CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t)));
+    c->n_ablk = (c->npix + 255) / 256;
+    CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double)));
+    CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault));
+    for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
+    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt[i]));
+#undef CREATE_TRY
+    *out = c;
+    return EMBA_OK;
+}
+
+void emba_destroy(emba_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_window(c);
+    dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own);
+    dev_free(c->d_count_own); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
+    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err);
+    dev_free(c->d_total); dev_free(c->d_scalar);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
+    for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, const uint8_t* pol, const int64_t* t_ns,
+                            size_t n, const uint16_t* hx, const uint16_t* hy, const int64_t* hbt, size_t n_halo)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (n && (!x || !y || !pol || !t_ns)) return fail(c, EMBA_ERR_INVALID_ARG, "event arrays are NULL");
+    if (n_halo && (!hx || !hy || !hbt)) return fail(c, EMBA_ERR_INVALID_ARG, "halo arrays are NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_window(c);
+
+    const size_t n_used = (n / 100) * 100;   // quirk Q1: std::ceil of an integer division (model.cpp:79)
+    const size_t nb = n_used / 100;
+    if (n_used + n_halo >= 0x7FFFFFFFull) return fail(c, EMBA_ERR_INVALID_ARG, "too many events for 32-bit indices");
+    for (size_t k = 0; k < n_used; ++k) {
+        if (x[k] >= c->sw || y[k] >= c->sh) return fail(c, EMBA_ERR_INVALID_ARG, "event %zu pixel (%u,%u) outside the sensor", k, x[k], y[k]);
+        if (k && t_ns[k] < t_ns[k - 1]) return fail(c, EMBA_ERR_INVALID_ARG, "timestamps not sorted at event %zu", k);
+    }
+    for (size_t h = 0; h < n_halo; ++h)
+        if (hx[h] >= c->sw || hy[h] >= c->sh) return fail(c, EMBA_ERR_INVALID_ARG, "halo event %zu outside the sensor", h);
+
+    c->n_in = n; c->n_used = n_used; c->n_halo = n_halo; c->n_batch = nb + n_halo;
+    c->n_sorted = n_used + n_halo;
+    c->h_batch_t.assign(c->n_batch ? c->n_batch : 1, 0);
+    for (size_t b = 0; b < nb; ++b) c->h_batch_t[b] = batch_mid_ns(t_ns[100 * b], t_ns[100 * b + 99]);
+    for (size_t h = 0; h < n_halo; ++h) c->h_batch_t[nb + h] = hbt[h];
+
+    // stable counting sort by sensor pixel == the per-pixel vectors of EventMap::addEvent (event_map.h:34-37)
+    const size_t S = c->S, ns = c->n_sorted;
+    std::vector<uint32_t> start(S + 1, 0);
+    for (size_t h = 0; h < n_halo; ++h) start[(size_t)hy[h] * c->sw + hx[h] + 1]++;
+    for (size_t k = 0; k < n_used; ++k) start[(size_t)y[k] * c->sw + x[k] + 1]++;
+    size_t n_cand = 0;
+    for (size_t p = 0; p < S; ++p) { if (start[p + 1] > 1) n_cand += start[p + 1] - 1; start[p + 1] += start[p]; }
+    c->n_cand = n_cand;
+    c->h_pix.assign(ns ? ns : 1, 0); c->h_batch.assign(ns ? ns : 1, 0); c->h_orig.assign(ns ? ns : 1, 0);
+    {
+        std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+        for (size_t h = 0; h < n_halo; ++h) {
+            const uint32_t p = (uint32_t)hy[h] * c->sw + hx[h];
+            const uint32_t i = cur[p]++;
+            c->h_pix[i] = p; c->h_batch[i] = (uint32_t)(nb + h); c->h_orig[i] = 0xFFFFFFFFu;
+        }
+        for (size_t k = 0; k < n_used; ++k) {
+            const uint32_t p = (uint32_t)y[k] * c->sw + x[k];
+            const uint32_t i = cur[p]++;
+            c->h_pix[i] = p | ((pol[k] ? 1u : 0u) << 31); c->h_batch[i] = (uint32_t)(k / 100); c->h_orig[i] = (uint32_t)k;
+        }
+    }
+    c->nblk = (long)((ns + kWarpNew - 1) / kWarpNew);
+
+    emba_status st;
+    if ((st = dev_alloc(c, &c->d_ev_pix, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_ev_batch, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_ev_slot, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_batch_t, c->n_batch))) return st;
+    if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
+    if ((st = dev_alloc(c, &c->d_rec, n_cand * kRecStride))) return st;
+    if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
+    if ((st = dev_alloc(c, &c->d_e_sorted, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_flag, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_inl_idx, ns))) return st;
+    if ((st = dev_alloc(c, &c->d_blk_cnt, (size_t)c->nblk))) return st;
+    if ((st = dev_alloc(c, &c->d_blk_off, (size_t)c->nblk))) return st;
+    if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
+    HIP_TRY(c, hipMemcpy(c->d_ev_pix, c->h_pix.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_ev_batch, c->h_batch.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_batch_t, c->h_batch_t.data(), std::max<size_t>(c->n_batch, 1) * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->d_flag, 0, std::max<size_t>(ns, 1)));
+    HIP_TRY(c, hipMemset(c->d_rec, 0, std::max<size_t>(n_cand, 1) * kRecStride * sizeof(double)));
+    c->have_events = true;
+    return EMBA_OK;
+}
+
+emba_status emba_event_counts(const emba_ctx* c, size_t* n_used, size_t* n_cand)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (n_used) *n_used = c->n_used;
+    if (n_cand) *n_cand = c->n_cand;
+    return EMBA_OK;
+}
+
+emba_status emba_upload_map(emba_ctx* c, const double* Gx, const double* Gy)
+{
+    if (!c || !Gx || !Gy) return c ? fail(c, EMBA_ERR_INVALID_ARG, "Gx/Gy NULL") : EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->d_Gx_own) {
+        emba_status st;
+        if ((st = dev_alloc(c, &c->d_Gx_own, c->npix))) return st;
+        if ((st = dev_alloc(c, &c->d_Gy_own, c->npix))) return st;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_Gx_own, Gx, c->npix * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_Gy_own, Gy, c->npix * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->d_Gx = c->d_Gx_own; c->d_Gy = c->d_Gy_own;
+    c->have_map = true;
+    return EMBA_OK;
+}
+
+emba_status emba_bind_map_dev(emba_ctx* c, const double* Gx_dev, const double* Gy_dev)
+{
+    if (!c || !Gx_dev || !Gy_dev) return c ? fail(c, EMBA_ERR_INVALID_ARG, "Gx/Gy NULL") : EMBA_ERR_INVALID_ARG;
+    c->d_Gx = Gx_dev; c->d_Gy = Gy_dev;
+    c->have_map = true;
+    return EMBA_OK;
+}
+
+emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, double* pack_dev, size_t pack_cap)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    c->d_count = count_map_dev ? count_map_dev : c->d_count_own;
+    if (pack_dev) { c->d_pack = pack_dev; c->pack_cap = pack_cap; c->pack_bound = true; }
+    else { c->pack_bound = false; c->d_pack = c->d_pack_own; c->pack_cap = c->pack_own_cap; }
+    return EMBA_OK;
+}
+
+emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!knots) return fail(c, EMBA_ERR_INVALID_ARG, "knots NULL");
+    if (!c->have_events) return fail(c, EMBA_ERR_STATE, "emba_set_events has not been called");
+    if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map: call emba_upload_map or emba_bind_map_dev");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st;
+    if ((st = prepare_keys(c, t0_ns, dt_ns, K))) return st;
+    c->K = K;
+    if ((st = ensure_pack(c, K))) return st;
+    if (c->knots_cap < K) {
+        dev_free(c->d_knots);
+        if ((st = dev_alloc(c, &c->d_knots, (size_t)4 * K))) return st;
+        c->knots_cap = K;
+    }
+    c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(c->d_knots, knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));   // num_ev_map.setTo(0), model.cpp:85
+
+    if (c->n_batch) {
+        const int nb = (int)c->n_batch;
+        hipLaunchKernelGGL(emba_pose_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
+                           t0_ns, dt_ns, c->d_pose, c->d_err);
+    }
+    hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
+                       c->d_texel);
+    if (c->n_sorted) {
+        WarpParams p{};
+        p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
+        p.nblk = c->nblk; p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->d_texel; p.W = c->W; p.H = c->H;
+        p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
+        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt;
+        if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
+        hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->eval_launched = true;
+    return EMBA_OK;
+}
+
+emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (c->n_sorted) {
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_blk_cnt, c->d_blk_off, c->nblk, c->d_total);
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->nblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag,
+                           c->d_blk_off, (long)c->n_sorted, c->d_ep, c->d_inl_idx);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+    }
+    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
+    c->n_inliers = (size_t)(uint32_t)c->h_pinned[0];
+    c->eval_done = true;
+    if (n_inliers) *n_inliers = c->n_inliers;
+    if (ep_out && c->n_inliers) HIP_TRY(c, hipMemcpy(ep_out, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
+    if (num_ev_map_out) HIP_TRY(c, hipMemcpy(num_ev_map_out, c->d_count, c->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return EMBA_OK;
+}
+
+emba_status emba_eval_data_error(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, const double* Gx,
+                                 const double* Gy, int32_t eval_deriv, double* ep_out, size_t* n_inliers,
+                                 int32_t* num_ev_map_out)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!eval_deriv) return fail(c, EMBA_ERR_INVALID_ARG, "eval_deriv=false is never used by the reference (solver.cpp:75,251) and is not provided");
+    emba_status st;
+    if ((st = emba_upload_map(c, Gx, Gy))) return st;
+    if ((st = emba_eval_launch(c, knots, K, t0_ns, dt_ns))) return st;
+    return emba_eval_finish(c, ep_out, n_inliers, num_ev_map_out);
+}
+
+emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack_len)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "formNormalEq needs the state of evaluateDataError (solver.cpp:99-102)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const long npix = (long)c->npix;
+    hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
+    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1);
+    hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
+                       c->d_ablk_off, c->d_compact, c->d_active);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[2], c->d_total + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->P = (size_t)(uint32_t)c->h_pinned[2];
+    c->thres = thres;
+    c->pack_len = (size_t)9 * c->K * c->K + (size_t)3 * c->K + 5 * c->P;
+    if (c->pack_len > c->pack_cap) return fail(c, EMBA_ERR_CAPACITY, "pack buffer too small: need %zu doubles, have %zu", c->pack_len, c->pack_cap);
+    c->active_done = true; c->accum_done = false;
+    if (P) *P = c->P;
+    if (pack_len) *pack_len = c->pack_len;
+    return EMBA_OK;
+}
+
+emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irls, double eta)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->active_done) return fail(c, EMBA_ERR_STATE, "emba_form_active has not been called");
+    if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (ep_host && c->n_inliers) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_ep, ep_host, c->n_inliers * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(emba_override_ep_kernel, dim3((unsigned)((c->n_sorted + 255) / 256)), dim3(256), 0, s, c->d_ep, c->d_flag,
+                           c->d_inl_idx, c->d_ev_slot, (long)c->n_sorted, c->d_rec, c->d_e_sorted);
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_pack, 0, c->pack_len * sizeof(double), s));   // Zero(), model.cpp:357-368
+    c->irls = irls; c->eta = eta;
+    if (c->n_cand) {
+        AccumParams p{};
+        p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.count = c->d_count; p.compact = c->d_compact;
+        p.thres = c->thres; p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c); p.A22b2 = pack_A22b2(c);
+        p.dim = 3 * c->K;
+        const long waves = ((long)c->n_cand + kAccumChunk - 1) / kAccumChunk;
+        if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
+        hipLaunchKernelGGL(emba_accumulate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p);
+        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->accum_done = true;
+    return EMBA_OK;
+}
+
+emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1, uint32_t* active_idx, size_t cap_P, double* A22,
+                             double* b2, double* A12_dense)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->accum_done) return fail(c, EMBA_ERR_STATE, "emba_form_accumulate has not been called");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t P = c->P;
+    const int dim = 3 * c->K;
+    if ((A22 || b2 || A12_dense || active_idx) && cap_P < P) return fail(c, EMBA_ERR_CAPACITY, "cap_P=%zu < P=%zu", cap_P, P);
+    if (alpha != 0.0 && P)
+        hipLaunchKernelGGL(emba_l2reg_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), c->d_active, (long)P,
+                           alpha, c->d_Gx, c->d_Gy);
+    HIP_TRY(c, hipGetLastError());
+    if (A11) HIP_TRY(c, hipMemcpyAsync(A11, pack_A11(c), (size_t)dim * dim * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (b1) HIP_TRY(c, hipMemcpyAsync(b1, pack_b1(c), (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (active_idx && P) HIP_TRY(c, hipMemcpyAsync(active_idx, c->d_active, P * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    double* d_A22 = nullptr; double* d_b2 = nullptr; double* d_A12 = nullptr;
+    emba_status st = EMBA_OK;
+    if ((A22 || b2) && P) {
+        if ((st = dev_alloc(c, &d_A22, 4 * P)) || (st = dev_alloc(c, &d_b2, 2 * P))) { dev_free(d_A22); return st; }
+        hipLaunchKernelGGL(emba_unpack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), (long)P, d_A22, d_b2);
+        if (A22) (void)hipMemcpyAsync(A22, d_A22, 4 * P * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (b2) (void)hipMemcpyAsync(b2, d_b2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s);
+    }
+    if (A12_dense && P) {
+        const size_t n12 = (size_t)dim * 2 * P;
+        if ((st = dev_alloc(c, &d_A12, n12))) { dev_free(d_A22); dev_free(d_b2); return st; }
+        (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
+        if (c->n_cand)
+            hipLaunchKernelGGL(emba_dense_a12_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key,
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, c->irls, c->eta, dim, d_A12);
+        (void)hipMemcpyAsync(A12_dense, d_A12, n12 * sizeof(double), hipMemcpyDeviceToHost, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    dev_free(d_A22); dev_free(d_b2); dev_free(d_A12);
+    if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "form_finish: %s", hipGetErrorString(e));
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+emba_status emba_form_normal_eq(emba_ctx* c, const double* ep, int32_t thres, int32_t irls, double eta, double alpha, double* A11,
+                                double* b1, size_t* P, uint32_t* active_idx, size_t cap_P, double* A22, double* b2, double* A12_dense)
+{
+    emba_status st;
+    size_t Pl = 0, pl = 0;
+    if ((st = emba_form_active(c, thres, &Pl, &pl))) return st;
+    if (P) *P = Pl;
+    if ((st = emba_form_accumulate(c, ep, irls, eta))) return st;
+    return emba_form_finish(c, alpha, A11, b1, active_idx, cap_P, A22, b2, A12_dense);
+}
+
+emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32_t* pix, double* w, double* jc, double* jp, double* dp)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->accum_done) return fail(c, EMBA_ERR_STATE, "no normal equations formed yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t M = c->n_cand;
+    if (!M) return EMBA_OK;
+    int32_t *d_c = nullptr, *d_p = nullptr, *d_x = nullptr; double *d_w = nullptr, *d_jc = nullptr, *d_jp = nullptr, *d_dp = nullptr;
+    emba_status st;
+    if ((st = dev_alloc(c, &d_c, M)) || (st = dev_alloc(c, &d_p, M)) || (st = dev_alloc(c, &d_x, M)) || (st = dev_alloc(c, &d_w, M)) ||
+        (st = dev_alloc(c, &d_jc, 6 * M)) || (st = dev_alloc(c, &d_jp, 6 * M)) || (st = dev_alloc(c, &d_dp, 2 * M))) {
+        dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp);
+        return st;
+    }
+    hipStream_t s = c->stream;
+    hipLaunchKernelGGL(emba_export_a12_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, (long)M,
+                       c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp);
+    if (cp_c) (void)hipMemcpyAsync(cp_c, d_c, M * 4, hipMemcpyDeviceToHost, s);
+    if (cp_p) (void)hipMemcpyAsync(cp_p, d_p, M * 4, hipMemcpyDeviceToHost, s);
+    if (pix) (void)hipMemcpyAsync(pix, d_x, M * 4, hipMemcpyDeviceToHost, s);
+    if (w) (void)hipMemcpyAsync(w, d_w, M * 8, hipMemcpyDeviceToHost, s);
+    if (jc) (void)hipMemcpyAsync(jc, d_jc, 6 * M * 8, hipMemcpyDeviceToHost, s);
+    if (jp) (void)hipMemcpyAsync(jp, d_jp, 6 * M * 8, hipMemcpyDeviceToHost, s);
+    if (dp) (void)hipMemcpyAsync(dp, d_dp, 2 * M * 8, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp);
+    if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "get_A12_sparse: %s", hipGetErrorString(e));
+    return EMBA_OK;
+}
+
+emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)
+{
+    if (!c || !cost) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "no residuals yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_scalar, 0, sizeof(double), s));
+    if (c->n_sorted) {
+        const unsigned grid = (unsigned)std::min<size_t>((c->n_sorted + 255) / 256, 2048);
+        hipLaunchKernelGGL(emba_data_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (long)c->n_sorted, (int)irls, eta,
+                           c->d_scalar);
+    }
+    double v = 0;
+    HIP_TRY(c, hipMemcpyAsync(&v, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (irls == 0) v *= 0.5;
+    else if (irls == 2) v *= 0.5 / eta;
+    *cost = v;
+    return EMBA_OK;
+}
+
+emba_status emba_reg_cost(emba_ctx* c, double alpha, double* cost)
+{
+    if (!c || !cost) return EMBA_ERR_INVALID_ARG;
+    if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_scalar + 1, 0, sizeof(double), s));
+    const unsigned grid = (unsigned)std::min<size_t>((c->npix + 255) / 256, 2048);
+    hipLaunchKernelGGL(emba_reg_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_Gx, c->d_Gy, (long)c->npix, c->d_scalar + 1);
+    double v = 0;
+    HIP_TRY(c, hipMemcpyAsync(&v, c->d_scalar + 1, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *cost = 0.5 * alpha * v;
+    return EMBA_OK;
+}
+
+emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx, int32_t* inlier_idx, int32_t* pm_int, double* dp,
+                            double* Gpm, double* temp)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t ns = c->n_sorted, n = c->n_in;
+    if (!ns) return EMBA_OK;
+    hipStream_t s = c->stream;
+    double *d_pm = nullptr, *d_D = nullptr, *d_dp = nullptr, *d_G = nullptr, *d_t = nullptr; int32_t* d_pi = nullptr;
+    emba_status st;
+    if ((st = dev_alloc(c, &d_pm, 2 * ns)) || (st = dev_alloc(c, &d_D, 12 * ns)) || (st = dev_alloc(c, &d_dp, 2 * ns)) ||
+        (st = dev_alloc(c, &d_G, 2 * ns)) || (st = dev_alloc(c, &d_t, 2 * ns)) || (st = dev_alloc(c, &d_pi, 2 * ns))) {
+        dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi);
+        return st;
+    }
+    (void)hipMemsetAsync(d_dp, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_G, 0, 2 * ns * 8, s);
+    (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
+    WarpParams p{};
+    p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
+    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->d_texel; p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
+    p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
+    p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
+    hipLaunchKernelGGL(emba_warp_residual_kernel<true>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+    std::vector<double> h_pm(2 * ns), h_D(12 * ns), h_dp(2 * ns), h_G(2 * ns), h_t(2 * ns), h_pose(c->n_batch * kPoseStride);
+    std::vector<int32_t> h_pi(2 * ns), h_inl(ns);
+    std::vector<uint8_t> h_flag(ns);
+    (void)hipMemcpyAsync(h_pm.data(), d_pm, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_D.data(), d_D, 12 * ns * 8, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_dp.data(), d_dp, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_G.data(), d_G, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_t.data(), d_t, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_pi.data(), d_pi, 2 * ns * 4, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, ns * 4, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_flag.data(), c->d_flag, ns, hipMemcpyDeviceToHost, s);
+    (void)hipMemcpyAsync(h_pose.data(), c->d_pose, h_pose.size() * 8, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipStreamSynchronize(s);
+    dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi);
+    if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "dump_state: %s", hipGetErrorString(e));
+    // pure re-indexing (pixel-major -> original time order); no arithmetic on the host
+    if (cp_idx) for (size_t k = 0; k < n; ++k) cp_idx[k] = -1;
+    if (inlier_idx) for (size_t k = 0; k < n; ++k) inlier_idx[k] = -2;
+    if (pm_int) for (size_t k = 0; k < 2 * n; ++k) pm_int[k] = -1;
+    if (pm) memset(pm, 0, 2 * n * 8); if (D) memset(D, 0, 12 * n * 8); if (dp) memset(dp, 0, 2 * n * 8);
+    if (Gpm) memset(Gpm, 0, 2 * n * 8); if (temp) memset(temp, 0, 2 * n * 8);
+    for (size_t i = 0; i < ns; ++i) {
+        const uint32_t k = c->h_orig[i];
+        if (k == 0xFFFFFFFFu) continue;  // halo
+        const bool cand = i > 0 && ((c->h_pix[i] & 0x7FFFFFFFu) == (c->h_pix[i - 1] & 0x7FFFFFFFu));
+        if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
+        if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
+        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)c->h_batch[i] * kPoseStride + 18];
+        if (inlier_idx) inlier_idx[k] = cand ? (h_flag[i] ? h_inl[i] : -1) : -2;
+        if (pm_int && h_flag[i]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
+        if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }
+        if (Gpm && h_flag[i]) { Gpm[2 * k] = h_G[2 * i]; Gpm[2 * k + 1] = h_G[2 * i + 1]; }
+        if (temp && h_flag[i]) { temp[2 * k] = h_t[2 * i]; temp[2 * k + 1] = h_t[2 * i + 1]; }
+    }
+    return EMBA_OK;
+}
+
+emba_status emba_sync(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMBA_OK;
+}
+
+emba_status emba_timer_start(emba_ctx* c, int32_t slot)
+{
+    if (!c || slot < 0 || slot >= 8) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev_start[slot], c->stream));
+    return EMBA_OK;
+}
+
+emba_status emba_timer_stop(emba_ctx* c, int32_t slot)
+{
+    if (!c || slot < 0 || slot >= 8) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    return EMBA_OK;
+}
+
+emba_status emba_timer_elapsed_ms(emba_ctx* c, int32_t slot, float* ms)
+{
+    if (!c || !ms || slot < 0 || slot >= 8) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipEventSynchronize(c->ev_stop[slot]));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev_start[slot], c->ev_stop[slot]));
+    return EMBA_OK;
+}
+
+emba_status emba_enable_kernel_timing(emba_ctx* c, int32_t on)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    c->kernel_timing = on != 0;
+    c->kt_warp_valid = c->kt_accum_valid = false;
+    return EMBA_OK;
+}
+
+emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (warp_ms) {
+        *warp_ms = -1.f;
+        if (c->kt_warp_valid) { HIP_TRY(c, hipEventSynchronize(c->kt[1])); HIP_TRY(c, hipEventElapsedTime(warp_ms, c->kt[0], c->kt[1])); }
+    }
+    if (accum_ms) {
+        *accum_ms = -1.f;
+        if (c->kt_accum_valid) { HIP_TRY(c, hipEventSynchronize(c->kt[3])); HIP_TRY(c, hipEventElapsedTime(accum_ms, c->kt[2], c->kt[3])); }
+    }
+    return EMBA_OK;
+}
+
+}  // extern "C"

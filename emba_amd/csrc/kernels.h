@@ -1,0 +1,600 @@
+// emba_amd/csrc/kernels.h — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the EMBA hot path.
+//
+// Data layout in HBM:
+//   events    pixel-major (sensor pixel, then time): ev_pix u32 (bit31 = polarity), ev_batch u32,
+//             ev_slot u32 (factor-record slot, kNoSlot if the event has no predecessor at its pixel)
+//   pose      one 160-B record per 100-event batch: R[9] J1[9] cp u   (J0 = I - J1)
+//   texel     per panorama pixel {Gx Gy Gxx Gxy Gyy pad} = 48 B   (one gather per measurement)
+//   records   one 128-B factor record per measurement candidate, stored in (cp_c,cp_p)-sorted slots:
+//             jc[6] jp[6] dp[2] e {u32 pano_idx, u32 aux}  — the sparse A12 factor + what A11/A22 need
+//   pack      [A11 (3K)^2 col-major | b1 3K | per active pixel {xx xy yy bx by}]  (one all-reduce)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+namespace emba {
+
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+constexpr uint32_t kInvalidPix = 0xFFFFFFFFu;
+constexpr int kPoseStride = 20;    // doubles per pose record
+constexpr int kTexelStride = 6;    // doubles per texel
+constexpr int kRecStride = 16;     // doubles per factor record
+constexpr int kWarpBlock = 256;    // threads per block of the warp kernel
+constexpr int kWarpNew = 255;      // new events per block (thread 0 re-warps the predecessor)
+constexpr int kAccumChunk = 512;   // record slots per wave in the accumulate kernel
+
+// Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"); give each
+// XCD a contiguous range of work so that neighbouring sensor pixels (= neighbouring panorama texels,
+// count-map and A22 lines) share one L2.  Speed only, never correctness.
+__device__ __forceinline__ long xcd_contiguous_block(long bid, long grid)
+{
+    const long per = grid >> 3;  // grid is a multiple of 8
+    return (bid & 7) * per + (bid >> 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2/a3: one thread per batch -> pose record.  LinearTrajectory::evaluate (trajectory.cpp:122-147) /
+// So3Spline<2>::evaluate (so3_spline.h:218-274).  s and u use the same int64 arithmetic as the reference.
+// ------------------------------------------------------------------------------------------------
+__global__ void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
+                                 int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const int64_t st = batch_t_ns[b] - t0_ns;
+    const int64_t s = (st >= 0) ? st / dt_ns : -1;
+    if (st < 0 || s + 2 > (int64_t)K) {  // BASALT_ASSERT_STREAM at so3_spline.h:221-229
+        atomicOr(err, 1);
+        return;
+    }
+    const double u = (double)(st % dt_ns) / (double)dt_ns;
+    double p0[4], p1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * s + i]; p1[i] = knots[4 * (s + 1) + i]; }
+    double R[9], J1[9];
+    spline2_eval(p0, p1, u, R, J1);
+    double* o = pose + (size_t)kPoseStride * b;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { o[i] = R[i]; o[9 + i] = J1[i]; }
+    o[18] = (double)s;
+    o[19] = u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1: texel pack.  0.125*Sobel3x3 with BORDER_REFLECT_101, Gxy := (dGx/dy + dGy/dx)/2 (model.cpp:88-97),
+// fused with the AoS interleave so that one measurement gathers one 48-B texel instead of 5 planes.
+// HBM-bound: reads 16 B/pixel (neighbours from L1/L2), writes 48 B/pixel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect101(int i, int n)
+{
+    if (n == 1) return 0;
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy,
+                                                         int H, int W, double* __restrict__ texel)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const int xl = reflect101(x - 1, W), xr = reflect101(x + 1, W);
+    const int yu = reflect101(y - 1, H), yd = reflect101(y + 1, H);
+    const double* gxu = Gx + (size_t)yu * W; const double* gxc = Gx + (size_t)y * W; const double* gxd = Gx + (size_t)yd * W;
+    const double* gyu = Gy + (size_t)yu * W; const double* gyc = Gy + (size_t)y * W; const double* gyd = Gy + (size_t)yd * W;
+    // d/dx: rows [-1 0 1], columns [1 2 1]
+    const double gxx = ((gxu[xr] - gxu[xl]) + (gxd[xr] - gxd[xl])) + 2 * (gxc[xr] - gxc[xl]);
+    const double gyx = ((gyu[xr] - gyu[xl]) + (gyd[xr] - gyd[xl])) + 2 * (gyc[xr] - gyc[xl]);
+    // d/dy: rows [1 2 1], columns [-1 0 1]
+    const double gxy = ((gxd[xl] + gxd[xr]) + 2 * gxd[x]) - ((gxu[xl] + gxu[xr]) + 2 * gxu[x]);
+    const double gyy = ((gyd[xl] + gyd[xr]) + 2 * gyd[x]) - ((gyu[xl] + gyu[xr]) + 2 * gyu[x]);
+    double2* t = reinterpret_cast<double2*>(texel + (size_t)kTexelStride * ((size_t)y * W + x));
+    t[0] = make_double2(gxc[x], gyc[x]);
+    t[1] = make_double2(0.125 * gxx, 0.5 * (0.125 * gxy + 0.125 * gyx));
+    t[2] = make_double2(0.125 * gyy, 0.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4-a7 (+ the per-measurement half of a9): the dominant kernel.
+// One thread per pixel-major event: gather the batch pose, warp (event_pano_warper.cpp:43-74 +
+// equirectangular_camera.h:18-45), chain the Jacobian (model.cpp:155-157), hand pm and the 2x6
+// Jacobian to the next thread through LDS (the predecessor at the same sensor pixel is the previous
+// array element), then pairing/outlier test/rounding/texel gather/residual/count (model.cpp:186-242)
+// and the two 1x6 rows j_c = temp*D_k, j_p = -Gpm*D_{k-1} (model.cpp:449,459) written as one 128-B record.
+// ------------------------------------------------------------------------------------------------
+struct WarpParams {
+    const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
+    const double* pose; const double* lut; const double* texel;
+    int W, H; double fx, fy, cx, cy, C_th, outlier_px;
+    int32_t* count; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt;
+    double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
+};
+
+template <bool DUMP>
+__global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpParams p)
+{
+    __shared__ double s_pm[2][kWarpBlock];
+    __shared__ double s_D[12][kWarpBlock];
+    __shared__ uint32_t s_pix[kWarpBlock];
+
+    const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (b >= p.nblk) return;  // whole block exits together
+    const int t = threadIdx.x;
+    const long i = b * kWarpNew + t - 1;
+    const bool valid = (i >= 0) && (i < p.n_sorted);
+
+    double pm[2] = {0, 0};
+    double D[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) D[k] = 0;
+    uint32_t pix = kInvalidPix, pol = 0;
+
+    if (valid) {
+        const uint32_t pw = p.ev_pix[i];
+        pix = pw & 0x7FFFFFFFu;
+        pol = pw >> 31;
+        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * p.ev_batch[i]);
+        double R[9], J1[9];
+        {
+            const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6], a7 = P2[7], a8 = P2[8];
+            R[0] = a0.x; R[1] = a0.y; R[2] = a1.x; R[3] = a1.y; R[4] = a2.x; R[5] = a2.y; R[6] = a3.x; R[7] = a3.y; R[8] = a4.x;
+            J1[0] = a4.y; J1[1] = a5.x; J1[2] = a5.y; J1[3] = a6.x; J1[4] = a6.y; J1[5] = a7.x; J1[6] = a7.y; J1[7] = a8.x; J1[8] = a8.y;
+        }
+        const double* bv = p.lut + 3 * (size_t)pix;
+        const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
+        double rb[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) rb[r] = sum3(R[3 * r] * b0, R[3 * r + 1] * b1, R[3 * r + 2] * b2);
+        double J23[6];
+        project_chain(rb, p.fx, p.fy, p.cx, p.cy, pm, J23);
+        // dpm_ddrot_cp = J23 * [I - J1 | J1]   (model.cpp:156; J0 = I - J1, so3_spline.h:261-270)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double s0 = 0, s1 = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const double j1 = J1[3 * k + c];
+                    const double j0 = ((k == c) ? 1.0 : 0.0) - j1;
+                    s0 += J23[3 * r + k] * j0;
+                    s1 += J23[3 * r + k] * j1;
+                }
+                D[6 * r + c] = s0;
+                D[6 * r + c + 3] = s1;
+            }
+        if (DUMP) {
+            p.d_pm[2 * i] = pm[0]; p.d_pm[2 * i + 1] = pm[1];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) p.d_D[12 * i + k] = D[k];
+        }
+    }
+
+    s_pm[0][t] = pm[0]; s_pm[1][t] = pm[1];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) s_D[k][t] = D[k];
+    s_pix[t] = pix;
+    __syncthreads();
+
+    bool inl = false;
+    const bool cand = valid && (t >= 1) && (s_pix[t - 1] == pix);
+    if (cand) {
+        const double dpx = pm[0] - s_pm[0][t - 1];
+        const double dpy = pm[1] - s_pm[1][t - 1];
+        const double dp_norm = sqrt(dpx * dpx + dpy * dpy);   // Eigen norm(), model.cpp:199
+        const double rx = round(pm[0]), ry = round(pm[1]);    // std::round, model.cpp:209-210
+        // Outlier iff dp_norm > 10 (model.cpp:200).  Where the reference is undefined (non-finite dp, or a
+        // rounded pixel outside the panorama read unchecked at model.cpp:213,227) the measurement is an
+        // outlier as well (DESIGN.md "Defined behaviour").
+        inl = (dp_norm <= p.outlier_px) && (rx >= 0.0) && (rx < (double)p.W) && (ry >= 0.0) && (ry < (double)p.H);
+        const uint32_t slot = p.ev_slot[i];
+        double* rec = p.rec + (size_t)kRecStride * slot;
+        if (DUMP) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
+        if (inl) {
+            const int pmx = (int)rx, pmy = (int)ry;
+            const uint32_t pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
+            const double2* T2 = reinterpret_cast<const double2*>(p.texel + (size_t)kTexelStride * pi);
+            const double2 g = T2[0], h0 = T2[1], h1 = T2[2];
+            const double gx = g.x, gy = g.y, gxx = h0.x, gxy = h0.y, gyy = h1.x;
+            const double C_pred = gx * dpx + gy * dpy;                  // model.cpp:217
+            const double C_meas = 2 * ((double)pol - 0.5) * p.C_th;    // model.cpp:219
+            const double e = C_meas - C_pred;                           // model.cpp:221
+            const double t0 = gx + (dpx * gxx + dpy * gxy);            // temp = Gpm + dp^T*G2, model.cpp:238
+            const double t1 = gy + (dpx * gxy + dpy * gyy);
+            if (DUMP) {
+                p.d_Gpm[2 * i] = gx; p.d_Gpm[2 * i + 1] = gy;
+                p.d_temp[2 * i] = t0; p.d_temp[2 * i + 1] = t1;
+                p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy;
+            } else {
+                atomicAdd(p.count + pi, 1);                             // model.cpp:227
+                double jc[6], jp[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    jc[j] = t0 * D[j] + t1 * D[6 + j];                                  // model.cpp:449
+                    jp[j] = (-gx) * s_D[j][t - 1] + (-gy) * s_D[6 + j][t - 1];          // model.cpp:459
+                }
+                double2* r2 = reinterpret_cast<double2*>(rec);
+                r2[0] = make_double2(jc[0], jc[1]); r2[1] = make_double2(jc[2], jc[3]); r2[2] = make_double2(jc[4], jc[5]);
+                r2[3] = make_double2(jp[0], jp[1]); r2[4] = make_double2(jp[2], jp[3]); r2[5] = make_double2(jp[4], jp[5]);
+                r2[6] = make_double2(dpx, dpy);
+                r2[7] = make_double2(e, __hiloint2double(0, (int)pi));
+                p.e_sorted[i] = e;
+            }
+        } else if (!DUMP) {
+            reinterpret_cast<double2*>(rec)[7] = make_double2(0.0, __hiloint2double(0, (int)kInvalidPix));
+        }
+    }
+    if (!DUMP) {
+        if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
+        const int n_inl = __syncthreads_count(inl ? 1 : 0);
+        if (t == 0) p.blk_cnt[b] = (uint32_t)n_inl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan of per-block counts (single block, sequential over 1024-wide tiles).
+// out[i] = sum_{j<i} in[j]; total[0] = sum of all.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void emba_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          long n, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (long base = 0; base < n; base += 1024) {
+        const long i = base + t;
+        const uint32_t v = (i < n) ? in[i] : 0;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wave[wv] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wv; ++w) woff += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < n) out[i] = carry + woff + x - v;
+        __syncthreads();
+        if (t == 1023) s_carry = carry + woff + x;
+        __syncthreads();
+    }
+    if (t == 0) total[0] = s_carry;
+}
+
+// Block-wide exclusive rank of a flag among 256 threads (4 waves) via ballots.
+__device__ __forceinline__ uint32_t block_rank_256(bool f, uint32_t* s_w /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(f);
+    const uint32_t within = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wv] = __popcll(m);
+    __syncthreads();
+    uint32_t off = 0;
+    for (int w = 0; w < wv; ++w) off += s_w[w];
+    return off + within;
+}
+
+// Residual compaction into the reference's order (model.cpp:221,256): pixel-major array order.
+__global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                              const uint32_t* __restrict__ blk_off, long n_sorted,
+                                                              double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+{
+    __shared__ uint32_t s_w[4];
+    const long b = blockIdx.x;
+    const int t = threadIdx.x;
+    const long i = b * kWarpNew + t;
+    const bool in = (t < kWarpNew) && (i < n_sorted);
+    const bool f = in && flag[i];
+    const uint32_t r = block_rank_256(f, s_w);
+    if (f) {
+        const uint32_t k = blk_off[b] + r;
+        ep[k] = e_sorted[i];
+        inl_idx[i] = (int32_t)k;
+    } else if (in) {
+        inl_idx[i] = -1;
+    }
+}
+
+// Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
+__global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const uint8_t* __restrict__ flag,
+                                        const int32_t* __restrict__ inl_idx, const uint32_t* __restrict__ ev_slot,
+                                        long n_sorted, double* __restrict__ rec, double* __restrict__ e_sorted)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sorted || !flag[i]) return;
+    const double e = ep_ext[inl_idx[i]];
+    rec[(size_t)kRecStride * ev_slot[i] + 14] = e;
+    e_sorted[i] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: active set (count >= thres) in ascending panorama index (model.cpp:325-344, 371-377).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* __restrict__ count, long npix, int thres,
+                                                                uint32_t* __restrict__ blk_cnt)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool f = (i < npix) && (count[i] >= thres);
+    const int c = __syncthreads_count(f ? 1 : 0);
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (uint32_t)c;
+}
+
+__global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* __restrict__ count, long npix, int thres,
+                                                                const uint32_t* __restrict__ blk_off,
+                                                                int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx)
+{
+    __shared__ uint32_t s_w[4];
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool f = (i < npix) && (count[i] >= thres);
+    const uint32_t r = block_rank_256(f, s_w);
+    if (i < npix) {
+        if (f) {
+            const uint32_t k = blk_off[blockIdx.x] + r;
+            compact[i] = (int32_t)k;
+            active_idx[k] = (uint32_t)i;
+        } else {
+            compact[i] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a9/a10: normal-equation accumulation over the factor records in (cp_c,cp_p)-sorted order.
+// A wave walks a contiguous chunk of slots; its key (cp_c<<16|cp_p) is almost always wave-uniform, so the
+// 12x12 symmetric outer product of v=[jc;jp] (78 values) + v*e (12) accumulates in REGISTERS, and is
+// reduced across the wave and flushed with fp64 atomics only when the key changes or the chunk ends
+// (model.cpp:454-477).  A22/b2 go straight to the compact per-pixel pack with fp64 atomics (:426-439).
+// IRLS weights per model.cpp:599-618.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
+}
+
+#define EMBA_TRI(r, c) ((r) * 12 - ((r) * ((r)-1)) / 2 + ((c) - (r)))  // r <= c, packed upper triangle of 12x12
+
+struct AccumParams {
+    const double* rec; const uint32_t* slot_key; long n_slots;
+    const int32_t* count; const int32_t* compact; int thres; int irls; double eta;
+    double* A11; double* b1; double* A22b2; int dim;  // dim = 3K
+};
+
+__device__ __forceinline__ void accum_flush(double* acc, double* accb, uint32_t key, const AccumParams& p, double* s_red)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 78; ++k) {
+        const double x = wave_sum(acc[k]);
+        if (lane == 0) s_red[k] = x;
+        acc[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        const double x = wave_sum(accb[k]);
+        if (lane == 0) s_red[78 + k] = x;
+        accb[k] = 0;
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
+    const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
+    for (int e = lane; e < 156; e += 64) {
+        if (e < 144) {
+            const int r = e / 12, c = e % 12;
+            const int lo = r < c ? r : c, hi = r < c ? c : r;
+            const double v = s_red[EMBA_TRI(lo, hi)];
+            const int row = (r < 6) ? bc + r : bp + r - 6;
+            const int col = (c < 6) ? bc + c : bp + c - 6;
+            if (v != 0.0) atomicAdd(p.A11 + (size_t)row + (size_t)p.dim * col, v);
+        } else {
+            const int r = e - 144;
+            const double v = s_red[78 + r];
+            const int row = (r < 6) ? bc + r : bp + r - 6;
+            if (v != 0.0) atomicAdd(p.b1 + row, v);
+        }
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(256) void emba_accumulate_kernel(AccumParams p)
+{
+    __shared__ double s_red_all[4][96];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* s_red = s_red_all[wv];
+    const long wave_id = (long)blockIdx.x * 4 + wv;
+    const long start = wave_id * kAccumChunk;
+    if (start >= p.n_slots) return;  // wave-uniform
+    const long end = (start + kAccumChunk < p.n_slots) ? start + kAccumChunk : p.n_slots;
+
+    double acc[78], accb[12];
+#pragma unroll
+    for (int k = 0; k < 78; ++k) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) accb[k] = 0;
+    uint32_t cur_key = p.slot_key[start];
+    bool dirty = false;
+
+    for (long base = start; base < end; base += 64) {
+        const long s = base + lane;
+        const bool in = s < end;
+        double v[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[k] = 0;
+        double sw = 0, ew = 0;
+        uint32_t key = cur_key;
+        if (in) {
+            key = p.slot_key[s];
+            const double2* r2 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * s);
+            const double2 tail = r2[7];
+            const uint32_t pi = (uint32_t)__double2loint(tail.y);
+            bool ok = (pi != kInvalidPix);
+            if (ok) ok = p.count[pi] >= p.thres;                    // model.cpp:409
+            if (ok) {
+                const double e = tail.x;
+                double w = 1.0;
+                if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);   // cauchy, model.cpp:603
+                else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }  // huber, :608-616
+                sw = w;
+                ew = w * e;
+                const double2 d = r2[6];
+                double* q = p.A22b2 + 5 * (size_t)p.compact[pi];
+                atomicAdd(q + 0, w * (d.x * d.x));                  // model.cpp:429-435 / 632
+                atomicAdd(q + 1, w * (d.x * d.y));
+                atomicAdd(q + 2, w * (d.y * d.y));
+                atomicAdd(q + 3, d.x * ew);                         // model.cpp:438-439 / 635-636
+                atomicAdd(q + 4, d.y * ew);
+                const double2 a0 = r2[0], a1 = r2[1], a2 = r2[2], a3 = r2[3], a4 = r2[4], a5 = r2[5];
+                v[0] = a0.x; v[1] = a0.y; v[2] = a1.x; v[3] = a1.y; v[4] = a2.x; v[5] = a2.y;
+                v[6] = a3.x; v[7] = a3.y; v[8] = a4.x; v[9] = a4.y; v[10] = a5.x; v[11] = a5.y;
+            }
+        }
+        unsigned long long remaining = __ballot(in);
+        while (remaining) {  // wave-uniform loop; one trip unless the chunk straddles a key boundary here
+            const int first = __ffsll((long long)remaining) - 1;
+            const uint32_t k0 = (uint32_t)__shfl((int)key, first);
+            if (k0 != cur_key) {
+                if (dirty) accum_flush(acc, accb, cur_key, p, s_red);
+                cur_key = k0;
+                dirty = false;
+            }
+            const bool mine = in && (key == k0);
+            const double msw = mine ? sw : 0.0, mew = mine ? ew : 0.0;
+            if (__ballot(mine && sw != 0.0)) dirty = true;
+#pragma unroll
+            for (int r = 0; r < 12; ++r) {
+                const double wvr = msw * v[r];
+#pragma unroll
+                for (int c = r; c < 12; ++c) acc[EMBA_TRI(r, c)] = fma(wvr, v[c], acc[EMBA_TRI(r, c)]);
+                accb[r] = fma(v[r], mew, accb[r]);
+            }
+            remaining &= ~__ballot(mine);
+        }
+    }
+    if (dirty) accum_flush(acc, accb, cur_key, p, s_red);
+}
+
+// a11: applyL2Reg (model.cpp:689-719) on the compact pack.
+__global__ void emba_l2reg_kernel(double* __restrict__ A22b2, const uint32_t* __restrict__ active_idx, long P, double alpha,
+                                  const double* __restrict__ Gx, const double* __restrict__ Gy)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    double* q = A22b2 + 5 * i;
+    const uint32_t pi = active_idx[i];
+    q[0] += alpha;
+    q[2] += alpha;
+    q[3] -= alpha * Gx[pi];
+    q[4] -= alpha * Gy[pi];
+}
+
+// pack -> boundary layout: A22 P*4 ([xx xy; xy yy]) and b2 2P.
+__global__ void emba_unpack_kernel(const double* __restrict__ A22b2, long P, double* __restrict__ A22, double* __restrict__ b2)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const double* q = A22b2 + 5 * i;
+    A22[4 * i + 0] = q[0]; A22[4 * i + 1] = q[1]; A22[4 * i + 2] = q[1]; A22[4 * i + 3] = q[2];
+    b2[2 * i] = q[3]; b2[2 * i + 1] = q[4];
+}
+
+// Weight and compact pixel of a record (shared by the dense-A12 and export kernels).
+__device__ __forceinline__ bool record_active(const double* rec, const int32_t* count, const int32_t* compact, int thres,
+                                              int irls, double eta, int32_t* cidx, double* w)
+{
+    const double2 tail = reinterpret_cast<const double2*>(rec)[7];
+    const uint32_t pi = (uint32_t)__double2loint(tail.y);
+    if (pi == kInvalidPix || count[pi] < thres) return false;
+    const double e = tail.x;
+    double ww = 1.0;
+    if (irls == 2) ww = 1.0 / (1.0 + eta * e * e);
+    else if (irls == 1) { const double a = fabs(e); ww = (a < eta) ? 1.0 : eta / a; }
+    *cidx = compact[pi];
+    *w = ww;
+    return true;
+}
+
+// Dense A12 (3K x 2P col-major) for the legacy interface (model.cpp:358,483-487); small sizes only.
+__global__ void emba_dense_a12_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key, long n_slots,
+                                      const int32_t* __restrict__ count, const int32_t* __restrict__ compact, int thres,
+                                      int irls, double eta, int dim, double* __restrict__ A12)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const double* r = rec + (size_t)kRecStride * s;
+    int32_t cidx; double w;
+    if (!record_active(r, count, compact, thres, irls, eta, &cidx, &w)) return;
+    const uint32_t key = slot_key[s];
+    const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
+    double* c0 = A12 + (size_t)dim * (2 * (size_t)cidx);
+    double* c1 = c0 + dim;
+    const double dx = r[12], dy = r[13];
+    for (int i = 0; i < 6; ++i) {
+        const double jc = w * r[i], jp = w * r[6 + i];
+        atomicAdd(c0 + bc + i, jc * dx); atomicAdd(c1 + bc + i, jc * dy);
+        atomicAdd(c0 + bp + i, jp * dx); atomicAdd(c1 + bp + i, jp * dy);
+    }
+}
+
+// Sparse A12 export: one rank-1 factor per candidate slot.
+__global__ void emba_export_a12_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key, long n_slots,
+                                       const int32_t* __restrict__ count, const int32_t* __restrict__ compact, int thres,
+                                       int irls, double eta, int32_t* __restrict__ cp_c, int32_t* __restrict__ cp_p,
+                                       int32_t* __restrict__ pix, double* __restrict__ w_out, double* __restrict__ jc,
+                                       double* __restrict__ jp, double* __restrict__ dp)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const double* r = rec + (size_t)kRecStride * s;
+    const uint32_t key = slot_key[s];
+    cp_c[s] = (int32_t)(key >> 16);
+    cp_p[s] = (int32_t)(key & 0xFFFFu);
+    int32_t cidx = -1; double w = 0.0;
+    const bool ok = record_active(r, count, compact, thres, irls, eta, &cidx, &w);
+    pix[s] = ok ? cidx : -1;
+    w_out[s] = ok ? w : 0.0;
+    for (int i = 0; i < 6; ++i) { jc[6 * s + i] = ok ? r[i] : 0.0; jp[6 * s + i] = ok ? r[6 + i] : 0.0; }
+    dp[2 * s] = ok ? r[12] : 0.0; dp[2 * s + 1] = ok ? r[13] : 0.0;
+}
+
+// a12: cost reductions.  out[0] += partial sums (fp64 atomics, one per block).
+__global__ __launch_bounds__(256) void emba_data_cost_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                             long n_sorted, int irls, double eta, double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_sorted; i += (long)gridDim.x * 256) {
+        if (!flag[i]) continue;
+        const double e = e_sorted[i];
+        if (irls == 0) acc += e * e;                                   // 0.5*ep.dot(ep), solver.cpp:88
+        else if (irls == 2) acc += log1p(eta * (e * e));               // model.cpp:283-290
+        else { const double a = fabs(e); acc += (a < eta) ? 0.5 * a * a : eta * a - 0.5 * eta * eta; }  // :294-312
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+__global__ __launch_bounds__(256) void emba_reg_cost_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, long npix,
+                                                            double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+        const double a = Gx[i], b = Gy[i];
+        acc += a * a + b * b;                                          // model.cpp:260-277
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+}  // namespace emba

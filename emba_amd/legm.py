@@ -1,0 +1,273 @@
+"""Host-side mirror of the reference's measurement-model interface `EMBA::LEGM`
+(reference include/emba/model.h:72-133) on plain numpy arrays, calling the HIP library through the
+C ABI of include/emba_hip.h.  Method names, argument meaning and error behaviour follow the reference:
+
+    LEGM(camera_info, C_th, pano_width, pano_height)        model.h:76-77   -> LEGM(sensor_w, sensor_h, bearing_lut, ...)
+    evaluateDataError(traj, Gx, Gy, events, eval_deriv, num_ev_map)  :83-84
+    evaluateRegError / evaluateRobustDataCost                :87, :90       -> regCost / dataCost (scalar, on device)
+    formNormalEq / formNormalEqIRLS                          :93-103
+    applyL2Reg                                               :106-108
+
+Differences forced by the boundary: the bearing-vector LUT is an input (the reference
+builds it from ROS camera_info, event_pano_warper.cpp:27-41); the trajectory is passed as its control
+quaternions + (t0_ns, dt_ns); events are registered once per window with set_events() because the per-pixel
+event lists are pose-independent.  Invariant violations raise EmbaError (the reference aborts via glog CHECK).
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import EmbaCfg, EmbaError
+
+_dp, _i32p, _u32p = _lib._dp, _lib._i32p, _lib._u32p
+_u16p, _u8p, _i64p = _lib._u16p, _lib._u8p, _lib._i64p
+
+COST_TYPES = {"quadratic": 0, "huber": 1, "cauchy": 2}
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+@dataclass
+class LinearTrajectory:
+    """The data `LinearTrajectory` hands to the hot path (reference include/utils/trajectory.h:109-190):
+    control rotations as unit quaternions (x,y,z,w) and the spline timing of trajectory.cpp:59-64
+    (t_beg_ns = int64(1e9*t_beg), dt_ns = int64(1e9*dt_knots))."""
+    knots_xyzw: np.ndarray
+    t0_ns: int
+    dt_ns: int
+
+    @classmethod
+    def from_seconds(cls, t_beg, dt_knots, knots_xyzw):
+        return cls(np.ascontiguousarray(knots_xyzw, dtype=np.float64).reshape(-1, 4), int(1e9 * t_beg), int(1e9 * dt_knots))
+
+    def size(self):
+        return self.knots_xyzw.shape[0]
+
+
+@dataclass
+class EventPacket:
+    """std::vector<dvs_msgs::Event> (model.h:17) as a struct of arrays; ts as int64 nanoseconds."""
+    x: np.ndarray
+    y: np.ndarray
+    polarity: np.ndarray
+    t_ns: np.ndarray
+
+    def size(self):
+        return int(self.x.size)
+
+
+class LEGM:
+    def __init__(self, sensor_w, sensor_h, bearing_lut, C_th, pano_width, pano_height, device=0, stream=None):
+        self._L = _lib.load()
+        self._ctx = C.c_void_p()
+        self.sensor_w, self.sensor_h = int(sensor_w), int(sensor_h)
+        self.W, self.H = int(pano_width), int(pano_height)
+        lut = np.ascontiguousarray(bearing_lut, dtype=np.float64).reshape(self.sensor_w * self.sensor_h, 3)
+        cfg = EmbaCfg(self.sensor_w, self.sensor_h, self.W, self.H, _p(lut, _dp), float(C_th), 100, 10.0, int(device),
+                      C.c_void_p(stream) if stream else None)
+        st = self._L.emba_create(C.byref(cfg), C.byref(self._ctx))
+        if st != _lib.OK:
+            self._ctx = C.c_void_p()
+            raise EmbaError(st, self._L.emba_last_error(None).decode())
+        self.n_events = 0
+        self.K = 0
+        self._P = 0
+        self._keep = []  # arrays that must outlive an asynchronous launch
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._L.emba_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != _lib.OK:
+            raise EmbaError(st, self._L.emba_last_error(self._ctx).decode())
+
+    # -- events (once per window) --------------------------------------------------------------
+    def set_events(self, events, halo=None):
+        """events: EventPacket sorted by time.  halo: optional (x, y, batch_t_ns) arrays (multi-GPU shards)."""
+        x = np.ascontiguousarray(events.x, dtype=np.uint16)
+        y = np.ascontiguousarray(events.y, dtype=np.uint16)
+        pol = np.ascontiguousarray(events.polarity, dtype=np.uint8)
+        t = np.ascontiguousarray(events.t_ns, dtype=np.int64)
+        if not (x.size == y.size == pol.size == t.size):
+            raise ValueError("event arrays differ in length")
+        hx = hy = ht = None
+        nh = 0
+        if halo is not None and len(halo[0]):
+            hx = np.ascontiguousarray(halo[0], dtype=np.uint16)
+            hy = np.ascontiguousarray(halo[1], dtype=np.uint16)
+            ht = np.ascontiguousarray(halo[2], dtype=np.int64)
+            nh = hx.size
+        self._check(self._L.emba_set_events(self._ctx, _p(x, _u16p), _p(y, _u16p), _p(pol, _u8p), _p(t, _i64p), x.size,
+                                            _p(hx, _u16p), _p(hy, _u16p), _p(ht, _i64p), nh))
+        self.n_events = x.size
+
+    def event_counts(self):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.emba_event_counts(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # -- reference-shaped one-shot interface ---------------------------------------------------
+    def evaluateDataError(self, traj, Gx, Gy, events=None, eval_deriv=True, num_ev_map=None):
+        """model.cpp:72-258.  Returns ep (inlier residuals, reference order); fills num_ev_map (int32 H x W)."""
+        if events is not None:
+            self.set_events(events)
+        Gx = np.ascontiguousarray(Gx, dtype=np.float64)
+        Gy = np.ascontiguousarray(Gy, dtype=np.float64)
+        if Gx.shape != (self.H, self.W) or Gy.shape != (self.H, self.W):
+            raise ValueError("Gx/Gy must be pano_height x pano_width float64")
+        knots = np.ascontiguousarray(traj.knots_xyzw, dtype=np.float64).reshape(-1, 4)
+        self.K = knots.shape[0]
+        ep = np.empty(max(self.n_events, 1), dtype=np.float64)
+        n_inl = C.c_size_t(0)
+        if num_ev_map is None:
+            num_ev_map = np.empty((self.H, self.W), dtype=np.int32)
+        assert num_ev_map.dtype == np.int32 and num_ev_map.flags.c_contiguous and num_ev_map.shape == (self.H, self.W)
+        self._check(self._L.emba_eval_data_error(self._ctx, _p(knots, _dp), self.K, int(traj.t0_ns), int(traj.dt_ns), _p(Gx, _dp),
+                                                 _p(Gy, _dp), 1 if eval_deriv else 0, _p(ep, _dp), C.byref(n_inl),
+                                                 _p(num_ev_map, _i32p)))
+        self.num_ev_map = num_ev_map
+        return ep[:n_inl.value].copy()
+
+    def dataCost(self, cost_type="quadratic", a=0.0):
+        """0.5*ep.dot(ep) (solver.cpp:88) or evaluateRobustDataCost (model.cpp:279-314), reduced on the device."""
+        v = C.c_double(0)
+        self._check(self._L.emba_data_cost(self._ctx, COST_TYPES[cost_type], float(a), C.byref(v)))
+        return v.value
+
+    def regCost(self, alpha):
+        """alpha*0.5*|evaluateRegError|^2 (model.cpp:260-277, solver.cpp:90), reduced on the device."""
+        v = C.c_double(0)
+        self._check(self._L.emba_reg_cost(self._ctx, float(alpha), C.byref(v)))
+        return v.value
+
+    def _form(self, ep, thres, irls, a, alpha, dense_A12):
+        ep_h = None if ep is None else np.ascontiguousarray(ep, dtype=np.float64)
+        P = C.c_size_t(0)
+        pl = C.c_size_t(0)
+        self._check(self._L.emba_form_active(self._ctx, int(thres), C.byref(P), C.byref(pl)))
+        self._P = P.value
+        self._check(self._L.emba_form_accumulate(self._ctx, _p(ep_h, _dp), irls, float(a)))
+        return self._finish(alpha, dense_A12)
+
+    def _finish(self, alpha, dense_A12):
+        P, dim = self._P, 3 * self.K
+        A11 = np.zeros((dim, dim), order="F"); b1 = np.zeros(dim)
+        active = np.zeros(max(P, 1), dtype=np.uint32)
+        A22 = np.zeros((max(P, 1), 2, 2)); b2 = np.zeros(2 * max(P, 1))
+        A12 = np.zeros((dim, 2 * P), order="F") if dense_A12 else None
+        self._check(self._L.emba_form_finish(self._ctx, float(alpha), _p(A11, _dp), _p(b1, _dp), _p(active, _u32p), max(P, 1),
+                                             _p(A22, _dp), _p(b2, _dp), _p(A12, _dp) if (dense_A12 and P) else None))
+        return dict(A11=A11, b1=b1, active=active[:P].copy(), A22=A22[:P], b2=b2[:2 * P], A12=A12, P=P)
+
+    def formNormalEq(self, ep, num_ctrl_poses, num_ev_map=None, thres_valid_pixel=5, dense_A12=False):
+        """model.cpp:316-491.  num_ev_map is accepted for signature parity; the device-resident copy produced by the
+        last evaluateDataError is what is used (they are the same object in the reference's call pattern, solver.cpp:114-126)."""
+        if num_ctrl_poses != self.K:
+            raise EmbaError(_lib.ERR_INVALID_ARG, "num_ctrl_poses differs from the trajectory used in evaluateDataError")
+        return self._form(ep, thres_valid_pixel, 0, 0.0, 0.0, dense_A12)
+
+    def formNormalEqIRLS(self, ep, num_ctrl_poses, num_ev_map=None, thres_valid_pixel=5, cost_type="huber", a=0.1,
+                         dense_A12=False):
+        """model.cpp:493-687."""
+        if num_ctrl_poses != self.K:
+            raise EmbaError(_lib.ERR_INVALID_ARG, "num_ctrl_poses differs from the trajectory used in evaluateDataError")
+        return self._form(ep, thres_valid_pixel, COST_TYPES[cost_type], a, 0.0, dense_A12)
+
+    def applyL2Reg(self, alpha, dense_A12=False):
+        """model.cpp:689-719, applied to the device-resident pack; returns the updated blocks (call once per formNormalEq)."""
+        return self._finish(alpha, dense_A12)
+
+    def A12_sparse(self):
+        """Rank-1 factors of A12 (one per measurement candidate; pix == -1 marks outliers/inactive)."""
+        _, M = self.event_counts()
+        out = dict(cp_c=np.zeros(M, np.int32), cp_p=np.zeros(M, np.int32), pix=np.zeros(M, np.int32), w=np.zeros(M),
+                   jc=np.zeros((M, 6)), jp=np.zeros((M, 6)), dp=np.zeros((M, 2)))
+        self._check(self._L.emba_get_A12_sparse(self._ctx, _p(out["cp_c"], _i32p), _p(out["cp_p"], _i32p), _p(out["pix"], _i32p),
+                                                _p(out["w"], _dp), _p(out["jc"], _dp), _p(out["jp"], _dp), _p(out["dp"], _dp)))
+        return out
+
+    def dump_state(self):
+        """Per-event State_LEGM (state.h:56-83) in original event order, for parity tests."""
+        n = self.n_events
+        d = dict(pm=np.zeros((n, 2)), D=np.zeros((n, 2, 6)), cp_idx=np.zeros(n, np.int32), inlier_idx=np.zeros(n, np.int32),
+                 pm_int=np.zeros((n, 2), np.int32), dp=np.zeros((n, 2)), Gpm=np.zeros((n, 2)), temp=np.zeros((n, 2)))
+        self._check(self._L.emba_dump_state(self._ctx, _p(d["pm"], _dp), _p(d["D"], _dp), _p(d["cp_idx"], _i32p),
+                                            _p(d["inlier_idx"], _i32p), _p(d["pm_int"], _i32p), _p(d["dp"], _dp), _p(d["Gpm"], _dp),
+                                            _p(d["temp"], _dp)))
+        return d
+
+    # -- phase-level, HBM-resident interface (bench.py, sharded host) -------------------------------
+    def upload_map(self, Gx, Gy):
+        Gx = np.ascontiguousarray(Gx, dtype=np.float64); Gy = np.ascontiguousarray(Gy, dtype=np.float64)
+        self._check(self._L.emba_upload_map(self._ctx, _p(Gx, _dp), _p(Gy, _dp)))
+        self._check(self._L.emba_sync(self._ctx))
+
+    def bind_map_dev(self, gx_ptr, gy_ptr):
+        self._check(self._L.emba_bind_map_dev(self._ctx, C.c_void_p(gx_ptr), C.c_void_p(gy_ptr)))
+
+    def bind_exchange_buffers(self, count_ptr, pack_ptr, pack_cap):
+        self._check(self._L.emba_bind_exchange_buffers(self._ctx, C.c_void_p(count_ptr) if count_ptr else None,
+                                                       C.c_void_p(pack_ptr) if pack_ptr else None, int(pack_cap)))
+
+    def eval_launch(self, traj):
+        knots = np.ascontiguousarray(traj.knots_xyzw, dtype=np.float64).reshape(-1, 4)
+        self.K = knots.shape[0]
+        self._keep = [knots]
+        self._check(self._L.emba_eval_launch(self._ctx, _p(knots, _dp), self.K, int(traj.t0_ns), int(traj.dt_ns)))
+
+    def eval_finish(self, want_ep=False, want_map=False):
+        n_inl = C.c_size_t(0)
+        ep = np.empty(max(self.n_events, 1)) if want_ep else None
+        nem = np.empty((self.H, self.W), dtype=np.int32) if want_map else None
+        self._check(self._L.emba_eval_finish(self._ctx, _p(ep, _dp), C.byref(n_inl), _p(nem, _i32p)))
+        return n_inl.value, (ep[:n_inl.value] if want_ep else None), nem
+
+    def form_active(self, thres):
+        P, pl = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.emba_form_active(self._ctx, int(thres), C.byref(P), C.byref(pl)))
+        self._P = P.value
+        return P.value, pl.value
+
+    def form_accumulate(self, cost_type="quadratic", a=0.0):
+        self._check(self._L.emba_form_accumulate(self._ctx, None, COST_TYPES[cost_type], float(a)))
+
+    def form_finish(self, alpha, download=False, dense_A12=False):
+        if download:
+            return self._finish(alpha, dense_A12)
+        self._check(self._L.emba_form_finish(self._ctx, float(alpha), None, None, None, 0, None, None, None))
+        return None
+
+    def sync(self):
+        self._check(self._L.emba_sync(self._ctx))
+
+    def timer_start(self, slot=0):
+        self._check(self._L.emba_timer_start(self._ctx, slot))
+
+    def timer_stop(self, slot=0):
+        self._check(self._L.emba_timer_stop(self._ctx, slot))
+
+    def timer_ms(self, slot=0):
+        ms = C.c_float(0)
+        self._check(self._L.emba_timer_elapsed_ms(self._ctx, slot, C.byref(ms)))
+        return ms.value
+
+    def enable_kernel_timing(self, on=True):
+        self._check(self._L.emba_enable_kernel_timing(self._ctx, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.emba_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,193 @@
+/* include/emba_hip.h — C ABI of the MI355X (gfx950) implementation of EMBA's hot path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer; its seam is the
+ * C++ object EMBA::LEGM (reference include/emba/model.h:72-133), owned by EMBA::EMBA
+ * (include/emba/emba.h:109) and called only from EMBA::solveTimeWindow (src/emba/solver.cpp:63-353).
+ * The functions below are what a thin `EMBA::LEGM` adapter binds (INTEGRATION.md shows it):
+ *
+ *   emba_create / emba_destroy      <- LEGM::LEGM / ~LEGM                 model.cpp:56-70, model.h:80
+ *   emba_set_events                 <- the EventPacket argument of evaluateDataError + the
+ *                                      pose-independent part of event_map_ (event_map.h:34-47)
+ *   emba_eval_data_error            <- LEGM::evaluateDataError            model.cpp:72-258
+ *   emba_form_normal_eq             <- LEGM::formNormalEq / formNormalEqIRLS + applyL2Reg
+ *                                                                          model.cpp:316-491, 493-687, 689-719
+ *   emba_data_cost / emba_reg_cost  <- 0.5*ep.ep, evaluateRobustDataCost, evaluateRegError
+ *                                                                          solver.cpp:88-91, model.cpp:260-314
+ *   emba_get_A12_sparse             <- the rank-1 factors of the dense A12 of model.cpp:358,483-487
+ *
+ * plus the phase-level entry points (emba_*_launch / *_finish) that keep every operand resident in
+ * HBM, used by bench.py and by the multi-GPU host (one process per GPU; the two exchanges per
+ * Gauss-Newton iteration — the int32 pixel-count map and the fp64 normal-equation pack — are
+ * all-reduced by the caller between phases on buffers it binds with emba_bind_exchange_buffers).
+ *
+ * Conventions: plain C, no C++ types, no exceptions across the boundary.  Every function returns an
+ * emba_status; the adapter turns non-zero into LOG(FATAL) to keep the reference's fail-fast
+ * contract (glog CHECKs at model.cpp:247,350,378).  All floating point is IEEE double, indices are
+ * int32/uint32, exactly as in the reference.  Single caller thread per context (non-reentrant), like
+ * the reference.  "host" pointers are ordinary host memory; "dev" pointers are HIP device memory of
+ * the context's device.  There is NO CPU fallback: without a GPU emba_create fails with
+ * EMBA_ERR_NO_DEVICE.
+ */
+#ifndef EMBA_HIP_H
+#define EMBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMBA_ABI_VERSION 1
+
+typedef enum {
+    EMBA_OK = 0,
+    EMBA_ERR_INVALID_ARG = 1,   /* null pointer, bad size, unsorted timestamps, pixel out of sensor */
+    EMBA_ERR_NO_DEVICE = 2,     /* no HIP device / requested ordinal absent */
+    EMBA_ERR_HIP = 3,           /* a HIP runtime call failed; see emba_last_error */
+    EMBA_ERR_TIME_RANGE = 4,    /* a batch midpoint lies outside the spline's knots
+                                   (BASALT_ASSERT at so3_spline.h:221-229 in the reference) */
+    EMBA_ERR_STATE = 5,         /* call order violated (e.g. form before eval) */
+    EMBA_ERR_CAPACITY = 6       /* a caller-provided buffer is too small */
+} emba_status;
+
+typedef struct emba_ctx emba_ctx;
+
+typedef struct {
+    int32_t sensor_w, sensor_h;   /* camera_info.width/height        (model.cpp:67-68) */
+    int32_t pano_w, pano_h;       /* panorama size, W = 2H           (emba.cpp:552-553) */
+    const double* bearing_lut;    /* host, sensor_w*sensor_h*3 f64, row-major by y*w+x: the
+                                     precomputed_bearing_vectors_ of event_pano_warper.cpp:27-41 */
+    double C_th;                  /* contrast threshold               (model.cpp:60) */
+    int32_t event_batch;          /* 0 or 100: the reference hard-codes 100 (model.cpp:78) */
+    double outlier_px;            /* 0 -> 10.0                        (model.cpp:200) */
+    int32_t device;               /* HIP device ordinal */
+    void* stream;                 /* hipStream_t to enqueue on, or NULL for the context's own stream */
+} emba_cfg;
+
+/* Library/ABI identification (no GPU needed). */
+int emba_abi_version(void);
+const char* emba_build_info(void);
+
+emba_status emba_create(const emba_cfg* cfg, emba_ctx** out);
+void emba_destroy(emba_ctx* ctx);
+/* Human-readable description of the last non-OK status on this context (or of a failed
+ * emba_create when ctx == NULL). */
+const char* emba_last_error(const emba_ctx* ctx);
+
+/* Once per time window.  Events sorted by time (rosbag_loading.cpp:61-65 order is taken as
+ * ground truth, quirk Q10); the last n % 100 events are ignored (quirk Q1, model.cpp:77-79).
+ * Builds the pose-independent structure the reference rebuilds on every evaluateDataError call:
+ * per-batch midpoint times (model.cpp:116-119), the per-sensor-pixel event lists
+ * (event_map.h:34-47) laid out pixel-major in HBM, and uploads them.
+ *
+ * Sharding: a rank holds a contiguous range of whole global batches and, in
+ * halo_*, for each sensor pixel the LAST event before its range (if any) together with the
+ * midpoint time of the batch that event belongs to; halo events are warped but are not
+ * measurements of this rank.  Pass n_halo = 0 on a single GPU. */
+emba_status emba_set_events(emba_ctx* ctx, const uint16_t* x, const uint16_t* y, const uint8_t* pol,
+                            const int64_t* t_ns, size_t n,
+                            const uint16_t* halo_x, const uint16_t* halo_y,
+                            const int64_t* halo_batch_t_ns, size_t n_halo);
+
+/* Number of events actually used (floor(n/100)*100) and of measurement candidates
+ * (events that have a predecessor at their sensor pixel). */
+emba_status emba_event_counts(const emba_ctx* ctx, size_t* n_used, size_t* n_candidates);
+
+/* ---- one-shot, host-buffer entry points (what the LEGM adapter calls) ------------------------ */
+
+/* LEGM::evaluateDataError(traj, Gx, Gy, events, eval_deriv=true, num_ev_map)   model.cpp:72-258.
+ * knots_xyzw: K unit quaternions (x,y,z,w) = traj->getControlPose(i).unit_quaternion();
+ * t0_ns/dt_ns: the spline's start_t_ns_/dt_ns_ (trajectory.cpp:59-64).
+ * Gx, Gy: host, pano_h*pano_w f64 row-major (CV_64FC1 continuous).
+ * ep_out: host, capacity >= n_used, receives the residuals in the reference's order (sensor pixel
+ * major, then time; model.cpp:179-186,221); *n_inliers = ep.size().  num_ev_map_out: host int32
+ * pano_h*pano_w (model.cpp:227) or NULL.  eval_deriv must be non-zero (the reference never passes
+ * false, solver.cpp:75,251; quirk Q4). */
+emba_status emba_eval_data_error(emba_ctx* ctx, const double* knots_xyzw, int32_t K, int64_t t0_ns,
+                                 int64_t dt_ns, const double* Gx, const double* Gy, int32_t eval_deriv,
+                                 double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out);
+
+/* LEGM::formNormalEq[IRLS] + LEGM::applyL2Reg   model.cpp:316-491, 493-687, 689-719.
+ * Uses the device-resident state of the last emba_eval_data_error (the reference's hidden
+ * event_map_ coupling, solver.cpp:99-102).  ep: host residuals to use (same layout as ep_out) or
+ * NULL for the device-resident ones.  irls: 0 quadratic, 1 huber, 2 cauchy (model.cpp:599-618);
+ * eta its parameter.  alpha: L2 weight; pass 0 to skip applyL2Reg.
+ * Outputs (host; any may be NULL): A11 3K*3K col-major, b1 3K, *P active pixels,
+ * active_idx (cap pano_h*pano_w, ascending pano index = std::set order, model.cpp:371-377),
+ * A22 P*4 (each block [xx xy; xy yy]), b2 2P, A12_dense 3K x 2P col-major (model.cpp:358; only
+ * sensible at small sizes — 3K*2P*8 bytes).  cap_P bounds A22/b2/A12 capacity in pixels. */
+emba_status emba_form_normal_eq(emba_ctx* ctx, const double* ep, int32_t thres_valid_pixel,
+                                int32_t irls, double eta, double alpha, double* A11, double* b1,
+                                size_t* P, uint32_t* active_idx, size_t cap_P, double* A22, double* b2,
+                                double* A12_dense);
+
+/* Sparse form of A12: one rank-1 factor per measurement candidate, in the device's
+ * (control-pose-pair)-sorted order.  A12[3*cp_c+i, 2*pix+d] += w*jc[i]*dp[d];
+ * A12[3*cp_p+i, 2*pix+d] += w*jp[i]*dp[d].  pix = -1 marks outliers / inactive pixels.
+ * All pointers host, capacity n_candidates (see emba_event_counts); any may be NULL. */
+emba_status emba_get_A12_sparse(emba_ctx* ctx, int32_t* cp_c, int32_t* cp_p, int32_t* pix, double* w,
+                                double* jc /*n*6*/, double* jp /*n*6*/, double* dp /*n*2*/);
+
+/* Cost terms of the caller (solver.cpp:88-91,257-268), reduced on the device from the resident
+ * residuals / map: data = 0.5*ep.ep (irls 0) or evaluateRobustDataCost (model.cpp:279-314);
+ * reg = 0.5*alpha*sum(Gx^2+Gy^2) over all pixels (model.cpp:260-277). */
+emba_status emba_data_cost(emba_ctx* ctx, int32_t irls, double eta, double* cost);
+emba_status emba_reg_cost(emba_ctx* ctx, double alpha, double* cost);
+
+/* Per-event state dump in ORIGINAL (time) order for parity tests: what State_LEGM holds after
+ * evaluateDataError (state.h:56-83).  All host, capacity n; any may be NULL.
+ * pm n*2, D n*12 (dpm_ddrot_cp row-major 2x6), cp_idx n, inlier_idx n (-1 outlier, -2 not a
+ * measurement), pm_int n*2 (-1 if not an inlier), dp/Gpm/temp n*2. */
+emba_status emba_dump_state(emba_ctx* ctx, double* pm, double* D, int32_t* cp_idx, int32_t* inlier_idx,
+                            int32_t* pm_int, double* dp, double* Gpm, double* temp);
+
+/* ---- phase-level, HBM-resident entry points (bench.py, multi-GPU host) ----------------------- */
+
+/* Copy the map to the device (host -> HBM), or adopt caller-owned device planes without a copy. */
+emba_status emba_upload_map(emba_ctx* ctx, const double* Gx_host, const double* Gy_host);
+emba_status emba_bind_map_dev(emba_ctx* ctx, const double* Gx_dev, const double* Gy_dev);
+
+/* Bind caller-owned device buffers that the caller all-reduces between phases:
+ *   count_map_dev : int32 pano_h*pano_w                       (exchange 1)
+ *   pack_dev      : f64, capacity pack_cap doubles, laid out [A11 9K^2 | b1 3K | A22b2 5P]
+ *                   with A22b2 = per active pixel {xx, xy, yy, bx, by}   (exchange 2)
+ * Pass NULLs to return to context-owned buffers. */
+emba_status emba_bind_exchange_buffers(emba_ctx* ctx, int32_t* count_map_dev, double* pack_dev,
+                                       size_t pack_cap);
+
+/* Phase E1: pose table, Hessian/texel pack, warp + residual + count + factor records.  Asynchronous
+ * on the context's stream.  After it the count map holds THIS rank's counts. */
+emba_status emba_eval_launch(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns,
+                             int64_t dt_ns);
+/* Phase E2: residual compaction into reference order; synchronizes; returns the inlier count and,
+ * if non-NULL, copies ep / the (possibly all-reduced) count map to the host. */
+emba_status emba_eval_finish(emba_ctx* ctx, double* ep_out_host, size_t* n_inliers,
+                             int32_t* num_ev_map_out_host);
+/* Phase F1: active set from the (all-reduced) count map; synchronizes to return P and the
+ * number of doubles of the pack [A11 | b1 | A22b2] that exchange 2 must all-reduce. */
+emba_status emba_form_active(emba_ctx* ctx, int32_t thres_valid_pixel, size_t* P, size_t* pack_len);
+/* Phase F2: zero the pack and accumulate this rank's measurements into it.  Asynchronous.
+ * ep_host as in emba_form_normal_eq. */
+emba_status emba_form_accumulate(emba_ctx* ctx, const double* ep_host, int32_t irls, double eta);
+/* Phase F3: applyL2Reg on the (all-reduced) pack, then optional download (any pointer may be NULL);
+ * synchronizes. */
+emba_status emba_form_finish(emba_ctx* ctx, double alpha, double* A11, double* b1, uint32_t* active_idx,
+                             size_t cap_P, double* A22, double* b2, double* A12_dense);
+
+/* Stream / event helpers so a host without HIP bindings can time the phases on the stream the
+ * kernels run on (bench.py's roofline leg). */
+emba_status emba_sync(emba_ctx* ctx);
+emba_status emba_timer_start(emba_ctx* ctx, int32_t slot);   /* records a hipEvent on the stream */
+emba_status emba_timer_stop(emba_ctx* ctx, int32_t slot);
+emba_status emba_timer_elapsed_ms(emba_ctx* ctx, int32_t slot, float* ms); /* synchronizes on stop */
+/* Device-measured duration (ms, HIP events around the launch) of the dominant kernel
+ * (warp+residual+record kernel, "emba_warp_residual_kernel") in the most recent emba_eval_launch,
+ * valid after a sync when kernel timing was enabled with emba_enable_kernel_timing(ctx, 1). */
+emba_status emba_enable_kernel_timing(emba_ctx* ctx, int32_t on);
+emba_status emba_last_kernel_ms(emba_ctx* ctx, float* warp_ms, float* accum_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMBA_HIP_H */

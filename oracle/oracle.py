@@ -1,0 +1,234 @@
+"""oracle/oracle.py — TEST INFRASTRUCTURE. NOT PART OF THE PRODUCT.
+
+ctypes bindings for the CPU checker libraries:
+  * oracle/libemba_oracle.so      — plain-C restatement of the reference hot path (emba_oracle.h)
+  * oracle/_ref/libref_basalt.so  — the reference's own basalt/Sophus/Eigen headers (ref_basalt.cpp),
+                                    present only where it was built (this container) or shipped prebuilt.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+The product package (emba_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libemba_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_basalt.so")
+
+_dp = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+
+
+def build():
+    """Compile the checker libraries (gcc/g++ only; no GPU toolchain involved)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def _ptr(a, ty):
+    return None if a is None else a.ctypes.data_as(ty)
+
+
+class _Dump(C.Structure):
+    _fields_ = [("pm", _dp), ("D", _dp), ("cp_idx", _i32p), ("inlier_idx", _i32p), ("pm_int", _i32p),
+                ("dp", _dp), ("Gpm", _dp), ("temp", _dp), ("prev", _i32p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.emba_oracle_create.restype = C.c_void_p
+        L.emba_oracle_create.argtypes = [C.c_int] * 4 + [_dp, C.c_double]
+        L.emba_oracle_destroy.argtypes = [C.c_void_p]
+        L.emba_oracle_batch_mid_ns.restype = C.c_int64
+        L.emba_oracle_batch_mid_ns.argtypes = [C.c_int64, C.c_int64]
+        L.emba_oracle_spline_eval.restype = C.c_int
+        L.emba_oracle_spline_eval.argtypes = [_dp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _dp, _dp,
+                                              C.POINTER(C.c_int), _dp]
+        L.emba_oracle_so3_exp.argtypes = [_dp, _dp]
+        L.emba_oracle_so3_log.argtypes = [_dp, _dp]
+        L.emba_oracle_left_jacobian.argtypes = [_dp, _dp, _dp]
+        L.emba_oracle_project.argtypes = [C.c_int, C.c_int, _dp, _dp, _dp]
+        L.emba_oracle_warp.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.emba_oracle_hessian.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp, _dp]
+        L.emba_oracle_eval_data_error.restype = C.c_long
+        L.emba_oracle_eval_data_error.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int64, C.c_int64, _dp, _dp,
+                                                  C.POINTER(C.c_uint16), C.POINTER(C.c_uint16),
+                                                  C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.c_size_t,
+                                                  _dp, _i32p, C.POINTER(_Dump)]
+        L.emba_oracle_form_normal_eq.restype = C.c_long
+        L.emba_oracle_form_normal_eq.argtypes = [C.c_void_p, _dp, C.c_int, _i32p, C.c_int, C.c_int,
+                                                 C.c_double, _dp, _dp, C.POINTER(C.c_uint32), _dp, _dp, _dp]
+        L.emba_oracle_apply_l2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_double, _dp,
+                                           _dp, _dp, _dp]
+        L.emba_oracle_data_cost.restype = C.c_double
+        L.emba_oracle_data_cost.argtypes = [_dp, C.c_size_t, C.c_int, C.c_double]
+        L.emba_oracle_reg_cost.restype = C.c_double
+        L.emba_oracle_reg_cost.argtypes = [_dp, _dp, C.c_size_t, C.c_double]
+        _lib = L
+    return _lib
+
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def ref():
+    """The reference's own basalt So3Spline<2> (oracle/_ref), or None when it was not built/shipped."""
+    global _ref
+    if _ref is None and ref_available():
+        R = C.CDLL(_REF)
+        R.ref_so3spline2_evaluate.restype = C.c_int
+        R.ref_so3spline2_evaluate.argtypes = [_dp, C.c_int, C.c_int64, C.c_int64, C.c_int64, _dp, _dp,
+                                              C.POINTER(C.c_int), _dp]
+        R.ref_so3_exp.argtypes = [_dp, _dp]
+        R.ref_so3_log.argtypes = [_dp, _dp]
+        R.ref_left_jacobian.argtypes = [_dp, _dp, _dp]
+        _ref = R
+    return _ref
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def spline_eval(knots_xyzw, t0_ns, dt_ns, t_ns, use_ref=False):
+    """Returns (q_xyzw[4], R[3,3], cp_idx, J36[3,6]) or None if t is outside the knots."""
+    knots = _f64(knots_xyzw).reshape(-1, 4)
+    q = np.zeros(4); R = np.zeros(9); J = np.zeros(18); s = C.c_int(0)
+    fn = ref().ref_so3spline2_evaluate if use_ref else lib().emba_oracle_spline_eval
+    rc = fn(_ptr(knots, _dp), knots.shape[0], int(t0_ns), int(dt_ns), int(t_ns), _ptr(q, _dp), _ptr(R, _dp),
+            C.byref(s), _ptr(J, _dp))
+    if rc != 0:
+        return None
+    return q, R.reshape(3, 3), s.value, J.reshape(3, 6)
+
+
+def so3_exp(w, use_ref=False):
+    w = _f64(w); q = np.zeros(4)
+    (ref().ref_so3_exp if use_ref else lib().emba_oracle_so3_exp)(_ptr(w, _dp), _ptr(q, _dp))
+    return q
+
+
+def so3_log(q, use_ref=False):
+    q = _f64(q); w = np.zeros(3)
+    (ref().ref_so3_log if use_ref else lib().emba_oracle_so3_log)(_ptr(q, _dp), _ptr(w, _dp))
+    return w
+
+
+def left_jacobian(phi, use_ref=False):
+    phi = _f64(phi); J = np.zeros(9); Ji = np.zeros(9)
+    (ref().ref_left_jacobian if use_ref else lib().emba_oracle_left_jacobian)(_ptr(phi, _dp), _ptr(J, _dp),
+                                                                             _ptr(Ji, _dp))
+    return J.reshape(3, 3), Ji.reshape(3, 3)
+
+
+def batch_mid_ns(t_first, t_last):
+    return lib().emba_oracle_batch_mid_ns(int(t_first), int(t_last))
+
+
+def project(pano_w, pano_h, rb):
+    rb = _f64(rb); pm = np.zeros(2); J = np.zeros(6)
+    lib().emba_oracle_project(pano_w, pano_h, _ptr(rb, _dp), _ptr(pm, _dp), _ptr(J, _dp))
+    return pm, J.reshape(2, 3)
+
+
+def hessian(Gx, Gy):
+    Gx = _f64(Gx); Gy = _f64(Gy)
+    H, W = Gx.shape
+    out = [np.zeros((H, W)) for _ in range(3)]
+    lib().emba_oracle_hessian(_ptr(Gx, _dp), _ptr(Gy, _dp), H, W, *[_ptr(o, _dp) for o in out])
+    return out
+
+
+def data_cost(ep, irls=0, a=0.0):
+    ep = _f64(ep)
+    return lib().emba_oracle_data_cost(_ptr(ep, _dp), ep.size, irls, a)
+
+
+def reg_cost(Gx, Gy, alpha):
+    Gx = _f64(Gx); Gy = _f64(Gy)
+    return lib().emba_oracle_reg_cost(_ptr(Gx, _dp), _ptr(Gy, _dp), Gx.size, alpha)
+
+
+class OracleLEGM:
+    """Mirror of EMBA::LEGM (include/emba/model.h:72-133) on plain numpy arrays, CPU oracle inside."""
+
+    def __init__(self, sensor_w, sensor_h, pano_w, pano_h, bearing_lut, C_th):
+        self.sw, self.sh, self.W, self.H = sensor_w, sensor_h, pano_w, pano_h
+        self.lut = _f64(bearing_lut).reshape(sensor_w * sensor_h, 3)
+        self._o = lib().emba_oracle_create(sensor_w, sensor_h, pano_w, pano_h, _ptr(self.lut, _dp), C_th)
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "_o", None):
+            lib().emba_oracle_destroy(self._o)
+            self._o = None
+
+    def warp(self, x, y, q_xyzw):
+        q = _f64(q_xyzw); pm = np.zeros(2); J = np.zeros(6)
+        lib().emba_oracle_warp(self._o, int(x), int(y), _ptr(q, _dp), _ptr(pm, _dp), _ptr(J, _dp))
+        return pm, J.reshape(2, 3)
+
+    def evaluate_data_error(self, knots_xyzw, t0_ns, dt_ns, Gx, Gy, x, y, pol, t_ns, dump=False):
+        knots = _f64(knots_xyzw).reshape(-1, 4)
+        Gx = _f64(Gx); Gy = _f64(Gy)
+        x = np.ascontiguousarray(x, dtype=np.uint16); y = np.ascontiguousarray(y, dtype=np.uint16)
+        pol = np.ascontiguousarray(pol, dtype=np.uint8); t_ns = np.ascontiguousarray(t_ns, dtype=np.int64)
+        n = x.size
+        self.n = n
+        ep = np.zeros(max(n, 1))
+        num_ev_map = np.zeros((self.H, self.W), dtype=np.int32)
+        d = None
+        dstruct = None
+        if dump:
+            d = dict(pm=np.zeros((n, 2)), D=np.zeros((n, 2, 6)), cp_idx=np.zeros(n, np.int32),
+                     inlier_idx=np.zeros(n, np.int32), pm_int=np.full((n, 2), -1, np.int32),
+                     dp=np.zeros((n, 2)), Gpm=np.zeros((n, 2)), temp=np.zeros((n, 2)),
+                     prev=np.zeros(n, np.int32))
+            dstruct = _Dump(_ptr(d["pm"], _dp), _ptr(d["D"], _dp), _ptr(d["cp_idx"], _i32p),
+                            _ptr(d["inlier_idx"], _i32p), _ptr(d["pm_int"], _i32p), _ptr(d["dp"], _dp),
+                            _ptr(d["Gpm"], _dp), _ptr(d["temp"], _dp), _ptr(d["prev"], _i32p))
+        m = lib().emba_oracle_eval_data_error(
+            self._o, _ptr(knots, _dp), knots.shape[0], int(t0_ns), int(dt_ns), _ptr(Gx, _dp), _ptr(Gy, _dp),
+            _ptr(x, C.POINTER(C.c_uint16)), _ptr(y, C.POINTER(C.c_uint16)), _ptr(pol, C.POINTER(C.c_uint8)),
+            _ptr(t_ns, C.POINTER(C.c_int64)), n, _ptr(ep, _dp), _ptr(num_ev_map, _i32p),
+            C.byref(dstruct) if dstruct is not None else None)
+        if m < 0:
+            raise ValueError("batch time outside the spline's knots")
+        ep = ep[:m].copy()
+        return (ep, num_ev_map, d) if dump else (ep, num_ev_map)
+
+    def form_normal_eq(self, ep, K, num_ev_map, thres, irls=0, a=0.0, dense_A12=False):
+        ep = _f64(ep)
+        nem = np.ascontiguousarray(num_ev_map, dtype=np.int32)
+        npix = self.W * self.H
+        A11 = np.zeros((3 * K, 3 * K), order="F"); b1 = np.zeros(3 * K)
+        active = np.zeros(npix, dtype=np.uint32)
+        P_guess = int((nem >= thres).sum())
+        A22 = np.zeros((max(P_guess, 1), 2, 2)); b2 = np.zeros(2 * max(P_guess, 1))
+        A12 = np.zeros((3 * K, 2 * P_guess), order="F") if dense_A12 else None
+        P = lib().emba_oracle_form_normal_eq(self._o, _ptr(ep, _dp), K, _ptr(nem, _i32p), thres, irls, a,
+                                             _ptr(A11, _dp), _ptr(b1, _dp), _ptr(active, C.POINTER(C.c_uint32)),
+                                             _ptr(A22, _dp), _ptr(b2, _dp), _ptr(A12, _dp))
+        assert P == P_guess
+        return dict(A11=A11, b1=b1, active=active[:P].copy(), A22=A22[:P], b2=b2[:2 * P], A12=A12, P=P)
+
+    def apply_l2(self, ne, alpha, Gx, Gy):
+        Gx = _f64(Gx); Gy = _f64(Gy)
+        if ne["P"] == 0:
+            return ne
+        lib().emba_oracle_apply_l2(self._o, ne["P"], _ptr(ne["active"], C.POINTER(C.c_uint32)), alpha,
+                                   _ptr(Gx, _dp), _ptr(Gy, _dp), _ptr(ne["A22"], _dp), _ptr(ne["b2"], _dp))
+        return ne

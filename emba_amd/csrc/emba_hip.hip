@@ -153,8 +153,8 @@ emba_status prepare_keys(emba_ctx* c, int64_t t0, int64_t dt, int K)
 {
     if (c->keys_ready && c->key_t0 == t0 && c->key_dt == dt && c->key_K == K) return EMBA_OK;
     if (dt <= 0 || K < 2 || K > 65535) return fail(c, EMBA_ERR_INVALID_ARG, "bad spline: dt_ns=%lld K=%d", (long long)dt, K);
-    std::vector<uint16_t> cp(c->h_batch_t.size());
-    for (size_t b = 0; b < cp.size(); ++b) {
+    std::vector<uint16_t> cp(c->n_batch ? c->n_batch : 1, 0);
+    for (size_t b = 0; b < c->n_batch; ++b) {
         const int64_t st = c->h_batch_t[b] - t0;
         const int64_t s = (st >= 0) ? st / dt : -1;
         if (st < 0 || s + 2 > (int64_t)K)
@@ -372,7 +372,7 @@ emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     if ((st = dev_alloc(c, &c->d_ev_slot, ns))) return st;
     if ((st = dev_alloc(c, &c->d_batch_t, c->n_batch))) return st;
     if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
-    if ((st = dev_alloc(c, &c->d_rec, n_cand * kRecStride))) return st;
+    if ((st = dev_alloc(c, &c->d_rec, std::max<size_t>(n_cand, 1) * kRecStride))) return st;
     if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
     if ((st = dev_alloc(c, &c->d_e_sorted, ns))) return st;
     if ((st = dev_alloc(c, &c->d_flag, ns))) return st;

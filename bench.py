@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — events/s through warp + Jacobian + J^T J build (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path over the resident workload: evaluateDataError(eval_deriv=true) + formNormalEq +
+applyL2Reg (reference solver.cpp:75/251 + :114-130) with events, map planes and LUT already in HBM when the timed region
+starts.  N=1: the BASELINE configuration (synthetic shapes-like: 1 M events, 240x180 sensor, 1024x2048 panorama, K=21,
+seed 20240907).  N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling — N x 1 M events over the same
+1 s window, sharded by time range with a per-pixel halo, int32 count-map all-reduce + fp64 normal-equation-pack all-reduce
+per step over RCCL (emba_amd/sharded.py).
+
+Prints ONE JSON line on rank 0.  The `roofline` object prices the dominant kernel (emba_warp_residual_kernel) with
+SURVEY §8d's 244 algorithmic bytes per event against the 8 TB/s HBM3E peak, its duration measured live with HIP events on
+the stream the kernel runs on.  `cpu_baseline` times the CPU oracle (single-threaded port of the reference algorithm) on the
+GPU box's host, rank 0, N=1 only; it is reported, not measured-as-product.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_EVENT = 244
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+EVENTS_PER_GPU = 1_000_000
+
+
+def cpu_baseline(w, budget_s=15.0):
+    """The oracle (plain-C, 1 thread, reference evaluation order) on the same workload; bounded to ~budget_s of CPU work."""
+    from oracle import oracle as O
+    o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+    ev = w.events
+    times = []
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        ep, nem = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns)
+        ne = o.form_normal_eq(ep, w.K, nem, w.thres_valid_pixel)
+        o.apply_l2(ne, w.alpha, w.Gx, w.Gy)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > budget_s or len(times) >= 25:
+            break
+    med = float(np.median(times[1:] if len(times) > 1 else times))
+    return {"value": ev.size() / med, "unit": "events/s", "cores": 1, "kind": "port",
+            "sample": f"full workload ({ev.size()} events), {len(times)} passes, median pass {med * 1e3:.1f} ms, "
+                      f"host nproc={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--events-per-gpu", type=int, default=EVENTS_PER_GPU)
+    ap.add_argument("--pano-h", type=int, default=1024)
+    ap.add_argument("--knots", type=int, default=21)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from emba_amd import LEGM
+    from emba_amd.sharded import HipEngine, ShardedLEGM
+    from emba_amd.synth import make_workload
+
+    n_total = args.events_per_gpu * world
+    w = make_workload(n_events=n_total, pano_h=args.pano_h, K=args.knots)
+    npix = w.pano_h * w.pano_w
+
+    # One explicit (non-null) HIP stream for our kernels AND for torch/RCCL, so that launches and collectives are ordered.
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=local_rank, stream=stream)
+    count_t = torch.zeros(npix, dtype=torch.int32, device=dev)
+    pack_t = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
+
+    class _Dist:  # torch.distributed or a 1-rank stand-in with the same three calls
+        @staticmethod
+        def get_rank(): return rank
+        @staticmethod
+        def get_world_size(): return world
+        @staticmethod
+        def all_reduce(t): dist.all_reduce(t)
+
+    sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w)
+    t_set = time.perf_counter()
+    local = sh.set_events(w.events)
+    m.upload_map(w.Gx, w.Gy)                                 # HBM-resident before the timed region
+    m.sync()
+    t_set = time.perf_counter() - t_set
+    m.enable_kernel_timing(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        return sh.iteration(w.traj, w.thres_valid_pixel, w.alpha)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    warp_ms, accum_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_inl, _ = step()
+        a, b = m.last_kernel_ms()
+        warp_ms.append(a); accum_ms.append(b)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total / (elapsed / args.steps)
+        wk = float(np.mean(warp_ms))
+        n_launch = local.size()
+        achieved = ALGO_BYTES_PER_EVENT * n_launch / (wk * 1e-3) / 1e9
+        out = {
+            "metric": "events/sec through warp+Jacobian+JtJ build, 1M events, 1024x2048 pano",
+            "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": w.describe(), "events_per_gpu": args.events_per_gpu, "total_events": n_total,
+                       "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
+                       "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM",
+                       "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
+                       "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3)},
+            "roofline": {"bound": "hbm", "kernel": "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_event": ALGO_BYTES_PER_EVENT, "events_per_launch": n_launch, "kernel_ms": wk,
+                         "accumulate_kernel_ms": float(np.mean(accum_ms)),
+                         "path_frac": ALGO_BYTES_PER_EVENT * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

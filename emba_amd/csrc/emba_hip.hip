@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,6 +47,9 @@ struct emba_ctx {
     double* d_Gx_own = nullptr; double* d_Gy_own = nullptr;
     const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // current map planes (own or bound)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
+    double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
+    int texel_mode = 0;   // 0 auto, 1 always pack texels, 2 always on-the-fly Hessian (EMBA_TEXEL=auto|pack|fly)
+    bool use_texel = false;
     int32_t* d_compact = nullptr;
     uint32_t* d_active = nullptr;
     uint32_t* d_ablk_cnt = nullptr; uint32_t* d_ablk_off = nullptr; size_t n_ablk = 0;
@@ -83,6 +87,7 @@ struct emba_ctx {
     bool kernel_timing = false;
     hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
     bool kt_warp_valid = false, kt_accum_valid = false;
+    int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
 };
 
 namespace {
@@ -263,6 +268,8 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->fx = (double)((c->W / 360.0) * 180.0 / M_PI);
     c->fy = (double)((c->H / 180.0) * 180.0 / M_PI);
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
+    if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
+    if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : 0;
 
 #define CREATE_TRY(call)                                                                                  \
     do {                                                                                                  \
@@ -283,6 +290,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipMalloc((void**)&c->d_texel, c->npix * kTexelStride * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&c->d_count_own, c->npix * sizeof(int32_t)));
     c->d_count = c->d_count_own;
+    CREATE_TRY(hipMalloc((void**)&c->d_pixacc, c->npix * kPixAccStride * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t)));
     c->n_ablk = (c->npix + 255) / 256;
@@ -306,7 +314,7 @@ void emba_destroy(emba_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_window(c);
     dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own);
-    dev_free(c->d_count_own); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
+    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
     dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -425,6 +433,7 @@ emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, doub
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     c->d_count = count_map_dev ? count_map_dev : c->d_count_own;
+    c->pix_dirty_all = true;   // the new count buffer says nothing about which pixacc lines are dirty
     if (pack_dev) { c->d_pack = pack_dev; c->pack_cap = pack_cap; c->pack_bound = true; }
     else { c->pack_bound = false; c->d_pack = c->d_pack_own; c->pack_cap = c->pack_own_cap; }
     return EMBA_OK;
@@ -450,21 +459,33 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemcpyAsync(c->d_knots, knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
     HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
-    HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));   // num_ev_map.setTo(0), model.cpp:85
+    if (c->pix_dirty_all) {   // num_ev_map.setTo(0), model.cpp:85 (+ the per-pixel accumulator lines)
+        HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
+        HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
+        c->pix_dirty_all = false;
+    } else {
+        hipLaunchKernelGGL(emba_clear_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, (long)c->npix, c->d_pixacc);
+    }
 
     if (c->n_batch) {
         const int nb = (int)c->n_batch;
         hipLaunchKernelGGL(emba_pose_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
                            t0_ns, dt_ns, c->d_pose, c->d_err);
     }
-    hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
-                       c->d_texel);
+    // Texel pack (one 48-B gather per measurement) pays off once the events outnumber the panorama pixels it costs;
+    // below that the warp kernel takes the 3x3 Hessian stencil straight from the Gx/Gy planes.
+    c->use_texel = c->texel_mode == 1 || (c->texel_mode == 0 && c->n_sorted > c->npix);
+    if (c->use_texel)
+        hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
+                           c->d_texel);
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
-        p.nblk = c->nblk; p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->d_texel; p.W = c->W; p.H = c->H;
+        p.nblk = c->nblk; p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
+        p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
         p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt;
+        p.ablate = c->ablate;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
@@ -522,7 +543,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
     hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1);
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, c->d_compact, c->d_active);
+                       c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[2], c->d_total + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -548,16 +569,29 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         hipLaunchKernelGGL(emba_override_ep_kernel, dim3((unsigned)((c->n_sorted + 255) / 256)), dim3(256), 0, s, c->d_ep, c->d_flag,
                            c->d_inl_idx, c->d_ev_slot, (long)c->n_sorted, c->d_rec, c->d_e_sorted);
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_pack, 0, c->pack_len * sizeof(double), s));   // Zero(), model.cpp:357-368
+    // A11 = Zero, b1 = Zero (model.cpp:357-361).  A22/b2 of the active pixels were gathered from the per-pixel
+    // accumulator by emba_form_active (quadratic cost, device-resident residuals); with IRLS weights or a
+    // caller-supplied ep they are rebuilt from the records instead.
+    const size_t head = (size_t)9 * c->K * c->K + (size_t)3 * c->K;
+    HIP_TRY(c, hipMemsetAsync(c->d_pack, 0, head * sizeof(double), s));
     c->irls = irls; c->eta = eta;
+    const bool generic_a22 = (irls != 0) || (ep_host != nullptr);
+    if (generic_a22 && c->P) {
+        HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));
+        if (c->n_cand)
+            hipLaunchKernelGGL(emba_a22_from_records_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec,
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c));
+    }
     if (c->n_cand) {
-        AccumParams p{};
-        p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.count = c->d_count; p.compact = c->d_compact;
-        p.thres = c->thres; p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c); p.A22b2 = pack_A22b2(c);
+        GramParams p{};
+        p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.count = c->d_count;
+        p.thres = c->thres; p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         p.dim = 3 * c->K;
-        const long waves = ((long)c->n_cand + kAccumChunk - 1) / kAccumChunk;
+        p.ablate = c->ablate;
+        const long waves = ((long)c->n_cand + kGramChunk - 1) / kGramChunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
-        hipLaunchKernelGGL(emba_accumulate_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p);
+        constexpr long wpb = kGramBlock / 64;
+        hipLaunchKernelGGL(emba_gram_kernel, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
     }
     HIP_TRY(c, hipGetLastError());
@@ -704,7 +738,8 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
-    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->d_texel; p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
+    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
+    p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
     hipLaunchKernelGGL(emba_warp_residual_kernel<true>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);

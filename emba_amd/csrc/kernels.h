@@ -7,6 +7,9 @@
 //   texel     per panorama pixel {Gx Gy Gxx Gxy Gyy pad} = 48 B   (one gather per measurement)
 //   records   one 128-B factor record per measurement candidate, stored in (cp_c,cp_p)-sorted slots:
 //             jc[6] jp[6] dp[2] e {u32 pano_idx, u32 aux}  — the sparse A12 factor + what A11/A22 need
+//   pixacc    per panorama pixel 64 B {sum dx*dx, dx*dy, dy*dy, dx*e, dy*e, pad x3}: the UNWEIGHTED A22/b2 sums of every
+//             inlier measurement, accumulated in the warp kernel next to the int32 count map; only touched lines are
+//             ever non-zero and they are cleared again by emba_clear_kernel at the start of the next evaluation
 //   pack      [A11 (3K)^2 col-major | b1 3K | per active pixel {xx xy yy bx by}]  (one all-reduce)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,7 +26,10 @@ constexpr int kTexelStride = 6;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
 constexpr int kWarpBlock = 256;    // threads per block of the warp kernel
 constexpr int kWarpNew = 255;      // new events per block (thread 0 re-warps the predecessor)
-constexpr int kAccumChunk = 512;   // record slots per wave in the accumulate kernel
+constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
+constexpr int kGramChunk = 256;    // record slots per wave in the Gram (A11/b1) kernel; multiple of 4
+constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table)
+constexpr int kGramKeys = 4;       // control-pose pairs the block-level LDS table can hold before falling back to global atomics
 
 // Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"); give each
 // XCD a contiguous range of work so that neighbouring sensor pixels (= neighbouring panorama texels,
@@ -75,12 +81,10 @@ __device__ __forceinline__ int reflect101(int i, int n)
     return i;
 }
 
-__global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy,
-                                                         int H, int W, double* __restrict__ texel)
+// Hessian stencil at (x,y); the arithmetic (and its order) is shared by the texel pack and by the on-the-fly path.
+__device__ __forceinline__ void hessian_at(const double* __restrict__ Gx, const double* __restrict__ Gy, int H, int W, int x, int y,
+                                           double& g_x, double& g_y, double& gxx_o, double& gxy_o, double& gyy_o)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W) return;
     const int xl = reflect101(x - 1, W), xr = reflect101(x + 1, W);
     const int yu = reflect101(y - 1, H), yd = reflect101(y + 1, H);
     const double* gxu = Gx + (size_t)yu * W; const double* gxc = Gx + (size_t)y * W; const double* gxd = Gx + (size_t)yd * W;
@@ -91,10 +95,24 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
     // d/dy: rows [1 2 1], columns [-1 0 1]
     const double gxy = ((gxd[xl] + gxd[xr]) + 2 * gxd[x]) - ((gxu[xl] + gxu[xr]) + 2 * gxu[x]);
     const double gyy = ((gyd[xl] + gyd[xr]) + 2 * gyd[x]) - ((gyu[xl] + gyu[xr]) + 2 * gyu[x]);
+    g_x = gxc[x]; g_y = gyc[x];
+    gxx_o = 0.125 * gxx;
+    gxy_o = 0.5 * (0.125 * gxy + 0.125 * gyx);
+    gyy_o = 0.125 * gyy;
+}
+
+__global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy,
+                                                         int H, int W, double* __restrict__ texel)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    double gx, gy, gxx, gxy, gyy;
+    hessian_at(Gx, Gy, H, W, x, y, gx, gy, gxx, gxy, gyy);
     double2* t = reinterpret_cast<double2*>(texel + (size_t)kTexelStride * ((size_t)y * W + x));
-    t[0] = make_double2(gxc[x], gyc[x]);
-    t[1] = make_double2(0.125 * gxx, 0.5 * (0.125 * gxy + 0.125 * gyx));
-    t[2] = make_double2(0.125 * gyy, 0.0);
+    t[0] = make_double2(gx, gy);
+    t[1] = make_double2(gxx, gxy);
+    t[2] = make_double2(gyy, 0.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -107,10 +125,12 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
 // ------------------------------------------------------------------------------------------------
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
-    const double* pose; const double* lut; const double* texel;
+    const double* pose; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy
+    const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
-    int32_t* count; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt;
+    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt;
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
+    int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
 };
 
 template <bool DUMP>
@@ -181,6 +201,8 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
 
     bool inl = false;
     const bool cand = valid && (t >= 1) && (s_pix[t - 1] == pix);
+    double a_xx = 0, a_xy = 0, a_yy = 0, a_bx = 0, a_by = 0;
+    uint32_t pi = kInvalidPix;
     if (cand) {
         const double dpx = pm[0] - s_pm[0][t - 1];
         const double dpy = pm[1] - s_pm[1][t - 1];
@@ -195,10 +217,17 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
         if (DUMP) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
         if (inl) {
             const int pmx = (int)rx, pmy = (int)ry;
-            const uint32_t pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
-            const double2* T2 = reinterpret_cast<const double2*>(p.texel + (size_t)kTexelStride * pi);
-            const double2 g = T2[0], h0 = T2[1], h1 = T2[2];
-            const double gx = g.x, gy = g.y, gxx = h0.x, gxy = h0.y, gyy = h1.x;
+            pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
+            double gx = 0.01, gy = 0.02, gxx = 0.001, gxy = 0.002, gyy = 0.003;
+            if (!(p.ablate & 4)) {
+                if (p.texel) {
+                    const double2* T2 = reinterpret_cast<const double2*>(p.texel + (size_t)kTexelStride * pi);
+                    const double2 g = T2[0], h0 = T2[1], h1 = T2[2];
+                    gx = g.x; gy = g.y; gxx = h0.x; gxy = h0.y; gyy = h1.x;
+                } else {
+                    hessian_at(p.Gx, p.Gy, p.H, p.W, pmx, pmy, gx, gy, gxx, gxy, gyy);
+                }
+            }
             const double C_pred = gx * dpx + gy * dpy;                  // model.cpp:217
             const double C_meas = 2 * ((double)pol - 0.5) * p.C_th;    // model.cpp:219
             const double e = C_meas - C_pred;                           // model.cpp:221
@@ -209,7 +238,9 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
                 p.d_temp[2 * i] = t0; p.d_temp[2 * i + 1] = t1;
                 p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy;
             } else {
-                atomicAdd(p.count + pi, 1);                             // model.cpp:227
+                if (!(p.ablate & 1)) atomicAdd(p.count + pi, 1);        // model.cpp:227
+                a_xx = dpx * dpx; a_xy = dpx * dpy; a_yy = dpy * dpy;   // model.cpp:429-431
+                a_bx = dpx * e; a_by = dpy * e;                         // model.cpp:438-439
                 double jc[6], jp[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
@@ -217,10 +248,13 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
                     jp[j] = (-gx) * s_D[j][t - 1] + (-gy) * s_D[6 + j][t - 1];          // model.cpp:459
                 }
                 double2* r2 = reinterpret_cast<double2*>(rec);
+                if (p.ablate & 2) { if (jc[0] + jc[1] + jc[2] + jc[3] + jc[4] + jc[5] + jp[0] + jp[1] + jp[2] + jp[3] + jp[4] + jp[5] == 1.2345) r2[0] = make_double2(e, dpx); }
+                else {
                 r2[0] = make_double2(jc[0], jc[1]); r2[1] = make_double2(jc[2], jc[3]); r2[2] = make_double2(jc[4], jc[5]);
                 r2[3] = make_double2(jp[0], jp[1]); r2[4] = make_double2(jp[2], jp[3]); r2[5] = make_double2(jp[4], jp[5]);
                 r2[6] = make_double2(dpx, dpy);
                 r2[7] = make_double2(e, __hiloint2double(0, (int)pi));
+                }
                 p.e_sorted[i] = e;
             }
         } else if (!DUMP) {
@@ -229,8 +263,25 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
     }
     if (!DUMP) {
         if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
-        const int n_inl = __syncthreads_count(inl ? 1 : 0);
+        const int n_inl = __syncthreads_count(inl ? 1 : 0);   // also: every read of s_D / s_pix above is done
         if (t == 0) p.blk_cnt[b] = (uint32_t)n_inl;
+        // Unweighted A22/b2 sums into the per-pixel accumulator line (model.cpp:426-439).  The five values of one
+        // measurement are contiguous in HBM, so they are issued by five ADJACENT lanes of one atomic wave-instruction
+        // (one 64-B request per measurement instead of five): stage through the LDS that held the Jacobians.
+        double* s_val = &s_D[0][0];                           // [kWarpBlock][6]
+        s_val[6 * t + 0] = a_xx; s_val[6 * t + 1] = a_xy; s_val[6 * t + 2] = a_yy; s_val[6 * t + 3] = a_bx; s_val[6 * t + 4] = a_by;
+        s_pix[t] = inl ? pi : kInvalidPix;
+        __syncthreads();
+        if (!(p.ablate & 8)) {
+            const int lane = t & 63, wbase = t & ~63;
+            const int j = lane & 7;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int tt = wbase + 8 * r + (lane >> 3);
+                const uint32_t q = s_pix[tt];
+                if (q != kInvalidPix && j < 5) atomicAdd(p.pixacc + (size_t)kPixAccStride * q + j, s_val[6 * tt + j]);
+            }
+        }
     }
 }
 
@@ -328,7 +379,8 @@ __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* _
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* __restrict__ count, long npix, int thres,
                                                                 const uint32_t* __restrict__ blk_off,
-                                                                int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx)
+                                                                int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx,
+                                                                const double* __restrict__ pixacc, double* __restrict__ A22b2)
 {
     __shared__ uint32_t s_w[4];
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -339,145 +391,198 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
             const uint32_t k = blk_off[blockIdx.x] + r;
             compact[i] = (int32_t)k;
             active_idx[k] = (uint32_t)i;
+            if (A22b2) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
+                const double2* a = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
+                const double2 a0 = a[0], a1 = a[1];
+                const double a4 = pixacc[(size_t)kPixAccStride * i + 4];
+                double* q = A22b2 + 5 * (size_t)k;
+                q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4;
+            }
         } else {
             compact[i] = -1;
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// a9/a10: normal-equation accumulation over the factor records in (cp_c,cp_p)-sorted order.
-// A wave walks a contiguous chunk of slots; its key (cp_c<<16|cp_p) is almost always wave-uniform, so the
-// 12x12 symmetric outer product of v=[jc;jp] (78 values) + v*e (12) accumulates in REGISTERS, and is
-// reduced across the wave and flushed with fp64 atomics only when the key changes or the chunk ends
-// (model.cpp:454-477).  A22/b2 go straight to the compact per-pixel pack with fp64 atomics (:426-439).
-// IRLS weights per model.cpp:599-618.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double x)
+// Start of an evaluation: zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched.
+// `count` still holds the previous (possibly all-reduced) counts, a superset of the locally touched pixels.
+__global__ __launch_bounds__(256) void emba_clear_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-    return x;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix) return;
+    if (count[i] != 0) {
+        count[i] = 0;
+        double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * i);
+        a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
+    }
 }
 
-#define EMBA_TRI(r, c) ((r) * 12 - ((r) * ((r)-1)) / 2 + ((c) - (r)))  // r <= c, packed upper triangle of 12x12
+// ------------------------------------------------------------------------------------------------
+// a9/a10: A11 / b1 as a batched Gram-matrix contraction on the fp64 matrix cores.
+// The 128-B factor record IS a 16-vector r = [jc(6) jp(6) dp(2) e tail]; for records that share the control-pose pair
+// (cp_c, cp_p), sum_k w_k r_k r_k^T holds every block the reference accumulates (model.cpp:454-477):
+//     rows/cols 0-5 x 0-5  -> A11(c,c)    0-5 x 6-11 -> A11(c,p)    6-11 x 0-5 -> A11(p,c)    6-11 x 6-11 -> A11(p,p)
+//     rows 0-11 of column 14 (e)           -> b1(c), b1(p)           (rows/cols 12-15 are by-products and are dropped)
+// v_mfma_f64_16x16x4_f64 consumes 4 records per instruction straight from a fully coalesced 512-B load (lane l holds
+// element l&15 of record l>>4, exactly the A/B operand layout), the accumulator is 4 doubles per lane, and the flush
+// needs no cross-lane reduction: lane l owns D[(l>>4)+4r][l&15].  Records are sorted by pair, so a wave flushes (fp64
+// atomics, <= 4 per lane) only when the pair changes or its chunk ends.  IRLS weights (model.cpp:599-618) scale the A operand.
+// ------------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
-struct AccumParams {
+struct GramParams {
     const double* rec; const uint32_t* slot_key; long n_slots;
-    const int32_t* count; const int32_t* compact; int thres; int irls; double eta;
-    double* A11; double* b1; double* A22b2; int dim;  // dim = 3K
+    const int32_t* count; int thres; int irls; double eta;
+    double* A11; double* b1; int dim;  // dim = 3K
+    int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
 };
 
-__device__ __forceinline__ void accum_flush(double* acc, double* accb, uint32_t key, const AccumParams& p, double* s_red)
+// Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
+__device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, const GramParams& p)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int k = 0; k < 78; ++k) {
-        const double x = wave_sum(acc[k]);
-        if (lane == 0) s_red[k] = x;
-        acc[k] = 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-        const double x = wave_sum(accb[k]);
-        if (lane == 0) s_red[78 + k] = x;
-        accb[k] = 0;
-    }
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // same-wave LDS write -> read
+    if (row >= 12 || v == 0.0 || (p.ablate & 32)) return;
     const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
-    for (int e = lane; e < 156; e += 64) {
-        if (e < 144) {
-            const int r = e / 12, c = e % 12;
-            const int lo = r < c ? r : c, hi = r < c ? c : r;
-            const double v = s_red[EMBA_TRI(lo, hi)];
-            const int row = (r < 6) ? bc + r : bp + r - 6;
-            const int col = (c < 6) ? bc + c : bp + c - 6;
-            if (v != 0.0) atomicAdd(p.A11 + (size_t)row + (size_t)p.dim * col, v);
-        } else {
-            const int r = e - 144;
-            const double v = s_red[78 + r];
-            const int row = (r < 6) ? bc + r : bp + r - 6;
-            if (v != 0.0) atomicAdd(p.b1 + row, v);
-        }
+    const int grow = (row < 6) ? bc + row : bp + row - 6;
+    if (col < 12) {
+        const int gcol = (col < 6) ? bc + col : bp + col - 6;
+        atomicAdd(p.A11 + (size_t)grow + (size_t)p.dim * gcol, v);
+    } else if (col == 14) {
+        atomicAdd(p.b1 + grow, v);
     }
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(256) void emba_accumulate_kernel(AccumParams p)
+// A wave hands its tile to the block's LDS combine table (fp64 LDS atomics; one tile per pair, kGramKeys pairs per
+// block) so that the 16 waves of a block cost ONE set of global atomics per pair instead of 16 — the global fp64
+// atomics all land on the few A11 blocks of the current pairs and serialise at the memory side otherwise.
+__device__ __forceinline__ void gram_flush(double4_t& acc, uint32_t key, const GramParams& p, uint32_t* s_tag, double* s_tile)
 {
-    __shared__ double s_red_all[4][96];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double* s_red = s_red_all[wv];
-    const long wave_id = (long)blockIdx.x * 4 + wv;
-    const long start = wave_id * kAccumChunk;
-    if (start >= p.n_slots) return;  // wave-uniform
-    const long end = (start + kAccumChunk < p.n_slots) ? start + kAccumChunk : p.n_slots;
-
-    double acc[78], accb[12];
-#pragma unroll
-    for (int k = 0; k < 78; ++k) acc[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) accb[k] = 0;
-    uint32_t cur_key = p.slot_key[start];
-    bool dirty = false;
-
-    for (long base = start; base < end; base += 64) {
-        const long s = base + lane;
-        const bool in = s < end;
-        double v[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) v[k] = 0;
-        double sw = 0, ew = 0;
-        uint32_t key = cur_key;
-        if (in) {
-            key = p.slot_key[s];
-            const double2* r2 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * s);
-            const double2 tail = r2[7];
-            const uint32_t pi = (uint32_t)__double2loint(tail.y);
-            bool ok = (pi != kInvalidPix);
-            if (ok) ok = p.count[pi] >= p.thres;                    // model.cpp:409
-            if (ok) {
-                const double e = tail.x;
-                double w = 1.0;
-                if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);   // cauchy, model.cpp:603
-                else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }  // huber, :608-616
-                sw = w;
-                ew = w * e;
-                const double2 d = r2[6];
-                double* q = p.A22b2 + 5 * (size_t)p.compact[pi];
-                atomicAdd(q + 0, w * (d.x * d.x));                  // model.cpp:429-435 / 632
-                atomicAdd(q + 1, w * (d.x * d.y));
-                atomicAdd(q + 2, w * (d.y * d.y));
-                atomicAdd(q + 3, d.x * ew);                         // model.cpp:438-439 / 635-636
-                atomicAdd(q + 4, d.y * ew);
-                const double2 a0 = r2[0], a1 = r2[1], a2 = r2[2], a3 = r2[3], a4 = r2[4], a5 = r2[5];
-                v[0] = a0.x; v[1] = a0.y; v[2] = a1.x; v[3] = a1.y; v[4] = a2.x; v[5] = a2.y;
-                v[6] = a3.x; v[7] = a3.y; v[8] = a4.x; v[9] = a4.y; v[10] = a5.x; v[11] = a5.y;
-            }
-        }
-        unsigned long long remaining = __ballot(in);
-        while (remaining) {  // wave-uniform loop; one trip unless the chunk straddles a key boundary here
-            const int first = __ffsll((long long)remaining) - 1;
-            const uint32_t k0 = (uint32_t)__shfl((int)key, first);
-            if (k0 != cur_key) {
-                if (dirty) accum_flush(acc, accb, cur_key, p, s_red);
-                cur_key = k0;
-                dirty = false;
-            }
-            const bool mine = in && (key == k0);
-            const double msw = mine ? sw : 0.0, mew = mine ? ew : 0.0;
-            if (__ballot(mine && sw != 0.0)) dirty = true;
-#pragma unroll
-            for (int r = 0; r < 12; ++r) {
-                const double wvr = msw * v[r];
-#pragma unroll
-                for (int c = r; c < 12; ++c) acc[EMBA_TRI(r, c)] = fma(wvr, v[c], acc[EMBA_TRI(r, c)]);
-                accb[r] = fma(v[r], mew, accb[r]);
-            }
-            remaining &= ~__ballot(mine);
+    const int lane = threadIdx.x & 63;
+    int slot = -1;
+    if (lane == 0) {
+        for (int k = 0; k < kGramKeys; ++k) {
+            const uint32_t old = atomicCAS(&s_tag[k], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { slot = k; break; }
         }
     }
-    if (dirty) accum_flush(acc, accb, cur_key, p, s_red);
+    slot = __shfl(slot, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) + 4 * r;      // C/D layout of v_mfma_f64_16x16x4_f64
+        const double v = acc[r];
+        if (slot >= 0) { if (v != 0.0 && row < 12) atomicAdd(&s_tile[slot * 256 + row * 16 + (lane & 15)], v); }
+        else gram_atomic_out(v, row, lane & 15, key, p);
+        acc[r] = 0.0;
+    }
+}
+
+__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
+{
+    __shared__ uint32_t s_tag[kGramKeys];
+    __shared__ double s_tile[kGramKeys * 256];
+    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
+    if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wave_id = (long)blockIdx.x * (kGramBlock / 64) + wv;
+    const long start = wave_id * kGramChunk;
+    const bool have_work = start < p.n_slots;   // wave-uniform
+    const long end = (start + kGramChunk < p.n_slots) ? start + kGramChunk : p.n_slots;
+    const int el = lane & 15, kk = lane >> 4;
+    if (have_work) {
+
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    uint32_t cur_key = p.slot_key[start];
+    bool dirty = false;
+    constexpr int U = 8;   // 8 independent 512-B loads in flight per wave and stage
+    for (long base = start; base < end; base += 4 * U) {
+        double x[U], e[U];
+        uint32_t pi[U], key[U];
+        int32_t cnt[U];
+        // stage 1: record elements, tails and keys — all independent loads
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long s = base + 4 * u + kk;
+            const bool in = s < end;
+            const double* r = p.rec + (size_t)kRecStride * (in ? s : start);
+            x[u] = r[el];
+            const double2 tail = *reinterpret_cast<const double2*>(r + 14);
+            e[u] = tail.x;
+            pi[u] = in ? (uint32_t)__double2loint(tail.y) : kInvalidPix;
+            key[u] = in ? p.slot_key[s] : 0xFFFFFFFFu;
+        }
+        // stage 2: the count gathers, issued together (unconditional, clamped index) so their latencies overlap
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt[u] = p.count[pi[u] != kInvalidPix ? pi[u] : 0u];
+        // stage 3: masks, weights, MFMAs
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = key[u] != 0xFFFFFFFFu;
+            const bool ok = (pi[u] != kInvalidPix) && (cnt[u] >= p.thres);   // model.cpp:396,409
+            double w = 1.0;
+            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e[u] * e[u]);      // cauchy, model.cpp:603
+            else if (p.irls == 1) { const double a = fabs(e[u]); w = (a < p.eta) ? 1.0 : p.eta / a; }  // huber, :608-616
+            const double a_op = ok ? w * x[u] : 0.0;                      // selects, not multiplies: stale slots may hold anything
+            const double b_op = ok ? x[u] : 0.0;
+            if (__ballot(in && key[u] != cur_key) == 0ull) {              // fast path: the whole group belongs to the current pair
+                if (__ballot(ok)) {
+                    dirty = true;
+                    if (!(p.ablate & 64)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc, 0, 0, 0);
+                }
+                continue;
+            }
+            unsigned long long remaining = __ballot(in);
+            while (remaining) {  // this group of 4 records straddles a pair boundary
+                const int first = __ffsll((long long)remaining) - 1;
+                const uint32_t k0 = (uint32_t)__shfl((int)key[u], first);
+                if (k0 != cur_key) {
+                    if (dirty) gram_flush(acc, cur_key, p, s_tag, s_tile);
+                    cur_key = k0;
+                    dirty = false;
+                }
+                const bool mine = in && (key[u] == k0);
+                if (__ballot(mine && ok)) {
+                    dirty = true;
+                    if (!(p.ablate & 64))
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? a_op : 0.0, mine ? b_op : 0.0, acc, 0, 0, 0);
+                }
+                remaining &= ~__ballot(mine);
+            }
+        }
+    }
+    if (dirty) gram_flush(acc, cur_key, p, s_tag, s_tile);
+    }  // have_work
+    __syncthreads();
+    // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
+    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
+        const uint32_t key = s_tag[i >> 8];
+        if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p);
+    }
+}
+
+// A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
+// case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.
+__global__ void emba_a22_from_records_kernel(const double* __restrict__ rec, long n_slots, const int32_t* __restrict__ count,
+                                             const int32_t* __restrict__ compact, int thres, int irls, double eta,
+                                             double* __restrict__ A22b2)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const double2* r2 = reinterpret_cast<const double2*>(rec + (size_t)kRecStride * s);
+    const double2 tail = r2[7];
+    const uint32_t pi = (uint32_t)__double2loint(tail.y);
+    if (pi == kInvalidPix || count[pi] < thres) return;
+    const double e = tail.x;
+    double w = 1.0;
+    if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
+    else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
+    const double ew = w * e;
+    const double2 d = r2[6];
+    double* q = A22b2 + 5 * (size_t)compact[pi];
+    atomicAdd(q + 0, w * (d.x * d.x));
+    atomicAdd(q + 1, w * (d.x * d.y));
+    atomicAdd(q + 2, w * (d.y * d.y));
+    atomicAdd(q + 3, d.x * ew);
+    atomicAdd(q + 4, d.y * ew);
 }
 
 // a11: applyL2Reg (model.cpp:689-719) on the compact pack.
@@ -561,6 +666,13 @@ __global__ void emba_export_a12_kernel(const double* __restrict__ rec, const uin
     w_out[s] = ok ? w : 0.0;
     for (int i = 0; i < 6; ++i) { jc[6 * s + i] = ok ? r[i] : 0.0; jp[6 * s + i] = ok ? r[6 + i] : 0.0; }
     dp[2 * s] = ok ? r[12] : 0.0; dp[2 * s + 1] = ok ? r[13] : 0.0;
+}
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+    return x;
 }
 
 // a12: cost reductions.  out[0] += partial sums (fp64 atomics, one per block).

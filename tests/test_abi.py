@@ -30,7 +30,7 @@ def test_header_symbols_all_exported_and_bound(hip_lib):
 def test_library_contains_gfx950_code_objects(hip_lib):
     from emba_amd import _lib
     blob = open(_lib.LIB_PATH, "rb").read()
-    assert b"gfx950" in blob and b"emba_warp_residual_kernel" in blob and b"emba_accumulate_kernel" in blob
+    assert b"gfx950" in blob and b"emba_warp_residual_kernel" in blob and b"emba_gram_kernel" in blob
 
 
 def test_no_cpu_fallback_without_gpu(hip_lib):

@@ -80,6 +80,8 @@ struct emba_ctx {
     int K = 0;
     bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
     size_t n_inliers = 0, P = 0, pack_len = 0;
+    bool inl_pending = false, P_pending = false;   // counters enqueued for readback but not yet resolved (no host sync yet)
+    double* h_knots = nullptr; int h_knots_cap = 0; hipEvent_t knots_copied = nullptr;   // pinned staging for the control poses
     int thres = 0, irls = 0; double eta = 0;
 
     // timing
@@ -227,6 +229,29 @@ inline double* pack_A22b2(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c
 
 long grid8(long n) { return (n + 7) / 8 * 8; }
 
+// Synchronize the stream and turn the counters that were read back asynchronously (inlier count, device error
+// word, active-pixel count) into host state.  Called only where the host really needs a value.
+emba_status resolve_pending(emba_ctx* c)
+{
+    if (!c->inl_pending && !c->P_pending) return EMBA_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->inl_pending) {
+        c->inl_pending = false;
+        if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
+        c->n_inliers = (size_t)(uint32_t)c->h_pinned[0];
+        c->eval_done = true;
+    }
+    if (c->P_pending) {
+        c->P_pending = false;
+        c->P = (size_t)(uint32_t)c->h_pinned[2];
+        c->pack_len = (size_t)9 * c->K * c->K + (size_t)3 * c->K + 5 * c->P;
+        if (c->pack_len > c->pack_cap)
+            return fail(c, EMBA_ERR_CAPACITY, "pack buffer too small: need %zu doubles, have %zu", c->pack_len, c->pack_cap);
+        c->active_done = true;
+    }
+    return EMBA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -302,6 +327,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault));
     for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt[i]));
+    CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = c;
     return EMBA_OK;
@@ -318,6 +344,8 @@ void emba_destroy(emba_ctx* c)
     dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_knots) (void)hipHostFree(c->h_knots);
+    if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
     for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -455,9 +483,18 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         if ((st = dev_alloc(c, &c->d_knots, (size_t)4 * K))) return st;
         c->knots_cap = K;
     }
+    if (c->h_knots_cap < K) {
+        if (c->h_knots) (void)hipHostFree(c->h_knots);
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_knots, (size_t)4 * K * sizeof(double), hipHostMallocDefault));
+        c->h_knots_cap = K;
+    }
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
+    c->inl_pending = c->P_pending = false;
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipMemcpyAsync(c->d_knots, knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventSynchronize(c->knots_copied));   // the previous upload has left the pinned staging buffer
+    memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(c->d_knots, c->h_knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(c->knots_copied, s));
     HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
     if (c->pix_dirty_all) {   // num_ev_map.setTo(0), model.cpp:85 (+ the per-pixel accumulator lines)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
@@ -511,10 +548,10 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     }
     HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
-    c->n_inliers = (size_t)(uint32_t)c->h_pinned[0];
-    c->eval_done = true;
+    c->inl_pending = true;
+    if (!ep_out && !n_inliers && !num_ev_map_out) return EMBA_OK;   // fully asynchronous: resolved at the next host sync point
+    emba_status st = resolve_pending(c);
+    if (st) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
     if (ep_out && c->n_inliers) HIP_TRY(c, hipMemcpy(ep_out, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
     if (num_ev_map_out) HIP_TRY(c, hipMemcpy(num_ev_map_out, c->d_count, c->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -536,7 +573,7 @@ emba_status emba_eval_data_error(emba_ctx* c, const double* knots, int32_t K, in
 emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack_len)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "formNormalEq needs the state of evaluateDataError (solver.cpp:99-102)");
+    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "formNormalEq needs the state of evaluateDataError (solver.cpp:99-102)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const long npix = (long)c->npix;
@@ -546,12 +583,11 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
                        c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[2], c->d_total + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    c->P = (size_t)(uint32_t)c->h_pinned[2];
     c->thres = thres;
-    c->pack_len = (size_t)9 * c->K * c->K + (size_t)3 * c->K + 5 * c->P;
-    if (c->pack_len > c->pack_cap) return fail(c, EMBA_ERR_CAPACITY, "pack buffer too small: need %zu doubles, have %zu", c->pack_len, c->pack_cap);
-    c->active_done = true; c->accum_done = false;
+    c->P_pending = true; c->active_done = false; c->accum_done = false;
+    if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
+    emba_status st = resolve_pending(c);
+    if (st) return st;
     if (P) *P = c->P;
     if (pack_len) *pack_len = c->pack_len;
     return EMBA_OK;
@@ -560,10 +596,12 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
 emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irls, double eta)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->active_done) return fail(c, EMBA_ERR_STATE, "emba_form_active has not been called");
+    if (!c->active_done && !c->P_pending) return fail(c, EMBA_ERR_STATE, "emba_form_active has not been called");
     if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    const bool generic_a22 = (irls != 0) || (ep_host != nullptr);
+    if (generic_a22) { emba_status st = resolve_pending(c); if (st) return st; }   // needs n_inliers / P on the host (rare path)
     if (ep_host && c->n_inliers) {
         HIP_TRY(c, hipMemcpyAsync(c->d_ep, ep_host, c->n_inliers * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(emba_override_ep_kernel, dim3((unsigned)((c->n_sorted + 255) / 256)), dim3(256), 0, s, c->d_ep, c->d_flag,
@@ -575,7 +613,6 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     const size_t head = (size_t)9 * c->K * c->K + (size_t)3 * c->K;
     HIP_TRY(c, hipMemsetAsync(c->d_pack, 0, head * sizeof(double), s));
     c->irls = irls; c->eta = eta;
-    const bool generic_a22 = (irls != 0) || (ep_host != nullptr);
     if (generic_a22 && c->P) {
         HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));
         if (c->n_cand)
@@ -606,18 +643,23 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     if (!c->accum_done) return fail(c, EMBA_ERR_STATE, "emba_form_accumulate has not been called");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (alpha != 0.0) {
+        // P may still be unresolved on the host: the kernel reads it from device memory, the grid covers the bound
+        const size_t bound = c->P_pending ? c->npix : c->P;
+        if (bound)
+            hipLaunchKernelGGL(emba_l2reg_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), c->d_active,
+                               c->d_total + 1, alpha, c->d_Gx, c->d_Gy);
+    }
+    HIP_TRY(c, hipGetLastError());
+    emba_status st = resolve_pending(c);   // the step's one host synchronization when nothing was resolved earlier
+    if (st) return st;
     const size_t P = c->P;
     const int dim = 3 * c->K;
     if ((A22 || b2 || A12_dense || active_idx) && cap_P < P) return fail(c, EMBA_ERR_CAPACITY, "cap_P=%zu < P=%zu", cap_P, P);
-    if (alpha != 0.0 && P)
-        hipLaunchKernelGGL(emba_l2reg_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), c->d_active, (long)P,
-                           alpha, c->d_Gx, c->d_Gy);
-    HIP_TRY(c, hipGetLastError());
     if (A11) HIP_TRY(c, hipMemcpyAsync(A11, pack_A11(c), (size_t)dim * dim * sizeof(double), hipMemcpyDeviceToHost, s));
     if (b1) HIP_TRY(c, hipMemcpyAsync(b1, pack_b1(c), (size_t)dim * sizeof(double), hipMemcpyDeviceToHost, s));
     if (active_idx && P) HIP_TRY(c, hipMemcpyAsync(active_idx, c->d_active, P * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     double* d_A22 = nullptr; double* d_b2 = nullptr; double* d_A12 = nullptr;
-    emba_status st = EMBA_OK;
     if ((A22 || b2) && P) {
         if ((st = dev_alloc(c, &d_A22, 4 * P)) || (st = dev_alloc(c, &d_b2, 2 * P))) { dev_free(d_A22); return st; }
         hipLaunchKernelGGL(emba_unpack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), (long)P, d_A22, d_b2);
@@ -656,6 +698,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->accum_done) return fail(c, EMBA_ERR_STATE, "no normal equations formed yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    { emba_status st0 = resolve_pending(c); if (st0) return st0; }
     const size_t M = c->n_cand;
     if (!M) return EMBA_OK;
     int32_t *d_c = nullptr, *d_p = nullptr, *d_x = nullptr; double *d_w = nullptr, *d_jc = nullptr, *d_jp = nullptr, *d_dp = nullptr;
@@ -684,8 +727,9 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
 emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)
 {
     if (!c || !cost) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "no residuals yet");
+    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "no residuals yet");
     HIP_TRY(c, hipSetDevice(c->device));
+    { emba_status st0 = resolve_pending(c); if (st0) return st0; }
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemsetAsync(c->d_scalar, 0, sizeof(double), s));
     if (c->n_sorted) {
@@ -722,8 +766,9 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
                             double* Gpm, double* temp)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
+    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
     HIP_TRY(c, hipSetDevice(c->device));
+    { emba_status st0 = resolve_pending(c); if (st0) return st0; }
     const size_t ns = c->n_sorted, n = c->n_in;
     if (!ns) return EMBA_OK;
     hipStream_t s = c->stream;
@@ -780,10 +825,23 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     return EMBA_OK;
 }
 
+emba_status emba_last_counts(emba_ctx* c, size_t* n_inliers, size_t* P)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    if (n_inliers) *n_inliers = c->n_inliers;
+    if (P) *P = c->P;
+    return EMBA_OK;
+}
+
 emba_status emba_sync(emba_ctx* c)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EMBA_OK;
 }

@@ -586,11 +586,11 @@ __global__ void emba_a22_from_records_kernel(const double* __restrict__ rec, lon
 }
 
 // a11: applyL2Reg (model.cpp:689-719) on the compact pack.
-__global__ void emba_l2reg_kernel(double* __restrict__ A22b2, const uint32_t* __restrict__ active_idx, long P, double alpha,
-                                  const double* __restrict__ Gx, const double* __restrict__ Gy)
+__global__ void emba_l2reg_kernel(double* __restrict__ A22b2, const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ P_dev,
+                                  double alpha, const double* __restrict__ Gx, const double* __restrict__ Gy)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
+    if (i >= (long)P_dev[0]) return;   // P lives in device memory: the host may not have read it back yet
     double* q = A22b2 + 5 * i;
     const uint32_t pi = active_idx[i];
     q[0] += alpha;

@@ -228,14 +228,20 @@ class LEGM:
         self._keep = [knots]
         self._check(self._L.emba_eval_launch(self._ctx, _p(knots, _dp), self.K, int(traj.t0_ns), int(traj.dt_ns)))
 
-    def eval_finish(self, want_ep=False, want_map=False):
+    def eval_finish(self, want_ep=False, want_map=False, sync=True):
+        if not sync and not want_ep and not want_map:      # enqueue only; counts via last_counts() after a sync point
+            self._check(self._L.emba_eval_finish(self._ctx, None, None, None))
+            return None, None, None
         n_inl = C.c_size_t(0)
         ep = np.empty(max(self.n_events, 1)) if want_ep else None
         nem = np.empty((self.H, self.W), dtype=np.int32) if want_map else None
         self._check(self._L.emba_eval_finish(self._ctx, _p(ep, _dp), C.byref(n_inl), _p(nem, _i32p)))
         return n_inl.value, (ep[:n_inl.value] if want_ep else None), nem
 
-    def form_active(self, thres):
+    def form_active(self, thres, sync=True):
+        if not sync:
+            self._check(self._L.emba_form_active(self._ctx, int(thres), None, None))
+            return None, None
         P, pl = C.c_size_t(0), C.c_size_t(0)
         self._check(self._L.emba_form_active(self._ctx, int(thres), C.byref(P), C.byref(pl)))
         self._P = P.value
@@ -246,9 +252,16 @@ class LEGM:
 
     def form_finish(self, alpha, download=False, dense_A12=False):
         if download:
+            self.last_counts()
             return self._finish(alpha, dense_A12)
         self._check(self._L.emba_form_finish(self._ctx, float(alpha), None, None, None, 0, None, None, None))
         return None
+
+    def last_counts(self):
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.emba_last_counts(self._ctx, C.byref(a), C.byref(b)))
+        self._P = b.value
+        return a.value, b.value
 
     def sync(self):
         self._check(self._L.emba_sync(self._ctx))

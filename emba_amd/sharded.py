@@ -103,15 +103,18 @@ class ShardedLEGM:
     def iteration(self, traj, thres_valid_pixel, alpha, cost_type="quadratic", a=0.0, download=False):
         """One evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks.  Map must be resident (upload_map)."""
         e, dist = self.engine, self.dist
+        multi = self.world > 1
         e.eval_launch(traj)                                   # E1
-        if self.world > 1:
+        if multi:
             dist.all_reduce(self.count)                       # X1 (SUM)
-        n_inl = e.eval_finish()                               # E2
-        self.P, self.pack_len = e.form_active(thres_valid_pixel)   # F1
+        e.eval_finish()                                       # E2 (enqueue only)
+        # F1: a single GPU never needs P on the host mid-step; with several ranks the host needs the pack length for X2
+        self.P, self.pack_len = e.form_active(thres_valid_pixel, sync=multi)
         e.form_accumulate(cost_type, a)                       # F2
-        if self.world > 1:
+        if multi:
             dist.all_reduce(self.pack[: self.pack_len])       # X2 (SUM)
-        out = e.form_finish(alpha, download)                  # F3
+        out = e.form_finish(alpha, download)                  # F3 — the step's host synchronization
+        n_inl, self.P = e.last_counts()
         return n_inl, out
 
 
@@ -135,10 +138,13 @@ class HipEngine:
         self.m.eval_launch(traj)
 
     def eval_finish(self):
-        return self.m.eval_finish()[0]
+        self.m.eval_finish(sync=False)
 
-    def form_active(self, thres):
-        return self.m.form_active(thres)
+    def form_active(self, thres, sync=True):
+        return self.m.form_active(thres, sync=sync)
+
+    def last_counts(self):
+        return self.m.last_counts()
 
     def form_accumulate(self, cost_type, a):
         self.m.form_accumulate(cost_type, a)

@@ -160,12 +160,14 @@ emba_status emba_bind_exchange_buffers(emba_ctx* ctx, int32_t* count_map_dev, do
  * on the context's stream.  After it the count map holds THIS rank's counts. */
 emba_status emba_eval_launch(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns,
                              int64_t dt_ns);
-/* Phase E2: residual compaction into reference order; synchronizes; returns the inlier count and,
- * if non-NULL, copies ep / the (possibly all-reduced) count map to the host. */
+/* Phase E2: residual compaction into reference order.  With any non-NULL output it synchronizes, returns the
+ * inlier count and copies ep / the (possibly all-reduced) count map to the host; with all three NULL it only
+ * enqueues work (the count is available from emba_last_counts after the next synchronizing call). */
 emba_status emba_eval_finish(emba_ctx* ctx, double* ep_out_host, size_t* n_inliers,
                              int32_t* num_ev_map_out_host);
-/* Phase F1: active set from the (all-reduced) count map; synchronizes to return P and the
- * number of doubles of the pack [A11 | b1 | A22b2] that exchange 2 must all-reduce. */
+/* Phase F1: active set from the (all-reduced) count map.  With P or pack_len non-NULL it synchronizes to return P
+ * and the number of doubles of the pack [A11 | b1 | A22b2] that exchange 2 must all-reduce; with both NULL it only
+ * enqueues work (single-GPU steps then need ONE host synchronization, in emba_form_finish). */
 emba_status emba_form_active(emba_ctx* ctx, int32_t thres_valid_pixel, size_t* P, size_t* pack_len);
 /* Phase F2: zero the pack and accumulate this rank's measurements into it.  Asynchronous.
  * ep_host as in emba_form_normal_eq. */
@@ -174,6 +176,10 @@ emba_status emba_form_accumulate(emba_ctx* ctx, const double* ep_host, int32_t i
  * synchronizes. */
 emba_status emba_form_finish(emba_ctx* ctx, double alpha, double* A11, double* b1, uint32_t* active_idx,
                              size_t cap_P, double* A22, double* b2, double* A12_dense);
+
+/* Inlier count of the last evaluation and active-pixel count of the last emba_form_active, once resolved
+ * (after any synchronizing call, e.g. emba_form_finish or emba_sync). */
+emba_status emba_last_counts(emba_ctx* ctx, size_t* n_inliers, size_t* P);
 
 /* Stream / event helpers so a host without HIP bindings can time the phases on the stream the
  * kernels run on (bench.py's roofline leg). */

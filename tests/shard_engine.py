@@ -1,0 +1,118 @@
+"""TEST INFRASTRUCTURE: a CPU 'engine' with the phase interface ShardedLEGM expects, built from the oracle's leaf
+functions (spline_eval, warp, hessian) on the events a rank is GIVEN (local + halo) and nothing else.  It lets the
+world_size-2 gloo tests exercise the real sharding logic (emba_amd/sharded.py: batch-aligned ranges, per-pixel halo,
+count all-reduce, pack all-reduce, L2 after the reduce) without a GPU.  The arithmetic follows model.cpp like the oracle
+does; sizes are kept small (pure-Python loops)."""
+import numpy as np
+import torch
+
+from oracle import oracle as O
+
+
+class OracleShardEngine:
+    def __init__(self, w):
+        self.w = w
+        self.o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+
+    def bind_exchange(self, count_tensor, pack_tensor):
+        self.count, self.pack = count_tensor, pack_tensor
+
+    def set_events(self, events, halo):
+        self.ev, self.halo = events, halo
+
+    def upload_map(self, Gx, Gy):
+        self.Gx, self.Gy = np.asarray(Gx), np.asarray(Gy)
+
+    def eval_launch(self, traj):
+        w, ev = self.w, self.ev
+        self.K = traj.size()
+        n_used = (ev.size() // 100) * 100
+        Gxx, Gxy, Gyy = O.hessian(self.Gx, self.Gy)
+        items = []   # (pixel, order, pol, pose_time, is_halo)
+        hx, hy, ht = self.halo
+        for i in range(len(hx)):
+            items.append((int(hy[i]) * w.sensor_w + int(hx[i]), -1 - (len(hx) - i), 0, int(ht[i]), True, int(hx[i]), int(hy[i])))
+        for k in range(n_used):
+            b = k // 100
+            tb = O.batch_mid_ns(ev.t_ns[100 * b], ev.t_ns[100 * b + 99])
+            items.append((int(ev.y[k]) * w.sensor_w + int(ev.x[k]), k, int(ev.polarity[k]), tb, False, int(ev.x[k]), int(ev.y[k])))
+        items.sort(key=lambda it: (it[0], it[1]))
+        pose_cache = {}
+
+        def state(it):
+            t = it[3]
+            if t not in pose_cache:
+                pose_cache[t] = O.spline_eval(traj.knots_xyzw, traj.t0_ns, traj.dt_ns, t)
+            q, R, s, J36 = pose_cache[t]
+            pm, J23 = self.o.warp(it[5], it[6], q)
+            return pm, J23 @ J36, s
+
+        count = np.zeros(w.pano_h * w.pano_w, dtype=np.int32)
+        self.meas = []
+        prev = None
+        for it in items:
+            cur = (it, state(it))
+            if prev is not None and prev[0][0] == it[0] and not it[4]:
+                (pm, D, s), (pmp, Dp, sp) = cur[1], prev[1]
+                dp = pm - pmp
+                if np.hypot(dp[0], dp[1]) <= 10:
+                    rx, ry = np.floor(pm[0] + 0.5), np.floor(pm[1] + 0.5)
+                    if 0 <= rx < w.pano_w and 0 <= ry < w.pano_h:
+                        pi = int(ry) * w.pano_w + int(rx)
+                        g = np.array([self.Gx.ravel()[pi], self.Gy.ravel()[pi]])
+                        e = 2 * (it[2] - 0.5) * w.C_th - g @ dp
+                        G2 = np.array([[Gxx.ravel()[pi], Gxy.ravel()[pi]], [Gxy.ravel()[pi], Gyy.ravel()[pi]]])
+                        temp = g + dp @ G2
+                        count[pi] += 1
+                        self.meas.append(dict(pix=it[0], k=it[1], pi=pi, e=e, dp=dp, jc=temp @ D, jp=-g @ Dp, c=s, p=sp))
+            prev = cur
+        self.count.copy_(torch.from_numpy(count))
+
+    def eval_finish(self):
+        self.ep = np.array([m["e"] for m in self.meas])          # already pixel-major, then time
+        self.ep_pix = np.array([m["pix"] for m in self.meas], dtype=np.int64)
+
+    def form_active(self, thres, sync=True):
+        cnt = self.count.numpy()
+        self.active = np.nonzero(cnt >= thres)[0]
+        self.compact = -np.ones(cnt.size, dtype=np.int64)
+        self.compact[self.active] = np.arange(self.active.size)
+        self.P = self.active.size
+        self.pack_len = 9 * self.K * self.K + 3 * self.K + 5 * self.P
+        return self.P, self.pack_len
+
+    def form_accumulate(self, cost_type, a):
+        K, P = self.K, self.P
+        A11 = np.zeros((3 * K, 3 * K)); b1 = np.zeros(3 * K); A22b2 = np.zeros((max(P, 1), 5))
+        for m in self.meas:
+            ci = self.compact[m["pi"]]
+            if ci < 0:
+                continue
+            e, dp = m["e"], m["dp"]
+            wgt = 1.0
+            if cost_type == "cauchy":
+                wgt = 1.0 / (1.0 + a * e * e)
+            elif cost_type == "huber":
+                wgt = 1.0 if abs(e) < a else a / abs(e)
+            A22b2[ci] += [wgt * dp[0] * dp[0], wgt * dp[0] * dp[1], wgt * dp[1] * dp[1], dp[0] * wgt * e, dp[1] * wgt * e]
+            v = np.concatenate([m["jc"], m["jp"]])
+            idx = np.r_[3 * m["c"]:3 * m["c"] + 6, 3 * m["p"]:3 * m["p"] + 6]
+            np.add.at(A11, (idx[:, None], idx[None, :]), wgt * np.outer(v, v))
+            np.add.at(b1, idx, v * wgt * e)
+        flat = np.concatenate([A11.ravel(order="F"), b1, A22b2[:P].ravel()])
+        self.pack[: self.pack_len].copy_(torch.from_numpy(flat))
+
+    def form_finish(self, alpha, download):
+        K, P = self.K, self.P
+        pk = self.pack[: self.pack_len].numpy().copy()
+        A22b2 = pk[9 * K * K + 3 * K:].reshape(P, 5)
+        if alpha:
+            A22b2[:, 0] += alpha; A22b2[:, 2] += alpha
+            A22b2[:, 3] -= alpha * self.Gx.ravel()[self.active]
+            A22b2[:, 4] -= alpha * self.Gy.ravel()[self.active]
+        A22 = np.stack([A22b2[:, 0], A22b2[:, 1], A22b2[:, 1], A22b2[:, 2]], axis=1).reshape(P, 2, 2)
+        return dict(A11=pk[:9 * K * K].reshape(3 * K, 3 * K, order="F"), b1=pk[9 * K * K:9 * K * K + 3 * K], active=self.active,
+                    A22=A22, b2=A22b2[:, 3:5].ravel(), P=P)
+
+    def last_counts(self):
+        return len(self.meas), self.P

@@ -1,0 +1,101 @@
+"""GPU test of the sharded path with the REAL engine (emba_amd.LEGM via HipEngine): two ranks as two threads on one MI355X,
+each with its own context/stream and its own time shard + halo, exchanging through an in-process all-reduce stand-in.
+Checks exchange 1 (count map), exchange 2 (pack), applyL2Reg-after-reduce and the residual merge against the single-context
+result and the oracle.  (The RCCL collectives themselves are exercised by bench.py --gpus N on a multi-GPU node.)"""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import assert_close, oracle_run, small_workload
+
+pytestmark = pytest.mark.gpu
+
+
+class _Shared:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.errors = []
+
+
+class _ThreadDist:
+    """torch.distributed-like handle for one rank-thread."""
+
+    def __init__(self, shared, rank, sync_fn):
+        self.s, self.rank, self.sync_fn = shared, rank, sync_fn
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.s.world
+
+    def all_reduce(self, t):
+        import torch
+        self.sync_fn()                       # producer kernels of this rank are done
+        self.s.slots[self.rank] = t
+        self.s.barrier.wait()
+        if self.rank == 0:
+            total = self.s.slots[0].clone()
+            for other in self.s.slots[1:]:
+                total += other
+            for sl in self.s.slots:
+                sl.copy_(total)
+            torch.cuda.synchronize()
+        self.s.barrier.wait()
+
+
+def _rank_main(shared, rank, w, results):
+    try:
+        import torch
+        from emba_amd import LEGM
+        from emba_amd.sharded import HipEngine, ShardedLEGM
+        dev = torch.device("cuda", 0)
+        npix = w.pano_h * w.pano_w
+        m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+        count = torch.zeros(npix, dtype=torch.int32, device=dev)
+        pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        sh = ShardedLEGM(HipEngine(m), _ThreadDist(shared, rank, m.sync), count, pack, w.sensor_w)
+        local = sh.set_events(w.events)
+        m.upload_map(w.Gx, w.Gy)
+        out = None
+        for _ in range(2):                    # twice: the per-pixel accumulator must be cleared between evaluations
+            n_inl, out = sh.iteration(w.traj, w.thres_valid_pixel, w.alpha, download=True)
+        d = m.dump_state()
+        _, ep, _ = m.eval_finish(want_ep=True)
+        pix = local.y.astype(np.int64) * w.sensor_w + local.x
+        ep_pix = np.zeros(ep.size, dtype=np.int64)
+        sel = d["inlier_idx"] >= 0
+        ep_pix[d["inlier_idx"][sel]] = pix[sel]
+        results[rank] = dict(ne=out, count=count.cpu().numpy(), ep=ep.copy(), ep_pix=ep_pix, n_inl=n_inl)
+    except Exception as e:  # noqa: BLE001
+        shared.errors.append((rank, repr(e)))
+        shared.barrier.abort()
+        raise
+
+
+@pytest.mark.parametrize("cfg", [dict(n_events=20000), dict(n_events=30050, pano_h=256, K=11, sensor=(64, 48), focal=60.0)])
+def test_two_rank_threads_on_one_gpu(oracle_mod, cfg):
+    import torch
+    assert torch.cuda.is_available()
+    from emba_amd.sharded import merge_ep
+    w = small_workload(**cfg)
+    world = 2
+    shared, results = _Shared(world), [None] * world
+    th = [threading.Thread(target=_rank_main, args=(shared, r, w, results)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not shared.errors, shared.errors
+    o = oracle_run(oracle_mod, w)
+    for r in range(world):
+        assert np.array_equal(results[r]["count"].reshape(w.pano_h, w.pano_w), o["num_ev_map"])       # exchange 1, bit-exact
+        ne = results[r]["ne"]
+        assert np.array_equal(ne["active"], o["ne"]["active"])
+        for name in ("A11", "b1", "A22", "b2"):
+            assert_close(ne[name], o["ne"][name], f"rank{r} {name}")
+    ep = merge_ep([results[r]["ep"] for r in range(world)], [results[r]["ep_pix"] for r in range(world)])
+    assert_close(ep, o["ep"], "merged ep")
+    assert sum(results[r]["n_inl"] for r in range(world)) == o["ep"].size

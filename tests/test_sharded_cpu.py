@@ -1,0 +1,95 @@
+"""CPU tests of the multi-GPU host logic (emba_amd/sharded.py) with world_size 2 over gloo: partition on the global batch
+grid, per-pixel halo, count-map all-reduce, pack all-reduce, applyL2Reg after the reduce, residual merge — checked against
+the single-process oracle.  The per-rank compute is a CPU stand-in built from oracle leaf functions (tests/shard_engine.py);
+the GPU engine is covered by tests/test_gpu_sharded.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import oracle_run, small_workload
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, cfg, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from shard_engine import OracleShardEngine
+        from emba_amd.sharded import ShardedLEGM
+        w = small_workload(**cfg)
+        npix = w.pano_h * w.pano_w
+        count = torch.zeros(npix, dtype=torch.int32)
+        pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64)
+        eng = OracleShardEngine(w)
+        sh = ShardedLEGM(eng, dist, count, pack, w.sensor_w)
+        sh.set_events(w.events)
+        eng.upload_map(w.Gx, w.Gy)
+        n_inl, ne = sh.iteration(w.traj, w.thres_valid_pixel, w.alpha, download=True)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), count=count.numpy(), ep=eng.ep, ep_pix=eng.ep_pix, n_local=sh.n_local,
+                 **{k: v for k, v in ne.items() if k != "P"})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [dict(n_events=2400, pano_h=64, K=5, sensor=(12, 8), focal=10.0),
+                                 dict(n_events=2950, pano_h=64, K=5, sensor=(12, 8), focal=10.0)])   # odd batch count + dropped tail
+def test_two_rank_gloo_matches_single_process_oracle(oracle_mod, tmp_path, cfg):
+    from emba_amd.sharded import merge_ep
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), cfg, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(tmp_path / f"rank{k}.npz") for k in range(world)]
+    w = small_workload(**cfg)
+    o = oracle_run(oracle_mod, w)
+    # exchange 1: every rank ends with the GLOBAL count map, equal to the single-process one (bit-exact)
+    for k in range(world):
+        assert np.array_equal(r[k]["count"].reshape(w.pano_h, w.pano_w), o["num_ev_map"])
+        assert np.array_equal(r[k]["active"], o["ne"]["active"])
+    # exchange 2 + L2 once: identical normal equations on every rank, equal to the oracle's
+    for k in range(world):
+        for name in ("A11", "b1", "A22", "b2"):
+            assert np.allclose(r[k][name], o["ne"][name], rtol=1e-9, atol=1e-12 * max(1.0, np.abs(o["ne"][name]).max())), (k, name)
+    assert np.array_equal(r[0]["A11"], r[1]["A11"])
+    # residuals: per-rank vectors merge into the reference order
+    ep = merge_ep([r[k]["ep"] for k in range(world)], [r[k]["ep_pix"] for k in range(world)])
+    assert ep.shape == o["ep"].shape and np.allclose(ep, o["ep"], rtol=1e-10, atol=1e-14)
+    assert int(r[0]["n_local"]) + int(r[1]["n_local"]) == (w.events.size() // 100) * 100
+
+
+def test_partition_and_halo_properties():
+    from emba_amd.sharded import batch_ranges, shard_events, batch_mid_ns
+    w = small_workload(n_events=10050, pano_h=64, K=5, sensor=(12, 8), focal=10.0)
+    for world in (1, 2, 3, 8):
+        rng = batch_ranges(w.events.size(), world)
+        assert rng[0][0] == 0 and rng[-1][1] == 10000 and all(a[1] == b[0] for a, b in zip(rng, rng[1:]))
+        assert all((hi - lo) % 100 == 0 for lo, hi in rng) and max(hi - lo for lo, hi in rng) - min(hi - lo for lo, hi in rng) <= 100
+        pix = w.events.y.astype(np.int64) * w.sensor_w + w.events.x
+        for rank, (lo, hi) in enumerate(rng):
+            local, (hx, hy, ht) = shard_events(w.events, w.sensor_w, rank, world)
+            assert local.size() == hi - lo
+            hp = hy.astype(np.int64) * w.sensor_w + hx
+            assert len(set(hp.tolist())) == hp.size                        # at most one halo event per sensor pixel
+            assert set(hp.tolist()) == set(pix[:lo].tolist())             # exactly the pixels seen before the range
+            for p_, t_ in zip(hp[:20], ht[:20]):                           # it is the LAST earlier event, with its batch's midpoint
+                k = np.nonzero(pix[:lo] == p_)[0][-1]
+                b = k // 100
+                assert t_ == batch_mid_ns(w.events.t_ns[100 * b], w.events.t_ns[100 * b + 99])
+
+
+def test_batch_mid_python_matches_oracle(oracle_mod):
+    from emba_amd.sharded import batch_mid_ns
+    rng = np.random.default_rng(4)
+    for _ in range(2000):
+        a = int(rng.integers(0, 2**40)); d = int(rng.integers(0, 2**34))
+        assert batch_mid_ns(a, a + d) == oracle_mod.batch_mid_ns(a, a + d)
+    for a, b in ((0, 1), (0, 3), (999_999_999, 3_000_000_001), (5, 5)):
+        assert batch_mid_ns(a, b) == oracle_mod.batch_mid_ns(a, b)

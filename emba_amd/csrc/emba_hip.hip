@@ -59,7 +59,9 @@ struct emba_ctx {
     int* d_err = nullptr;
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
-    int* h_pinned = nullptr;        // small pinned readback area (4 ints + 2 doubles)
+    int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P
+    int* h_pinned_dev = nullptr;    // the same memory through its device pointer
+    double* h_knots_dev = nullptr;  // device pointer of the pinned control-pose staging buffer
 
     // per-window (set_events) state
     bool have_events = false, have_map = false;
@@ -318,13 +320,15 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipMalloc((void**)&c->d_pixacc, c->npix * kPixAccStride * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t)));
-    c->n_ablk = (c->npix + 255) / 256;
+    c->n_ablk = (c->npix + kActivePix - 1) / kActivePix;
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double)));
-    CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
+    memset(c->h_pinned, 0, 64);
+    CREATE_TRY(hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0));
     for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
     for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt[i]));
     CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
@@ -485,24 +489,23 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     }
     if (c->h_knots_cap < K) {
         if (c->h_knots) (void)hipHostFree(c->h_knots);
-        HIP_TRY(c, hipHostMalloc((void**)&c->h_knots, (size_t)4 * K * sizeof(double), hipHostMallocDefault));
+        HIP_TRY(c, hipHostMalloc((void**)&c->h_knots, (size_t)4 * K * sizeof(double), hipHostMallocMapped));
+        HIP_TRY(c, hipHostGetDevicePointer((void**)&c->h_knots_dev, c->h_knots, 0));
         c->h_knots_cap = K;
     }
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false;
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipEventSynchronize(c->knots_copied));   // the previous upload has left the pinned staging buffer
+    HIP_TRY(c, hipEventSynchronize(c->knots_copied));   // the previous prep kernel has consumed the pinned staging buffer
     memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
-    HIP_TRY(c, hipMemcpyAsync(c->d_knots, c->h_knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipEventRecord(c->knots_copied, s));
-    HIP_TRY(c, hipMemsetAsync(c->d_err, 0, sizeof(int), s));
-    if (c->pix_dirty_all) {   // num_ev_map.setTo(0), model.cpp:85 (+ the per-pixel accumulator lines)
+    if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
         c->pix_dirty_all = false;
-    } else {
-        hipLaunchKernelGGL(emba_clear_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, (long)c->npix, c->d_pixacc);
     }
+    hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, s, c->d_count, (long)c->npix,
+                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K);
+    HIP_TRY(c, hipEventRecord(c->knots_copied, s));
 
     if (c->n_batch) {
         const int nb = (int)c->n_batch;
@@ -539,15 +542,16 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     if (c->n_sorted) {
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_blk_cnt, c->d_blk_off, c->nblk, c->d_total);
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_blk_cnt, c->d_blk_off, c->nblk, c->d_total,
+                           c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
         hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->nblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag,
                            c->d_blk_off, (long)c->n_sorted, c->d_ep, c->d_inl_idx);
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     }
-    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     c->inl_pending = true;
     if (!ep_out && !n_inliers && !num_ev_map_out) return EMBA_OK;   // fully asynchronous: resolved at the next host sync point
     emba_status st = resolve_pending(c);
@@ -577,12 +581,13 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const long npix = (long)c->npix;
+    const long head = (long)9 * c->K * c->K + (long)3 * c->K;
     hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
-    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1);
+    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1,
+                       c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c));
+                       c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[2], c->d_total + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     c->thres = thres;
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
@@ -610,8 +615,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     // A11 = Zero, b1 = Zero (model.cpp:357-361).  A22/b2 of the active pixels were gathered from the per-pixel
     // accumulator by emba_form_active (quadratic cost, device-resident residuals); with IRLS weights or a
     // caller-supplied ep they are rebuilt from the records instead.
-    const size_t head = (size_t)9 * c->K * c->K + (size_t)3 * c->K;
-    HIP_TRY(c, hipMemsetAsync(c->d_pack, 0, head * sizeof(double), s));
+    // (the head of the pack, A11 | b1, was zeroed by emba_form_active's write kernel)
     c->irls = irls; c->eta = eta;
     if (generic_a22 && c->P) {
         HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));

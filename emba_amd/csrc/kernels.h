@@ -290,17 +290,21 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
 // out[i] = sum_{j<i} in[j]; total[0] = sum of all.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void emba_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          long n, uint32_t* __restrict__ total)
+                                                          long n, uint32_t* __restrict__ total, int* __restrict__ total_host,
+                                                          const int* __restrict__ err_dev, int* __restrict__ err_host)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (t == 0) s_carry = 0;
     __syncthreads();
-    for (long base = 0; base < n; base += 1024) {
-        const long i = base + t;
-        const uint32_t v = (i < n) ? in[i] : 0;
-        uint32_t x = v;
+    for (long base = 0; base < n; base += 4096) {     // 4 consecutive entries per thread
+        const long i = base + 4 * t;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? in[i + k] : 0;
+        const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+        uint32_t x = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o);
@@ -311,12 +315,18 @@ __global__ __launch_bounds__(1024) void emba_scan_kernel(const uint32_t* __restr
         uint32_t woff = 0;
         for (int w = 0; w < wv; ++w) woff += s_wave[w];
         const uint32_t carry = s_carry;
-        if (i < n) out[i] = carry + woff + x - v;
+        uint32_t run = carry + woff + x - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i + k < n) out[i + k] = run; run += v[k]; }
         __syncthreads();
         if (t == 1023) s_carry = carry + woff + x;
         __syncthreads();
     }
-    if (t == 0) total[0] = s_carry;
+    if (t == 0) {
+        total[0] = s_carry;
+        if (total_host) total_host[0] = (int)s_carry;       // pinned, device-visible host word: no copy node needed
+        if (err_host) err_host[0] = err_dev[0];
+    }
 }
 
 // Block-wide exclusive rank of a flag among 256 threads (4 waves) via ballots.
@@ -367,28 +377,65 @@ __global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const
 
 // ------------------------------------------------------------------------------------------------
 // a8: active set (count >= thres) in ascending panorama index (model.cpp:325-344, 371-377).
+// 2048 pixels per block, 8 consecutive pixels per thread (two 16-B loads), so a 1024x2048 panorama needs 1024 block
+// counts and the scan between the two kernels is a single tile.
 // ------------------------------------------------------------------------------------------------
+constexpr int kActivePix = 2048;
+
+__device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ count, long p0, long npix, int thres)
+{
+    uint32_t m = 0;
+    if (p0 + 8 <= npix) {
+        const int4 a = *reinterpret_cast<const int4*>(count + p0), b = *reinterpret_cast<const int4*>(count + p0 + 4);
+        m = (a.x >= thres) | ((a.y >= thres) << 1) | ((a.z >= thres) << 2) | ((a.w >= thres) << 3) | ((b.x >= thres) << 4) |
+            ((b.y >= thres) << 5) | ((b.z >= thres) << 6) | ((b.w >= thres) << 7);
+    } else {
+        for (int k = 0; k < 8; ++k) if (p0 + k < npix && count[p0 + k] >= thres) m |= 1u << k;
+    }
+    return m;
+}
+
 __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* __restrict__ count, long npix, int thres,
                                                                 uint32_t* __restrict__ blk_cnt)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool f = (i < npix) && (count[i] >= thres);
-    const int c = __syncthreads_count(f ? 1 : 0);
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (uint32_t)c;
+    __shared__ uint32_t s_w[4];
+    const long p0 = (long)blockIdx.x * kActivePix + 8 * threadIdx.x;
+    uint32_t c = __popc(active_mask8(count, p0, npix, thres));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* __restrict__ count, long npix, int thres,
                                                                 const uint32_t* __restrict__ blk_off,
                                                                 int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx,
-                                                                const double* __restrict__ pixacc, double* __restrict__ A22b2)
+                                                                const double* __restrict__ pixacc, double* __restrict__ A22b2,
+                                                                double* __restrict__ pack_head, long head_len)
 {
     __shared__ uint32_t s_w[4];
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const bool f = (i < npix) && (count[i] >= thres);
-    const uint32_t r = block_rank_256(f, s_w);
-    if (i < npix) {
-        if (f) {
-            const uint32_t k = blk_off[blockIdx.x] + r;
+    // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < head_len; i += (long)gridDim.x * 256) pack_head[i] = 0.0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long p0 = (long)blockIdx.x * kActivePix + 8 * threadIdx.x;
+    const uint32_t m = active_mask8(count, p0, npix, thres);
+    const uint32_t mine = __popc(m);
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint32_t k = blk_off[blockIdx.x] + x - mine;
+    for (int w = 0; w < wv; ++w) k += s_w[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long i = p0 + j;
+        if (i >= npix) break;
+        if (m & (1u << j)) {
             compact[i] = (int32_t)k;
             active_idx[k] = (uint32_t)i;
             if (A22b2) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
@@ -398,22 +445,44 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
                 double* q = A22b2 + 5 * (size_t)k;
                 q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4;
             }
+            ++k;
         } else {
             compact[i] = -1;
         }
     }
 }
 
-// Start of an evaluation: zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched.
-// `count` still holds the previous (possibly all-reduced) counts, a superset of the locally touched pixels.
-__global__ __launch_bounds__(256) void emba_clear_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc)
+// Start of an evaluation ("prep"): zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched
+// (`count` still holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels); block 0 also
+// resets the device error word and pulls the control poses from the pinned host staging buffer (no copy / memset nodes).
+__global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc,
+                                                        int* __restrict__ err, const double* __restrict__ knots_host,
+                                                        double* __restrict__ knots_dev, int n_knot_doubles)
 {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= npix) return;
-    if (count[i] != 0) {
-        count[i] = 0;
-        double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * i);
-        a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) err[0] = 0;
+        for (int i = threadIdx.x; i < n_knot_doubles; i += 256) knots_dev[i] = knots_host[i];
+    }
+    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p0 >= npix) return;
+    if (p0 + 4 <= npix) {
+        const int4 c = *reinterpret_cast<const int4*>(count + p0);
+        if ((c.x | c.y | c.z | c.w) == 0) return;
+        *reinterpret_cast<int4*>(count + p0) = make_int4(0, 0, 0, 0);
+        const int cc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (cc[k] != 0) {
+                double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * (p0 + k));
+                a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
+            }
+    } else {
+        for (long i = p0; i < npix; ++i)
+            if (count[i] != 0) {
+                count[i] = 0;
+                double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * i);
+                a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
+            }
     }
 }
 

@@ -544,8 +544,8 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     if (c->n_sorted) {
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_blk_cnt, c->d_blk_off, c->nblk, c->d_total,
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
-        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->nblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag,
-                           c->d_blk_off, (long)c->n_sorted, c->d_ep, c->d_inl_idx);
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)((c->nblk + 3) / 4)), dim3(256), 0, s, c->d_e_sorted, c->d_flag,
+                           c->d_blk_off, (long)c->n_sorted, c->nblk, c->d_ep, c->d_inl_idx);
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));

@@ -24,8 +24,9 @@ constexpr uint32_t kInvalidPix = 0xFFFFFFFFu;
 constexpr int kPoseStride = 20;    // doubles per pose record
 constexpr int kTexelStride = 6;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
-constexpr int kWarpBlock = 256;    // threads per block of the warp kernel
-constexpr int kWarpNew = 255;      // new events per block (thread 0 re-warps the predecessor)
+constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: no barriers, neighbours talk through DPP
+constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
+constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
 constexpr int kGramChunk = 256;    // record slots per wave in the Gram (A11/b1) kernel; multiple of 4
 constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table)
@@ -133,16 +134,21 @@ struct WarpParams {
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
 };
 
+// lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
+__device__ __forceinline__ int dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ double dpp_shr1(double v)
+{
+    return __hiloint2double(dpp_shr1(__double2hiint(v)), dpp_shr1(__double2loint(v)));
+}
+
 template <bool DUMP>
 __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpParams p)
 {
-    __shared__ double s_pm[2][kWarpBlock];
-    __shared__ double s_D[12][kWarpBlock];
-    __shared__ uint32_t s_pix[kWarpBlock];
+    __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
 
     const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    if (b >= p.nblk) return;  // whole block exits together
-    const int t = threadIdx.x;
+    if (b >= p.nblk) return;  // the whole wave exits together
+    const int t = threadIdx.x;   // == lane
     const long i = b * kWarpNew + t - 1;
     const bool valid = (i >= 0) && (i < p.n_sorted);
 
@@ -193,27 +199,28 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
         }
     }
 
-    s_pm[0][t] = pm[0]; s_pm[1][t] = pm[1];
+    // The predecessor at the same sensor pixel is the previous array element = the previous lane.
+    const double pmp0 = dpp_shr1(pm[0]), pmp1 = dpp_shr1(pm[1]);
+    double Dp[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) s_D[k][t] = D[k];
-    s_pix[t] = pix;
-    __syncthreads();
+    for (int k = 0; k < 12; ++k) Dp[k] = dpp_shr1(D[k]);
+    const uint32_t pix_prev = (uint32_t)dpp_shr1((int)pix);
 
     bool inl = false;
-    const bool cand = valid && (t >= 1) && (s_pix[t - 1] == pix);
-    double a_xx = 0, a_xy = 0, a_yy = 0, a_bx = 0, a_by = 0;
+    const bool cand = valid && (t >= 1) && (pix_prev == pix);
     uint32_t pi = kInvalidPix;
+    double jc[6], jp[6], dpx = 0, dpy = 0, e = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { jc[j] = 0; jp[j] = 0; }
     if (cand) {
-        const double dpx = pm[0] - s_pm[0][t - 1];
-        const double dpy = pm[1] - s_pm[1][t - 1];
+        dpx = pm[0] - pmp0;
+        dpy = pm[1] - pmp1;
         const double dp_norm = sqrt(dpx * dpx + dpy * dpy);   // Eigen norm(), model.cpp:199
         const double rx = round(pm[0]), ry = round(pm[1]);    // std::round, model.cpp:209-210
         // Outlier iff dp_norm > 10 (model.cpp:200).  Where the reference is undefined (non-finite dp, or a
         // rounded pixel outside the panorama read unchecked at model.cpp:213,227) the measurement is an
         // outlier as well (DESIGN.md "Defined behaviour").
         inl = (dp_norm <= p.outlier_px) && (rx >= 0.0) && (rx < (double)p.W) && (ry >= 0.0) && (ry < (double)p.H);
-        const uint32_t slot = p.ev_slot[i];
-        double* rec = p.rec + (size_t)kRecStride * slot;
         if (DUMP) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
         if (inl) {
             const int pmx = (int)rx, pmy = (int)ry;
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
             }
             const double C_pred = gx * dpx + gy * dpy;                  // model.cpp:217
             const double C_meas = 2 * ((double)pol - 0.5) * p.C_th;    // model.cpp:219
-            const double e = C_meas - C_pred;                           // model.cpp:221
+            e = C_meas - C_pred;                                        // model.cpp:221
             const double t0 = gx + (dpx * gxx + dpy * gxy);            // temp = Gpm + dp^T*G2, model.cpp:238
             const double t1 = gy + (dpx * gxy + dpy * gyy);
             if (DUMP) {
@@ -239,49 +246,55 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
                 p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy;
             } else {
                 if (!(p.ablate & 1)) atomicAdd(p.count + pi, 1);        // model.cpp:227
-                a_xx = dpx * dpx; a_xy = dpx * dpy; a_yy = dpy * dpy;   // model.cpp:429-431
-                a_bx = dpx * e; a_by = dpy * e;                         // model.cpp:438-439
-                double jc[6], jp[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    jc[j] = t0 * D[j] + t1 * D[6 + j];                                  // model.cpp:449
-                    jp[j] = (-gx) * s_D[j][t - 1] + (-gy) * s_D[6 + j][t - 1];          // model.cpp:459
-                }
-                double2* r2 = reinterpret_cast<double2*>(rec);
-                if (p.ablate & 2) { if (jc[0] + jc[1] + jc[2] + jc[3] + jc[4] + jc[5] + jp[0] + jp[1] + jp[2] + jp[3] + jp[4] + jp[5] == 1.2345) r2[0] = make_double2(e, dpx); }
-                else {
-                r2[0] = make_double2(jc[0], jc[1]); r2[1] = make_double2(jc[2], jc[3]); r2[2] = make_double2(jc[4], jc[5]);
-                r2[3] = make_double2(jp[0], jp[1]); r2[4] = make_double2(jp[2], jp[3]); r2[5] = make_double2(jp[4], jp[5]);
-                r2[6] = make_double2(dpx, dpy);
-                r2[7] = make_double2(e, __hiloint2double(0, (int)pi));
+                    jc[j] = t0 * D[j] + t1 * D[6 + j];                  // model.cpp:449
+                    jp[j] = (-gx) * Dp[j] + (-gy) * Dp[6 + j];          // model.cpp:459
                 }
                 p.e_sorted[i] = e;
             }
-        } else if (!DUMP) {
-            reinterpret_cast<double2*>(rec)[7] = make_double2(0.0, __hiloint2double(0, (int)kInvalidPix));
         }
     }
-    if (!DUMP) {
-        if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
-        const int n_inl = __syncthreads_count(inl ? 1 : 0);   // also: every read of s_D / s_pix above is done
-        if (t == 0) p.blk_cnt[b] = (uint32_t)n_inl;
-        // Unweighted A22/b2 sums into the per-pixel accumulator line (model.cpp:426-439).  The five values of one
-        // measurement are contiguous in HBM, so they are issued by five ADJACENT lanes of one atomic wave-instruction
-        // (one 64-B request per measurement instead of five): stage through the LDS that held the Jacobians.
-        double* s_val = &s_D[0][0];                           // [kWarpBlock][6]
-        s_val[6 * t + 0] = a_xx; s_val[6 * t + 1] = a_xy; s_val[6 * t + 2] = a_yy; s_val[6 * t + 3] = a_bx; s_val[6 * t + 4] = a_by;
-        s_pix[t] = inl ? pi : kInvalidPix;
-        __syncthreads();
-        if (!(p.ablate & 8)) {
-            const int lane = t & 63, wbase = t & ~63;
-            const int j = lane & 7;
+    if (DUMP) return;
+
+    if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
+    const unsigned long long cand_mask = __ballot(cand), inl_mask = __ballot(inl);
+    if (t == 0) p.blk_cnt[b] = (uint32_t)__popcll(inl_mask);
+
+    // Record stores and the per-pixel A22/b2 sums (model.cpp:426-439), issued COOPERATIVELY: a 128-B record (or the
+    // five accumulator doubles of one pixel) is one contiguous line in HBM, so eight adjacent lanes write one record
+    // per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial
+    // lines per instruction, store-issue bound).  Records pass through a per-wave LDS tile, half a wave at a time.
+    const uint32_t slot = cand ? p.ev_slot[i] : kNoSlot;
+    const int c8 = t & 7;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const int tt = wbase + 8 * r + (lane >> 3);
-                const uint32_t q = s_pix[tt];
-                if (q != kInvalidPix && j < 5) atomicAdd(p.pixacc + (size_t)kPixAccStride * q + j, s_val[6 * tt + j]);
+    for (int half = 0; half < 2; ++half) {
+        if ((t >> 5) == half && cand) {
+            double2* w2 = reinterpret_cast<double2*>(s_tile + (t & 31) * kRecLds);
+            w2[0] = make_double2(jc[0], jc[1]); w2[1] = make_double2(jc[2], jc[3]); w2[2] = make_double2(jc[4], jc[5]);
+            w2[3] = make_double2(jp[0], jp[1]); w2[4] = make_double2(jp[2], jp[3]); w2[5] = make_double2(jp[4], jp[5]);
+            w2[6] = make_double2(dpx, dpy);
+            w2[7] = make_double2(e, __hiloint2double(0, (int)pi));     // outliers: pi == kInvalidPix marks the slot invalid
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 8 * r + (t >> 3);
+            const int src = 32 * half + rr;
+            const bool is_c = (cand_mask >> src) & 1ull, is_i = (inl_mask >> src) & 1ull;
+            const uint32_t slot_r = (uint32_t)__shfl((int)slot, src);
+            const double2* rd = reinterpret_cast<const double2*>(s_tile + rr * kRecLds);
+            if (is_c && (is_i || c8 == 7) && !(p.ablate & 2))
+                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * slot_r)[c8] = rd[c8];
+            if (is_i && c8 < 5 && !(p.ablate & 8)) {
+                const double2 d = rd[6], tl = rd[7];
+                const uint32_t q = (uint32_t)__double2loint(tl.y);
+                const double a = (c8 < 3) ? ((c8 == 2) ? d.y : d.x) : tl.x;      // xx: dx*dx  xy: dx*dy  yy: dy*dy  bx: dx*e  by: dy*e
+                const double bq = (c8 == 0 || c8 == 3) ? d.x : d.y;
+                atomicAdd(p.pixacc + (size_t)kPixAccStride * q + c8, (c8 < 3) ? a * bq : bq * a);
             }
         }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it
     }
 }
 
@@ -344,18 +357,18 @@ __device__ __forceinline__ uint32_t block_rank_256(bool f, uint32_t* s_w /*[4]*/
 
 // Residual compaction into the reference's order (model.cpp:221,256): pixel-major array order.
 __global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
-                                                              const uint32_t* __restrict__ blk_off, long n_sorted,
+                                                              const uint32_t* __restrict__ blk_off, long n_sorted, long nblk,
                                                               double* __restrict__ ep, int32_t* __restrict__ inl_idx)
 {
-    __shared__ uint32_t s_w[4];
-    const long b = blockIdx.x;
-    const int t = threadIdx.x;
-    const long i = b * kWarpNew + t;
-    const bool in = (t < kWarpNew) && (i < n_sorted);
+    // same partition as the warp kernel: wave-blocks of kWarpNew events; four of them per 256-thread block, ranks by ballot
+    const int lane = threadIdx.x & 63;
+    const long wb = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long i = wb * kWarpNew + lane;
+    const bool in = (lane < kWarpNew) && (wb < nblk) && (i < n_sorted);
     const bool f = in && flag[i];
-    const uint32_t r = block_rank_256(f, s_w);
+    const unsigned long long m = __ballot(f);
     if (f) {
-        const uint32_t k = blk_off[b] + r;
+        const uint32_t k = blk_off[wb] + __popcll(m & ((1ull << lane) - 1ull));
         ep[k] = e_sorted[i];
         inl_idx[i] = (int32_t)k;
     } else if (in) {

@@ -29,6 +29,22 @@ HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (
 EVENTS_PER_GPU = 1_000_000
 
 
+def pmc_traffic(workload_desc):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (scripts/profile.sh +
+    scripts/summarize_profiles.py: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction 2*FETCH+WRITE).  Counters
+    cannot be collected from inside this process, so the latest committed summary for the same workload is reported."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload_desc:
+            best = d
+    return best
+
+
 def cpu_baseline(w, budget_s=15.0):
     """The oracle (plain-C, 1 thread, reference evaluation order) on the same workload; bounded to ~budget_s of CPU work."""
     from oracle import oracle as O
@@ -139,6 +155,7 @@ def main():
         value = n_total / (elapsed / args.steps)
         wk = float(np.mean(warp_ms))
         n_launch = local.size()
+        tr = pmc_traffic(w.describe()) if world == 1 else None
         achieved = ALGO_BYTES_PER_EVENT * n_launch / (wk * 1e-3) / 1e9
         out = {
             "metric": "events/sec through warp+Jacobian+JtJ build, 1M events, 1024x2048 pano",
@@ -151,7 +168,9 @@ def main():
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3)},
             "roofline": {"bound": "hbm", "kernel": "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (tr["hbm_bytes_per_launch"] if tr else None), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_launch,
                          "bytes_per_event": ALGO_BYTES_PER_EVENT, "events_per_launch": n_launch, "kernel_ms": wk,
                          "accumulate_kernel_ms": float(np.mean(accum_ms)),
                          "path_frac": ALGO_BYTES_PER_EVENT * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},

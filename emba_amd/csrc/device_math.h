@@ -158,8 +158,8 @@ __device__ __forceinline__ void left_jacobian_inv(const double* phi, double* J)
 }
 
 // basalt::So3Spline<2>::evaluate (so3_spline.h:218-274) for one query; knots (x,y,z,w).
-// Outputs R (row-major value), J1 = d_val_d_knot[1] (row-major); d_val_d_knot[0] = I - J1.
-__device__ __forceinline__ void spline2_eval(const double* p0, const double* p1, double u, double* R, double* J1)
+// Outputs the value as unit quaternion q (x,y,z,w) and J1 = d_val_d_knot[1] (row-major); d_val_d_knot[0] = I - J1.
+__device__ __forceinline__ void spline2_eval(const double* p0, const double* p1, double u, double* q_out, double* J1)
 {
     double p0inv[4] = {-p0[0], -p0[1], -p0[2], p0[3]};
     quat_normalize(p0inv);                       // SO3::inverse -> SO3(conjugate) normalizes
@@ -181,7 +181,7 @@ __device__ __forceinline__ void spline2_eval(const double* p0, const double* p1,
     double e[4], res[4];
     so3_exp(kdelta, e);
     so3_mul(p0, e, res);
-    quat_to_matrix(res, R);
+    q_out[0] = res[0]; q_out[1] = res[1]; q_out[2] = res[2]; q_out[3] = res[3];
 }
 
 // EquirectangularCamera::projectToImage (include/utils/equirectangular_camera.h:18-45) chained with

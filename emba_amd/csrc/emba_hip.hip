@@ -48,8 +48,10 @@ struct emba_ctx {
     const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // current map planes (own or bound)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
-    int texel_mode = 0;   // 0 auto, 1 always pack texels, 2 always on-the-fly Hessian (EMBA_TEXEL=auto|pack|fly)
-    bool use_texel = false;
+    int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (EMBA_TEXEL=auto|pack|fly|rect)
+    int use_texel = 0;    // what the current evaluation uses: 0 fly, 1 full pack, 3 rectangle
+    int* d_rect = nullptr;       // {xmin,ymin,xmax,ymax} of the pixels the previous evaluation touched
+    int* d_blk_rect = nullptr;   // per prep-block boxes
     int32_t* d_compact = nullptr;
     uint32_t* d_active = nullptr;
     uint32_t* d_ablk_cnt = nullptr; uint32_t* d_ablk_off = nullptr; size_t n_ablk = 0;
@@ -296,7 +298,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->fy = (double)((c->H / 180.0) * 180.0 / M_PI);
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
     if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
-    if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : 0;
+    if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
 #define CREATE_TRY(call)                                                                                  \
     do {                                                                                                  \
@@ -324,6 +326,9 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int)));
+    { const int init[4] = {0x7FFFFFFF, 0x7FFFFFFF, -1, -1}; CREATE_TRY(hipMemcpy(c->d_rect, init, sizeof init, hipMemcpyHostToDevice)); }
+    CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, ((c->npix + 1023) / 1024) * 4 * sizeof(int)));
     CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t)));
     CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double)));
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
@@ -345,7 +350,7 @@ void emba_destroy(emba_ctx* c)
     free_window(c);
     dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own);
     dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
-    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err);
+    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_knots) (void)hipHostFree(c->h_knots);
@@ -503,25 +508,31 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
         c->pix_dirty_all = false;
     }
-    hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, s, c->d_count, (long)c->npix,
-                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K);
+    int* rect_cur = c->d_rect;
+    const int n_prep_blk = (int)((c->npix + 1023) / 1024);
+    hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)n_prep_blk), dim3(256), 0, s, c->d_count, (long)c->npix,
+                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect);
     HIP_TRY(c, hipEventRecord(c->knots_copied, s));
 
-    if (c->n_batch) {
+    {   // pose table (+ one extra block that reduces the prep kernel's per-block boxes into the texel rectangle)
         const int nb = (int)c->n_batch;
-        hipLaunchKernelGGL(emba_pose_kernel, dim3((nb + 63) / 64), dim3(64), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
-                           t0_ns, dt_ns, c->d_pose, c->d_err);
+        hipLaunchKernelGGL(emba_pose_kernel, dim3((nb + 63) / 64 + 1), dim3(64), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
+                           t0_ns, dt_ns, c->d_pose, c->d_err, c->d_blk_rect, n_prep_blk, rect_cur);
     }
-    // Texel pack (one 48-B gather per measurement) pays off once the events outnumber the panorama pixels it costs;
-    // below that the warp kernel takes the 3x3 Hessian stencil straight from the Gx/Gy planes.
-    c->use_texel = c->texel_mode == 1 || (c->texel_mode == 0 && c->n_sorted > c->npix);
-    if (c->use_texel)
+    // Hessian source: with more events than panorama pixels the full texel pack (one 48-B gather per measurement instead of
+    // an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
+    // evaluation touched, and the warp kernel falls back to the stencil outside it.
+    c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > c->npix ? 1 : 3);
+    if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
                            c->d_texel);
+    else if (c->use_texel == 3)
+        hipLaunchKernelGGL(emba_texel_rect_kernel, dim3(1024), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W, rect_cur, c->d_texel);
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
         p.nblk = c->nblk; p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
+        p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
         p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt;
@@ -787,7 +798,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
-    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
+    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
@@ -819,7 +830,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
         const bool cand = i > 0 && ((c->h_pix[i] & 0x7FFFFFFFu) == (c->h_pix[i - 1] & 0x7FFFFFFFu));
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
         if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
-        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)c->h_batch[i] * kPoseStride + 18];
+        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)c->h_batch[i] * kPoseStride + 13];
         if (inlier_idx) inlier_idx[k] = cand ? (h_flag[i] ? h_inl[i] : -1) : -2;
         if (pm_int && h_flag[i]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
         if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }

@@ -3,7 +3,8 @@
 // Data layout in HBM:
 //   events    pixel-major (sensor pixel, then time): ev_pix u32 (bit31 = polarity), ev_batch u32,
 //             ev_slot u32 (factor-record slot, kNoSlot if the event has no predecessor at its pixel)
-//   pose      one 160-B record per 100-event batch: R[9] J1[9] cp u   (J0 = I - J1)
+//   pose      one 112-B record per 100-event batch: q[4] J1[9] cp   (R = matrix(q) per event like rot.matrix() at
+//             event_pano_warper.cpp:55; J0 = I - J1)
 //   texel     per panorama pixel {Gx Gy Gxx Gxy Gyy pad} = 48 B   (one gather per measurement)
 //   records   one 128-B factor record per measurement candidate, stored in (cp_c,cp_p)-sorted slots:
 //             jc[6] jp[6] dp[2] e {u32 pano_idx, u32 aux}  — the sparse A12 factor + what A11/A22 need
@@ -21,7 +22,7 @@ namespace emba {
 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kInvalidPix = 0xFFFFFFFFu;
-constexpr int kPoseStride = 20;    // doubles per pose record
+constexpr int kPoseStride = 14;    // doubles per pose record: q[4] J1[9] cp  (112 B = 7 x 16-B gathers per event)
 constexpr int kTexelStride = 6;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
 constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: no barriers, neighbours talk through DPP
@@ -46,8 +47,23 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long grid)
 // So3Spline<2>::evaluate (so3_spline.h:218-274).  s and u use the same int64 arithmetic as the reference.
 // ------------------------------------------------------------------------------------------------
 __global__ void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
-                                 int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
+                                 int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
+                                 const int* __restrict__ blk_rect, int n_blk_rect, int* __restrict__ rect_out)
 {
+    if (blockIdx.x == gridDim.x - 1) {   // the extra, last block: bounding box of the per-block boxes of the prep kernel
+        int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+        for (int i = threadIdx.x; i < n_blk_rect; i += 64) {
+            const int4 r = reinterpret_cast<const int4*>(blk_rect)[i];
+            xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+            xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        }
+        if (threadIdx.x == 0) { rect_out[0] = xmin; rect_out[1] = ymin; rect_out[2] = xmax; rect_out[3] = ymax; }
+        return;
+    }
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const int64_t st = batch_t_ns[b] - t0_ns;
@@ -60,13 +76,14 @@ __global__ void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb,
     double p0[4], p1[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * s + i]; p1[i] = knots[4 * (s + 1) + i]; }
-    double R[9], J1[9];
-    spline2_eval(p0, p1, u, R, J1);
+    double q[4], J1[9];
+    spline2_eval(p0, p1, u, q, J1);
     double* o = pose + (size_t)kPoseStride * b;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { o[i] = R[i]; o[9 + i] = J1[i]; }
-    o[18] = (double)s;
-    o[19] = u;
+    for (int i = 0; i < 4; ++i) o[i] = q[i];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[4 + i] = J1[i];
+    o[13] = (double)s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -102,6 +119,36 @@ __device__ __forceinline__ void hessian_at(const double* __restrict__ Gx, const 
     gyy_o = 0.125 * gyy;
 }
 
+// Texel rectangle: the bounding box (+ margin) of the pixels the PREVIOUS evaluation touched, accumulated by the prep kernel.
+// Inside it the warp kernel gathers one 48-B texel (3 cache accesses); outside it falls back to the 3x3 stencil on the Gx/Gy
+// planes (18 accesses).  Consecutive LM trial points move the footprint by a few pixels, so almost every gather is a texel.
+// rect = {x0, y0, x1, y1} inclusive; empty if x1 < x0.  acc = raw {xmin, ymin, xmax, ymax} from the prep kernel.
+constexpr int kRectMargin = 24;
+__device__ __forceinline__ void texel_rect(const int* __restrict__ acc, int W, int H, int& x0, int& y0, int& x1, int& y1)
+{
+    const int ax0 = acc[0], ay0 = acc[1], ax1 = acc[2], ay1 = acc[3];
+    if (ax1 < ax0 || ay1 < ay0) { x0 = 0; y0 = 0; x1 = -1; y1 = -1; return; }
+    x0 = max(ax0 - kRectMargin, 0); y0 = max(ay0 - kRectMargin, 0);
+    x1 = min(ax1 + kRectMargin, W - 1); y1 = min(ay1 + kRectMargin, H - 1);
+}
+
+__global__ __launch_bounds__(256) void emba_texel_rect_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, int H, int W,
+                                                              const int* __restrict__ rect_acc, double* __restrict__ texel)
+{
+    int x0, y0, x1, y1;
+    texel_rect(rect_acc, W, H, x0, y0, x1, y1);
+    const long rw = x1 - x0 + 1, total = rw * (long)(y1 - y0 + 1);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int x = x0 + (int)(idx % rw), y = y0 + (int)(idx / rw);
+        double gx, gy, gxx, gxy, gyy;
+        hessian_at(Gx, Gy, H, W, x, y, gx, gy, gxx, gxy, gyy);
+        double2* t = reinterpret_cast<double2*>(texel + (size_t)kTexelStride * ((size_t)y * W + x));
+        t[0] = make_double2(gx, gy);
+        t[1] = make_double2(gxx, gxy);
+        t[2] = make_double2(gyy, 0.0);
+    }
+}
+
 __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy,
                                                          int H, int W, double* __restrict__ texel)
 {
@@ -127,6 +174,7 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
     const double* pose; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy
+    const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
     int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt;
@@ -165,9 +213,10 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
         const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * p.ev_batch[i]);
         double R[9], J1[9];
         {
-            const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6], a7 = P2[7], a8 = P2[8];
-            R[0] = a0.x; R[1] = a0.y; R[2] = a1.x; R[3] = a1.y; R[4] = a2.x; R[5] = a2.y; R[6] = a3.x; R[7] = a3.y; R[8] = a4.x;
-            J1[0] = a4.y; J1[1] = a5.x; J1[2] = a5.y; J1[3] = a6.x; J1[4] = a6.y; J1[5] = a7.x; J1[6] = a7.y; J1[7] = a8.x; J1[8] = a8.y;
+            const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6];
+            const double q[4] = {a0.x, a0.y, a1.x, a1.y};
+            quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
+            J1[0] = a2.x; J1[1] = a2.y; J1[2] = a3.x; J1[3] = a3.y; J1[4] = a4.x; J1[5] = a4.y; J1[6] = a5.x; J1[7] = a5.y; J1[8] = a6.x;
         }
         const double* bv = p.lut + 3 * (size_t)pix;
         const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
@@ -227,7 +276,13 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
             pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
             double gx = 0.01, gy = 0.02, gxx = 0.001, gxy = 0.002, gyy = 0.003;
             if (!(p.ablate & 4)) {
-                if (p.texel) {
+                bool use_tex = p.texel != nullptr;
+                if (use_tex && p.rect_acc) {
+                    int x0, y0, x1, y1;
+                    texel_rect(p.rect_acc, p.W, p.H, x0, y0, x1, y1);
+                    use_tex = pmx >= x0 && pmx <= x1 && pmy >= y0 && pmy <= y1;
+                }
+                if (use_tex) {
                     const double2* T2 = reinterpret_cast<const double2*>(p.texel + (size_t)kTexelStride * pi);
                     const double2 g = T2[0], h0 = T2[1], h1 = T2[2];
                     gx = g.x; gy = g.y; gxx = h0.x; gxy = h0.y; gyy = h1.x;
@@ -470,32 +525,50 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
 // resets the device error word and pulls the control poses from the pinned host staging buffer (no copy / memset nodes).
 __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc,
                                                         int* __restrict__ err, const double* __restrict__ knots_host,
-                                                        double* __restrict__ knots_dev, int n_knot_doubles)
+                                                        double* __restrict__ knots_dev, int n_knot_doubles, int W,
+                                                        int* __restrict__ blk_rect)
 {
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) err[0] = 0;
         for (int i = threadIdx.x; i < n_knot_doubles; i += 256) knots_dev[i] = knots_host[i];
     }
     const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (p0 >= npix) return;
-    if (p0 + 4 <= npix) {
-        const int4 c = *reinterpret_cast<const int4*>(count + p0);
-        if ((c.x | c.y | c.z | c.w) == 0) return;
-        *reinterpret_cast<int4*>(count + p0) = make_int4(0, 0, 0, 0);
-        const int cc[4] = {c.x, c.y, c.z, c.w};
+    int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+    if (p0 < npix) {
+        int cc[4] = {0, 0, 0, 0};
+        if (p0 + 4 <= npix) {
+            const int4 c = *reinterpret_cast<const int4*>(count + p0);
+            cc[0] = c.x; cc[1] = c.y; cc[2] = c.z; cc[3] = c.w;
+            if ((c.x | c.y | c.z | c.w) != 0) *reinterpret_cast<int4*>(count + p0) = make_int4(0, 0, 0, 0);
+        } else {
+            for (int k = 0; k < 4 && p0 + k < npix; ++k) { cc[k] = count[p0 + k]; if (cc[k]) count[p0 + k] = 0; }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (cc[k] != 0) {
                 double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * (p0 + k));
                 a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
+                const int idx = (int)(p0 + k), y = idx / W, x = idx - y * W;
+                xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
             }
-    } else {
-        for (long i = p0; i < npix; ++i)
-            if (count[i] != 0) {
-                count[i] = 0;
-                double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * i);
-                a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
-            }
+    }
+    // bounding box of the touched pixels of this block -> blk_rect[block]; the pose kernel's extra block reduces them into the
+    // texel rectangle of THIS evaluation (no global atomics: they would all land on the same four words and serialise).
+    __shared__ int s_box[4][4];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+    }
+    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int4 r;
+        r.x = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+        r.y = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+        r.z = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
+        r.w = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+        reinterpret_cast<int4*>(blk_rect)[blockIdx.x] = r;
     }
 }
 

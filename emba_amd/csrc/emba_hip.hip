@@ -75,7 +75,7 @@ struct emba_ctx {
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr;
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
-    uint32_t* d_blk_cnt = nullptr; uint32_t* d_blk_off = nullptr;
+    uint32_t* d_blk_cnt = nullptr; uint32_t* d_grp_cnt = nullptr; uint32_t* d_grp_off = nullptr; long ngrp = 0;
     double* d_ep = nullptr;
     // key order cache
     bool keys_ready = false; int64_t key_t0 = 0, key_dt = 0; int key_K = 0;
@@ -84,6 +84,7 @@ struct emba_ctx {
     int K = 0;
     bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
     size_t n_inliers = 0, P = 0, pack_len = 0;
+    bool ep_deferred = false;   // residual compaction not launched yet (it rides along with the active-set kernels)
     bool inl_pending = false, P_pending = false;   // counters enqueued for readback but not yet resolved (no host sync yet)
     double* h_knots = nullptr; int h_knots_cap = 0; hipEvent_t knots_copied = nullptr;   // pinned staging for the control poses
     int thres = 0, irls = 0; double eta = 0;
@@ -137,7 +138,7 @@ void free_window(emba_ctx* c)
 {
     dev_free(c->d_ev_pix); dev_free(c->d_ev_batch); dev_free(c->d_ev_slot); dev_free(c->d_batch_t);
     dev_free(c->d_pose); dev_free(c->d_rec); dev_free(c->d_slot_key); dev_free(c->d_e_sorted);
-    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_blk_cnt); dev_free(c->d_blk_off);
+    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_blk_cnt); dev_free(c->d_grp_cnt); dev_free(c->d_grp_off);
     dev_free(c->d_ep);
     c->have_events = false; c->keys_ready = false;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
@@ -233,10 +234,33 @@ inline double* pack_A22b2(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c
 
 long grid8(long n) { return (n + 7) / 8 * 8; }
 
+// Standalone residual compaction (scan of the per-wave inlier counts, then the compaction): used when the host asks for
+// ep / counts before the active-set kernels run; otherwise emba_form_active launches it fused with its own stages.
+emba_status launch_ep_compaction(emba_ctx* c)
+{
+    if (!c->ep_deferred) return EMBA_OK;
+    c->ep_deferred = false;
+    hipStream_t s = c->stream;
+    if (c->n_sorted) {
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_grp_cnt, c->d_grp_off, c->ngrp, c->d_total,
+                           c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->ngrp), dim3(1024), 0, s, c->d_e_sorted, c->d_flag,
+                           c->d_blk_cnt, c->d_grp_off, (long)c->n_sorted, c->nblk, c->d_ep, c->d_inl_idx);
+        HIP_TRY(c, hipGetLastError());
+    } else {
+        HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
+    c->inl_pending = true;
+    return EMBA_OK;
+}
+
 // Synchronize the stream and turn the counters that were read back asynchronously (inlier count, device error
 // word, active-pixel count) into host state.  Called only where the host really needs a value.
 emba_status resolve_pending(emba_ctx* c)
 {
+    { emba_status st = launch_ep_compaction(c); if (st) return st; }
     if (!c->inl_pending && !c->P_pending) return EMBA_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->inl_pending) {
@@ -422,8 +446,11 @@ emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     if ((st = dev_alloc(c, &c->d_e_sorted, ns))) return st;
     if ((st = dev_alloc(c, &c->d_flag, ns))) return st;
     if ((st = dev_alloc(c, &c->d_inl_idx, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_blk_cnt, (size_t)c->nblk))) return st;
-    if ((st = dev_alloc(c, &c->d_blk_off, (size_t)c->nblk))) return st;
+    c->ngrp = (c->nblk + kEpGroup - 1) / kEpGroup;
+    if ((st = dev_alloc(c, &c->d_blk_cnt, (size_t)c->ngrp * kEpGroup))) return st;
+    if ((st = dev_alloc(c, &c->d_grp_cnt, (size_t)c->ngrp))) return st;
+    if ((st = dev_alloc(c, &c->d_grp_off, (size_t)c->ngrp))) return st;
+    HIP_TRY(c, hipMemset(c->d_blk_cnt, 0, std::max<size_t>((size_t)c->ngrp * kEpGroup, 1) * sizeof(uint32_t)));
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
     HIP_TRY(c, hipMemcpy(c->d_ev_pix, c->h_pix.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->d_ev_batch, c->h_batch.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
@@ -499,7 +526,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->h_knots_cap = K;
     }
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
-    c->inl_pending = c->P_pending = false;
+    c->inl_pending = c->P_pending = false; c->ep_deferred = false;
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventSynchronize(c->knots_copied));   // the previous prep kernel has consumed the pinned staging buffer
     memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
@@ -511,23 +538,25 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     int* rect_cur = c->d_rect;
     const int n_prep_blk = (int)((c->npix + 1023) / 1024);
     hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)n_prep_blk), dim3(256), 0, s, c->d_count, (long)c->npix,
-                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect);
+                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect, c->d_grp_cnt, (int)c->ngrp);
     HIP_TRY(c, hipEventRecord(c->knots_copied, s));
 
-    {   // pose table (+ one extra block that reduces the prep kernel's per-block boxes into the texel rectangle)
-        const int nb = (int)c->n_batch;
-        hipLaunchKernelGGL(emba_pose_kernel, dim3((nb + 63) / 64 + 1), dim3(64), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
-                           t0_ns, dt_ns, c->d_pose, c->d_err, c->d_blk_rect, n_prep_blk, rect_cur);
-    }
     // Hessian source: with more events than panorama pixels the full texel pack (one 48-B gather per measurement instead of
     // an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
     // evaluation touched, and the warp kernel falls back to the stencil outside it.
     c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > c->npix ? 1 : 3);
+    {   // pose table and (rectangle mode) texels in ONE launch: both depend only on the prep kernel
+        const int nb = (int)c->n_batch;
+        const int n_pose_blk = (nb + 63) / 64;
+        const int n_tex_blk = (c->use_texel == 3) ? 512 : 0;
+        if (n_pose_blk + n_tex_blk)
+            hipLaunchKernelGGL(emba_pose_texel_kernel, dim3(n_pose_blk + n_tex_blk), dim3(256), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
+                               t0_ns, dt_ns, c->d_pose, c->d_err, n_pose_blk, n_tex_blk, c->d_Gx, c->d_Gy, c->H, c->W, c->d_blk_rect,
+                               n_prep_blk, rect_cur, c->d_texel);
+    }
     if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
                            c->d_texel);
-    else if (c->use_texel == 3)
-        hipLaunchKernelGGL(emba_texel_rect_kernel, dim3(1024), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W, rect_cur, c->d_texel);
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
@@ -535,7 +564,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
-        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt;
+        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.grp_cnt = c->d_grp_cnt;
         p.ablate = c->ablate;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
@@ -551,20 +580,8 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
     HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    if (c->n_sorted) {
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_blk_cnt, c->d_blk_off, c->nblk, c->d_total,
-                           c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
-        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)((c->nblk + 3) / 4)), dim3(256), 0, s, c->d_e_sorted, c->d_flag,
-                           c->d_blk_off, (long)c->n_sorted, c->nblk, c->d_ep, c->d_inl_idx);
-        HIP_TRY(c, hipGetLastError());
-    } else {
-        HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[0], c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
-    }
-    c->inl_pending = true;
-    if (!ep_out && !n_inliers && !num_ev_map_out) return EMBA_OK;   // fully asynchronous: resolved at the next host sync point
+    c->ep_deferred = true;
+    if (!ep_out && !n_inliers && !num_ev_map_out) return EMBA_OK;   // fully asynchronous: the compaction rides with the next phase
     emba_status st = resolve_pending(c);
     if (st) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
@@ -588,14 +605,29 @@ emba_status emba_eval_data_error(emba_ctx* c, const double* knots, int32_t K, in
 emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack_len)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "formNormalEq needs the state of evaluateDataError (solver.cpp:99-102)");
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "formNormalEq needs the state of evaluateDataError (solver.cpp:99-102)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const long npix = (long)c->npix;
     const long head = (long)9 * c->K * c->K + (long)3 * c->K;
-    hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
-    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(1024), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1,
-                       c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
+    if (c->ep_deferred && c->n_sorted) {
+        // residual compaction (scan -> compact) and active set (count -> scan) share two launches
+        c->ep_deferred = false;
+        PostWarpParams q{};
+        q.count = c->d_count; q.npix = npix; q.thres = thres; q.ablk_cnt = c->d_ablk_cnt; q.ablk_off = c->d_ablk_off; q.n_ablk = (long)c->n_ablk;
+        q.total_P = c->d_total + 1; q.total_P_host = c->h_pinned_dev + 2;
+        q.blk_cnt = c->d_blk_cnt; q.grp_cnt = c->d_grp_cnt; q.grp_off = c->d_grp_off; q.ngrp = c->ngrp; q.nblk = c->nblk; q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
+        q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
+        q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.n_sorted = (long)c->n_sorted; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
+        hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)c->n_ablk + 1), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3((unsigned)c->ngrp + 1), dim3(1024), 0, s, q);
+        c->inl_pending = true;
+    } else {
+        { emba_status st0 = launch_ep_compaction(c); if (st0) return st0; }
+        hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1,
+                           c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
+    }
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
                        c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head);
     HIP_TRY(c, hipGetLastError());
@@ -742,7 +774,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
 emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)
 {
     if (!c || !cost) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "no residuals yet");
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no residuals yet");
     HIP_TRY(c, hipSetDevice(c->device));
     { emba_status st0 = resolve_pending(c); if (st0) return st0; }
     hipStream_t s = c->stream;
@@ -781,7 +813,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
                             double* Gpm, double* temp)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done && !c->inl_pending) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
     HIP_TRY(c, hipSetDevice(c->device));
     { emba_status st0 = resolve_pending(c); if (st0) return st0; }
     const size_t ns = c->n_sorted, n = c->n_in;

@@ -27,6 +27,7 @@ constexpr int kTexelStride = 6;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
 constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: no barriers, neighbours talk through DPP
 constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
+constexpr int kEpGroup = 16;       // waves per residual-compaction block (1024 threads); the inlier scan runs over these groups
 constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
 constexpr int kGramChunk = 256;    // record slots per wave in the Gram (A11/b1) kernel; multiple of 4
@@ -46,25 +47,9 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long grid)
 // a2/a3: one thread per batch -> pose record.  LinearTrajectory::evaluate (trajectory.cpp:122-147) /
 // So3Spline<2>::evaluate (so3_spline.h:218-274).  s and u use the same int64 arithmetic as the reference.
 // ------------------------------------------------------------------------------------------------
-__global__ void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
-                                 int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
-                                 const int* __restrict__ blk_rect, int n_blk_rect, int* __restrict__ rect_out)
+__device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
+                                            int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
 {
-    if (blockIdx.x == gridDim.x - 1) {   // the extra, last block: bounding box of the per-block boxes of the prep kernel
-        int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
-        for (int i = threadIdx.x; i < n_blk_rect; i += 64) {
-            const int4 r = reinterpret_cast<const int4*>(blk_rect)[i];
-            xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
-            xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
-        }
-        if (threadIdx.x == 0) { rect_out[0] = xmin; rect_out[1] = ymin; rect_out[2] = xmax; rect_out[3] = ymax; }
-        return;
-    }
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
     const int64_t st = batch_t_ns[b] - t0_ns;
     const int64_t s = (st >= 0) ? st / dt_ns : -1;
@@ -132,13 +117,37 @@ __device__ __forceinline__ void texel_rect(const int* __restrict__ acc, int W, i
     x1 = min(ax1 + kRectMargin, W - 1); y1 = min(ay1 + kRectMargin, H - 1);
 }
 
-__global__ __launch_bounds__(256) void emba_texel_rect_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, int H, int W,
-                                                              const int* __restrict__ rect_acc, double* __restrict__ texel)
+__device__ __forceinline__ void texel_rect_blocks(long blk, long nblocks, const double* __restrict__ Gx, const double* __restrict__ Gy,
+                                                  int H, int W, const int* __restrict__ blk_rect, int n_blk_rect, int* __restrict__ rect_out,
+                                                  double* __restrict__ texel)
 {
+    // every texel block reduces the prep kernel's per-block boxes itself (32 KB from L2), so it does not depend on anyone
+    __shared__ int s_box[4][4];
+    __shared__ int s_rect[4];
+    int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+    for (int i = threadIdx.x; i < n_blk_rect; i += 256) {
+        const int4 r = reinterpret_cast<const int4*>(blk_rect)[i];
+        xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+    }
+    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_rect[0] = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+        s_rect[1] = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+        s_rect[2] = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
+        s_rect[3] = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+        if (blk == 0) { rect_out[0] = s_rect[0]; rect_out[1] = s_rect[1]; rect_out[2] = s_rect[2]; rect_out[3] = s_rect[3]; }   // for the warp kernel
+    }
+    __syncthreads();
     int x0, y0, x1, y1;
-    texel_rect(rect_acc, W, H, x0, y0, x1, y1);
+    texel_rect(s_rect, W, H, x0, y0, x1, y1);
     const long rw = x1 - x0 + 1, total = rw * (long)(y1 - y0 + 1);
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = blk * 256 + threadIdx.x; idx < total; idx += nblocks * 256) {
         const int x = x0 + (int)(idx % rw), y = y0 + (int)(idx / rw);
         double gx, gy, gxx, gxy, gyy;
         hessian_at(Gx, Gy, H, W, x, y, gx, gy, gxx, gxy, gyy);
@@ -163,6 +172,18 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
     t[2] = make_double2(gyy, 0.0);
 }
 
+// Pose table and texel rectangle in one launch (both only need the prep kernel): blocks [0, n_pose_blk) evaluate the spline for
+// 256 batches each, the remaining n_tex_blk blocks pack the texels of the rectangle.
+__global__ __launch_bounds__(256) void emba_pose_texel_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
+                                                              int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
+                                                              int n_pose_blk, int n_tex_blk, const double* __restrict__ Gx,
+                                                              const double* __restrict__ Gy, int H, int W, const int* __restrict__ blk_rect,
+                                                              int n_blk_rect, int* __restrict__ rect_out, double* __restrict__ texel)
+{
+    if ((int)blockIdx.x < n_pose_blk) { if (threadIdx.x < 64) pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err); }
+    else texel_rect_blocks((long)blockIdx.x - n_pose_blk, n_tex_blk, Gx, Gy, H, W, blk_rect, n_blk_rect, rect_out, texel);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a4-a7 (+ the per-measurement half of a9): the dominant kernel.
 // One thread per pixel-major event: gather the batch pose, warp (event_pano_warper.cpp:43-74 +
@@ -177,7 +198,7 @@ struct WarpParams {
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
-    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt;
+    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt; uint32_t* grp_cnt;
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
 };
@@ -314,7 +335,11 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
 
     if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
     const unsigned long long cand_mask = __ballot(cand), inl_mask = __ballot(inl);
-    if (t == 0) p.blk_cnt[b] = (uint32_t)__popcll(inl_mask);
+    if (t == 0) {   // inliers of this wave, and of its group of kEpGroup waves (what the single-tile scan runs over)
+        const uint32_t n_inl = (uint32_t)__popcll(inl_mask);
+        p.blk_cnt[b] = n_inl;
+        if (n_inl) atomicAdd(p.grp_cnt + (b / kEpGroup), n_inl);
+    }
 
     // Record stores and the per-pixel A22/b2 sums (model.cpp:426-439), issued COOPERATIVELY: a 128-B record (or the
     // five accumulator doubles of one pixel) is one contiguous line in HBM, so eight adjacent lanes write one record
@@ -357,37 +382,42 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
 // Exclusive scan of per-block counts (single block, sequential over 1024-wide tiles).
 // out[i] = sum_{j<i} in[j]; total[0] = sum of all.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void emba_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                          long n, uint32_t* __restrict__ total, int* __restrict__ total_host,
-                                                          const int* __restrict__ err_dev, int* __restrict__ err_host)
+// out[i] = sum_{j<i} in[j] for one 256-thread block, 16 consecutive entries per thread and tile.
+__device__ __forceinline__ void block_scan_256(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, long n,
+                                               uint32_t* __restrict__ total, int* __restrict__ total_host,
+                                               const int* __restrict__ err_dev, int* __restrict__ err_host)
 {
-    __shared__ uint32_t s_wave[16];
+    // (callable from blocks of >= 256 threads: every thread must call it, threads >= 256 only keep the barriers company)
+    __shared__ uint32_t s_wave[4];
     __shared__ uint32_t s_carry;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool worker = t < 256;
     if (t == 0) s_carry = 0;
     __syncthreads();
-    for (long base = 0; base < n; base += 4096) {     // 4 consecutive entries per thread
-        const long i = base + 4 * t;
-        uint32_t v[4];
+    for (long base = 0; base < n; base += 4096) {
+        const long i = base + 16 * t;
+        uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? in[i + k] : 0;
-        const uint32_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+        for (int k = 0; k < 16; ++k) v[k] = (worker && i + k < n) ? in[i + k] : 0;
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mine += v[k];
         uint32_t x = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o);
             if (lane >= o) x += y;
         }
-        if (lane == 63) s_wave[wv] = x;
+        if (worker && lane == 63) s_wave[wv] = x;
         __syncthreads();
         uint32_t woff = 0;
-        for (int w = 0; w < wv; ++w) woff += s_wave[w];
+        for (int w = 0; w < wv && w < 4; ++w) woff += s_wave[w];
         const uint32_t carry = s_carry;
         uint32_t run = carry + woff + x - mine;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { if (i + k < n) out[i + k] = run; run += v[k]; }
+        for (int k = 0; k < 16; ++k) { if (worker && i + k < n) out[i + k] = run; run += v[k]; }
         __syncthreads();
-        if (t == 1023) s_carry = carry + woff + x;
+        if (t == 255) s_carry = carry + woff + x;
         __syncthreads();
     }
     if (t == 0) {
@@ -395,6 +425,13 @@ __global__ __launch_bounds__(1024) void emba_scan_kernel(const uint32_t* __restr
         if (total_host) total_host[0] = (int)s_carry;       // pinned, device-visible host word: no copy node needed
         if (err_host) err_host[0] = err_dev[0];
     }
+}
+
+__global__ __launch_bounds__(256) void emba_scan_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                         long n, uint32_t* __restrict__ total, int* __restrict__ total_host,
+                                                         const int* __restrict__ err_dev, int* __restrict__ err_host)
+{
+    block_scan_256(in, out, n, total, total_host, err_dev, err_host);
 }
 
 // Block-wide exclusive rank of a flag among 256 threads (4 waves) via ballots.
@@ -411,24 +448,35 @@ __device__ __forceinline__ uint32_t block_rank_256(bool f, uint32_t* s_w /*[4]*/
 }
 
 // Residual compaction into the reference's order (model.cpp:221,256): pixel-major array order.
-__global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
-                                                              const uint32_t* __restrict__ blk_off, long n_sorted, long nblk,
-                                                              double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+__device__ __forceinline__ void compact_ep_block(long blk, const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                 const uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ grp_off, long n_sorted,
+                                                 long nblk, double* __restrict__ ep, int32_t* __restrict__ inl_idx)
 {
-    // same partition as the warp kernel: wave-blocks of kWarpNew events; four of them per 256-thread block, ranks by ballot
-    const int lane = threadIdx.x & 63;
-    const long wb = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // same partition as the warp kernel: wave-blocks of kWarpNew events, kEpGroup of them per 1024-thread block; the block's
+    // offset comes from the scan over groups, the wave's from the <= 15 per-wave counts before it, the lane's from a ballot
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long wb = blk * kEpGroup + wv;
     const long i = wb * kWarpNew + lane;
     const bool in = (lane < kWarpNew) && (wb < nblk) && (i < n_sorted);
     const bool f = in && flag[i];
     const unsigned long long m = __ballot(f);
+    if (!m && !in) return;
+    uint32_t off = grp_off[blk];
+    for (int j = 0; j < wv; ++j) off += blk_cnt[blk * kEpGroup + j];
     if (f) {
-        const uint32_t k = blk_off[wb] + __popcll(m & ((1ull << lane) - 1ull));
+        const uint32_t k = off + __popcll(m & ((1ull << lane) - 1ull));
         ep[k] = e_sorted[i];
         inl_idx[i] = (int32_t)k;
     } else if (in) {
         inl_idx[i] = -1;
     }
+}
+
+__global__ __launch_bounds__(1024) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                               const uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ grp_off,
+                                                               long n_sorted, long nblk, double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+{
+    compact_ep_block(blockIdx.x, e_sorted, flag, blk_cnt, grp_off, n_sorted, nblk, ep, inl_idx);
 }
 
 // Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
@@ -463,17 +511,44 @@ __device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ cou
     return m;
 }
 
-__global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* __restrict__ count, long npix, int thres,
-                                                                uint32_t* __restrict__ blk_cnt)
+__device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
+                                                   uint32_t* __restrict__ blk_cnt)
 {
     __shared__ uint32_t s_w[4];
-    const long p0 = (long)blockIdx.x * kActivePix + 8 * threadIdx.x;
+    const long p0 = blk * kActivePix + 8 * threadIdx.x;
     uint32_t c = __popc(active_mask8(count, p0, npix, thres));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) blk_cnt[blk] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* __restrict__ count, long npix, int thres,
+                                                                uint32_t* __restrict__ blk_cnt)
+{
+    active_count_block(blockIdx.x, count, npix, thres, blk_cnt);
+}
+
+// The two small post-warp chains (residual compaction: scan -> compact; active set: count -> scan -> write) are independent of
+// each other, so their stages share launches ("heterogeneous" kernels): A = {active count blocks | one ep-scan block},
+// B = {one active-scan block | ep-compaction blocks}.  Two launches fewer on the step's critical path.
+struct PostWarpParams {
+    const int32_t* count; long npix; int thres; uint32_t* ablk_cnt; uint32_t* ablk_off; long n_ablk; uint32_t* total_P; int* total_P_host;
+    const uint32_t* blk_cnt; const uint32_t* grp_cnt; uint32_t* grp_off; long ngrp; long nblk; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
+    const double* e_sorted; const uint8_t* flag; long n_sorted; double* ep; int32_t* inl_idx;
+};
+
+__global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
+{
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt);
+    else block_scan_256(p.grp_cnt, p.grp_off, p.ngrp, p.total_inl, p.total_inl_host, p.err_dev, p.err_host);
+}
+
+__global__ __launch_bounds__(1024) void emba_post_warp_b_kernel(PostWarpParams p)
+{
+    if (blockIdx.x == 0) block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
+    else compact_ep_block((long)blockIdx.x - 1, p.e_sorted, p.flag, p.blk_cnt, p.grp_off, p.n_sorted, p.nblk, p.ep, p.inl_idx);
 }
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* __restrict__ count, long npix, int thres,
@@ -499,12 +574,20 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
     __syncthreads();
     uint32_t k = blk_off[blockIdx.x] + x - mine;
     for (int w = 0; w < wv; ++w) k += s_w[w];
+    if (p0 + 8 <= npix) {   // compact index of 8 consecutive pixels: two 16-B stores
+        int cv[8];
+        uint32_t kk = k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cv[j] = (m & (1u << j)) ? (int)(kk++) : -1;
+        reinterpret_cast<int4*>(compact + p0)[0] = make_int4(cv[0], cv[1], cv[2], cv[3]);
+        reinterpret_cast<int4*>(compact + p0)[1] = make_int4(cv[4], cv[5], cv[6], cv[7]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const long i = p0 + j;
         if (i >= npix) break;
         if (m & (1u << j)) {
-            compact[i] = (int32_t)k;
+            if (p0 + 8 > npix) compact[i] = (int32_t)k;
             active_idx[k] = (uint32_t)i;
             if (A22b2) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
                 const double2* a = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
@@ -514,7 +597,7 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
                 q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4;
             }
             ++k;
-        } else {
+        } else if (p0 + 8 > npix) {
             compact[i] = -1;
         }
     }
@@ -526,8 +609,9 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
 __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc,
                                                         int* __restrict__ err, const double* __restrict__ knots_host,
                                                         double* __restrict__ knots_dev, int n_knot_doubles, int W,
-                                                        int* __restrict__ blk_rect)
+                                                        int* __restrict__ blk_rect, uint32_t* __restrict__ grp_cnt, int n_grp)
 {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_grp; i += gridDim.x * 256) grp_cnt[i] = 0;   // per-group inlier counters
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) err[0] = 0;
         for (int i = threadIdx.x; i < n_knot_doubles; i += 256) knots_dev[i] = knots_host[i];

@@ -209,6 +209,12 @@ __device__ __forceinline__ double dpp_shr1(double v)
 {
     return __hiloint2double(dpp_shr1(__double2hiint(v)), dpp_shr1(__double2loint(v)));
 }
+// lane l <- lane l+1 (lane 63 <- 0): wave_shl:1
+__device__ __forceinline__ int dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ double dpp_shl1(double v)
+{
+    return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
+}
 
 template <bool DUMP>
 __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpParams p)
@@ -270,16 +276,15 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
     }
 
     // The predecessor at the same sensor pixel is the previous array element = the previous lane.
+    // (Only pm and the pixel id travel forward now; the predecessor's 2x6 Jacobian stays where it is and the two map gradients
+    // travel BACKWARD instead — see j_p below — which keeps 24 VGPRs free across the long-latency texel gather.)
     const double pmp0 = dpp_shr1(pm[0]), pmp1 = dpp_shr1(pm[1]);
-    double Dp[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) Dp[k] = dpp_shr1(D[k]);
     const uint32_t pix_prev = (uint32_t)dpp_shr1((int)pix);
 
     bool inl = false;
     const bool cand = valid && (t >= 1) && (pix_prev == pix);
     uint32_t pi = kInvalidPix;
-    double jc[6], jp[6], dpx = 0, dpy = 0, e = 0;
+    double jc[6], jp[6], dpx = 0, dpy = 0, e = 0, ngx = 0, ngy = 0;   // ngx, ngy = -Gpm of an inlier (0 otherwise)
 #pragma unroll
     for (int j = 0; j < 6; ++j) { jc[j] = 0; jp[j] = 0; }
     if (cand) {
@@ -323,15 +328,20 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
             } else {
                 if (!(p.ablate & 1)) atomicAdd(p.count + pi, 1);        // model.cpp:227
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    jc[j] = t0 * D[j] + t1 * D[6 + j];                  // model.cpp:449
-                    jp[j] = (-gx) * Dp[j] + (-gy) * Dp[6 + j];          // model.cpp:459
-                }
+                for (int j = 0; j < 6; ++j) jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
+                ngx = -gx; ngy = -gy;
                 p.e_sorted[i] = e;
             }
         }
     }
     if (DUMP) return;
+
+    {   // j_p = -Gpm_k * D_{k-1} (model.cpp:459): lane k-1 owns D_{k-1}; it receives -Gpm_k from lane k, forms the 1x6 row
+        // with the same two products and one sum as before, and hands the row forward.
+        const double gxn = dpp_shl1(ngx), gyn = dpp_shl1(ngy);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) jp[j] = dpp_shr1(gxn * D[j] + gyn * D[6 + j]);
+    }
 
     if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
     const unsigned long long cand_mask = __ballot(cand), inl_mask = __ballot(inl);
@@ -371,7 +381,8 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
                 const uint32_t q = (uint32_t)__double2loint(tl.y);
                 const double a = (c8 < 3) ? ((c8 == 2) ? d.y : d.x) : tl.x;      // xx: dx*dx  xy: dx*dy  yy: dy*dy  bx: dx*e  by: dy*e
                 const double bq = (c8 == 0 || c8 == 3) ? d.x : d.y;
-                atomicAdd(p.pixacc + (size_t)kPixAccStride * q + c8, (c8 < 3) ? a * bq : bq * a);
+                const double val = (c8 < 3) ? a * bq : bq * a;
+                atomicAdd(p.pixacc + (size_t)kPixAccStride * q + c8, val);
             }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it

@@ -289,3 +289,53 @@ def test_full_size_properties(gpu):
     assert np.allclose(ne3["A11"], 4 * ne["A11"], rtol=1e-9, atol=1e-9 * np.abs(ne["A11"]).max())
     assert np.allclose(ne3["b2"], 2 * ne["b2"], rtol=1e-9, atol=1e-12)
     assert np.allclose(ne3["A22"], ne["A22"], rtol=1e-10)
+
+
+def test_baseline_size_against_oracle(gpu, oracle_mod):
+    """The BASELINE configuration itself (1 M events, 240x180, 1024x2048, K=21) against the oracle: the CPU side takes about a
+    second, so the full-size check does not have to rely on properties alone."""
+    from emba_amd.synth import make_workload
+    w = make_workload()
+    g = gpu_run(w)
+    o = oracle_run(oracle_mod, w)
+    assert np.array_equal(g["num_ev_map"], o["num_ev_map"])            # 675 197 rounded pixels, bit-exact
+    assert g["ep"].shape == o["ep"].shape
+    assert_close(g["ep"], o["ep"], "ep")
+    errs = compare_normal_eq(g["ne"], o["ne"])
+    print("baseline-size parity:", errs)
+    assert g["legm"].dataCost() == pytest.approx(oracle_mod.data_cost(o["ep"]), rel=1e-11)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_events=1500000, pano_h=2048, K=256, sensor=(640, 480), focal=520.0, dt_knots=0.004, thres_valid_pixel=2),   # city/synthetic-like: big sensor, big pano, many knots
+    dict(n_events=300000, pano_h=512, K=47, sensor=(128, 128), focal=91.4015, dt_knots=0.05, t_beg=0.1),  # playroom.launch shape (2.3 s window)
+    dict(n_events=400000, pano_h=256, K=6, sensor=(32, 24), focal=30.0),                         # dense stream: ~500 events per sensor pixel
+])
+def test_other_configurations_against_oracle(gpu, oracle_mod, cfg):
+    from emba_amd.synth import make_workload
+    w = make_workload(**cfg)
+    g = gpu_run(w)
+    o = oracle_run(oracle_mod, w)
+    assert np.array_equal(g["num_ev_map"], o["num_ev_map"])
+    assert_close(g["ep"], o["ep"], "ep")
+    compare_normal_eq(g["ne"], o["ne"])
+    assert o["ep"].size > 10000 and o["ne"]["P"] > 100, "degenerate test input"
+
+
+@pytest.mark.parametrize("mode", ["fly", "pack", "rect"])
+def test_hessian_sources_agree(gpu, oracle_mod, mode, monkeypatch):
+    """The three ways the warp kernel can obtain the Hessian (3x3 stencil on the planes, full texel pack, texel rectangle of the
+    previous footprint) must give identical results; run two evaluations so that the rectangle is populated."""
+    monkeypatch.setenv("EMBA_TEXEL", mode)
+    w = small_workload(n_events=30000)
+    m = make_legm(w)
+    m.set_events(w.events)
+    o = oracle_run(oracle_mod, w)
+    for it in range(3):
+        nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+        ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, None, True, nem)
+        m.formNormalEq(ep, w.K, nem, w.thres_valid_pixel)
+        ne = m.applyL2Reg(w.alpha)
+        assert np.array_equal(nem, o["num_ev_map"])
+        assert_close(ep, o["ep"], "ep")
+        compare_normal_eq(ne, o["ne"])

@@ -220,6 +220,7 @@ template <bool DUMP>
 __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpParams p)
 {
     __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
+    __shared__ double s_acc[32 * 6];                                        // per-run sums {xx xy yy bx by n} of the staged half
 
     const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
     if (b >= p.nblk) return;  // the whole wave exits together
@@ -326,7 +327,6 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
                 p.d_temp[2 * i] = t0; p.d_temp[2 * i + 1] = t1;
                 p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy;
             } else {
-                if (!(p.ablate & 1)) atomicAdd(p.count + pi, 1);        // model.cpp:227
 #pragma unroll
                 for (int j = 0; j < 6; ++j) jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
                 ngx = -gx; ngy = -gy;
@@ -351,10 +351,32 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
         if (n_inl) atomicAdd(p.grp_cnt + (b / kEpGroup), n_inl);
     }
 
-    // Record stores and the per-pixel A22/b2 sums (model.cpp:426-439), issued COOPERATIVELY: a 128-B record (or the
-    // five accumulator doubles of one pixel) is one contiguous line in HBM, so eight adjacent lanes write one record
-    // per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial
-    // lines per instruction, store-issue bound).  Records pass through a per-wave LDS tile, half a wave at a time.
+    // Per-pixel sums (model.cpp:227 count, :426-439 A22/b2).  Consecutive events of a sensor pixel often land on the SAME panorama
+    // pixel (dense streams: the camera moves a fraction of a pixel between them), and every atomic costs one memory-side request
+    // whatever it carries, so runs of adjacent lanes with equal pixel are summed first (segmented inclusive scan over the wave,
+    // heads where the pixel changes) and only the last lane of a run emits: one int add of the run length, five fp64 adds.
+    double v0 = dpx * dpx, v1 = dpx * dpy, v2 = dpy * dpy, v3 = dpx * e, v4 = dpy * e;   // zero unless inlier (dpx,dpy,e are)
+    if (!inl) { v0 = 0; v1 = 0; v2 = 0; v3 = 0; v4 = 0; }
+    int run_n = inl ? 1 : 0;
+    const uint32_t key = inl ? pi : (kInvalidPix - (uint32_t)t);                     // non-inliers never join a run
+    const bool head = (t == 0) || (key != (uint32_t)dpp_shr1((int)key));
+    {
+        int flag = head ? 1 : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int f_up = __shfl_up(flag, d), n_up = __shfl_up(run_n, d);
+            const double a0 = __shfl_up(v0, d), a1 = __shfl_up(v1, d), a2 = __shfl_up(v2, d), a3 = __shfl_up(v3, d), a4 = __shfl_up(v4, d);
+            if (t >= d && !flag) { v0 += a0; v1 += a1; v2 += a2; v3 += a3; v4 += a4; run_n += n_up; flag = f_up; }
+        }
+    }
+    const int head_next = dpp_shl1(head ? 1 : 0);                                    // (cross-lane reads stay in uniform control flow)
+    const bool emit = inl && ((t == 63) || (head_next != 0));                        // last lane of its run
+    const unsigned long long emit_mask = __ballot(emit);
+
+    // Record stores and the emitted sums, issued COOPERATIVELY: a 128-B record (or the five accumulator doubles of one pixel)
+    // is one contiguous line in HBM, so eight adjacent lanes write one record per wave-instruction (8 full lines per
+    // instruction) instead of every lane writing into its own line (64 partial lines per instruction, store-issue bound).
+    // Records pass through a per-wave LDS tile, half a wave at a time.
     const uint32_t slot = cand ? p.ev_slot[i] : kNoSlot;
     const int c8 = t & 7;
 #pragma unroll
@@ -365,24 +387,26 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
             w2[3] = make_double2(jp[0], jp[1]); w2[4] = make_double2(jp[2], jp[3]); w2[5] = make_double2(jp[4], jp[5]);
             w2[6] = make_double2(dpx, dpy);
             w2[7] = make_double2(e, __hiloint2double(0, (int)pi));     // outliers: pi == kInvalidPix marks the slot invalid
+            if (emit) {
+                double* a = s_acc + (t & 31) * 6;
+                a[0] = v0; a[1] = v1; a[2] = v2; a[3] = v3; a[4] = v4; a[5] = (double)run_n;
+            }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int rr = 8 * r + (t >> 3);
             const int src = 32 * half + rr;
-            const bool is_c = (cand_mask >> src) & 1ull, is_i = (inl_mask >> src) & 1ull;
+            const bool is_c = (cand_mask >> src) & 1ull, is_i = (inl_mask >> src) & 1ull, is_e = (emit_mask >> src) & 1ull;
             const uint32_t slot_r = (uint32_t)__shfl((int)slot, src);
             const double2* rd = reinterpret_cast<const double2*>(s_tile + rr * kRecLds);
             if (is_c && (is_i || c8 == 7) && !(p.ablate & 2))
                 reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * slot_r)[c8] = rd[c8];
-            if (is_i && c8 < 5 && !(p.ablate & 8)) {
-                const double2 d = rd[6], tl = rd[7];
-                const uint32_t q = (uint32_t)__double2loint(tl.y);
-                const double a = (c8 < 3) ? ((c8 == 2) ? d.y : d.x) : tl.x;      // xx: dx*dx  xy: dx*dy  yy: dy*dy  bx: dx*e  by: dy*e
-                const double bq = (c8 == 0 || c8 == 3) ? d.x : d.y;
-                const double val = (c8 < 3) ? a * bq : bq * a;
-                atomicAdd(p.pixacc + (size_t)kPixAccStride * q + c8, val);
+            if (is_e && c8 < 6) {
+                const uint32_t q = (uint32_t)__double2loint(rd[7].y);
+                const double a = s_acc[rr * 6 + c8];
+                if (c8 < 5) { if (!(p.ablate & 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * q + c8, a); }
+                else if (!(p.ablate & 1)) atomicAdd(p.count + q, (int)a);          // model.cpp:227, run length at once
             }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it

@@ -47,6 +47,10 @@ SIGNATURES = {
     "emba_dump_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, _dp, _dp, _dp]),
     "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emba_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "emba_map_accept": (C.c_int, [C.c_void_p]),
+    "emba_map_reject": (C.c_int, [C.c_void_p]),
+    "emba_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "emba_eval_launch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64]),
     "emba_eval_finish": (C.c_int, [C.c_void_p, _dp, _szp, _i32p]),

@@ -45,7 +45,10 @@ struct emba_ctx {
     double* d_lut = nullptr;
     double* d_texel = nullptr;
     double* d_Gx_own = nullptr; double* d_Gy_own = nullptr;
-    const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // current map planes (own or bound)
+    const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // the map planes the next evaluation reads (current or trial)
+    const double* d_Gx_cur = nullptr; const double* d_Gy_cur = nullptr;   // current (accepted) map: own upload, bound, or accepted trial
+    double* d_Gx_trial = nullptr; double* d_Gy_trial = nullptr; bool map_is_trial = false;
+    double* d_x2 = nullptr; size_t x2_cap = 0;
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
     int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (EMBA_TEXEL=auto|pack|fly|rect)
@@ -372,7 +375,7 @@ void emba_destroy(emba_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_window(c);
-    dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own);
+    dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own); dev_free(c->d_Gx_trial); dev_free(c->d_Gy_trial); dev_free(c->d_x2);
     dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
     dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
     dev_free(c->d_total); dev_free(c->d_scalar);
@@ -480,7 +483,8 @@ emba_status emba_upload_map(emba_ctx* c, const double* Gx, const double* Gy)
     }
     HIP_TRY(c, hipMemcpyAsync(c->d_Gx_own, Gx, c->npix * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_Gy_own, Gy, c->npix * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    c->d_Gx = c->d_Gx_own; c->d_Gy = c->d_Gy_own;
+    c->d_Gx = c->d_Gx_cur = c->d_Gx_own; c->d_Gy = c->d_Gy_cur = c->d_Gy_own;
+    c->map_is_trial = false;
     c->have_map = true;
     return EMBA_OK;
 }
@@ -488,8 +492,72 @@ emba_status emba_upload_map(emba_ctx* c, const double* Gx, const double* Gy)
 emba_status emba_bind_map_dev(emba_ctx* c, const double* Gx_dev, const double* Gy_dev)
 {
     if (!c || !Gx_dev || !Gy_dev) return c ? fail(c, EMBA_ERR_INVALID_ARG, "Gx/Gy NULL") : EMBA_ERR_INVALID_ARG;
-    c->d_Gx = Gx_dev; c->d_Gy = Gy_dev;
+    c->d_Gx = c->d_Gx_cur = Gx_dev; c->d_Gy = c->d_Gy_cur = Gy_dev;
+    c->map_is_trial = false;
     c->have_map = true;
+    return EMBA_OK;
+}
+
+emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
+    if (!c->active_done && !c->P_pending) return fail(c, EMBA_ERR_STATE, "updateMap needs the active set of formNormalEq");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    if (c->P && !x2_host) return fail(c, EMBA_ERR_INVALID_ARG, "x2 NULL");
+    if (!c->d_Gx_trial) {
+        if ((st = dev_alloc(c, &c->d_Gx_trial, c->npix))) return st;
+        if ((st = dev_alloc(c, &c->d_Gy_trial, c->npix))) return st;
+    }
+    if (c->x2_cap < 2 * c->P) {
+        dev_free(c->d_x2);
+        if ((st = dev_alloc(c, &c->d_x2, 2 * c->P))) return st;
+        c->x2_cap = 2 * c->P;
+    }
+    hipStream_t s = c->stream;
+    if (c->P) HIP_TRY(c, hipMemcpyAsync(c->d_x2, x2_host, 2 * c->P * sizeof(double), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(emba_update_map_kernel, dim3((unsigned)((c->npix + 255) / 256)), dim3(256), 0, s, c->d_Gx_cur, c->d_Gy_cur, c->d_compact,
+                       c->d_x2, damping, (long)c->npix, c->d_Gx_trial, c->d_Gy_trial);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));   // x2_host may be freed by the caller
+    c->d_Gx = c->d_Gx_trial; c->d_Gy = c->d_Gy_trial;
+    c->map_is_trial = true;
+    return EMBA_OK;
+}
+
+emba_status emba_map_accept(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->map_is_trial) return fail(c, EMBA_ERR_STATE, "no trial map (call emba_update_map first)");
+    // the trial buffers become the current map; the previous current buffers (if ours) become the next trial buffers
+    double* old_x = (c->d_Gx_cur == c->d_Gx_own) ? c->d_Gx_own : nullptr;
+    double* old_y = (c->d_Gy_cur == c->d_Gy_own) ? c->d_Gy_own : nullptr;
+    c->d_Gx_own = c->d_Gx_trial; c->d_Gy_own = c->d_Gy_trial;
+    c->d_Gx_cur = c->d_Gx = c->d_Gx_own; c->d_Gy_cur = c->d_Gy = c->d_Gy_own;
+    c->d_Gx_trial = old_x; c->d_Gy_trial = old_y;
+    c->map_is_trial = false;
+    return EMBA_OK;
+}
+
+emba_status emba_map_reject(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->map_is_trial) return fail(c, EMBA_ERR_STATE, "no trial map (call emba_update_map first)");
+    c->d_Gx = c->d_Gx_cur; c->d_Gy = c->d_Gy_cur;
+    c->map_is_trial = false;
+    return EMBA_OK;
+}
+
+emba_status emba_download_map(emba_ctx* c, double* Gx_host, double* Gy_host)
+{
+    if (!c || !Gx_host || !Gy_host) return c ? fail(c, EMBA_ERR_INVALID_ARG, "Gx/Gy NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(Gx_host, c->d_Gx, c->npix * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(Gy_host, c->d_Gy, c->npix * sizeof(double), hipMemcpyDeviceToHost));
     return EMBA_OK;
 }
 
@@ -597,7 +665,7 @@ emba_status emba_eval_data_error(emba_ctx* c, const double* knots, int32_t K, in
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!eval_deriv) return fail(c, EMBA_ERR_INVALID_ARG, "eval_deriv=false is never used by the reference (solver.cpp:75,251) and is not provided");
     emba_status st;
-    if ((st = emba_upload_map(c, Gx, Gy))) return st;
+    if (Gx || Gy) { if ((st = emba_upload_map(c, Gx, Gy))) return st; }   // both NULL: evaluate on the resident (current or trial) map
     if ((st = emba_eval_launch(c, knots, K, t0_ns, dt_ns))) return st;
     return emba_eval_finish(c, ep_out, n_inliers, num_ev_map_out);
 }

@@ -873,6 +873,18 @@ __global__ void emba_l2reg_kernel(double* __restrict__ A22b2, const uint32_t* __
     q[4] -= alpha * Gy[pi];
 }
 
+// f2: LEGM::updateMap (model.cpp:863-903) from the current map into the trial map.
+__global__ void emba_update_map_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, const int32_t* __restrict__ compact,
+                                       const double* __restrict__ x2, double damping, long npix, double* __restrict__ Gx_new,
+                                       double* __restrict__ Gy_new)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const int32_t k = compact[i];
+    Gx_new[i] = (k >= 0) ? Gx[i] + damping * x2[2 * (size_t)k] : 0.0;         // :874 / :897
+    Gy_new[i] = (k >= 0) ? Gy[i] + damping * x2[2 * (size_t)k + 1] : 0.0;     // :875 / :898
+}
+
 // pack -> boundary layout: A22 P*4 ([xx xy; xy yy]) and b2 2P.
 __global__ void emba_unpack_kernel(const double* __restrict__ A22b2, long P, double* __restrict__ A22, double* __restrict__ b2)
 {

@@ -124,10 +124,13 @@ class LEGM:
         """model.cpp:72-258.  Returns ep (inlier residuals, reference order); fills num_ev_map (int32 H x W)."""
         if events is not None:
             self.set_events(events)
-        Gx = np.ascontiguousarray(Gx, dtype=np.float64)
-        Gy = np.ascontiguousarray(Gy, dtype=np.float64)
-        if Gx.shape != (self.H, self.W) or Gy.shape != (self.H, self.W):
-            raise ValueError("Gx/Gy must be pano_height x pano_width float64")
+        if Gx is None and Gy is None:      # evaluate on the map already resident on the device (uploaded, updated or bound)
+            pass
+        else:
+            Gx = np.ascontiguousarray(Gx, dtype=np.float64)
+            Gy = np.ascontiguousarray(Gy, dtype=np.float64)
+            if Gx.shape != (self.H, self.W) or Gy.shape != (self.H, self.W):
+                raise ValueError("Gx/Gy must be pano_height x pano_width float64")
         knots = np.ascontiguousarray(traj.knots_xyzw, dtype=np.float64).reshape(-1, 4)
         self.K = knots.shape[0]
         ep = np.empty(max(self.n_events, 1), dtype=np.float64)
@@ -189,6 +192,23 @@ class LEGM:
     def applyL2Reg(self, alpha, dense_A12=False):
         """model.cpp:689-719, applied to the device-resident pack; returns the updated blocks (call once per formNormalEq)."""
         return self._finish(alpha, dense_A12)
+
+    def updateMap(self, x2, damping_factor):
+        """model.cpp:863-903 on the device-resident map: builds the TRIAL map (active += damping*x2, all other pixels 0) that
+        the following evaluateDataError(traj, None, None) uses; report the LM decision with acceptMap() / rejectMap()."""
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        self._check(self._L.emba_update_map(self._ctx, _p(x2, _dp), float(damping_factor)))
+
+    def acceptMap(self):
+        self._check(self._L.emba_map_accept(self._ctx))
+
+    def rejectMap(self):
+        self._check(self._L.emba_map_reject(self._ctx))
+
+    def downloadMap(self):
+        Gx = np.empty((self.H, self.W)); Gy = np.empty((self.H, self.W))
+        self._check(self._L.emba_download_map(self._ctx, _p(Gx, _dp), _p(Gy, _dp)))
+        return Gx, Gy
 
     def A12_sparse(self):
         """Rank-1 factors of A12 (one per measurement candidate; pix == -1 marks outliers/inactive)."""

@@ -99,7 +99,8 @@ emba_status emba_event_counts(const emba_ctx* ctx, size_t* n_used, size_t* n_can
 /* LEGM::evaluateDataError(traj, Gx, Gy, events, eval_deriv=true, num_ev_map)   model.cpp:72-258.
  * knots_xyzw: K unit quaternions (x,y,z,w) = traj->getControlPose(i).unit_quaternion();
  * t0_ns/dt_ns: the spline's start_t_ns_/dt_ns_ (trajectory.cpp:59-64).
- * Gx, Gy: host, pano_h*pano_w f64 row-major (CV_64FC1 continuous).
+ * Gx, Gy: host, pano_h*pano_w f64 row-major (CV_64FC1 continuous); both NULL = use the map already resident on the
+ * device (emba_upload_map / emba_bind_map_dev / emba_update_map).
  * ep_out: host, capacity >= n_used, receives the residuals in the reference's order (sensor pixel
  * major, then time; model.cpp:179-186,221); *n_inliers = ep.size().  num_ev_map_out: host int32
  * pano_h*pano_w (model.cpp:227) or NULL.  eval_deriv must be non-zero (the reference never passes
@@ -147,6 +148,17 @@ emba_status emba_dump_state(emba_ctx* ctx, double* pm, double* D, int32_t* cp_id
 /* Copy the map to the device (host -> HBM), or adopt caller-owned device planes without a copy. */
 emba_status emba_upload_map(emba_ctx* ctx, const double* Gx_host, const double* Gy_host);
 emba_status emba_bind_map_dev(emba_ctx* ctx, const double* Gx_dev, const double* Gy_dev);
+
+/* LM-loop residency: LEGM::updateMap(Gx_new, Gy_new, x2, damping, active, inactive), model.cpp:863-903, on
+ * the device-resident map with the active set of the last emba_form_active: trial = current; trial[active_i] += damping*x2[2i],
+ * x2[2i+1]; trial[every other pixel] = 0.  From then on evaluations use the TRIAL map (pass Gx = Gy = NULL to
+ * emba_eval_data_error, or call emba_eval_launch) until the caller reports the LM decision: emba_map_accept makes the trial map
+ * current (solver.cpp:299-339), emba_map_reject drops it (:340-352).  x2_host: 2P doubles.  emba_download_map copies the map
+ * the next evaluation would use. */
+emba_status emba_update_map(emba_ctx* ctx, const double* x2_host, double damping);
+emba_status emba_map_accept(emba_ctx* ctx);
+emba_status emba_map_reject(emba_ctx* ctx);
+emba_status emba_download_map(emba_ctx* ctx, double* Gx_host, double* Gy_host);
 
 /* Bind caller-owned device buffers that the caller all-reduces between phases:
  *   count_map_dev : int32 pano_h*pano_w                       (exchange 1)

@@ -642,6 +642,23 @@ void emba_oracle_apply_l2(const emba_oracle* o, size_t P, const uint32_t* active
     }
 }
 
+/* f2 — LEGM::updateMap, model.cpp:863-903: active pixels (ascending, i-th <-> x2[2i], x2[2i+1]) are incremented (:869-878),
+ * inactive pixels — all the others — are set to zero (:892-901). */
+void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, const double* x2, double damping,
+                            double* Gx, double* Gy)
+{
+    uint8_t* act = (uint8_t*)calloc(npix ? npix : 1, 1);
+    for (size_t i = 0; i < P; ++i) {
+        const size_t p = active_idx[i];
+        Gx[p] += damping * x2[2 * i];
+        Gy[p] += damping * x2[2 * i + 1];
+        act[p] = 1;
+    }
+    for (size_t p = 0; p < npix; ++p)
+        if (!act[p]) { Gx[p] = 0.0; Gy[p] = 0.0; }
+    free(act);
+}
+
 /* a12 — 0.5*ep.dot(ep) (solver.cpp:88,265) or evaluateRobustDataCost (model.cpp:279-314) */
 double emba_oracle_data_cost(const double* ep, size_t m, int irls, double a)
 {

@@ -8,7 +8,7 @@
  * Pinning status (see DESIGN.md "Oracle"):
  *   a3 (SO(3) linear spline value + Jacobian, Sophus exp/log, basalt Jl/Jl^-1):
  *        PINNED against the reference's own unmodified headers compiled into
- *        oracle/_ref/libref_basalt.so and against tests/golden/so3_spline_n2.bin.
+ *        oracle/_ref/libref_basalt.so and against tests/golden/so3_spline_n2.npz.
  *   a1,a2,a4-a12 (ros::Time midpoint, cv::Sobel, warp, projection, pairing, normal eq.):
  *        PARITY UNPINNED — the reference holds no golden vectors / assertions for them
  *         and model.cpp / event_pano_warper.cpp / trajectory.cpp /
@@ -94,6 +94,10 @@ long emba_oracle_form_normal_eq(emba_oracle* o, const double* ep, int K, const i
 /* a11: LEGM::applyL2Reg (model.cpp:689-719). */
 void emba_oracle_apply_l2(const emba_oracle* o, size_t P, const uint32_t* active_idx, double alpha,
                           const double* Gx, const double* Gy, double* A22, double* b2);
+
+/* f2: LEGM::updateMap (model.cpp:863-903), in place: active pixels += damping*x2, every other pixel := 0. */
+void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, const double* x2, double damping,
+                            double* Gx, double* Gy);
 
 /* a12: cost terms.  0.5*ep.ep (src/emba/solver.cpp:88); evaluateRobustDataCost (model.cpp:279-314);
  * 0.5*alpha*|evaluateRegError|^2 (model.cpp:260-277, solver.cpp:90). */

@@ -69,6 +69,7 @@ def lib():
                                                  C.c_double, _dp, _dp, C.POINTER(C.c_uint32), _dp, _dp, _dp]
         L.emba_oracle_apply_l2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_double, _dp,
                                            _dp, _dp, _dp]
+        L.emba_oracle_update_map.argtypes = [C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, _dp, C.c_double, _dp, _dp]
         L.emba_oracle_data_cost.restype = C.c_double
         L.emba_oracle_data_cost.argtypes = [_dp, C.c_size_t, C.c_int, C.c_double]
         L.emba_oracle_reg_cost.restype = C.c_double
@@ -150,6 +151,14 @@ def hessian(Gx, Gy):
     out = [np.zeros((H, W)) for _ in range(3)]
     lib().emba_oracle_hessian(_ptr(Gx, _dp), _ptr(Gy, _dp), H, W, *[_ptr(o, _dp) for o in out])
     return out
+
+
+def update_map(active, x2, damping, Gx, Gy):
+    """LEGM::updateMap (model.cpp:863-903) on copies; returns (Gx_new, Gy_new)."""
+    Gx = _f64(Gx).copy(); Gy = _f64(Gy).copy()
+    act = np.ascontiguousarray(active, dtype=np.uint32); x2 = _f64(x2)
+    lib().emba_oracle_update_map(act.size, _ptr(act, C.POINTER(C.c_uint32)), Gx.size, _ptr(x2, _dp), float(damping), _ptr(Gx, _dp), _ptr(Gy, _dp))
+    return Gx, Gy
 
 
 def data_cost(ep, irls=0, a=0.0):

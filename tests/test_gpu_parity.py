@@ -339,3 +339,48 @@ def test_hessian_sources_agree(gpu, oracle_mod, mode, monkeypatch):
         assert np.array_equal(nem, o["num_ev_map"])
         assert_close(ep, o["ep"], "ep")
         compare_normal_eq(ne, o["ne"])
+
+
+def test_lm_loop_map_residency(gpu, oracle_mod):
+    """the map stays on the device across LM trial points.  updateMap (model.cpp:863-903) builds the trial map,
+    evaluateDataError(traj, None, None) runs on it, accept/reject follow the LM decision (solver.cpp:299-352)."""
+    from emba_amd import EmbaError
+    w = small_workload(n_events=20000)
+    m = make_legm(w)
+    m.set_events(w.events)
+    rng = np.random.default_rng(1)
+    Gx, Gy = w.Gx.copy(), w.Gy.copy()                       # oracle-side current map
+    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+    ep0 = m.evaluateDataError(w.traj, Gx, Gy, None, True, nem)   # uploads once
+    with pytest.raises(EmbaError):
+        m.acceptMap()                                        # nothing to accept yet
+    for step, decision in enumerate(["reject", "accept", "accept"]):
+        m.formNormalEq(ep0, w.K, nem, w.thres_valid_pixel)
+        ne = m.applyL2Reg(w.alpha)
+        x2 = rng.normal(size=2 * ne["P"]) * 0.01
+        m.updateMap(x2, 0.7)
+        Gx_t, Gy_t = oracle_mod.update_map(ne["active"], x2, 0.7, Gx, Gy)
+        dx, dy = m.downloadMap()
+        assert np.allclose(dx, Gx_t, rtol=0, atol=1e-16) and np.allclose(dy, Gy_t, rtol=0, atol=1e-16)
+        assert (dx.ravel()[np.setdiff1d(np.arange(dx.size), ne["active"])] == 0).all()
+        # trial evaluation on the resident map == oracle on the updated map
+        wt = small_workload(n_events=20000); wt.Gx, wt.Gy = Gx_t, Gy_t
+        ot = oracle_run(oracle_mod, wt)
+        nem_t = np.zeros_like(nem)
+        ep_t = m.evaluateDataError(w.traj, None, None, None, True, nem_t)
+        assert np.array_equal(nem_t, ot["num_ev_map"])
+        assert_close(ep_t, ot["ep"], "trial ep")
+        assert m.regCost(w.alpha) == pytest.approx(oracle_mod.reg_cost(Gx_t, Gy_t, w.alpha), rel=1e-12)
+        if decision == "reject":
+            m.rejectMap()
+            nem_b = np.zeros_like(nem)
+            ep_b = m.evaluateDataError(w.traj, None, None, None, True, nem_b)
+            assert np.array_equal(nem_b, nem) and np.array_equal(ep_b, ep0)     # back on the old map, bit for bit
+        else:
+            m.acceptMap()
+            Gx, Gy, ep0, nem = Gx_t, Gy_t, ep_t, nem_t
+            ne2 = m.formNormalEq(ep0, w.K, nem, w.thres_valid_pixel)
+            compare_normal_eq(m.applyL2Reg(w.alpha), ot["ne"])
+            nem_c = np.zeros_like(nem)
+            ep0 = m.evaluateDataError(w.traj, None, None, None, True, nem_c)     # state for the next formNormalEq
+            assert np.array_equal(nem_c, nem)

@@ -285,3 +285,14 @@ def test_empty_and_tiny_inputs(oracle_mod):
     w = small_workload(n_events=0)
     r = oracle_run(O, w, alpha=0)
     assert r["ep"].size == 0 and r["ne"]["P"] == 0
+
+
+def test_update_map_known_answers(oracle_mod):
+    """LEGM::updateMap (model.cpp:863-903): active += damping*x2 in ascending order, every other pixel := 0."""
+    Gx = np.arange(12.0).reshape(3, 4) + 1; Gy = -Gx
+    act = np.array([1, 5, 6], dtype=np.uint32); x2 = np.array([10.0, 20, 30, 40, 50, 60])
+    nx, ny = oracle_mod.update_map(act, x2, 0.5, Gx, Gy)
+    ex = np.zeros(12); ey = np.zeros(12)
+    ex[[1, 5, 6]] = Gx.ravel()[[1, 5, 6]] + 0.5 * x2[0::2]; ey[[1, 5, 6]] = Gy.ravel()[[1, 5, 6]] + 0.5 * x2[1::2]
+    assert np.array_equal(nx.ravel(), ex) and np.array_equal(ny.ravel(), ey)
+    assert np.array_equal(Gx, np.arange(12.0).reshape(3, 4) + 1)          # inputs untouched (the reference clones first, solver.cpp:237)

@@ -9,9 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libemba_hip.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY = range(7)
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY, ERR_NUMERIC, ERR_LIBRARY = range(9)
 STATUS_NAMES = ["EMBA_OK", "EMBA_ERR_INVALID_ARG", "EMBA_ERR_NO_DEVICE", "EMBA_ERR_HIP", "EMBA_ERR_TIME_RANGE",
-                "EMBA_ERR_STATE", "EMBA_ERR_CAPACITY"]
+                "EMBA_ERR_STATE", "EMBA_ERR_CAPACITY", "EMBA_ERR_NUMERIC", "EMBA_ERR_LIBRARY"]
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)
@@ -47,6 +47,7 @@ SIGNATURES = {
     "emba_dump_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, _dp, _dp, _dp]),
     "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "emba_solve_normal_eq": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, _dp, _dp]),
     "emba_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "emba_map_accept": (C.c_int, [C.c_void_p]),
     "emba_map_reject": (C.c_int, [C.c_void_p]),

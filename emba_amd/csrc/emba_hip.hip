@@ -16,6 +16,9 @@
 #include <vector>
 
 #include "kernels.h"
+#include "solve_kernels.h"
+
+#include <dlfcn.h>
 
 using namespace emba;
 
@@ -98,6 +101,12 @@ struct emba_ctx {
     hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
     bool kt_warp_valid = false, kt_accum_valid = false;
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
+    bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
+    // rocBLAS, loaded on first use (plain SYRK/GEMV of the Schur solve only; the hot path never touches it)
+    void* rb_lib = nullptr; void* rb_handle = nullptr;
+    int (*rb_create)(void**) = nullptr; int (*rb_destroy)(void*) = nullptr; int (*rb_set_stream)(void*, hipStream_t) = nullptr;
+    int (*rb_dsyrk)(void*, int, int, int, int, const double*, const double*, int, const double*, double*, int) = nullptr;
+    int (*rb_dgemv)(void*, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
 };
 
 namespace {
@@ -384,6 +393,8 @@ void emba_destroy(emba_ctx* c)
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
     for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
+    if (c->rb_handle && c->rb_destroy) (void)c->rb_destroy(c->rb_handle);
+    if (c->rb_lib) dlclose(c->rb_lib);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -747,7 +758,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
     }
     HIP_TRY(c, hipGetLastError());
-    c->accum_done = true;
+    c->accum_done = true; c->finish_done = false;
     return EMBA_OK;
 }
 
@@ -794,6 +805,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     dev_free(d_A22); dev_free(d_b2); dev_free(d_A12);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "form_finish: %s", hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
+    c->finish_done = true;
     return EMBA_OK;
 }
 
@@ -1006,3 +1018,116 @@ emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 }
 
 }  // extern "C"
+
+namespace {
+emba_status load_rocblas(emba_ctx* c)
+{
+    if (c->rb_handle) return EMBA_OK;
+    c->rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!c->rb_lib) c->rb_lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
+    if (!c->rb_lib) return fail(c, EMBA_ERR_LIBRARY, "cannot load librocblas.so: %s", dlerror());
+    c->rb_create = (int (*)(void**))dlsym(c->rb_lib, "rocblas_create_handle");
+    c->rb_destroy = (int (*)(void*))dlsym(c->rb_lib, "rocblas_destroy_handle");
+    c->rb_set_stream = (int (*)(void*, hipStream_t))dlsym(c->rb_lib, "rocblas_set_stream");
+    c->rb_dsyrk = (decltype(c->rb_dsyrk))dlsym(c->rb_lib, "rocblas_dsyrk");
+    c->rb_dgemv = (decltype(c->rb_dgemv))dlsym(c->rb_lib, "rocblas_dgemv");
+    if (!c->rb_create || !c->rb_destroy || !c->rb_set_stream || !c->rb_dsyrk || !c->rb_dgemv)
+        return fail(c, EMBA_ERR_LIBRARY, "librocblas.so lacks an expected symbol");
+    if (c->rb_create(&c->rb_handle) != 0) { c->rb_handle = nullptr; return fail(c, EMBA_ERR_LIBRARY, "rocblas_create_handle failed"); }
+    if (c->rb_set_stream(c->rb_handle, c->stream) != 0) return fail(c, EMBA_ERR_LIBRARY, "rocblas_set_stream failed");
+    return EMBA_OK;
+}
+// rocBLAS enum values (rocblas-types.h): operation none = 111, transpose = 112; fill upper = 121, lower = 122
+constexpr int kRbNone = 111, kRbTrans = 112, kRbLower = 122;
+}  // namespace
+
+extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEq needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    if ((st = load_rocblas(c))) return st;
+    hipStream_t s = c->stream;
+    const int n = 3 * c->K;
+    const int skip = fix_first_pose ? 3 : 0, m = n - skip;
+    const size_t P = c->P, M = c->n_cand;
+    if (m <= 0) return fail(c, EMBA_ERR_INVALID_ARG, "nothing to solve for");
+
+    // workspaces (this is not the per-iteration hot path: plain allocations)
+    uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr, *d_blk = nullptr, *d_blk_off = nullptr, *d_tot = nullptr;
+    double *d_S = nullptr, *d_rhs = nullptr, *d_U = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_z = nullptr, *d_x2 = nullptr;
+    int* d_info = nullptr;
+    const size_t nblk = (P + 2047) / 2048;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)n)));   // <= 6 GB of U
+    auto cleanup = [&]() {
+        dev_free(d_off); dev_free(d_cursor); dev_free(d_bucket); dev_free(d_blk); dev_free(d_blk_off); dev_free(d_tot); dev_free(d_S);
+        dev_free(d_rhs); dev_free(d_U); dev_free(d_y); dev_free(d_cf); dev_free(d_z); dev_free(d_x2); dev_free(d_info);
+    };
+#define SOLVE_TRY(expr) do { emba_status st_ = (expr); if (st_) { cleanup(); return st_; } } while (0)
+#define SOLVE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
+    SOLVE_TRY(dev_alloc(c, &d_off, P + 1)); SOLVE_TRY(dev_alloc(c, &d_cursor, P)); SOLVE_TRY(dev_alloc(c, &d_bucket, M));
+    SOLVE_TRY(dev_alloc(c, &d_blk, nblk)); SOLVE_TRY(dev_alloc(c, &d_blk_off, nblk)); SOLVE_TRY(dev_alloc(c, &d_tot, 1));
+    SOLVE_TRY(dev_alloc(c, &d_S, (size_t)n * n)); SOLVE_TRY(dev_alloc(c, &d_rhs, (size_t)n)); SOLVE_TRY(dev_alloc(c, &d_U, (size_t)n * 2 * chunk));
+    SOLVE_TRY(dev_alloc(c, &d_y, 2 * P)); SOLVE_TRY(dev_alloc(c, &d_cf, 3 * P)); SOLVE_TRY(dev_alloc(c, &d_z, 2 * chunk)); SOLVE_TRY(dev_alloc(c, &d_x2, 2 * P));
+    SOLVE_TRY(dev_alloc(c, &d_info, 1));
+    SOLVE_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
+    SOLVE_HIP(hipMemsetAsync(d_cursor, 0, std::max<size_t>(P, 1) * sizeof(uint32_t), s));
+    SOLVE_HIP(hipMemsetAsync(d_off, 0, (P + 1) * sizeof(uint32_t), s));
+
+    // per-pixel record lists
+    if (P) {
+        hipLaunchKernelGGL(emba_csr_scan1_kernel, dim3((unsigned)nblk), dim3(256), 0, s, c->d_count, c->d_active, (long)P, d_off, d_blk);
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, d_blk, d_blk_off, (long)nblk, d_tot, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(emba_csr_scan3_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_off, (long)P, d_blk_off, d_tot);
+        if (M)
+            hipLaunchKernelGGL(emba_csr_fill_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, (long)M, c->d_count, c->d_compact,
+                               c->thres, d_off, d_cursor, d_bucket);
+    }
+    hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, d_rhs);
+    SOLVE_HIP(hipGetLastError());
+
+    SchurBuildParams bp{};
+    bp.rec = c->d_rec; bp.slot_key = c->d_slot_key; bp.off = d_off; bp.bucket = d_bucket; bp.A22b2 = pack_A22b2(c); bp.lambda = lambda;
+    bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = n; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
+    const size_t lds = (size_t)4 * 2 * n * sizeof(double);
+    if (lds > 160 * 1024) { cleanup(); return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", c->K); }
+    if (lds > 64 * 1024) SOLVE_HIP(hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const double neg1 = -1.0, one = 1.0, zero = 0.0;
+    auto build = [&](size_t p0, size_t p1) {
+        bp.p0 = (long)p0; bp.p1 = (long)p1;
+        const unsigned grid = (unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096);
+        hipLaunchKernelGGL(emba_schur_build_kernel, dim3(grid), dim3(256), lds, s, bp);
+    };
+    // pass 1: S -= U U^T (lower triangle), rhs -= U y, chunk by chunk
+    for (size_t p0 = 0; p0 < P; p0 += chunk) {
+        const size_t p1 = std::min(P, p0 + chunk);
+        build(p0, p1);
+        const int kc = (int)(2 * (p1 - p0));
+        if (c->rb_dsyrk(c->rb_handle, kRbLower, kRbNone, m, kc, &neg1, d_U + skip, n, &one, d_S + skip + (size_t)skip * n, n) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dsyrk failed"); }
+        if (c->rb_dgemv(c->rb_handle, kRbNone, m, kc, &neg1, d_U + skip, n, d_y + 2 * p0, 1, &one, d_rhs + skip, 1) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dgemv failed"); }
+    }
+    // x1 = S \ rhs (Cholesky), rows 0..skip-1 stay out of the system
+    hipLaunchKernelGGL(emba_chol_solve_kernel, dim3(1), dim3(1024), 0, s, d_S + skip + (size_t)skip * n, m, n, d_rhs + skip, d_info);
+    if (skip) SOLVE_HIP(hipMemsetAsync(d_rhs, 0, skip * sizeof(double), s));
+    // pass 2: x2 = C^-T (y - U^T x1)
+    for (size_t p0 = 0; p0 < P; p0 += chunk) {
+        const size_t p1 = std::min(P, p0 + chunk);
+        if (P > chunk) build(p0, p1);     // a single chunk is still resident from pass 1
+        const int kc = (int)(2 * (p1 - p0));
+        if (c->rb_dgemv(c->rb_handle, kRbTrans, m, kc, &one, d_U + skip, n, d_rhs + skip, 1, &zero, d_z, 1) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dgemv failed"); }
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, s, d_y, d_z, d_cf, (long)p0, (long)p1, d_x2);
+    }
+    SOLVE_HIP(hipGetLastError());
+    int info = 0;
+    SOLVE_HIP(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (x1_host) SOLVE_HIP(hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (x2_host && P) SOLVE_HIP(hipMemcpyAsync(x2_host, d_x2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    SOLVE_HIP(hipStreamSynchronize(s));
+    cleanup();
+#undef SOLVE_TRY
+#undef SOLVE_HIP
+    if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    return EMBA_OK;
+}

@@ -193,6 +193,13 @@ class LEGM:
         """model.cpp:689-719, applied to the device-resident pack; returns the updated blocks (call once per formNormalEq)."""
         return self._finish(alpha, dense_A12)
 
+    def solveNormalEq(self, lam, fix_first_pose=False):
+        """model.cpp:721-792 on the device-resident, L2-regularised normal equations (call after applyL2Reg, solver.cpp:130,190):
+        returns (x1 [3K, zeros for a fixed first pose], x2 [2P])."""
+        x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
+        self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
+        return x1, x2[:2 * self._P]
+
     def updateMap(self, x2, damping_factor):
         """model.cpp:863-903 on the device-resident map: builds the TRIAL map (active += damping*x2, all other pixels 0) that
         the following evaluateDataError(traj, None, None) uses; report the LM decision with acceptMap() / rejectMap()."""

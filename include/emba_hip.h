@@ -48,7 +48,9 @@ typedef enum {
     EMBA_ERR_TIME_RANGE = 4,    /* a batch midpoint lies outside the spline's knots
                                    (BASALT_ASSERT at so3_spline.h:221-229 in the reference) */
     EMBA_ERR_STATE = 5,         /* call order violated (e.g. form before eval) */
-    EMBA_ERR_CAPACITY = 6       /* a caller-provided buffer is too small */
+    EMBA_ERR_CAPACITY = 6,      /* a caller-provided buffer is too small */
+    EMBA_ERR_NUMERIC = 7,       /* the damped system is not positive definite (Cholesky pivot <= 0) */
+    EMBA_ERR_LIBRARY = 8        /* rocBLAS (used for the plain SYRK/GEMV of the Schur solve) could not be loaded */
 } emba_status;
 
 typedef struct emba_ctx emba_ctx;
@@ -159,6 +161,15 @@ emba_status emba_update_map(emba_ctx* ctx, const double* x2_host, double damping
 emba_status emba_map_accept(emba_ctx* ctx);
 emba_status emba_map_reject(emba_ctx* ctx);
 emba_status emba_download_map(emba_ctx* ctx, double* Gx_host, double* Gy_host);
+
+/* Schur-complement solve: LEGM::solveNormalEq(A11, A12, A22_blocks, b1, b2, lambda, x1, x2), model.cpp:721-792,
+ * on the device-resident normal equations of the last emba_form_finish (so after applyL2Reg, as in solver.cpp:130,190-202),
+ * consuming the SPARSE A12 factors: S = A11m - A12 A22m^-1 A12^T is formed chunk-wise from per-pixel column pairs built from the
+ * records, x1 = S \ (b1 - A12 A22m^-1 b2) by Cholesky, x2 = A22m^-1 (b2 - A12^T x1).  LM damping as the reference:
+ * A11m = A11 + lambda*diag(A11), A22m = A22 + lambda*diag(A22).  fix_first_pose != 0 reproduces the first-window trim of
+ * solver.cpp:156-165 (rows/cols 0..2 dropped; x1[0..2] = 0 on return).  x1_host: 3K doubles, x2_host: 2P doubles (either may
+ * be NULL).  Single GPU only (a sharded Schur step needs the per-pixel A12 columns of all ranks). */
+emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
 
 /* Bind caller-owned device buffers that the caller all-reduces between phases:
  *   count_map_dev : int32 pano_h*pano_w                       (exchange 1)

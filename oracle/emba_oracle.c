@@ -659,6 +659,72 @@ void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, c
     free(act);
 }
 
+/* f1 — LEGM::solveNormalEq, model.cpp:721-792 */
+int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double* A12, const double* A22, const double* b1,
+                                const double* b2, double lambda, double* x1, double* x2)
+{
+    const size_t dm = 2 * P;
+    double* Binv = (double*)malloc((P ? P : 1) * 4 * sizeof(double));
+    double* W = (double*)calloc((size_t)n * (dm ? dm : 1), sizeof(double));
+    double* S = (double*)malloc((size_t)n * n * sizeof(double));
+    double* rhs = (double*)malloc((size_t)n * sizeof(double));
+    /* A11m = A11 + lambda*diag(A11), :728-730 */
+    for (int c = 0; c < n; ++c)
+        for (int r = 0; r < n; ++r) S[r + (size_t)n * c] = A11[r + (size_t)n * c] + ((r == c) ? lambda * A11[r + (size_t)n * c] : 0.0);
+    /* A22m_i = A22_i + lambda*diag(A22_i), inverse of each 2x2, :743-759 */
+    for (size_t i = 0; i < P; ++i) {
+        const double a = A22[4 * i] + lambda * A22[4 * i], b = A22[4 * i + 1], c = A22[4 * i + 2], d = A22[4 * i + 3] + lambda * A22[4 * i + 3];
+        const double det = a * d - b * c;
+        Binv[4 * i] = d / det; Binv[4 * i + 1] = -b / det; Binv[4 * i + 2] = -c / det; Binv[4 * i + 3] = a / det;
+    }
+    /* W = A12 * A22m_inv, :784 */
+    for (size_t i = 0; i < P; ++i)
+        for (int r = 0; r < n; ++r) {
+            const double a0 = A12[r + (size_t)n * (2 * i)], a1 = A12[r + (size_t)n * (2 * i + 1)];
+            W[r + (size_t)n * (2 * i)] = a0 * Binv[4 * i] + a1 * Binv[4 * i + 2];
+            W[r + (size_t)n * (2 * i + 1)] = a0 * Binv[4 * i + 1] + a1 * Binv[4 * i + 3];
+        }
+    /* S = A11m - W * A12^T, :786 ; rhs = b1 - W*b2, :789 */
+    for (int r = 0; r < n; ++r) {
+        double acc = b1[r];
+        for (size_t k = 0; k < dm; ++k) acc -= W[r + (size_t)n * k] * b2[k];
+        rhs[r] = acc;
+    }
+    for (size_t k = 0; k < dm; ++k)
+        for (int c = 0; c < n; ++c) {
+            const double a = A12[c + (size_t)n * k];
+            if (a == 0.0) continue;
+            for (int r = 0; r < n; ++r) S[r + (size_t)n * c] -= W[r + (size_t)n * k] * a;
+        }
+    /* x1 = S.ldlt().solve(rhs), :789 — unpivoted LDL^T in place (lower) */
+    int bad = 0;
+    for (int j = 0; j < n; ++j) {
+        double d = S[j + (size_t)n * j];
+        for (int k = 0; k < j; ++k) d -= S[j + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
+        if (d == 0.0) { bad = 1; break; }
+        S[j + (size_t)n * j] = d;
+        for (int r = j + 1; r < n; ++r) {
+            double v = S[r + (size_t)n * j];
+            for (int k = 0; k < j; ++k) v -= S[r + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
+            S[r + (size_t)n * j] = v / d;
+        }
+    }
+    if (!bad) {
+        for (int r = 0; r < n; ++r) { double v = rhs[r]; for (int k = 0; k < r; ++k) v -= S[r + (size_t)n * k] * x1[k]; x1[r] = v; }
+        for (int r = 0; r < n; ++r) x1[r] /= S[r + (size_t)n * r];
+        for (int r = n - 1; r >= 0; --r) { double v = x1[r]; for (int k = r + 1; k < n; ++k) v -= S[k + (size_t)n * r] * x1[k]; x1[r] = v; }
+        /* x2 = A22m_inv * (b2 - A12^T x1), :791 */
+        for (size_t i = 0; i < P; ++i) {
+            double t0 = b2[2 * i], t1 = b2[2 * i + 1];
+            for (int r = 0; r < n; ++r) { t0 -= A12[r + (size_t)n * (2 * i)] * x1[r]; t1 -= A12[r + (size_t)n * (2 * i + 1)] * x1[r]; }
+            x2[2 * i] = Binv[4 * i] * t0 + Binv[4 * i + 1] * t1;
+            x2[2 * i + 1] = Binv[4 * i + 2] * t0 + Binv[4 * i + 3] * t1;
+        }
+    }
+    free(Binv); free(W); free(S); free(rhs);
+    return bad;
+}
+
 /* a12 — 0.5*ep.dot(ep) (solver.cpp:88,265) or evaluateRobustDataCost (model.cpp:279-314) */
 double emba_oracle_data_cost(const double* ep, size_t m, int irls, double a)
 {

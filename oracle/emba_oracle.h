@@ -99,6 +99,13 @@ void emba_oracle_apply_l2(const emba_oracle* o, size_t P, const uint32_t* active
 void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, const double* x2, double damping,
                             double* Gx, double* Gy);
 
+/* f1: LEGM::solveNormalEq (model.cpp:721-792), dense like the reference (small sizes only): A11 n x n and A12 n x 2P
+ * column-major, A22 P x [xx xy; xy yy], LM damping A?m = A + lambda*diag(A).  x1[n], x2[2P].  The n x n solve is an unpivoted
+ * LDL^T (the reference uses Eigen's pivoted ldlt; for the positive definite S of a damped system both give the solution to
+ * rounding).  Returns 0, or 1 if a pivot vanishes. */
+int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double* A12, const double* A22, const double* b1,
+                                const double* b2, double lambda, double* x1, double* x2);
+
 /* a12: cost terms.  0.5*ep.ep (src/emba/solver.cpp:88); evaluateRobustDataCost (model.cpp:279-314);
  * 0.5*alpha*|evaluateRegError|^2 (model.cpp:260-277, solver.cpp:90). */
 double emba_oracle_data_cost(const double* ep, size_t m, int irls, double a);

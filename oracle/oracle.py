@@ -70,6 +70,8 @@ def lib():
         L.emba_oracle_apply_l2.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.c_double, _dp,
                                            _dp, _dp, _dp]
         L.emba_oracle_update_map.argtypes = [C.c_size_t, C.POINTER(C.c_uint32), C.c_size_t, _dp, C.c_double, _dp, _dp]
+        L.emba_oracle_solve_normal_eq.restype = C.c_int
+        L.emba_oracle_solve_normal_eq.argtypes = [C.c_int, C.c_size_t, _dp, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp]
         L.emba_oracle_data_cost.restype = C.c_double
         L.emba_oracle_data_cost.argtypes = [_dp, C.c_size_t, C.c_int, C.c_double]
         L.emba_oracle_reg_cost.restype = C.c_double
@@ -159,6 +161,22 @@ def update_map(active, x2, damping, Gx, Gy):
     act = np.ascontiguousarray(active, dtype=np.uint32); x2 = _f64(x2)
     lib().emba_oracle_update_map(act.size, _ptr(act, C.POINTER(C.c_uint32)), Gx.size, _ptr(x2, _dp), float(damping), _ptr(Gx, _dp), _ptr(Gy, _dp))
     return Gx, Gy
+
+
+def solve_normal_eq(ne, lam, fix_first_pose=False):
+    """LEGM::solveNormalEq (model.cpp:721-792) on a dict from OracleLEGM.form_normal_eq(dense_A12=True) (after apply_l2).
+    fix_first_pose trims rows/cols 0..2 like solver.cpp:156-165; x1 comes back with zeros there."""
+    A11 = np.asfortranarray(ne["A11"]); A12 = np.asfortranarray(ne["A12"]); b1 = _f64(ne["b1"])
+    sk = 3 if fix_first_pose else 0
+    A11s = np.asfortranarray(A11[sk:, sk:]); A12s = np.asfortranarray(A12[sk:, :]); b1s = _f64(b1[sk:])
+    n, P = A11s.shape[0], ne["P"]
+    A22 = _f64(ne["A22"]); b2 = _f64(ne["b2"])
+    x1 = np.zeros(n); x2 = np.zeros(2 * max(P, 1))
+    rc = lib().emba_oracle_solve_normal_eq(n, P, _ptr(A11s, _dp), _ptr(A12s, _dp), _ptr(A22, _dp), _ptr(b1s, _dp), _ptr(b2, _dp), float(lam),
+                                           _ptr(x1, _dp), _ptr(x2, _dp))
+    if rc:
+        raise ValueError("singular system")
+    return np.concatenate([np.zeros(sk), x1]), x2[:2 * P]
 
 
 def data_cost(ep, irls=0, a=0.0):

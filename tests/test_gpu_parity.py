@@ -384,3 +384,65 @@ def test_lm_loop_map_residency(gpu, oracle_mod):
             nem_c = np.zeros_like(nem)
             ep0 = m.evaluateDataError(w.traj, None, None, None, True, nem_c)     # state for the next formNormalEq
             assert np.array_equal(nem_c, nem)
+
+
+@pytest.mark.parametrize("cfg,lam,fix,cost", [
+    (dict(n_events=20000), 1e-3, True, ("quadratic", 0.0)),
+    (dict(n_events=20000), 10.0, False, ("quadratic", 0.0)),
+    (dict(n_events=30000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01), 1e-2, True, ("huber", 0.1)),
+    (dict(n_events=8000, pano_h=64, K=4, sensor=(16, 12), focal=12.0), 1e-3, True, ("cauchy", 1.0)),
+])
+def test_schur_solve_parity(gpu, oracle_mod, cfg, lam, fix, cost):
+    """SURVEY §8f1: LEGM::solveNormalEq (model.cpp:721-792) on the device from the sparse A12 factors, against the dense CPU
+    restatement; also the residual of the full damped system."""
+    w = small_workload(**cfg)
+    irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
+    g = gpu_run(w, cost_type=cost[0], a=cost[1])
+    o = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
+    x1, x2 = g["legm"].solveNormalEq(lam, fix_first_pose=fix)
+    ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+    assert x1.shape == ox1.shape and x2.shape == ox2.shape
+    assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max())
+    assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+    if fix:
+        assert (x1[:3] == 0).all()
+    # calling it again (e.g. a rejected step retried with a larger lambda, solver.cpp:181-202) works on the same state
+    x1b, x2b = g["legm"].solveNormalEq(10 * lam, fix_first_pose=fix)
+    ob1, ob2 = oracle_mod.solve_normal_eq(o["ne"], 10 * lam, fix)
+    assert np.allclose(x1b, ob1, rtol=1e-7, atol=1e-9 * np.abs(ob1).max()) and np.allclose(x2b, ob2, rtol=1e-7, atol=1e-9 * np.abs(ob2).max())
+
+
+def test_lm_iterations_decrease_cost(gpu, oracle_mod):
+    """A few full Levenberg-Marquardt iterations entirely through the device path (evaluate -> form -> L2 -> solve -> update map and
+    poses -> evaluate), following solver.cpp:63-353: with a good damping the accepted steps must lower the total cost."""
+    from emba_amd.synth import so3_exp_xyzw
+    w = small_workload(n_events=30000)
+    m = make_legm(w)
+    m.set_events(w.events)
+    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+    traj = type(w.traj)(w.traj.knots_xyzw.copy(), w.traj.t0_ns, w.traj.dt_ns)
+    ep = m.evaluateDataError(traj, w.Gx, w.Gy, None, True, nem)
+    cost = m.dataCost() + m.regCost(w.alpha)
+    lam, accepted = 1e-2, 0
+    for it in range(6):
+        m.formNormalEq(ep, w.K, nem, w.thres_valid_pixel)
+        m.applyL2Reg(w.alpha)
+        x1, x2 = m.solveNormalEq(lam, fix_first_pose=True)
+        knots_new = traj.knots_xyzw.copy()
+        for i in range(1, w.K):                           # left perturbation exp(x1_i) * knot_i, first pose fixed (trajectory.cpp:296-304)
+            e = so3_exp_xyzw(x1[3 * i:3 * i + 3])
+            ex, ey, ez, ew = e; bx, by, bz, bw = knots_new[i]
+            q = np.array([ew * bx + ex * bw + ey * bz - ez * by, ew * by + ey * bw + ez * bx - ex * bz,
+                          ew * bz + ez * bw + ex * by - ey * bx, ew * bw - ex * bx - ey * by - ez * bz])
+            knots_new[i] = q / np.linalg.norm(q)
+        m.updateMap(x2, 1.0)
+        trial = type(traj)(knots_new, traj.t0_ns, traj.dt_ns)
+        nem_new = np.zeros_like(nem)
+        ep_new = m.evaluateDataError(trial, None, None, None, True, nem_new)
+        cost_new = m.dataCost() + m.regCost(w.alpha)
+        if cost_new < cost:
+            m.acceptMap(); traj, ep, nem, cost, lam, accepted = trial, ep_new, nem_new, cost_new, lam / 10, accepted + 1
+        else:
+            m.rejectMap(); lam *= 10
+            ep = m.evaluateDataError(traj, None, None, None, True, nem)    # restore the state formNormalEq reads
+    assert accepted >= 2, "LM made no progress"

@@ -296,3 +296,25 @@ def test_update_map_known_answers(oracle_mod):
     ex[[1, 5, 6]] = Gx.ravel()[[1, 5, 6]] + 0.5 * x2[0::2]; ey[[1, 5, 6]] = Gy.ravel()[[1, 5, 6]] + 0.5 * x2[1::2]
     assert np.array_equal(nx.ravel(), ex) and np.array_equal(ny.ravel(), ey)
     assert np.array_equal(Gx, np.arange(12.0).reshape(3, 4) + 1)          # inputs untouched (the reference clones first, solver.cpp:237)
+
+
+def test_solve_normal_eq_solves_the_damped_system(oracle_mod):
+    """LEGM::solveNormalEq (model.cpp:721-792): x = [x1; x2] must solve [A11m A12; A12^T A22m] x = [b1; b2]."""
+    w = small_workload(n_events=6000, pano_h=128, K=5, sensor=(24, 16), focal=20.0)
+    r = oracle_run(oracle_mod, w, dense_A12=True, thres=2)
+    ne = r["ne"]
+    for lam, fix in ((1e-3, False), (1.0, True)):
+        x1, x2 = oracle_mod.solve_normal_eq(ne, lam, fix)
+        K, P = w.K, ne["P"]
+        A = np.zeros((3 * K + 2 * P, 3 * K + 2 * P)); b = np.concatenate([ne["b1"], ne["b2"]])
+        A[:3 * K, :3 * K] = ne["A11"] + lam * np.diag(np.diag(ne["A11"]))
+        A[:3 * K, 3 * K:] = ne["A12"]; A[3 * K:, :3 * K] = ne["A12"].T
+        for i in range(P):
+            blk = ne["A22"][i] + lam * np.diag(np.diag(ne["A22"][i]))
+            A[3 * K + 2 * i:3 * K + 2 * i + 2, 3 * K + 2 * i:3 * K + 2 * i + 2] = blk
+        keep = np.arange(3 if fix else 0, A.shape[0])
+        x = np.linalg.solve(A[np.ix_(keep, keep)], b[keep])
+        got = np.concatenate([x1, x2])[keep]
+        assert np.allclose(got, x, rtol=1e-8, atol=1e-10 * np.abs(x).max())
+        if fix:
+            assert (x1[:3] == 0).all()

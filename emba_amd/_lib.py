@@ -9,9 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libemba_hip.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY, ERR_NUMERIC, ERR_LIBRARY = range(9)
+OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY, ERR_NUMERIC = range(8)
 STATUS_NAMES = ["EMBA_OK", "EMBA_ERR_INVALID_ARG", "EMBA_ERR_NO_DEVICE", "EMBA_ERR_HIP", "EMBA_ERR_TIME_RANGE",
-                "EMBA_ERR_STATE", "EMBA_ERR_CAPACITY", "EMBA_ERR_NUMERIC", "EMBA_ERR_LIBRARY"]
+                "EMBA_ERR_STATE", "EMBA_ERR_CAPACITY", "EMBA_ERR_NUMERIC"]
 
 _dp = C.POINTER(C.c_double)
 _i32p = C.POINTER(C.c_int32)

@@ -10,7 +10,7 @@ DEPS = [SRC, os.path.join(_HERE, "csrc", "kernels.h"), os.path.join(_HERE, "csrc
         os.path.join(ROOT, "include", "emba_hip.h")]
 OUT = os.path.join(_HERE, "libemba_hip.so")
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-ldl"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 
 def hipcc():

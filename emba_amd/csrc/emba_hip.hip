@@ -18,8 +18,6 @@
 #include "kernels.h"
 #include "solve_kernels.h"
 
-#include <dlfcn.h>
-
 using namespace emba;
 
 namespace {
@@ -102,11 +100,6 @@ struct emba_ctx {
     bool kt_warp_valid = false, kt_accum_valid = false;
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
-    // rocBLAS, loaded on first use (plain SYRK/GEMV of the Schur solve only; the hot path never touches it)
-    void* rb_lib = nullptr; void* rb_handle = nullptr;
-    int (*rb_create)(void**) = nullptr; int (*rb_destroy)(void*) = nullptr; int (*rb_set_stream)(void*, hipStream_t) = nullptr;
-    int (*rb_dsyrk)(void*, int, int, int, int, const double*, const double*, int, const double*, double*, int) = nullptr;
-    int (*rb_dgemv)(void*, int, int, int, const double*, const double*, int, const double*, int, const double*, double*, int) = nullptr;
 };
 
 namespace {
@@ -393,8 +386,6 @@ void emba_destroy(emba_ctx* c)
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
     for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
-    if (c->rb_handle && c->rb_destroy) (void)c->rb_destroy(c->rb_handle);
-    if (c->rb_lib) dlclose(c->rb_lib);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1019,28 +1010,6 @@ emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 
 }  // extern "C"
 
-namespace {
-emba_status load_rocblas(emba_ctx* c)
-{
-    if (c->rb_handle) return EMBA_OK;
-    c->rb_lib = dlopen("librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!c->rb_lib) c->rb_lib = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_LOCAL);
-    if (!c->rb_lib) return fail(c, EMBA_ERR_LIBRARY, "cannot load librocblas.so: %s", dlerror());
-    c->rb_create = (int (*)(void**))dlsym(c->rb_lib, "rocblas_create_handle");
-    c->rb_destroy = (int (*)(void*))dlsym(c->rb_lib, "rocblas_destroy_handle");
-    c->rb_set_stream = (int (*)(void*, hipStream_t))dlsym(c->rb_lib, "rocblas_set_stream");
-    c->rb_dsyrk = (decltype(c->rb_dsyrk))dlsym(c->rb_lib, "rocblas_dsyrk");
-    c->rb_dgemv = (decltype(c->rb_dgemv))dlsym(c->rb_lib, "rocblas_dgemv");
-    if (!c->rb_create || !c->rb_destroy || !c->rb_set_stream || !c->rb_dsyrk || !c->rb_dgemv)
-        return fail(c, EMBA_ERR_LIBRARY, "librocblas.so lacks an expected symbol");
-    if (c->rb_create(&c->rb_handle) != 0) { c->rb_handle = nullptr; return fail(c, EMBA_ERR_LIBRARY, "rocblas_create_handle failed"); }
-    if (c->rb_set_stream(c->rb_handle, c->stream) != 0) return fail(c, EMBA_ERR_LIBRARY, "rocblas_set_stream failed");
-    return EMBA_OK;
-}
-// rocBLAS enum values (rocblas-types.h): operation none = 111, transpose = 112; fill upper = 121, lower = 122
-constexpr int kRbNone = 111, kRbTrans = 112, kRbLower = 122;
-}  // namespace
-
 extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
@@ -1048,35 +1017,39 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;
-    if ((st = load_rocblas(c))) return st;
     hipStream_t s = c->stream;
     const int n = 3 * c->K;
     const int skip = fix_first_pose ? 3 : 0, m = n - skip;
     const size_t P = c->P, M = c->n_cand;
     if (m <= 0) return fail(c, EMBA_ERR_INVALID_ARG, "nothing to solve for");
+    const int na = n + 1;                              // augmented: row n carries y / the right-hand side
+    const long lds_ = (na + 15) / 16 * 16;             // leading dimension of S_aug and of U
 
-    // workspaces (this is not the per-iteration hot path: plain allocations)
+    // workspaces (not the per-iteration hot path: plain allocations, freed on return)
     uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr, *d_blk = nullptr, *d_blk_off = nullptr, *d_tot = nullptr;
-    double *d_S = nullptr, *d_rhs = nullptr, *d_U = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_z = nullptr, *d_x2 = nullptr;
+    double *d_S = nullptr, *d_rhs = nullptr, *d_U = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_x2 = nullptr, *d_slab = nullptr;
     int* d_info = nullptr;
     const size_t nblk = (P + 2047) / 2048;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)n)));   // <= 6 GB of U
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
+    const int nb64 = (na + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
+    const int nks_max = std::max(1, 1024 / nbp);
     auto cleanup = [&]() {
         dev_free(d_off); dev_free(d_cursor); dev_free(d_bucket); dev_free(d_blk); dev_free(d_blk_off); dev_free(d_tot); dev_free(d_S);
-        dev_free(d_rhs); dev_free(d_U); dev_free(d_y); dev_free(d_cf); dev_free(d_z); dev_free(d_x2); dev_free(d_info);
+        dev_free(d_rhs); dev_free(d_U); dev_free(d_y); dev_free(d_cf); dev_free(d_x2); dev_free(d_slab); dev_free(d_info);
     };
 #define SOLVE_TRY(expr) do { emba_status st_ = (expr); if (st_) { cleanup(); return st_; } } while (0)
 #define SOLVE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
     SOLVE_TRY(dev_alloc(c, &d_off, P + 1)); SOLVE_TRY(dev_alloc(c, &d_cursor, P)); SOLVE_TRY(dev_alloc(c, &d_bucket, M));
     SOLVE_TRY(dev_alloc(c, &d_blk, nblk)); SOLVE_TRY(dev_alloc(c, &d_blk_off, nblk)); SOLVE_TRY(dev_alloc(c, &d_tot, 1));
-    SOLVE_TRY(dev_alloc(c, &d_S, (size_t)n * n)); SOLVE_TRY(dev_alloc(c, &d_rhs, (size_t)n)); SOLVE_TRY(dev_alloc(c, &d_U, (size_t)n * 2 * chunk));
-    SOLVE_TRY(dev_alloc(c, &d_y, 2 * P)); SOLVE_TRY(dev_alloc(c, &d_cf, 3 * P)); SOLVE_TRY(dev_alloc(c, &d_z, 2 * chunk)); SOLVE_TRY(dev_alloc(c, &d_x2, 2 * P));
-    SOLVE_TRY(dev_alloc(c, &d_info, 1));
+    SOLVE_TRY(dev_alloc(c, &d_S, (size_t)lds_ * na)); SOLVE_TRY(dev_alloc(c, &d_rhs, (size_t)n)); SOLVE_TRY(dev_alloc(c, &d_U, (size_t)lds_ * 2 * chunk));
+    SOLVE_TRY(dev_alloc(c, &d_y, 2 * P)); SOLVE_TRY(dev_alloc(c, &d_cf, 3 * P)); SOLVE_TRY(dev_alloc(c, &d_x2, 2 * P));
+    SOLVE_TRY(dev_alloc(c, &d_slab, (size_t)nks_max * nbp * 4096)); SOLVE_TRY(dev_alloc(c, &d_info, 1));
     SOLVE_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
     SOLVE_HIP(hipMemsetAsync(d_cursor, 0, std::max<size_t>(P, 1) * sizeof(uint32_t), s));
     SOLVE_HIP(hipMemsetAsync(d_off, 0, (P + 1) * sizeof(uint32_t), s));
+    SOLVE_HIP(hipMemsetAsync(d_S, 0, (size_t)lds_ * na * sizeof(double), s));
 
-    // per-pixel record lists
+    // per-pixel record lists (CSR over the active pixels)
     if (P) {
         hipLaunchKernelGGL(emba_csr_scan1_kernel, dim3((unsigned)nblk), dim3(256), 0, s, c->d_count, c->d_active, (long)P, d_off, d_blk);
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, d_blk, d_blk_off, (long)nblk, d_tot, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
@@ -1085,40 +1058,52 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
             hipLaunchKernelGGL(emba_csr_fill_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, (long)M, c->d_count, c->d_compact,
                                c->thres, d_off, d_cursor, d_bucket);
     }
-    hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, d_rhs);
+    hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
     SOLVE_HIP(hipGetLastError());
 
+    // S_aug -= U_aug U_aug^T, one chunk of pixels at a time
     SchurBuildParams bp{};
     bp.rec = c->d_rec; bp.slot_key = c->d_slot_key; bp.off = d_off; bp.bucket = d_bucket; bp.A22b2 = pack_A22b2(c); bp.lambda = lambda;
-    bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = n; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
-    const size_t lds = (size_t)4 * 2 * n * sizeof(double);
-    if (lds > 160 * 1024) { cleanup(); return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", c->K); }
-    if (lds > 64 * 1024) SOLVE_HIP(hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const double neg1 = -1.0, one = 1.0, zero = 0.0;
-    auto build = [&](size_t p0, size_t p1) {
+    bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
+    const size_t lds_bytes = (size_t)4 * 2 * n * sizeof(double);
+    if (lds_bytes > 160 * 1024) { cleanup(); return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", c->K); }
+    if (lds_bytes > 64 * 1024) SOLVE_HIP(hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    for (size_t p0 = 0; p0 < P; p0 += chunk) {
+        const size_t p1 = std::min(P, p0 + chunk);
         bp.p0 = (long)p0; bp.p1 = (long)p1;
-        const unsigned grid = (unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096);
-        hipLaunchKernelGGL(emba_schur_build_kernel, dim3(grid), dim3(256), lds, s, bp);
-    };
-    // pass 1: S -= U U^T (lower triangle), rhs -= U y, chunk by chunk
-    for (size_t p0 = 0; p0 < P; p0 += chunk) {
-        const size_t p1 = std::min(P, p0 + chunk);
-        build(p0, p1);
-        const int kc = (int)(2 * (p1 - p0));
-        if (c->rb_dsyrk(c->rb_handle, kRbLower, kRbNone, m, kc, &neg1, d_U + skip, n, &one, d_S + skip + (size_t)skip * n, n) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dsyrk failed"); }
-        if (c->rb_dgemv(c->rb_handle, kRbNone, m, kc, &neg1, d_U + skip, n, d_y + 2 * p0, 1, &one, d_rhs + skip, 1) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dgemv failed"); }
+        hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
+        const long kc = (long)(2 * (p1 - p0));
+        const int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 64));
+        SyrkParams sp{};
+        sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.direct = (nks == 1);
+        hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
+        if (nks > 1)
+            hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256)), dim3(256), 0, s, d_slab, nks, nbp, na, d_S, lds_);
     }
-    // x1 = S \ rhs (Cholesky), rows 0..skip-1 stay out of the system
-    hipLaunchKernelGGL(emba_chol_solve_kernel, dim3(1), dim3(1024), 0, s, d_S + skip + (size_t)skip * n, m, n, d_rhs + skip, d_info);
-    if (skip) SOLVE_HIP(hipMemsetAsync(d_rhs, 0, skip * sizeof(double), s));
-    // pass 2: x2 = C^-T (y - U^T x1)
-    for (size_t p0 = 0; p0 < P; p0 += chunk) {
-        const size_t p1 = std::min(P, p0 + chunk);
-        if (P > chunk) build(p0, p1);     // a single chunk is still resident from pass 1
-        const int kc = (int)(2 * (p1 - p0));
-        if (c->rb_dgemv(c->rb_handle, kRbTrans, m, kc, &one, d_U + skip, n, d_rhs + skip, 1, &zero, d_z, 1) != 0) { cleanup(); return fail(c, EMBA_ERR_LIBRARY, "rocblas_dgemv failed"); }
-        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, s, d_y, d_z, d_cf, (long)p0, (long)p1, d_x2);
+    hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);
+
+    // blocked Cholesky of S[skip:n, skip:n] (x1 = S \ rhs; the reference calls Eigen's ldlt, model.cpp:789)
+    {
+        double* Sm = d_S + (size_t)lds_ * skip + skip;
+        for (int jb = 0; jb < m; jb += 64) {
+            const int nb = std::min(64, m - jb);
+            hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(256), 0, s, Sm, lds_, jb, nb, d_info);
+            const int below = m - jb - nb;
+            if (below > 0) {
+                hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 255) / 256), dim3(256), 0, s, Sm, lds_, m, jb, nb);
+                const int tb = (below + 63) / 64;
+                SyrkParams tp{};
+                tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below; tp.k = nb;
+                tp.C = Sm + (size_t)lds_ * (jb + nb) + (jb + nb); tp.ldc = lds_; tp.slab = nullptr; tp.nbp = tb * (tb + 1) / 2; tp.direct = 1;
+                hipLaunchKernelGGL(emba_syrk_kernel, dim3(tp.nbp, 1), dim3(256), 0, s, tp);
+            }
+        }
+        hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
     }
+    // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
+    if (P)
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, d_off, d_bucket, d_y,
+                           d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2);
     SOLVE_HIP(hipGetLastError());
     int info = 0;
     SOLVE_HIP(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -9,8 +9,10 @@
 //
 // With the 2x2 Cholesky factor A22m_i = C_i C_i^T the products factor as U = A12 * C^-T (per pixel a 3K x 2 column pair),
 // y = C^-1 b2:   S = A11m - U U^T,  rhs = b1 - U y,  x2 = C^-T (y - U^T x1).  U is built densely a chunk of pixels at a time
-// (one wave per pixel, its two columns assembled in LDS from the records of that pixel — no global atomics), the two big
-// products are plain library SYRK/GEMV calls (rocBLAS), the 3K x 3K factorization is a single-workgroup Cholesky.
+// (one wave per pixel, its two columns assembled in LDS from the records of that pixel — no global atomics) with y as an extra
+// ROW, so that one split-K SYRK on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; n is small, the K dimension is 2P: library
+// SYRK/GEMM kernels do not split K and take 10 ms here) yields S and rhs together; the n x n factorization is a blocked
+// right-looking Cholesky whose trailing updates reuse the same SYRK kernel; x2 comes straight from the records.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -116,75 +118,250 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             u0[r] = t0;
             u1[r] = (a1 - t0 * c10) / c11;
         }
+        if (lane == 0) { u0[p.n] = y0; u1[p.n] = y1; }     // extra row: (U_aug U_aug^T)[r][n] = (U y)[r], the rhs update comes with the SYRK
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
-// S = A11 + lambda*diag(A11) (full square copy; SYRK then updates the lower triangle), rhs = b1
+// Augmented system matrix (n+1) x (n+1), leading dimension lds: [A11 + lambda*diag(A11), . ; b1^T, 0] — the SYRK with the
+// augmented U then leaves S in the leading n x n lower triangle and rhs = b1 - U y in row n.
 __global__ void emba_schur_init_kernel(const double* __restrict__ A11, const double* __restrict__ b1, int n, double lambda,
-                                       double* __restrict__ S, double* __restrict__ rhs)
+                                       double* __restrict__ S, long lds)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < (long)n * n) {
         const int r = (int)(i % n), c = (int)(i / n);
         const double a = A11[i];
-        S[i] = (r == c) ? a + lambda * a : a;       // model.cpp:728-730
+        S[(size_t)lds * c + r] = (r == c) ? a + lambda * a : a;       // model.cpp:728-730
     }
-    if (i < n) rhs[i] = b1[i];
+    if (i < n) S[(size_t)lds * i + n] = b1[i];
+    if (i == 0) S[(size_t)lds * n + n] = 0.0;
 }
 
-// In-place Cholesky (lower, column-major, leading dimension ld) of the m x m matrix A and solution of A x = b (b overwritten by x).
-// One workgroup.  info[0] |= 2 if a pivot is not positive.
-__global__ __launch_bounds__(1024) void emba_chol_solve_kernel(double* __restrict__ A, int m, int ld, double* __restrict__ b, int* __restrict__ info)
+// rhs[c] = S_aug[n][c] (row n of the augmented matrix) for c >= skip, 0 before
+__global__ void emba_schur_rhs_kernel(const double* __restrict__ S, long lds, int n, int skip, double* __restrict__ rhs)
 {
-    __shared__ double s_piv;
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int j = 0; j < m; ++j) {
-        if (t == 0) {
-            const double d = A[(size_t)j * ld + j];
-            if (!(d > 0.0)) atomicOr(info, 2);
-            s_piv = sqrt(d);
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) rhs[c] = (c >= skip) ? S[(size_t)lds * c + n] : 0.0;
+}
+
+// ---- split-K SYRK on the fp64 matrix cores ------------------------------------------------------------------------------
+// C (lower triangle, column-major, ldc) -= A A^T for A = n x k column-major (lda).  Output is cut into 64x64 blocks (block
+// pairs I >= J); grid.x = block pair, grid.y = K slice; the 4 waves of a block split the slice, every wave keeps its 4x4 tiles
+// of 16x16 in registers (lane l holds A[I0+16ib+(l&15)][col 4s+(l>>4)] — the A/B operand layout — straight from memory),
+// the block combines its waves in LDS and either subtracts from C directly (one slice) or writes a partial slab that
+// emba_syrk_reduce_kernel sums (many slices: all the atomics of a direct update would land on the same n^2 words).
+struct SyrkParams {
+    const double* A; long lda; int n; long k; double* C; long ldc; double* slab; int nbp; int direct;
+};
+
+__device__ __forceinline__ void syrk_block_pair(int bp, int& I, int& J)
+{   // bp -> (I, J), I >= J, row-major over the lower triangle
+    int i = (int)((sqrt(8.0 * bp + 1.0) - 1.0) * 0.5);
+    while ((long)i * (i + 1) / 2 > bp) --i;
+    while ((long)(i + 1) * (i + 2) / 2 <= bp) ++i;
+    I = i; J = bp - i * (i + 1) / 2;
+}
+
+__global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
+{
+    __shared__ double s_tile[64 * 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int el = lane & 15, kk = lane >> 4;
+    int I, J;
+    syrk_block_pair(blockIdx.x, I, J);
+    const int I0 = 64 * I, J0 = 64 * J;
+    const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
+    const long kb = (long)blockIdx.y * kslice, ke = (kb + kslice < p.k) ? kb + kslice : p.k;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (long c4 = kb + 4 * wv; c4 < ke; c4 += 16) {
+        const long col = c4 + kk;
+        const bool cok = col < ke;
+        const double* colp = p.A + (size_t)p.lda * (cok ? col : kb);
+        double av[4], bv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
+            av[t] = (cok && ri < p.n) ? colp[ri] : 0.0;
+            bv[t] = (cok && rj < p.n) ? colp[rj] : 0.0;
         }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    }
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) s_tile[i] = 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * a + kk + 4 * r, colt = 16 * b + el;      // C/D layout of v_mfma_f64_16x16x4_f64
+                atomicAdd(&s_tile[colt * 64 + row], acc[a][b][r]);
+            }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int row = I0 + (i & 63), colg = J0 + (i >> 6);
+        if (p.direct) { if (row < p.n && colg < p.n && row >= colg) p.C[(size_t)p.ldc * colg + row] -= s_tile[i]; }
+        else p.slab[((size_t)blockIdx.y * p.nbp + blockIdx.x) * 4096 + i] = s_tile[i];
+    }
+}
+
+__global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks, int nbp, int n, double* __restrict__ C, long ldc)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)nbp * 4096) return;
+    const int bp = (int)(idx >> 12), i = (int)(idx & 4095);
+    int I, J;
+    syrk_block_pair(bp, I, J);
+    const int row = 64 * I + (i & 63), col = 64 * J + (i >> 6);
+    if (row >= n || col >= n || row < col) return;
+    double acc = 0.0;
+    for (int ks = 0; ks < nks; ++ks) acc += slab[((size_t)ks * nbp + bp) * 4096 + i];
+    C[(size_t)ldc * col + row] -= acc;
+}
+
+// ---- blocked Cholesky (lower, column-major), panels of 64 ---------------------------------------------------------------
+// (1) factor the diagonal block in LDS
+__global__ __launch_bounds__(256) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
+{
+    __shared__ double s[64 * 65];
+    const int t = threadIdx.x;
+    for (int i = t; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = A[(size_t)ld * (jb + c) + jb + r]; }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+        const double d = s[j * 65 + j];
         __syncthreads();
-        const double piv = s_piv;
-        for (int r = j + t; r < m; r += nt) A[(size_t)j * ld + r] = (r == j) ? piv : A[(size_t)j * ld + r] / piv;
+        if (t == 0) { if (!(d > 0.0)) atomicOr(info, 2); s[j * 65 + j] = sqrt(d); }
         __syncthreads();
-        // trailing update of the lower triangle: A[r][c] -= L[r][j] * L[c][j]  for j < c <= r
-        const int rem = m - j - 1;
-        for (long idx = t; idx < (long)rem * rem; idx += nt) {
-            const int c = j + 1 + (int)(idx / rem), r = j + 1 + (int)(idx % rem);
-            if (r >= c) A[(size_t)c * ld + r] -= A[(size_t)j * ld + r] * A[(size_t)j * ld + c];
+        const double piv = s[j * 65 + j];
+        if (t > j && t < nb) s[j * 65 + t] /= piv;
+        __syncthreads();
+        for (int i = t; i < (nb - j - 1) * (nb - j - 1); i += 256) {
+            const int c = j + 1 + i / (nb - j - 1), r = j + 1 + i % (nb - j - 1);
+            if (r >= c) s[c * 65 + r] -= s[j * 65 + r] * s[j * 65 + c];
         }
         __syncthreads();
     }
-    // forward substitution L z = b, then back substitution L^T x = z (column-oriented, one column per step)
-    for (int j = 0; j < m; ++j) {
-        if (t == 0) b[j] /= A[(size_t)j * ld + j];
+    for (int i = t; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; if (r >= c) A[(size_t)ld * (jb + c) + jb + r] = s[c * 65 + r]; }
+}
+
+// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)
+__global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
+{
+    __shared__ double s[64 * 65];
+    for (int i = threadIdx.x; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+    __syncthreads();
+    const int r = jb + nb + blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    double x[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) x[c] = (c < nb) ? A[(size_t)ld * (jb + c) + r] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        if (c < nb) {
+            double v = x[c];
+#pragma unroll
+            for (int k = 0; k < c; ++k) v -= x[k] * s[k * 65 + c];     // L_diag[c][k]
+            x[c] = v / s[c * 65 + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 64; ++c) if (c < nb) A[(size_t)ld * (jb + c) + r] = x[c];
+}
+
+// Solve L L^T x = b in place (one workgroup; 64-wide blocks: substitution inside a block by one wave in LDS, then the rest of the
+// right-hand side is updated by all threads).
+__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b)
+{
+    __shared__ double s_l[64 * 65];
+    __shared__ double s_x[64];
+    const int t = threadIdx.x;
+    // forward: L z = b
+    for (int jb = 0; jb < n; jb += 64) {
+        const int nb = (n - jb < 64) ? n - jb : 64;
+        for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+        if (t < 64) s_x[t] = (t < nb) ? b[jb + t] : 0.0;
         __syncthreads();
-        const double bj = b[j];
-        for (int r = j + 1 + t; r < m; r += nt) b[r] -= A[(size_t)j * ld + r] * bj;
+        if (t < 64) {
+            double v = s_x[t];
+            for (int j = 0; j < nb; ++j) {
+                const double xj = __shfl(v, j) / s_l[j * 65 + j];
+                if (t == j) v = xj; else if (t > j && t < nb) v -= s_l[j * 65 + t] * xj;
+            }
+            s_x[t] = v;
+            if (t < nb) b[jb + t] = v;
+        }
+        __syncthreads();
+        for (int r = jb + nb + t; r < n; r += 1024) {
+            double v = b[r];
+            for (int c = 0; c < nb; ++c) v -= L[(size_t)ld * (jb + c) + r] * s_x[c];
+            b[r] = v;
+        }
         __syncthreads();
     }
-    for (int j = m - 1; j >= 0; --j) {
-        if (t == 0) b[j] /= A[(size_t)j * ld + j];
+    // backward: L^T x = z
+    for (int jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {
+        const int nb = (n - jb < 64) ? n - jb : 64;
+        for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+        if (t < 64) s_x[t] = (t < nb) ? b[jb + t] : 0.0;
         __syncthreads();
-        const double bj = b[j];
-        for (int r = t; r < j; r += nt) b[r] -= A[(size_t)r * ld + j] * bj;   // L^T[r][j] = L[j][r], stored at column r, row j
+        if (t < 64) {
+            double v = s_x[t];
+            for (int j = nb - 1; j >= 0; --j) {
+                const double xj = __shfl(v, j) / s_l[j * 65 + j];
+                if (t == j) v = xj; else if (t < j) v -= s_l[t * 65 + j] * xj;      // L^T[t][j] = L[j][t]
+            }
+            s_x[t] = v;
+            if (t < nb) b[jb + t] = v;
+        }
+        __syncthreads();
+        for (int r = t; r < jb; r += 1024) {
+            double v = b[r];
+            for (int c = 0; c < nb; ++c) v -= L[(size_t)ld * r + jb + c] * s_x[c];    // L^T[r][jb+c] = L[jb+c][r]
+            b[r] = v;
+        }
         __syncthreads();
     }
 }
 
-// x2_i = C_i^-T (y_i - z_i)     with z = U^T x1                                     model.cpp:791
-__global__ void emba_schur_x2_kernel(const double* __restrict__ yv, const double* __restrict__ z, const double* __restrict__ cfac,
-                                     long p0, long p1, double* __restrict__ x2)
+// x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,
+// then z = C^-1 (A12_i^T x1)  (since U^T x1 = C^-1 A12^T x1)                                                       model.cpp:791
+__global__ void emba_schur_x2_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key, const uint32_t* __restrict__ off,
+                                     const uint32_t* __restrict__ bucket, const double* __restrict__ yv, const double* __restrict__ cfac,
+                                     const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
 {
-    const long i = p0 + (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p1) return;
-    const double t0 = yv[2 * i] - z[2 * (i - p0)], t1 = yv[2 * i + 1] - z[2 * (i - p0) + 1];
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    double a0 = 0.0, a1 = 0.0;
+    for (uint32_t b = off[i]; b < off[i + 1]; ++b) {
+        const uint32_t s = bucket[b];
+        const double* r = rec + (size_t)kRecStride * s;
+        const uint32_t key = slot_key[s];
+        const double* xc = x1 + 3 * (key >> 16);
+        const double* xp = x1 + 3 * (key & 0xFFFFu);
+        double d = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d += r[j] * xc[j] + r[6 + j] * xp[j];
+        const double e = r[14];
+        double w = 1.0;
+        if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
+        else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
+        a0 += w * d * r[12];
+        a1 += w * d * r[13];
+    }
     const double c00 = cfac[3 * i], c10 = cfac[3 * i + 1], c11 = cfac[3 * i + 2];
-    const double b = t1 / c11;
-    x2[2 * i + 1] = b;
-    x2[2 * i] = (t0 - c10 * b) / c00;
+    const double z0 = a0 / c00, z1 = (a1 - c10 * z0) / c11;              // z = C^-1 (A12_i^T x1)
+    const double t0 = yv[2 * i] - z0, t1 = yv[2 * i + 1] - z1;
+    const double bq = t1 / c11;                                          // x2 = C^-T t
+    x2[2 * i + 1] = bq;
+    x2[2 * i] = (t0 - c10 * bq) / c00;
 }
 
 }  // namespace emba

@@ -49,8 +49,7 @@ typedef enum {
                                    (BASALT_ASSERT at so3_spline.h:221-229 in the reference) */
     EMBA_ERR_STATE = 5,         /* call order violated (e.g. form before eval) */
     EMBA_ERR_CAPACITY = 6,      /* a caller-provided buffer is too small */
-    EMBA_ERR_NUMERIC = 7,       /* the damped system is not positive definite (Cholesky pivot <= 0) */
-    EMBA_ERR_LIBRARY = 8        /* rocBLAS (used for the plain SYRK/GEMV of the Schur solve) could not be loaded */
+    EMBA_ERR_NUMERIC = 7        /* the damped system is not positive definite (Cholesky pivot <= 0) */
 } emba_status;
 
 typedef struct emba_ctx emba_ctx;

@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--pano-h", type=int, default=1024)
     ap.add_argument("--knots", type=int, default=21)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="rehearsal on ONE GPU: initialise RCCL with world_size 1 and run both all-reduces of the sharded protocol")
     args = ap.parse_args()
 
     import torch
@@ -90,9 +92,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_collectives
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from emba_amd import LEGM
     from emba_amd.sharded import HipEngine, ShardedLEGM
@@ -119,6 +123,7 @@ def main():
         def all_reduce(t): dist.all_reduce(t)
 
     sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w)
+    sh.force_collectives = args.force_collectives
     t_set = time.perf_counter()
     local = sh.set_events(w.events)
     m.upload_map(w.Gx, w.Gy)                                 # HBM-resident before the timed region
@@ -127,7 +132,7 @@ def main():
     m.enable_kernel_timing(True)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -178,7 +183,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

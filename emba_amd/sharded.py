@@ -93,6 +93,7 @@ class ShardedLEGM:
         engine.bind_exchange(count_tensor, pack_tensor)
         self.P = 0
         self.pack_len = 0
+        self.force_collectives = False   # rehearse the exchanges with a single rank
 
     def set_events(self, events):
         local, halo = shard_events(events, self.sensor_w, self.rank, self.world)
@@ -103,7 +104,7 @@ class ShardedLEGM:
     def iteration(self, traj, thres_valid_pixel, alpha, cost_type="quadratic", a=0.0, download=False):
         """One evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks.  Map must be resident (upload_map)."""
         e, dist = self.engine, self.dist
-        multi = self.world > 1
+        multi = self.world > 1 or self.force_collectives
         e.eval_launch(traj)                                   # E1
         if multi:
             dist.all_reduce(self.count)                       # X1 (SUM)

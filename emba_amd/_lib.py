@@ -58,6 +58,7 @@ SIGNATURES = {
     "emba_form_active": (C.c_int, [C.c_void_p, C.c_int32, _szp, _szp]),
     "emba_form_accumulate": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_double]),
     "emba_form_finish": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u32p, C.c_size_t, _dp, _dp, _dp]),
+    "emba_step": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
     "emba_last_counts": (C.c_int, [C.c_void_p, _szp, _szp]),
     "emba_sync": (C.c_int, [C.c_void_p]),
     "emba_timer_start": (C.c_int, [C.c_void_p, C.c_int32]),

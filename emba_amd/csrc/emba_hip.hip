@@ -90,7 +90,7 @@ struct emba_ctx {
     size_t n_inliers = 0, P = 0, pack_len = 0;
     bool ep_deferred = false;   // residual compaction not launched yet (it rides along with the active-set kernels)
     bool inl_pending = false, P_pending = false;   // counters enqueued for readback but not yet resolved (no host sync yet)
-    double* h_knots = nullptr; int h_knots_cap = 0; hipEvent_t knots_copied = nullptr;   // pinned staging for the control poses
+    double* h_knots = nullptr; int h_knots_cap = 0; hipEvent_t knots_copied = nullptr; bool knots_in_flight = false;   // pinned staging for the control poses
     int thres = 0, irls = 0; double eta = 0;
 
     // timing
@@ -268,6 +268,7 @@ emba_status resolve_pending(emba_ctx* c)
     { emba_status st = launch_ep_compaction(c); if (st) return st; }
     if (!c->inl_pending && !c->P_pending) return EMBA_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->knots_in_flight = false;
     if (c->inl_pending) {
         c->inl_pending = false;
         if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
@@ -598,7 +599,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false;
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipEventSynchronize(c->knots_copied));   // the previous prep kernel has consumed the pinned staging buffer
+    if (c->knots_in_flight) HIP_TRY(c, hipStreamSynchronize(s));   // the previous prep kernel must have consumed the pinned staging buffer
     memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
@@ -609,7 +610,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     const int n_prep_blk = (int)((c->npix + 1023) / 1024);
     hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)n_prep_blk), dim3(256), 0, s, c->d_count, (long)c->npix,
                        c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect, c->d_grp_cnt, (int)c->ngrp);
-    HIP_TRY(c, hipEventRecord(c->knots_copied, s));
+    c->knots_in_flight = true;   // cleared by the next host synchronisation (an event here would cost a ~6 us bubble per step)
 
     // Hessian source: with more events than panorama pixels the full texel pack (one 48-B gather per measurement instead of
     // an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
@@ -793,6 +794,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
         (void)hipMemcpyAsync(A12_dense, d_A12, n12 * sizeof(double), hipMemcpyDeviceToHost, s);
     }
     hipError_t e = hipStreamSynchronize(s);
+    c->knots_in_flight = false;
     dev_free(d_A22); dev_free(d_b2); dev_free(d_A12);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "form_finish: %s", hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
@@ -940,6 +942,20 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
         if (Gpm && h_flag[i]) { Gpm[2 * k] = h_G[2 * i]; Gpm[2 * k + 1] = h_G[2 * i + 1]; }
         if (temp && h_flag[i]) { temp[2 * k] = h_t[2 * i]; temp[2 * k + 1] = h_t[2 * i + 1]; }
     }
+    return EMBA_OK;
+}
+
+emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, int32_t thres, int32_t irls, double eta,
+                      double alpha, size_t* n_inliers, size_t* P)
+{
+    emba_status st;
+    if ((st = emba_eval_launch(c, knots, K, t0_ns, dt_ns))) return st;
+    if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
+    if ((st = emba_form_active(c, thres, nullptr, nullptr))) return st;
+    if ((st = emba_form_accumulate(c, nullptr, irls, eta))) return st;
+    if ((st = emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr))) return st;
+    if (n_inliers) *n_inliers = c->n_inliers;
+    if (P) *P = c->P;
     return EMBA_OK;
 }
 

@@ -290,6 +290,19 @@ class LEGM:
         self._P = b.value
         return a.value, b.value
 
+    def step(self, traj, thres_valid_pixel, alpha, cost_type="quadratic", a=0.0):
+        """One whole resident step (evaluateDataError + formNormalEq[IRLS] + applyL2Reg) in a single library call."""
+        if getattr(self, "_step_traj", None) is not traj:       # cache the contiguous knot array of this trajectory object
+            self._step_knots = np.ascontiguousarray(traj.knots_xyzw, dtype=np.float64).reshape(-1, 4)
+            self._step_traj = traj
+        knots = self._step_knots
+        self.K = knots.shape[0]
+        a_, b_ = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.emba_step(self._ctx, _p(knots, _dp), self.K, int(traj.t0_ns), int(traj.dt_ns), int(thres_valid_pixel),
+                                      COST_TYPES[cost_type], float(a), float(alpha), C.byref(a_), C.byref(b_)))
+        self._P = b_.value
+        return a_.value, b_.value
+
     def sync(self):
         self._check(self._L.emba_sync(self._ctx))
 

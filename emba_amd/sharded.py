@@ -105,6 +105,9 @@ class ShardedLEGM:
         """One evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks.  Map must be resident (upload_map)."""
         e, dist = self.engine, self.dist
         multi = self.world > 1 or self.force_collectives
+        if not multi and not download and hasattr(e, "step"):     # single GPU, nothing to exchange: one library call per step
+            n_inl, self.P = e.step(traj, thres_valid_pixel, alpha, cost_type, a)
+            return n_inl, None
         e.eval_launch(traj)                                   # E1
         if multi:
             dist.all_reduce(self.count)                       # X1 (SUM)
@@ -146,6 +149,9 @@ class HipEngine:
 
     def last_counts(self):
         return self.m.last_counts()
+
+    def step(self, traj, thres, alpha, cost_type, a):
+        return self.m.step(traj, thres, alpha, cost_type, a)
 
     def form_accumulate(self, cost_type, a):
         self.m.form_accumulate(cost_type, a)

@@ -199,6 +199,12 @@ emba_status emba_form_accumulate(emba_ctx* ctx, const double* ep_host, int32_t i
 emba_status emba_form_finish(emba_ctx* ctx, double alpha, double* A11, double* b1, uint32_t* active_idx,
                              size_t cap_P, double* A22, double* b2, double* A12_dense);
 
+/* One whole resident step in one call (what bench.py times on a single GPU): emba_eval_launch + emba_eval_finish +
+ * emba_form_active + emba_form_accumulate(device-resident ep) + emba_form_finish(alpha, no downloads), one host
+ * synchronisation at the end.  n_inliers / P may be NULL. */
+emba_status emba_step(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns, int64_t dt_ns,
+                      int32_t thres_valid_pixel, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
+
 /* Inlier count of the last evaluation and active-pixel count of the last emba_form_active, once resolved
  * (after any synchronizing call, e.g. emba_form_finish or emba_sync). */
 emba_status emba_last_counts(emba_ctx* ctx, size_t* n_inliers, size_t* P);

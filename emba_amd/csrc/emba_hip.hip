@@ -88,6 +88,8 @@ struct emba_ctx {
     int K = 0;
     bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
     size_t n_inliers = 0, P = 0, pack_len = 0;
+    bool compact_valid = false;   // d_compact matches the current active set (built on demand)
+    double fused_alpha = 0.0; bool l2_fused = false;   // emba_step on one GPU folds applyL2Reg into the active-set gather
     bool ep_deferred = false;   // residual compaction not launched yet (it rides along with the active-set kernels)
     bool inl_pending = false, P_pending = false;   // counters enqueued for readback but not yet resolved (no host sync yet)
     double* h_knots = nullptr; int h_knots_cap = 0; hipEvent_t knots_copied = nullptr; bool knots_in_flight = false;   // pinned staging for the control poses
@@ -238,6 +240,21 @@ inline double* pack_b1(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c->K
 inline double* pack_A22b2(emba_ctx* c) { return c->d_pack + (size_t)9 * c->K * c->K + (size_t)3 * c->K; }
 
 long grid8(long n) { return (n + 7) / 8 * 8; }
+
+// The pano -> compact index map is only read by the generic (weighted / external-ep) A22 path, the A12 exports and the Schur solve,
+// so it is produced when one of them asks (8 MB less traffic on every ordinary step).
+emba_status ensure_compact(emba_ctx* c)
+{
+    if (c->compact_valid) return EMBA_OK;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_compact, 0xFF, c->npix * sizeof(int32_t), s));
+    const size_t bound = c->P_pending ? c->npix : c->P;
+    if (bound)
+        hipLaunchKernelGGL(emba_compact_map_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, s, c->d_active, c->d_total + 1, c->d_compact);
+    HIP_TRY(c, hipGetLastError());
+    c->compact_valid = true;
+    return EMBA_OK;
+}
 
 // Standalone residual compaction (scan of the per-wave inlier counts, then the compaction): used when the host asks for
 // ep / counts before the active-set kernels run; otherwise emba_form_active launches it fused with its own stages.
@@ -520,6 +537,7 @@ emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping)
         c->x2_cap = 2 * c->P;
     }
     hipStream_t s = c->stream;
+    if ((st = ensure_compact(c))) return st;
     if (c->P) HIP_TRY(c, hipMemcpyAsync(c->d_x2, x2_host, 2 * c->P * sizeof(double), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(emba_update_map_kernel, dim3((unsigned)((c->npix + 255) / 256)), dim3(256), 0, s, c->d_Gx_cur, c->d_Gy_cur, c->d_compact,
                        c->d_x2, damping, (long)c->npix, c->d_Gx_trial, c->d_Gy_trial);
@@ -700,8 +718,11 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
                            c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
     }
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, c->d_compact, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head);
+                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy);
     HIP_TRY(c, hipGetLastError());
+    c->compact_valid = false;
+    c->l2_fused = (c->fused_alpha != 0.0);
+    c->fused_alpha = 0.0;
     c->thres = thres;
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
@@ -732,6 +753,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     // (the head of the pack, A11 | b1, was zeroed by emba_form_active's write kernel)
     c->irls = irls; c->eta = eta;
     if (generic_a22 && c->P) {
+        { emba_status st = ensure_compact(c); if (st) return st; }
         HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));
         if (c->n_cand)
             hipLaunchKernelGGL(emba_a22_from_records_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec,
@@ -761,7 +783,8 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     if (!c->accum_done) return fail(c, EMBA_ERR_STATE, "emba_form_accumulate has not been called");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    if (alpha != 0.0) {
+    if (alpha != 0.0 && !c->l2_fused) {   // (l2_fused doubles as "already applied to this set of blocks": applyL2Reg acts once)
+        c->l2_fused = true;
         // P may still be unresolved on the host: the kernel reads it from device memory, the grid covers the bound
         const size_t bound = c->P_pending ? c->npix : c->P;
         if (bound)
@@ -785,6 +808,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
         if (b2) (void)hipMemcpyAsync(b2, d_b2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s);
     }
     if (A12_dense && P) {
+        if ((st = ensure_compact(c))) { dev_free(d_A22); dev_free(d_b2); return st; }
         const size_t n12 = (size_t)dim * 2 * P;
         if ((st = dev_alloc(c, &d_A12, n12))) { dev_free(d_A22); dev_free(d_b2); return st; }
         (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
@@ -829,6 +853,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
         return st;
     }
     hipStream_t s = c->stream;
+    if ((st = ensure_compact(c))) { dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp); return st; }
     hipLaunchKernelGGL(emba_export_a12_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, (long)M,
                        c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp);
     if (cp_c) (void)hipMemcpyAsync(cp_c, d_c, M * 4, hipMemcpyDeviceToHost, s);
@@ -951,6 +976,7 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     emba_status st;
     if ((st = emba_eval_launch(c, knots, K, t0_ns, dt_ns))) return st;
     if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
+    c->fused_alpha = (irls == 0) ? alpha : 0.0;   // quadratic cost: A22/b2 come from the per-pixel accumulator, L2 rides along
     if ((st = emba_form_active(c, thres, nullptr, nullptr))) return st;
     if ((st = emba_form_accumulate(c, nullptr, irls, eta))) return st;
     if ((st = emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr))) return st;
@@ -1060,6 +1086,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     SOLVE_TRY(dev_alloc(c, &d_S, (size_t)lds_ * na)); SOLVE_TRY(dev_alloc(c, &d_rhs, (size_t)n)); SOLVE_TRY(dev_alloc(c, &d_U, (size_t)lds_ * 2 * chunk));
     SOLVE_TRY(dev_alloc(c, &d_y, 2 * P)); SOLVE_TRY(dev_alloc(c, &d_cf, 3 * P)); SOLVE_TRY(dev_alloc(c, &d_x2, 2 * P));
     SOLVE_TRY(dev_alloc(c, &d_slab, (size_t)nks_max * nbp * 4096)); SOLVE_TRY(dev_alloc(c, &d_info, 1));
+    SOLVE_TRY(ensure_compact(c));
     SOLVE_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
     SOLVE_HIP(hipMemsetAsync(d_cursor, 0, std::max<size_t>(P, 1) * sizeof(uint32_t), s));
     SOLVE_HIP(hipMemsetAsync(d_off, 0, (P + 1) * sizeof(uint32_t), s));

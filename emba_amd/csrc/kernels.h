@@ -590,8 +590,10 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
                                                                 const uint32_t* __restrict__ blk_off,
                                                                 int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx,
                                                                 const double* __restrict__ pixacc, double* __restrict__ A22b2,
-                                                                double* __restrict__ pack_head, long head_len)
-{
+                                                                double* __restrict__ pack_head, long head_len, double alpha,
+                                                                const double* __restrict__ Gx, const double* __restrict__ Gy)
+{   // compact == nullptr: the pano->compact index map is not needed by this step's consumers (it is produced on demand);
+    // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU).
     __shared__ uint32_t s_w[4];
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < head_len; i += (long)gridDim.x * 256) pack_head[i] = 0.0;
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
     __syncthreads();
     uint32_t k = blk_off[blockIdx.x] + x - mine;
     for (int w = 0; w < wv; ++w) k += s_w[w];
-    if (p0 + 8 <= npix) {   // compact index of 8 consecutive pixels: two 16-B stores
+    if (compact && p0 + 8 <= npix) {   // compact index of 8 consecutive pixels: two 16-B stores
         int cv[8];
         uint32_t kk = k;
 #pragma unroll
@@ -622,20 +624,28 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
         const long i = p0 + j;
         if (i >= npix) break;
         if (m & (1u << j)) {
-            if (p0 + 8 > npix) compact[i] = (int32_t)k;
+            if (compact && p0 + 8 > npix) compact[i] = (int32_t)k;
             active_idx[k] = (uint32_t)i;
             if (A22b2) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
                 const double2* a = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
                 const double2 a0 = a[0], a1 = a[1];
                 const double a4 = pixacc[(size_t)kPixAccStride * i + 4];
                 double* q = A22b2 + 5 * (size_t)k;
-                q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4;
+                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * Gx[i]; q[4] = a4 - alpha * Gy[i]; }
+                else { q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4; }
             }
             ++k;
-        } else if (p0 + 8 > npix) {
+        } else if (compact && p0 + 8 > npix) {
             compact[i] = -1;
         }
     }
+}
+
+// pano -> compact index map from the active list (on demand: generic A22 path, dense/sparse A12 export, Schur solve)
+__global__ void emba_compact_map_kernel(const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ P_dev, int32_t* __restrict__ compact)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)P_dev[0]) compact[active_idx[i]] = (int32_t)i;
 }
 
 // Start of an evaluation ("prep"): zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched

@@ -194,8 +194,8 @@ emba_status emba_form_active(emba_ctx* ctx, int32_t thres_valid_pixel, size_t* P
 /* Phase F2: zero the pack and accumulate this rank's measurements into it.  Asynchronous.
  * ep_host as in emba_form_normal_eq. */
 emba_status emba_form_accumulate(emba_ctx* ctx, const double* ep_host, int32_t irls, double eta);
-/* Phase F3: applyL2Reg on the (all-reduced) pack, then optional download (any pointer may be NULL);
- * synchronizes. */
+/* Phase F3: applyL2Reg on the (all-reduced) pack — at most once per emba_form_accumulate, later calls with alpha != 0 only
+ * download — then optional download (any pointer may be NULL); synchronizes. */
 emba_status emba_form_finish(emba_ctx* ctx, double alpha, double* A11, double* b1, uint32_t* active_idx,
                              size_t cap_P, double* A22, double* b2, double* A12_dense);
 

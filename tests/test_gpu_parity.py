@@ -446,3 +446,27 @@ def test_lm_iterations_decrease_cost(gpu, oracle_mod):
             m.rejectMap(); lam *= 10
             ep = m.evaluateDataError(traj, None, None, None, True, nem)    # restore the state formNormalEq reads
     assert accepted >= 2, "LM made no progress"
+
+
+@pytest.mark.parametrize("cost", [("quadratic", 0.0), ("huber", 0.1)])
+def test_single_call_step_matches_oracle(gpu, oracle_mod, cost):
+    """emba_step (what bench.py times on one GPU: the whole resident step in one call, applyL2Reg folded into the active-set
+    gather for the quadratic cost) must leave exactly the normal equations of the phase-by-phase path."""
+    w = small_workload(n_events=30000)
+    m = make_legm(w)
+    m.set_events(w.events)
+    m.upload_map(w.Gx, w.Gy)
+    irls = {"quadratic": 0, "huber": 1}[cost[0]]
+    o = oracle_run(oracle_mod, w, irls=irls, a=cost[1])
+    for it in range(3):
+        n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha, cost[0], cost[1])
+        assert n_inl == o["ep"].size and P == o["ne"]["P"]
+        ne = m._finish(w.alpha, False)                     # download only: L2 was already applied inside the step
+        compare_normal_eq(ne, o["ne"])
+        _, ep, nem = m.eval_finish(want_ep=True, want_map=True)
+        assert np.array_equal(nem, o["num_ev_map"])
+        assert_close(ep, o["ep"], "ep")
+    x1, x2 = m.solveNormalEq(1e-2, fix_first_pose=True)    # and the solve works on that state
+    o2 = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
+    ox1, ox2 = oracle_mod.solve_normal_eq(o2["ne"], 1e-2, True)
+    assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()) and np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())

@@ -102,6 +102,8 @@ struct emba_ctx {
     bool kt_warp_valid = false, kt_accum_valid = false;
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
+    // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
+    struct { void* p = nullptr; size_t bytes = 0; } ws[16];
 };
 
 namespace {
@@ -404,6 +406,7 @@ void emba_destroy(emba_ctx* c)
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
     for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
+    for (auto& w : c->ws) if (w.p) (void)hipFree(w.p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1067,7 +1070,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     const int na = n + 1;                              // augmented: row n carries y / the right-hand side
     const long lds_ = (na + 15) / 16 * 16;             // leading dimension of S_aug and of U
 
-    // workspaces (not the per-iteration hot path: plain allocations, freed on return)
+    // grow-only workspaces cached in the context
     uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr, *d_blk = nullptr, *d_blk_off = nullptr, *d_tot = nullptr;
     double *d_S = nullptr, *d_rhs = nullptr, *d_U = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_x2 = nullptr, *d_slab = nullptr;
     int* d_info = nullptr;
@@ -1075,17 +1078,25 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
     const int nb64 = (na + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
     const int nks_max = std::max(1, 1024 / nbp);
-    auto cleanup = [&]() {
-        dev_free(d_off); dev_free(d_cursor); dev_free(d_bucket); dev_free(d_blk); dev_free(d_blk_off); dev_free(d_tot); dev_free(d_S);
-        dev_free(d_rhs); dev_free(d_U); dev_free(d_y); dev_free(d_cf); dev_free(d_x2); dev_free(d_slab); dev_free(d_info);
+    auto cleanup = [&]() {};
+    auto ws_get = [&](int slot, size_t bytes, void** out) -> emba_status {
+        auto& w = c->ws[slot];
+        if (w.bytes < bytes || !w.p) {
+            if (w.p) (void)hipFree(w.p);
+            w.p = nullptr; w.bytes = 0;
+            if (hipMalloc(&w.p, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(c, EMBA_ERR_HIP, "hipMalloc of %zu bytes failed in the Schur solve", bytes);
+            w.bytes = std::max<size_t>(bytes, 8);
+        }
+        *out = w.p;
+        return EMBA_OK;
     };
 #define SOLVE_TRY(expr) do { emba_status st_ = (expr); if (st_) { cleanup(); return st_; } } while (0)
 #define SOLVE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-    SOLVE_TRY(dev_alloc(c, &d_off, P + 1)); SOLVE_TRY(dev_alloc(c, &d_cursor, P)); SOLVE_TRY(dev_alloc(c, &d_bucket, M));
-    SOLVE_TRY(dev_alloc(c, &d_blk, nblk)); SOLVE_TRY(dev_alloc(c, &d_blk_off, nblk)); SOLVE_TRY(dev_alloc(c, &d_tot, 1));
-    SOLVE_TRY(dev_alloc(c, &d_S, (size_t)lds_ * na)); SOLVE_TRY(dev_alloc(c, &d_rhs, (size_t)n)); SOLVE_TRY(dev_alloc(c, &d_U, (size_t)lds_ * 2 * chunk));
-    SOLVE_TRY(dev_alloc(c, &d_y, 2 * P)); SOLVE_TRY(dev_alloc(c, &d_cf, 3 * P)); SOLVE_TRY(dev_alloc(c, &d_x2, 2 * P));
-    SOLVE_TRY(dev_alloc(c, &d_slab, (size_t)nks_max * nbp * 4096)); SOLVE_TRY(dev_alloc(c, &d_info, 1));
+    SOLVE_TRY(ws_get(0, (P + 1) * 4, (void**)&d_off)); SOLVE_TRY(ws_get(1, P * 4, (void**)&d_cursor)); SOLVE_TRY(ws_get(2, M * 4, (void**)&d_bucket));
+    SOLVE_TRY(ws_get(3, nblk * 4, (void**)&d_blk)); SOLVE_TRY(ws_get(4, nblk * 4, (void**)&d_blk_off)); SOLVE_TRY(ws_get(5, 4, (void**)&d_tot));
+    SOLVE_TRY(ws_get(6, (size_t)lds_ * na * 8, (void**)&d_S)); SOLVE_TRY(ws_get(7, (size_t)n * 8, (void**)&d_rhs));
+    SOLVE_TRY(ws_get(8, (size_t)lds_ * 2 * chunk * 8, (void**)&d_U)); SOLVE_TRY(ws_get(9, 2 * P * 8, (void**)&d_y)); SOLVE_TRY(ws_get(10, 3 * P * 8, (void**)&d_cf));
+    SOLVE_TRY(ws_get(11, 2 * P * 8, (void**)&d_x2)); SOLVE_TRY(ws_get(12, (size_t)nks_max * nbp * 4096 * 8, (void**)&d_slab)); SOLVE_TRY(ws_get(13, 4, (void**)&d_info));
     SOLVE_TRY(ensure_compact(c));
     SOLVE_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
     SOLVE_HIP(hipMemsetAsync(d_cursor, 0, std::max<size_t>(P, 1) * sizeof(uint32_t), s));
@@ -1145,7 +1156,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     }
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)
-        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, d_off, d_bucket, d_y,
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, c->d_rec, c->d_slot_key, d_off, d_bucket, d_y,
                            d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2);
     SOLVE_HIP(hipGetLastError());
     int info = 0;

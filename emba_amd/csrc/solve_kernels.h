@@ -94,20 +94,27 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         for (int r = lane; r < p.n; r += 64) { c0[r] = 0.0; c1[r] = 0.0; }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
-        for (uint32_t b = b0; b < b1; ++b) {
-            const uint32_t s = p.bucket[b];
-            const double x = (lane < 16) ? p.rec[(size_t)kRecStride * s + lane] : 0.0;
-            const double dx = __shfl(x, 12), dy = __shfl(x, 13), e = __shfl(x, 14);
+        const int el = lane & 15, kk = lane >> 4;
+        for (uint32_t b = b0; b < b1; b += 4) {      // four records per trip (lane l: element l&15 of record l>>4): one memory latency for four
+            const uint32_t bb = b + kk;
+            const bool in = bb < b1;
+            const uint32_t s = in ? p.bucket[bb] : 0u;
+            const double x = in ? p.rec[(size_t)kRecStride * s + el] : 0.0;
+            const int g = lane & 48;
+            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
             double w = 1.0;
             if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
             else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
-            const uint32_t key = p.slot_key[s];
+            const uint32_t key = in ? p.slot_key[s] : 0u;
             const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
             const double wx = w * x;                                            // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
-            if (lane < 6) { c0[bc + lane] += wx * dx; c1[bc + lane] += wx * dy; }
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // rows of c and p may overlap: two ordered steps
-            if (lane >= 6 && lane < 12) { c0[bp + lane - 6] += wx * dx; c1[bp + lane - 6] += wx * dy; }
-            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {                                       // rows of different records / of c and p may coincide: ordered steps
+                if (in && kk == q && el < 6) { c0[bc + el] += wx * dx; c1[bc + el] += wx * dy; }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (in && kk == q && el >= 6 && el < 12) { c0[bp + el - 6] += wx * dx; c1[bp + el - 6] += wx * dy; }
+                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
         // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11
         double* u0 = p.U + (size_t)p.ldu * (2 * (i - p.p0));
@@ -333,35 +340,43 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
 
 // x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,
 // then z = C^-1 (A12_i^T x1)  (since U^T x1 = C^-1 A12^T x1)                                                       model.cpp:791
-__global__ void emba_schur_x2_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key, const uint32_t* __restrict__ off,
-                                     const uint32_t* __restrict__ bucket, const double* __restrict__ yv, const double* __restrict__ cfac,
-                                     const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
+__global__ __launch_bounds__(256) void emba_schur_x2_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key,
+                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ bucket,
+                                                            const double* __restrict__ yv, const double* __restrict__ cfac,
+                                                            const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P) return;
-    double a0 = 0.0, a1 = 0.0;
-    for (uint32_t b = off[i]; b < off[i + 1]; ++b) {
-        const uint32_t s = bucket[b];
-        const double* r = rec + (size_t)kRecStride * s;
-        const uint32_t key = slot_key[s];
-        const double* xc = x1 + 3 * (key >> 16);
-        const double* xp = x1 + 3 * (key & 0xFFFFu);
-        double d = 0.0;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) d += r[j] * xc[j] + r[6 + j] * xp[j];
-        const double e = r[14];
-        double w = 1.0;
-        if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
-        else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
-        a0 += w * d * r[12];
-        a1 += w * d * r[13];
+    // one wave per pixel, four records per trip (lane l: element l&15 of record l>>4), 12-term dot products by xor-shuffles
+    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4, g = lane & 48;
+    const long nwaves = (long)gridDim.x * 4;
+    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < P; i += nwaves) {
+        double a0 = 0.0, a1 = 0.0;
+        const uint32_t b0 = off[i], b1 = off[i + 1];
+        for (uint32_t b = b0; b < b1; b += 4) {
+            const uint32_t bb = b + kk;
+            const bool in = bb < b1;
+            const uint32_t s = in ? bucket[bb] : 0u;
+            const double x = in ? rec[(size_t)kRecStride * s + el] : 0.0;
+            const uint32_t key = in ? slot_key[s] : 0u;
+            const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
+            double d = (in && el < 12) ? x * x1[row] : 0.0;
+            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
+            double w = 1.0;
+            if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
+            else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
+            if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
+        }
+        a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+        if (lane == 0) {
+            const double c00 = cfac[3 * i], c10 = cfac[3 * i + 1], c11 = cfac[3 * i + 2];
+            const double z0 = a0 / c00, z1 = (a1 - c10 * z0) / c11;          // z = C^-1 (A12_i^T x1)
+            const double t0 = yv[2 * i] - z0, t1 = yv[2 * i + 1] - z1;
+            const double bq = t1 / c11;                                      // x2 = C^-T t
+            x2[2 * i + 1] = bq;
+            x2[2 * i] = (t0 - c10 * bq) / c00;
+        }
     }
-    const double c00 = cfac[3 * i], c10 = cfac[3 * i + 1], c11 = cfac[3 * i + 2];
-    const double z0 = a0 / c00, z1 = (a1 - c10 * z0) / c11;              // z = C^-1 (A12_i^T x1)
-    const double t0 = yv[2 * i] - z0, t1 = yv[2 * i + 1] - z1;
-    const double bq = t1 / c11;                                          // x2 = C^-T t
-    x2[2 * i + 1] = bq;
-    x2[2 * i] = (t0 - c10 * bq) / c00;
 }
 
 }  // namespace emba

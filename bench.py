@@ -122,7 +122,8 @@ def main():
         @staticmethod
         def all_reduce(t): dist.all_reduce(t)
 
-    sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w)
+    count_u8 = torch.zeros(npix, dtype=torch.uint8, device=dev)   # exchange 1 travels as saturated bytes (emba_amd/sharded.py)
+    sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w, count_u8)
     sh.force_collectives = args.force_collectives
     t_set = time.perf_counter()
     local = sh.set_events(w.events)

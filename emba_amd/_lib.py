@@ -53,6 +53,8 @@ SIGNATURES = {
     "emba_map_reject": (C.c_int, [C.c_void_p]),
     "emba_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "emba_count_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "emba_count_expand": (C.c_int, [C.c_void_p, C.c_void_p]),
     "emba_eval_launch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64]),
     "emba_eval_finish": (C.c_int, [C.c_void_p, _dp, _szp, _i32p]),
     "emba_form_active": (C.c_int, [C.c_void_p, C.c_int32, _szp, _szp]),

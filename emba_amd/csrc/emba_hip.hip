@@ -595,6 +595,24 @@ emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, doub
     return EMBA_OK;
 }
 
+emba_status emba_count_compress(emba_ctx* c, uint8_t* u8_dev, int32_t cap)
+{
+    if (!c || !u8_dev || cap < 1 || cap > 255) return c ? fail(c, EMBA_ERR_INVALID_ARG, "count_compress: bad arguments") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    hipLaunchKernelGGL(emba_count_compress_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, c->d_count, (long)c->npix, (int)cap, u8_dev);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+emba_status emba_count_expand(emba_ctx* c, const uint8_t* u8_dev)
+{
+    if (!c || !u8_dev) return c ? fail(c, EMBA_ERR_INVALID_ARG, "count_expand: NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    hipLaunchKernelGGL(emba_count_expand_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, u8_dev, (long)c->npix, c->d_count);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
 emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;

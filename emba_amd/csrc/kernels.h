@@ -641,6 +641,31 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
     }
 }
 
+// Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
+__global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)
+{
+    const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p0 + 4 <= npix) {
+        const int4 c = *reinterpret_cast<const int4*>(count + p0);
+        uchar4 o;
+        o.x = (unsigned char)min(c.x, cap); o.y = (unsigned char)min(c.y, cap); o.z = (unsigned char)min(c.z, cap); o.w = (unsigned char)min(c.w, cap);
+        *reinterpret_cast<uchar4*>(out + p0) = o;
+    } else {
+        for (long i = p0; i < npix; ++i) out[i] = (uint8_t)min(count[i], cap);
+    }
+}
+
+__global__ void emba_count_expand_kernel(const uint8_t* __restrict__ in, long npix, int32_t* __restrict__ count)
+{
+    const long p0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (p0 + 4 <= npix) {
+        const uchar4 c = *reinterpret_cast<const uchar4*>(in + p0);
+        *reinterpret_cast<int4*>(count + p0) = make_int4(c.x, c.y, c.z, c.w);
+    } else {
+        for (long i = p0; i < npix; ++i) count[i] = in[i];
+    }
+}
+
 // pano -> compact index map from the active list (on demand: generic A22 path, dense/sparse A12 export, Schur solve)
 __global__ void emba_compact_map_kernel(const uint32_t* __restrict__ active_idx, const uint32_t* __restrict__ P_dev, int32_t* __restrict__ compact)
 {

@@ -249,6 +249,12 @@ class LEGM:
         self._check(self._L.emba_bind_exchange_buffers(self._ctx, C.c_void_p(count_ptr) if count_ptr else None,
                                                        C.c_void_p(pack_ptr) if pack_ptr else None, int(pack_cap)))
 
+    def count_compress(self, u8_ptr, cap):
+        self._check(self._L.emba_count_compress(self._ctx, C.c_void_p(u8_ptr), int(cap)))
+
+    def count_expand(self, u8_ptr):
+        self._check(self._L.emba_count_expand(self._ctx, C.c_void_p(u8_ptr)))
+
     def eval_launch(self, traj):
         knots = np.ascontiguousarray(traj.knots_xyzw, dtype=np.float64).reshape(-1, 4)
         self.K = knots.shape[0]

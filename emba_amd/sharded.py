@@ -4,7 +4,8 @@ Gauss-Newton iteration over RCCL/xGMI (torch.distributed backend "nccl") — SUR
 The reference is single-process; this is new work, not a port.  The protocol per iteration:
 
     E1  every rank: pose table, texel pack, warp+residual+count+records on its own events   (no communication)
-    X1  all_reduce(SUM) of the int32 pixel-count map     — activity (count >= thres) is a global property (model.cpp:333,409)
+    X1  all_reduce(SUM) of the pixel-count map           — activity (count >= thres) is a global property (model.cpp:333,409);
+        sent as one saturated BYTE per pixel (min(count, 255 // world)) when thres allows: the merged map only feeds `>= thres`
     E2  residual compaction (local), F1 active set from the GLOBAL counts (identical on every rank)
     F2  every rank accumulates its measurements into the pack [A11 | b1 | A22b2(P)]
     X2  all_reduce(SUM) of the fp64 pack (one call; A11 is 9K^2 doubles, A22b2 5P doubles)
@@ -85,10 +86,12 @@ def merge_ep(ep_parts, pix_parts):
 class ShardedLEGM:
     """LEGM over `dist` (a torch.distributed-like module: all_reduce, get_rank, get_world_size)."""
 
-    def __init__(self, engine, dist, count_tensor, pack_tensor, sensor_w):
+    def __init__(self, engine, dist, count_tensor, pack_tensor, sensor_w, count_u8_tensor=None):
+        """count_u8_tensor: optional uint8 tensor (one byte per panorama pixel) enabling the compressed exchange 1."""
         self.engine, self.dist = engine, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.count, self.pack = count_tensor, pack_tensor
+        self.count_u8 = count_u8_tensor
         self.sensor_w = sensor_w
         engine.bind_exchange(count_tensor, pack_tensor)
         self.P = 0
@@ -110,7 +113,13 @@ class ShardedLEGM:
             return n_inl, None
         e.eval_launch(traj)                                   # E1
         if multi:
-            dist.all_reduce(self.count)                       # X1 (SUM)
+            cap = 255 // max(self.world, 1)
+            if self.count_u8 is not None and thres_valid_pixel <= cap and hasattr(e, "count_compress"):
+                e.count_compress(self.count_u8, cap)          # int32 -> min(count, cap) bytes
+                dist.all_reduce(self.count_u8)                # X1 (SUM) on a quarter of the bytes; cannot overflow: world * cap <= 255
+                e.count_expand(self.count_u8)                 # saturated global counts back into the int32 map
+            else:
+                dist.all_reduce(self.count)                   # X1 (SUM), exact counts
         e.eval_finish()                                       # E2 (enqueue only)
         # F1: a single GPU never needs P on the host mid-step; with several ranks the host needs the pack length for X2
         self.P, self.pack_len = e.form_active(thres_valid_pixel, sync=multi)
@@ -152,6 +161,12 @@ class HipEngine:
 
     def step(self, traj, thres, alpha, cost_type, a):
         return self.m.step(traj, thres, alpha, cost_type, a)
+
+    def count_compress(self, u8_tensor, cap):
+        self.m.count_compress(u8_tensor.data_ptr(), cap)
+
+    def count_expand(self, u8_tensor):
+        self.m.count_expand(u8_tensor.data_ptr())
 
     def form_accumulate(self, cost_type, a):
         self.m.form_accumulate(cost_type, a)

@@ -178,6 +178,13 @@ emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first
 emba_status emba_bind_exchange_buffers(emba_ctx* ctx, int32_t* count_map_dev, double* pack_dev,
                                        size_t pack_cap);
 
+/* Exchange-1 compression for multi-GPU hosts: the merged count map only decides `count >= thres` (model.cpp:333,409), so each rank
+ * may send min(count, cap) as ONE BYTE per pixel (cap * world_size <= 255, thres <= cap) — a quarter of the int32 volume on the
+ * xGMI links.  emba_count_compress writes the saturated bytes of the context's count map to u8_dev (pano_h*pano_w bytes);
+ * emba_count_expand stores the (all-reduced) bytes back as int32.  After that the map holds saturated, not exact, totals. */
+emba_status emba_count_compress(emba_ctx* ctx, uint8_t* u8_dev, int32_t cap);
+emba_status emba_count_expand(emba_ctx* ctx, const uint8_t* u8_dev);
+
 /* Phase E1: pose table, Hessian/texel pack, warp + residual + count + factor records.  Asynchronous
  * on the context's stream.  After it the count map holds THIS rank's counts. */
 emba_status emba_eval_launch(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns,

@@ -68,6 +68,12 @@ class OracleShardEngine:
             prev = cur
         self.count.copy_(torch.from_numpy(count))
 
+    def count_compress(self, u8, cap):
+        u8.copy_(torch.clamp(self.count, max=cap).to(torch.uint8))
+
+    def count_expand(self, u8):
+        self.count.copy_(u8.to(torch.int32))
+
     def eval_finish(self):
         self.ep = np.array([m["e"] for m in self.meas])          # already pixel-major, then time
         self.ep_pix = np.array([m["pix"] for m in self.meas], dtype=np.int64)

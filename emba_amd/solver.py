@@ -1,0 +1,90 @@
+"""The caller of the hot path: EMBA::solveTimeWindow (reference src/emba/solver.cpp:11-368) — the Levenberg-Marquardt loop —
+driving the device-resident path end to end: evaluateDataError / formNormalEq[IRLS] / applyL2Reg (hot path), solveNormalEq (f1),
+updateMap + accept/reject (f2) all stay in HBM; only the 3K pose increments and the scalar costs cross to the host, where updateTraj
+runs as in the reference.  Same constants and control flow as the reference: lambda 1e-3, x10 / /10, lambda in [1e-300, 1e3],
+relative-cost tolerance counted over consecutive accepted steps."""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import io as emba_io
+
+
+@dataclass
+class LMSettings:               # include/emba/params.h:4-12, values of launch/shapes.launch:31-33
+    max_num_iter: int = 50
+    tol_fun: float = 1e-3
+    num_times_tol_fun_sat: int = 2
+
+
+@dataclass
+class BASettings:               # include/emba/params.h:14-61, values of launch/shapes.launch:28-60
+    use_IRLS: bool = False
+    cost_type: str = "quadratic"
+    eta: float = 0.1
+    thres_valid_pixel: int = 5
+    alpha: float = 5.0
+    damping_factor: float = 1.0
+    first_time_window: bool = True      # the first control pose is held fixed (solver.cpp:156-165, 227-230)
+
+
+@dataclass
+class LMResult:
+    traj: object
+    cost_min: float
+    iterations: int
+    converged: bool
+    log: list = field(default_factory=list)      # (iter, log10(lambda), cost_min, cost_new, accepted)
+
+
+def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSettings(), verbose=False):
+    """model: emba_amd.LEGM.  The refined map stays on the device (model.downloadMap()); returns LMResult."""
+    lam, lam_max, lam_min = 1e-3, 1e3, 1e-300                                       # solver.cpp:15-17
+    cost_min_old = cost_new = cost_min = 1e99
+    it, count_tol, decreased = 0, 0, True
+    cost_type = ba.cost_type if ba.use_IRLS else "quadratic"
+    model.set_events(events)
+    num_ev_map = np.zeros((model.H, model.W), dtype=np.int32)
+    log = []
+    while it <= lm.max_num_iter and cost_min > 1e-16 and lam_min <= lam <= lam_max:   # solver.cpp:63-64
+        if decreased:
+            if it == 0:                                                              # :69-91
+                model.evaluateDataError(traj, Gx, Gy, None, True, num_ev_map)        # uploads the initial map once
+                cost_min = model.dataCost(cost_type, ba.eta) + model.regCost(ba.alpha)
+            if ba.use_IRLS:                                                          # :114-126 (device-resident ep)
+                model.formNormalEqIRLS(None, traj.size(), None, ba.thres_valid_pixel, ba.cost_type, ba.eta)
+            else:
+                model.formNormalEq(None, traj.size(), None, ba.thres_valid_pixel)
+            model.applyL2Reg(ba.alpha)                                               # :130
+        x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)       # :190-202
+        traj_new = emba_io.incremental_update(traj, x1, ba.first_time_window)        # :226-234
+        model.updateMap(x2, ba.damping_factor)                                       # :237-240 (trial map, on the device)
+        model.evaluateDataError(traj_new, None, None, None, True, num_ev_map)        # :251
+        cost_new = model.dataCost(cost_type, ba.eta) + model.regCost(ba.alpha)       # :257-268
+        it += 1
+        accepted = cost_new < cost_min
+        log.append((it, float(np.log10(lam)), cost_min, cost_new, accepted))
+        if verbose:
+            print(f"iter #{it}: log10(lambda) = {np.log10(lam):.0f}  cost_min = {cost_min:.6e}  cost_new = {cost_new:.6e}  {'accept' if accepted else 'reject'}")
+        if accepted:                                                                 # :299-339
+            decreased = True
+            traj = traj_new
+            model.acceptMap()
+            lam /= 10
+            cost_min_old, cost_min = cost_min, cost_new
+            if abs(1 - cost_min / (cost_min_old + 1e-10)) < lm.tol_fun:
+                count_tol += 1
+                if count_tol >= lm.num_times_tol_fun_sat:
+                    return LMResult(traj, cost_min, it, True, log)
+        else:                                                                        # :340-352
+            decreased = False
+            model.rejectMap()
+            # formNormalEq is not re-run after a rejection (A, b are reused, solver.cpp:66-131), but the device state it reads
+            # was overwritten by the trial evaluation: restore it so that a later accepted step forms from the right state
+            model.evaluateDataError(traj, None, None, None, True, num_ev_map)
+            model.formNormalEqIRLS(None, traj.size(), None, ba.thres_valid_pixel, ba.cost_type, ba.eta) if ba.use_IRLS else \
+                model.formNormalEq(None, traj.size(), None, ba.thres_valid_pixel)
+            model.applyL2Reg(ba.alpha)
+            lam *= 10
+            count_tol = 0
+    return LMResult(traj, cost_min, it, False, log)

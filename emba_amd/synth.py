@@ -92,3 +92,96 @@ def make_workload(n_events=1_000_000, pano_h=1024, K=21, sensor=(240, 180), foca
     y = rng.integers(0, sh, size=n, dtype=np.uint16)
     pol = rng.integers(0, 2, size=n, dtype=np.uint8)
     return Workload(sw, sh, pano_w, pano_h, lut, C_th, Gx, Gy, traj, EventPacket(x, y, pol, t_ns), thres_valid_pixel, alpha)
+
+
+# ---- a physically consistent scene: events generated FROM a panorama and a rotation, for end-to-end checks of the LM loop ------
+class SinusoidScene:
+    """Log-intensity panorama L(px, py) = sum_k a_k sin(2 pi m_k px / W + phi_k) cos(pi n_k py / H + psi_k): periodic in px,
+    analytic gradient, so the gradient map handed to the solver is the exact derivative the event generator integrates."""
+
+    def __init__(self, pano_h, n_terms=12, max_freq=(14, 7), amp=1.0, seed=3):
+        rng = np.random.default_rng(seed)
+        self.H, self.W = int(pano_h), 2 * int(pano_h)
+        self.m = rng.integers(1, max_freq[0] + 1, size=n_terms).astype(np.float64)
+        self.n = rng.integers(0, max_freq[1] + 1, size=n_terms).astype(np.float64)
+        self.a = amp * rng.uniform(0.3, 1.0, size=n_terms) / np.sqrt(n_terms)
+        self.phi = rng.uniform(0, 2 * np.pi, size=n_terms)
+        self.psi = rng.uniform(0, 2 * np.pi, size=n_terms)
+
+    def value(self, px, py):
+        ax = 2 * np.pi * self.m * px[..., None] / self.W + self.phi
+        ay = np.pi * self.n * py[..., None] / self.H + self.psi
+        return (self.a * np.sin(ax) * np.cos(ay)).sum(-1)
+
+    def gradient_map(self):
+        """(Gx, Gy) at integer pixel coordinates (the hot path samples G at round(p), model.cpp:209-217)."""
+        py, px = np.meshgrid(np.arange(self.H, dtype=np.float64), np.arange(self.W, dtype=np.float64), indexing="ij")
+        ax = 2 * np.pi * self.m * px[..., None] / self.W + self.phi
+        ay = np.pi * self.n * py[..., None] / self.H + self.psi
+        Gx = (self.a * (2 * np.pi * self.m / self.W) * np.cos(ax) * np.cos(ay)).sum(-1)
+        Gy = (-self.a * (np.pi * self.n / self.H) * np.sin(ax) * np.sin(ay)).sum(-1)
+        return np.ascontiguousarray(Gx), np.ascontiguousarray(Gy)
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def project_equirect(pano_w, pano_h, P):
+    """Equirectangular projection of bearing vectors [n,3] (reference include/utils/equirectangular_camera.h:25-40)."""
+    fx = pano_w / (2 * np.pi); fy = pano_h / np.pi
+    rho = np.linalg.norm(P, axis=-1)
+    return pano_w / 2.0 + np.arctan2(P[..., 0], P[..., 2]) * fx, pano_h / 2.0 + np.arcsin(P[..., 1] / rho) * fy
+
+
+def simulate_events(scene, traj, lut, sensor, C_th, n_steps=4000):
+    """Ideal event camera rotating along `traj` in front of `scene`: each sensor pixel fires (polarity = sign) whenever its
+    log intensity has changed by C_th since its last event; timestamps by linear interpolation inside a time step."""
+    from . import so3
+    sw, sh = sensor
+    knots = traj.knots_xyzw
+    K = knots.shape[0]
+    t_end = traj.t0_ns + traj.dt_ns * (K - 1)
+    ts = np.linspace(traj.t0_ns, t_end - 1, n_steps + 1)
+    L_prev = L_ref = None
+    ex, ey, ep, et = [], [], [], []
+    pix = np.arange(sw * sh)
+    for s, t in enumerate(ts):
+        i = min(int((t - traj.t0_ns) // traj.dt_ns), K - 2)
+        u = (t - traj.t0_ns - i * traj.dt_ns) / traj.dt_ns
+        q = so3.mul(knots[i], so3.exp(u * so3.log(so3.mul(so3.inverse(knots[i]), knots[i + 1]))))
+        px, py = project_equirect(scene.W, scene.H, lut @ _quat_to_R(q).T)
+        L = scene.value(px, py)
+        if s == 0:
+            L_prev, L_ref = L, L.copy()
+            continue
+        while True:
+            d = L - L_ref
+            fire = np.abs(d) >= C_th
+            if not fire.any():
+                break
+            sgn = np.sign(d[fire])
+            L_ref[fire] += sgn * C_th
+            frac = np.clip((L_ref[fire] - L_prev[fire]) / (L[fire] - L_prev[fire]), 0.0, 1.0)
+            ex.append(pix[fire] % sw); ey.append(pix[fire] // sw); ep.append((sgn > 0).astype(np.uint8))
+            et.append((ts[s - 1] + frac * (t - ts[s - 1])).astype(np.int64))
+        L_prev = L
+    x = np.concatenate(ex).astype(np.uint16); y = np.concatenate(ey).astype(np.uint16)
+    p = np.concatenate(ep); t = np.concatenate(et)
+    order = np.argsort(t, kind="stable")
+    return EventPacket(x[order], y[order], p[order], t[order])
+
+
+def make_scene_workload(pano_h=256, K=6, sensor=(64, 48), focal=60.0, C_th=0.2, dt_knots=0.05, t_beg=0.1, yaw_rate=0.5, amp=8.0,
+                        n_steps=4000, seed=3, thres_valid_pixel=5, alpha=5.0):
+    """Ground-truth trajectory + analytic scene + the events that motion produces; Gx, Gy are the TRUE gradient map."""
+    sw, sh = sensor
+    lut = pinhole_bearing_lut(sw, sh, focal, focal, sw / 2.0, sh / 2.0)
+    scene = SinusoidScene(pano_h, amp=amp, seed=seed)
+    Gx, Gy = scene.gradient_map()
+    traj = make_trajectory(K, dt_knots, t_beg, yaw_rate)
+    ev = simulate_events(scene, traj, lut, sensor, C_th, n_steps)
+    return Workload(sw, sh, 2 * pano_h, pano_h, lut, C_th, Gx, Gy, traj, ev, thres_valid_pixel, alpha)

@@ -41,3 +41,59 @@ def oracle_run(O, w, thres=None, irls=0, a=0.0, alpha=None, dense_A12=False, dum
     if al:
         o.apply_l2(ne, al, w.Gx, w.Gy)
     return dict(ep=ep, num_ev_map=nem, ne=ne, dump=r[2] if dump else None, oracle=o)
+
+
+class OracleModel:
+    """The CPU oracle behind the method names emba_amd.solver.solve_time_window drives, so the SAME LM loop can run on the
+    oracle and on the device path and their iteration logs compared (test infrastructure only)."""
+
+    def __init__(self, O, w):
+        self.O = O
+        self.o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+        self.H, self.W = w.pano_h, w.pano_w
+        self.cur = self.trial = None
+
+    def set_events(self, ev):
+        self.ev = ev
+
+    def evaluateDataError(self, traj, Gx, Gy, events=None, eval_deriv=True, num_ev_map=None):
+        if Gx is not None:
+            self.cur, self.trial = (np.array(Gx, dtype=np.float64), np.array(Gy, dtype=np.float64)), None
+        self.used = self.trial if self.trial is not None else self.cur
+        ev = self.ev
+        self.ep, self.nem = self.o.evaluate_data_error(traj.knots_xyzw, traj.t0_ns, traj.dt_ns, self.used[0], self.used[1],
+                                                       ev.x, ev.y, ev.polarity, ev.t_ns)
+        self.K = traj.size()
+        if num_ev_map is not None:
+            num_ev_map[...] = self.nem
+        return self.ep
+
+    def dataCost(self, cost_type="quadratic", a=0.0):
+        return self.O.data_cost(self.ep, {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a)
+
+    def regCost(self, alpha):
+        return self.O.reg_cost(self.used[0], self.used[1], alpha)
+
+    def formNormalEq(self, ep, K, nem, thres):
+        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, 0, 0.0, True)
+
+    def formNormalEqIRLS(self, ep, K, nem, thres, cost_type, a):
+        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a, True)
+
+    def applyL2Reg(self, alpha):
+        self.o.apply_l2(self.ne, alpha, self.used[0], self.used[1])
+
+    def solveNormalEq(self, lam, fix_first_pose=False):
+        return self.O.solve_normal_eq(self.ne, lam, fix_first_pose)
+
+    def updateMap(self, x2, damping):
+        self.trial = self.O.update_map(self.ne["active"], x2, damping, self.cur[0], self.cur[1])
+
+    def acceptMap(self):
+        self.cur, self.trial = self.trial, None
+
+    def rejectMap(self):
+        self.trial = None
+
+    def downloadMap(self):
+        return self.trial if self.trial is not None else self.cur

@@ -470,3 +470,31 @@ def test_single_call_step_matches_oracle(gpu, oracle_mod, cost):
     o2 = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
     ox1, ox2 = oracle_mod.solve_normal_eq(o2["ne"], 1e-2, True)
     assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()) and np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+
+
+@pytest.mark.parametrize("ba_kw", [dict(alpha=0.0), dict(alpha=5.0), dict(use_IRLS=True, cost_type="huber", eta=0.1, alpha=1.0)])
+def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw):
+    """SURVEY §8f4: EMBA::solveTimeWindow (solver.cpp:11-368) end to end — emba_amd.solver drives the device-resident path (hot path
+    + f1 solve + f2 map) on events simulated from a scene; the same loop on the CPU oracle must take the same accept/reject
+    decisions, reach the same costs and the same refined trajectory and map."""
+    from emba_amd import synth
+    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+    from helpers import OracleModel
+    from test_lm_solver_cpu import knot_errors, perturbed
+    w = synth.make_scene_workload(n_steps=1000)
+    init = perturbed(w)
+    ba, lm = BASettings(**ba_kw), LMSettings(max_num_iter=12)
+    om = OracleModel(oracle_mod, w)
+    ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, lm)
+    m = make_legm(w)
+    rg = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, lm)
+    assert [e[4] for e in rg.log] == [e[4] for e in ro.log], "accept/reject sequence differs"
+    assert rg.iterations == ro.iterations and rg.converged == ro.converged
+    for g, o in zip(rg.log, ro.log):
+        assert g[3] == pytest.approx(o[3], rel=1e-7) and g[2] == pytest.approx(o[2], rel=1e-7)
+    assert np.abs(rg.traj.knots_xyzw - ro.traj.knots_xyzw).max() < 1e-7
+    for d, o in zip(m.downloadMap(), om.downloadMap()):
+        assert np.abs(d - o).max() < 1e-7 * np.abs(o).max()
+    assert rg.cost_min < rg.log[0][2]
+    if ba.alpha == 0.0:
+        assert knot_errors(rg.traj, w.traj).mean() < knot_errors(init, w.traj).mean()

@@ -37,30 +37,58 @@ class LMResult:
     log: list = field(default_factory=list)      # (iter, log10(lambda), cost_min, cost_new, accepted)
 
 
-def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSettings(), verbose=False):
-    """model: emba_amd.LEGM.  The refined map stays on the device (model.downloadMap()); returns LMResult."""
+class _Phases:
+    """The three things the loop asks of the model, through the reference-shaped methods (evaluateDataError returns ep and the count
+    map to the host, as LEGM::evaluateDataError does) or, with resident=True, through the phase-level calls that leave both in HBM."""
+
+    def __init__(self, model, ba, resident):
+        self.m, self.ba, self.resident = model, ba, resident
+        self.cost_type = ba.cost_type if ba.use_IRLS else "quadratic"
+        self.nem = None if resident else np.zeros((model.H, model.W), dtype=np.int32)
+
+    def evaluate(self, traj, Gx=None, Gy=None):
+        m = self.m
+        if self.resident:
+            if Gx is not None:
+                m.upload_map(Gx, Gy)
+            m.eval_launch(traj)
+            m.eval_finish()
+        else:
+            m.evaluateDataError(traj, Gx, Gy, None, True, self.nem)
+        return m.dataCost(self.cost_type, self.ba.eta) + m.regCost(self.ba.alpha)
+
+    def form(self, K):
+        m, ba = self.m, self.ba
+        if self.resident:
+            m.form_active(ba.thres_valid_pixel)
+            m.form_accumulate(self.cost_type, ba.eta)
+            m.form_finish(ba.alpha)
+        else:
+            if ba.use_IRLS:                                                          # :114-126 (ep stays on the device)
+                m.formNormalEqIRLS(None, K, None, ba.thres_valid_pixel, ba.cost_type, ba.eta)
+            else:
+                m.formNormalEq(None, K, None, ba.thres_valid_pixel)
+            m.applyL2Reg(ba.alpha)                                                   # :130
+
+
+def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSettings(), verbose=False, resident=False):
+    """model: emba_amd.LEGM.  The refined map stays on the device (model.downloadMap()); returns LMResult.
+    resident=True keeps residuals and count map in HBM too (only costs, counts and the 3K pose increments reach the host)."""
     lam, lam_max, lam_min = 1e-3, 1e3, 1e-300                                       # solver.cpp:15-17
     cost_min_old = cost_new = cost_min = 1e99
     it, count_tol, decreased = 0, 0, True
-    cost_type = ba.cost_type if ba.use_IRLS else "quadratic"
+    ph = _Phases(model, ba, resident)
     model.set_events(events)
-    num_ev_map = np.zeros((model.H, model.W), dtype=np.int32)
     log = []
     while it <= lm.max_num_iter and cost_min > 1e-16 and lam_min <= lam <= lam_max:   # solver.cpp:63-64
         if decreased:
-            if it == 0:                                                              # :69-91
-                model.evaluateDataError(traj, Gx, Gy, None, True, num_ev_map)        # uploads the initial map once
-                cost_min = model.dataCost(cost_type, ba.eta) + model.regCost(ba.alpha)
-            if ba.use_IRLS:                                                          # :114-126 (device-resident ep)
-                model.formNormalEqIRLS(None, traj.size(), None, ba.thres_valid_pixel, ba.cost_type, ba.eta)
-            else:
-                model.formNormalEq(None, traj.size(), None, ba.thres_valid_pixel)
-            model.applyL2Reg(ba.alpha)                                               # :130
+            if it == 0:                                                              # :69-91, uploads the initial map once
+                cost_min = ph.evaluate(traj, Gx, Gy)
+            ph.form(traj.size())                                                     # :93-131
         x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)       # :190-202
         traj_new = emba_io.incremental_update(traj, x1, ba.first_time_window)        # :226-234
         model.updateMap(x2, ba.damping_factor)                                       # :237-240 (trial map, on the device)
-        model.evaluateDataError(traj_new, None, None, None, True, num_ev_map)        # :251
-        cost_new = model.dataCost(cost_type, ba.eta) + model.regCost(ba.alpha)       # :257-268
+        cost_new = ph.evaluate(traj_new)                                             # :251-268
         it += 1
         accepted = cost_new < cost_min
         log.append((it, float(np.log10(lam)), cost_min, cost_new, accepted))
@@ -79,12 +107,10 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
         else:                                                                        # :340-352
             decreased = False
             model.rejectMap()
-            # formNormalEq is not re-run after a rejection (A, b are reused, solver.cpp:66-131), but the device state it reads
-            # was overwritten by the trial evaluation: restore it so that a later accepted step forms from the right state
-            model.evaluateDataError(traj, None, None, None, True, num_ev_map)
-            model.formNormalEqIRLS(None, traj.size(), None, ba.thres_valid_pixel, ba.cost_type, ba.eta) if ba.use_IRLS else \
-                model.formNormalEq(None, traj.size(), None, ba.thres_valid_pixel)
-            model.applyL2Reg(ba.alpha)
+            # the reference reuses its host copies of A, b after a rejection (formNormalEq is skipped, solver.cpp:66-131); here that
+            # state lives on the device and the trial evaluation overwrote it: restore it at the accepted point
+            ph.evaluate(traj)
+            ph.form(traj.size())
             lam *= 10
             count_tol = 0
     return LMResult(traj, cost_min, it, False, log)

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--cost", default="quadratic", choices=["quadratic", "huber", "cauchy"])
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--max-iter", type=int, default=50)
+    ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     if a.alpha is None:
         a.alpha = 0.0 if a.demo else 5.0
@@ -69,7 +70,7 @@ def main():
                     damping_factor=a.damping_factor)
     print(f"{events.size()} events, {traj.size()} control poses, panorama {H}x{W}")
     t0 = time.time()
-    res = solve_time_window(model, traj, events, Gx, Gy, ba, LMSettings(max_num_iter=a.max_iter), verbose=True)
+    res = solve_time_window(model, traj, events, Gx, Gy, ba, LMSettings(max_num_iter=a.max_iter), verbose=a.verbose, resident=True)
     dt = time.time() - t0
     print(f"{res.iterations} LM iterations in {dt * 1e3:.1f} ms ({'converged' if res.converged else 'stopped'}), cost {res.cost_min:.6e}")
     if truth is not None:

@@ -472,8 +472,9 @@ def test_single_call_step_matches_oracle(gpu, oracle_mod, cost):
     assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()) and np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
 
 
+@pytest.mark.parametrize("resident", [False, True])
 @pytest.mark.parametrize("ba_kw", [dict(alpha=0.0), dict(alpha=5.0), dict(use_IRLS=True, cost_type="huber", eta=0.1, alpha=1.0)])
-def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw):
+def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw, resident):
     """SURVEY §8f4: EMBA::solveTimeWindow (solver.cpp:11-368) end to end — emba_amd.solver drives the device-resident path (hot path
     + f1 solve + f2 map) on events simulated from a scene; the same loop on the CPU oracle must take the same accept/reject
     decisions, reach the same costs and the same refined trajectory and map."""
@@ -487,7 +488,7 @@ def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw):
     om = OracleModel(oracle_mod, w)
     ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, lm)
     m = make_legm(w)
-    rg = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, lm)
+    rg = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, lm, resident=resident)
     assert [e[4] for e in rg.log] == [e[4] for e in ro.log], "accept/reject sequence differs"
     assert rg.iterations == ro.iterations and rg.converged == ro.converged
     for g, o in zip(rg.log, ro.log):

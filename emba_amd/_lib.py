@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemba_hip.so")
+LIB_PATH = os.environ.get("EMBA_LIB", os.path.join(_HERE, "libemba_hip.so"))   # EMBA_LIB: development builds of the same ABI
 
 OK, ERR_INVALID_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_TIME_RANGE, ERR_STATE, ERR_CAPACITY, ERR_NUMERIC = range(8)
 STATUS_NAMES = ["EMBA_OK", "EMBA_ERR_INVALID_ARG", "EMBA_ERR_NO_DEVICE", "EMBA_ERR_HIP", "EMBA_ERR_TIME_RANGE",

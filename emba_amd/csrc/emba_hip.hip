@@ -56,7 +56,7 @@ struct emba_ctx {
     int use_texel = 0;    // what the current evaluation uses: 0 fly, 1 full pack, 3 rectangle
     int* d_rect = nullptr;       // {xmin,ymin,xmax,ymax} of the pixels the previous evaluation touched
     int* d_blk_rect = nullptr;   // per prep-block boxes
-    int32_t* d_compact = nullptr;
+    int32_t* d_compact = nullptr; uint8_t* d_active_bits = nullptr;   // 1 bit per pixel: count >= thres of the current active set
     uint32_t* d_active = nullptr;
     uint32_t* d_ablk_cnt = nullptr; uint32_t* d_ablk_off = nullptr; size_t n_ablk = 0;
     double* d_pack_own = nullptr; size_t pack_own_cap = 0;
@@ -100,6 +100,7 @@ struct emba_ctx {
     bool kernel_timing = false;
     hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
     bool kt_warp_valid = false, kt_accum_valid = false;
+    int n_cu = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
@@ -347,6 +348,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->fy = (double)((c->H / 180.0) * 180.0 / M_PI);
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
     if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
 #define CREATE_TRY(call)                                                                                  \
@@ -370,6 +372,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->d_count = c->d_count_own;
     CREATE_TRY(hipMalloc((void**)&c->d_pixacc, c->npix * kPixAccStride * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_active_bits, (c->npix + 31) / 32 * 4 + 8));
     CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t)));
     c->n_ablk = (c->npix + kActivePix - 1) / kActivePix;
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t)));
@@ -398,7 +401,7 @@ void emba_destroy(emba_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_window(c);
     dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own); dev_free(c->d_Gx_trial); dev_free(c->d_Gy_trial); dev_free(c->d_x2);
-    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
+    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active_bits); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
     dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -467,7 +470,7 @@ emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     if ((st = dev_alloc(c, &c->d_ev_slot, ns))) return st;
     if ((st = dev_alloc(c, &c->d_batch_t, c->n_batch))) return st;
     if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
-    if ((st = dev_alloc(c, &c->d_rec, std::max<size_t>(n_cand, 1) * kRecStride))) return st;
+    if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride))) return st;
     if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
     if ((st = dev_alloc(c, &c->d_e_sorted, ns))) return st;
     if ((st = dev_alloc(c, &c->d_flag, ns))) return st;
@@ -739,7 +742,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
                            c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
     }
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy);
+                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy, c->d_active_bits);
     HIP_TRY(c, hipGetLastError());
     c->compact_valid = false;
     c->l2_fused = (c->fused_alpha != 0.0);
@@ -782,11 +785,17 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     }
     if (c->n_cand) {
         GramParams p{};
-        p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.count = c->d_count;
-        p.thres = c->thres; p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
+        p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
+        p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
-        const long waves = ((long)c->n_cand + kGramChunk - 1) / kGramChunk;
+        // slots per wave: one 16-wave block per CU with equal shares when that gives between kGramChunkMin and kGramChunk slots
+        // (1 M events: 236), else the fixed chunk and several rounds
+        long chunk = ((long)c->n_cand + (long)c->n_cu * (kGramBlock / 64) - 1) / ((long)c->n_cu * (kGramBlock / 64));
+        chunk = (chunk + 7) & ~7L;
+        chunk = std::min<long>(std::max<long>(chunk, kGramChunkMin), kGramChunk);
+        p.chunk = (int)chunk;
+        const long waves = ((long)c->n_cand + chunk - 1) / chunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
         constexpr long wpb = kGramBlock / 64;
         hipLaunchKernelGGL(emba_gram_kernel, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);

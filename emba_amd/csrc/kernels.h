@@ -30,6 +30,11 @@ constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the p
 constexpr int kEpGroup = 16;       // waves per residual-compaction block (1024 threads); the inlier scan runs over these groups
 constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
+#ifndef GRAM_U
+#define GRAM_U 4
+#endif
+constexpr int kGramPad = 256;     // record slots allocated past the last one: the Gram kernel's stages read whole 8-record groups
+constexpr int kGramChunkMin = 64; // smallest share of record slots a wave of the Gram kernel is given
 constexpr int kGramChunk = 256;    // record slots per wave in the Gram (A11/b1) kernel; multiple of 4
 constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table)
 constexpr int kGramKeys = 4;       // control-pose pairs the block-level LDS table can hold before falling back to global atomics
@@ -216,8 +221,11 @@ __device__ __forceinline__ double dpp_shl1(double v)
     return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
 }
 
+#ifndef WARP_OCC
+#define WARP_OCC
+#endif
 template <bool DUMP>
-__global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpParams p)
+__global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
 {
     __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
     __shared__ double s_acc[32 * 6];                                        // per-run sums {xx xy yy bx by n} of the staged half
@@ -238,7 +246,8 @@ __global__ __launch_bounds__(kWarpBlock) void emba_warp_residual_kernel(WarpPara
         const uint32_t pw = p.ev_pix[i];
         pix = pw & 0x7FFFFFFFu;
         pol = pw >> 31;
-        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * p.ev_batch[i]);
+        const uint32_t bi = (p.ablate & 16) ? (p.ev_batch[i] & 1u) : p.ev_batch[i];   // 16: static camera (diagnostic)
+        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
         double R[9], J1[9];
         {
             const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6];
@@ -591,8 +600,10 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
                                                                 int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx,
                                                                 const double* __restrict__ pixacc, double* __restrict__ A22b2,
                                                                 double* __restrict__ pack_head, long head_len, double alpha,
-                                                                const double* __restrict__ Gx, const double* __restrict__ Gy)
-{   // compact == nullptr: the pano->compact index map is not needed by this step's consumers (it is produced on demand);
+                                                                const double* __restrict__ Gx, const double* __restrict__ Gy,
+                                                                uint8_t* __restrict__ active_bits)
+{   // active_bits: one bit per panorama pixel (pixel p = bit p&31 of 32-bit word p>>5), the Gram kernel's activity lookup
+    // compact == nullptr: the pano->compact index map is not needed by this step's consumers (it is produced on demand);
     // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU).
     __shared__ uint32_t s_w[4];
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
@@ -600,6 +611,7 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long p0 = (long)blockIdx.x * kActivePix + 8 * threadIdx.x;
     const uint32_t m = active_mask8(count, p0, npix, thres);
+    if (p0 < npix) active_bits[p0 >> 3] = (uint8_t)m;
     const uint32_t mine = __popc(m);
     uint32_t x = mine;
 #pragma unroll
@@ -740,30 +752,39 @@ __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ co
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct GramParams {
-    const double* rec; const uint32_t* slot_key; long n_slots;
-    const int32_t* count; int thres; int irls; double eta;
+    const double* rec; const uint32_t* slot_key; long n_slots; int chunk;   // chunk: record slots per wave (multiple of 8)
+    const uint32_t* active_bits; int irls; double eta;                    // active_bits: count >= thres per pixel (model.cpp:333,409)
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
-__device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, const GramParams& p)
+__device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, double* A11, double* b1, int dim, int ablate)
 {
-    if (row >= 12 || v == 0.0 || (p.ablate & 32)) return;
+    if (row >= 12 || v == 0.0 || (ablate & 32)) return;
     const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
     const int grow = (row < 6) ? bc + row : bp + row - 6;
     if (col < 12) {
         const int gcol = (col < 6) ? bc + col : bp + col - 6;
-        atomicAdd(p.A11 + (size_t)grow + (size_t)p.dim * gcol, v);
+        atomicAdd(A11 + (size_t)grow + (size_t)dim * gcol, v);
     } else if (col == 14) {
-        atomicAdd(p.b1 + grow, v);
+        atomicAdd(b1 + grow, v);
     }
 }
 
-// A wave hands its tile to the block's LDS combine table (fp64 LDS atomics; one tile per pair, kGramKeys pairs per
-// block) so that the 16 waves of a block cost ONE set of global atomics per pair instead of 16 — the global fp64
-// atomics all land on the few A11 blocks of the current pairs and serialise at the memory side otherwise.
-__device__ __forceinline__ void gram_flush(double4_t& acc, uint32_t key, const GramParams& p, uint32_t* s_tag, double* s_tile)
+// Operand layout of the Gram kernel.  A wave-instruction loads 8 consecutive records as 16 B per lane (1 KiB, the access width
+// HBM streams fastest at): lane l holds elements (2m, 2m+1), m = l&7, of record R = l>>3.  Fed to v_mfma_f64_16x16x4_f64 as they
+// stand (operand row/col index l&15 = 8(R&1)+m, k index l>>4 = R>>1), the products of the EVEN elements give
+//     D[i][j] = sum_k r_{2k}[2i] r_{2k}[2j]  (i,j < 8: even records)   and   D[8+i][8+j] = the same over the odd records,
+// the two off-diagonal quadrants mix records and are ignored.  Three MFMAs (even x even, odd x even, odd x odd elements) per 8
+// records therefore hold the whole symmetric 16x16 Gram sum, with no cross-lane data movement at all.
+//
+// A wave hands its three tiles to the block's LDS combine table (fp64 LDS atomics; one 16x16 table per pair, kGramKeys pairs
+// per block) so that the 16 waves of a block cost ONE set of global atomics per pair instead of 16 — the global fp64 atomics
+// all land on the few A11 blocks of the current pairs and serialise at the memory side otherwise.  Called once or twice per
+// wave: a real function (arguments by value, in registers), so that its index arithmetic stays out of the streaming loop.
+__device__ __attribute__((noinline)) void gram_flush(double4_t ee, double4_t oe, double4_t oo, uint32_t key, double* A11, double* b1,
+                                                     int dim, int ablate, uint32_t* s_tag, double* s_tile)
 {
     const int lane = threadIdx.x & 63;
     int slot = -1;
@@ -774,14 +795,34 @@ __device__ __forceinline__ void gram_flush(double4_t& acc, uint32_t key, const G
         }
     }
     slot = __shfl(slot, 0);
+    auto out = [&](double v, int row, int col) {   // entry (row, col) of the symmetric 16x16 sum; rows >= 12 and cols 12, 13, 15 are not used
+        if (v == 0.0 || row >= 12 || !(col < 12 || col == 14)) return;
+        if (slot >= 0) atomicAdd(&s_tile[slot * 256 + row * 16 + col], v);
+        else gram_atomic_out(v, row, col, key, A11, b1, dim, ablate);
+    };
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int row = (lane >> 4) + 4 * r;      // C/D layout of v_mfma_f64_16x16x4_f64
-        const double v = acc[r];
-        if (slot >= 0) { if (v != 0.0 && row < 12) atomicAdd(&s_tile[slot * 256 + row * 16 + (lane & 15)], v); }
-        else gram_atomic_out(v, row, lane & 15, key, p);
-        acc[r] = 0.0;
+        const int i = (lane >> 4) + 4 * r, j = lane & 15;      // C/D layout of v_mfma_f64_16x16x4_f64
+        if ((i >> 3) == (j >> 3)) {                             // same-record quadrants only
+            const int i2 = 2 * (i & 7), j2 = 2 * (j & 7);
+            out(ee[r], i2, j2);
+            out(oe[r], i2 + 1, j2);
+            out(oe[r], j2, i2 + 1);                             // even x odd = transpose of odd x even
+            out(oo[r], i2 + 1, j2 + 1);
+        }
     }
+}
+
+// elements 14 (residual) and 15 ({pano_idx, aux}) of the record whose 8 lanes this lane belongs to: they sit in lane 8R+7
+// (ds_swizzle bit-mask mode inside 32 lanes: lane' = (lane & 0x18) | 7; no address VGPR, no memory request)
+__device__ __forceinline__ double rec_elem14(double2 v)
+{
+    return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(v.x), (7 << 5) | 0x18),
+                            __builtin_amdgcn_ds_swizzle(__double2loint(v.x), (7 << 5) | 0x18));
+}
+__device__ __forceinline__ uint32_t rec_elem15_lo(double2 v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2loint(v.y), (7 << 5) | 0x18);
 }
 
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
@@ -791,80 +832,133 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
     if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long wave_id = (long)blockIdx.x * (kGramBlock / 64) + wv;
-    const long start = wave_id * kGramChunk;
+    const long start = wave_id * p.chunk;
     const bool have_work = start < p.n_slots;   // wave-uniform
-    const long end = (start + kGramChunk < p.n_slots) ? start + kGramChunk : p.n_slots;
-    const int el = lane & 15, kk = lane >> 4;
+    const long end = (start + p.chunk < p.n_slots) ? start + p.chunk : p.n_slots;
+    const int m = lane & 7, R = lane >> 3;
     if (have_work) {
 
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
     uint32_t cur_key = p.slot_key[start];
     bool dirty = false;
-    constexpr int U = 8;   // 8 independent 512-B loads in flight per wave and stage
-    for (long base = start; base < end; base += 4 * U) {
-        double x[U], e[U];
-        uint32_t pi[U], key[U];
-        int32_t cnt[U];
-        // stage 1: record elements, tails and keys — all independent loads
+    double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
+    auto flush = [&]() {
+        gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, p.dim, p.ablate, s_tag, s_tile);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
+    };
+    constexpr int U = GRAM_U;   // independent 1-KiB loads (8 records each) per wave and stage
+    // One fully coalesced 16-B-per-lane load per 8 records is ALL the fast path reads: the residual and the pixel index of a
+    // record come from its last lane (ds_swizzle), the pair key is wave-uniform (slots are sorted by pair, so equal first and
+    // last keys of a stage mean one pair), and activity comes from a 1-bit map that stays in L2.  Two stages in flight: B's
+    // records are on their way while A's activity lookups and MFMAs run.
+    double2 xA[U], xB[U];
+    uint32_t act[U], k_first = 0, k_last = 0;
+    const int len = (int)(end - start);                              // <= kGramChunk: stage offsets are 32-bit
+    const double2* rec0 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * start) + lane;
+    const uint32_t* key0 = p.slot_key + start;
+    auto load_records = [&](int off, double2* x) {   // may run up to 8 U records past `end`: the record buffer is padded
+        const double2* q = rec0 + 8 * off;           // (kGramPad) and those slots are masked
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = q[64 * u];
+    };
+    auto lookup = [&](int off, const double2* x) {
+        // first and last pair key of the stage (uniform addresses), issued ahead of the next stage's records
+        k_first = key0[off];
+        k_last = key0[(off + 8 * U < len ? off + 8 * U : len) - 1];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long s = base + 4 * u + kk;
-            const bool in = s < end;
-            const double* r = p.rec + (size_t)kRecStride * (in ? s : start);
-            x[u] = r[el];
-            const double2 tail = *reinterpret_cast<const double2*>(r + 14);
-            e[u] = tail.x;
-            pi[u] = in ? (uint32_t)__double2loint(tail.y) : kInvalidPix;
-            key[u] = in ? p.slot_key[s] : 0xFFFFFFFFu;
+            const uint32_t pi = rec_elem15_lo(x[u]);
+            const bool in = off + 8 * u + R < len;
+            act[u] = (in && pi != kInvalidPix) ? ((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31) : 0u;
         }
-        // stage 2: the count gathers, issued together (unconditional, clamped index) so their latencies overlap
+    };
+    auto weight = [&](const double2& x) {
+        double w = 1.0;
+        if (p.irls) {
+            const double e = rec_elem14(x);
+            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);          // cauchy, model.cpp:603
+            else { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }   // huber, :608-616
+        }
+        return w;
+    };
+    auto consume = [&](int off, const double2* x) {
+        if ((k_first == cur_key) && (k_last == cur_key)) {             // fast path: the whole stage belongs to the current pair
 #pragma unroll
-        for (int u = 0; u < U; ++u) cnt[u] = p.count[pi[u] != kInvalidPix ? pi[u] : 0u];
-        // stage 3: masks, weights, MFMAs
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool in = key[u] != 0xFFFFFFFFu;
-            const bool ok = (pi[u] != kInvalidPix) && (cnt[u] >= p.thres);   // model.cpp:396,409
-            double w = 1.0;
-            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e[u] * e[u]);      // cauchy, model.cpp:603
-            else if (p.irls == 1) { const double a = fabs(e[u]); w = (a < p.eta) ? 1.0 : p.eta / a; }  // huber, :608-616
-            const double a_op = ok ? w * x[u] : 0.0;                      // selects, not multiplies: stale slots may hold anything
-            const double b_op = ok ? x[u] : 0.0;
-            if (__ballot(in && key[u] != cur_key) == 0ull) {              // fast path: the whole group belongs to the current pair
+            for (int u = 0; u < U; ++u) {
+                const bool ok = act[u] & 1u;                               // model.cpp:396,409
+                const double w = weight(x[u]);
+                // selects, not multiplies: stale slots may hold anything
+                const double ax = ok ? w * x[u].x : 0.0, ay = ok ? w * x[u].y : 0.0, bx = ok ? x[u].x : 0.0, by = ok ? x[u].y : 0.0;
                 if (__ballot(ok)) {
                     dirty = true;
-                    if (!(p.ablate & 64)) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, b_op, acc, 0, 0, 0);
+                    if (!(p.ablate & 64)) {
+                        acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
+                        acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
+                        acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
+                    }
                 }
-                continue;
             }
+            return;
+        }
+        // The stage straddles a pair boundary (a few dozen waves per launch): group the 8 records of each MFMA step by pair.
+        // One copy of the code — the loop is kept rolled by rotating the stage's registers instead of indexing them.
+        double2 y[U];
+        uint32_t a_[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { y[u] = x[u]; a_[u] = act[u]; }
+#pragma unroll 1
+        for (int u = 0; u < U; ++u) {
+            const bool ok = a_[0] & 1u;
+            const double w = weight(y[0]);
+            const int s = off + 8 * u + R;
+            const bool in = s < len;
+            const uint32_t key = in ? key0[s] : 0xFFFFFFFFu;
             unsigned long long remaining = __ballot(in);
-            while (remaining) {  // this group of 4 records straddles a pair boundary
+            while (remaining) {
                 const int first = __ffsll((long long)remaining) - 1;
-                const uint32_t k0 = (uint32_t)__shfl((int)key[u], first);
+                const uint32_t k0 = (uint32_t)__shfl((int)key, first);
                 if (k0 != cur_key) {
-                    if (dirty) gram_flush(acc, cur_key, p, s_tag, s_tile);
+                    if (dirty) flush();
                     cur_key = k0;
                     dirty = false;
                 }
-                const bool mine = in && (key[u] == k0);
-                if (__ballot(mine && ok)) {
+                const bool mine = in && (key == k0), use = mine && ok;
+                if (__ballot(use)) {
                     dirty = true;
-                    if (!(p.ablate & 64))
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mine ? a_op : 0.0, mine ? b_op : 0.0, acc, 0, 0, 0);
+                    const double ax = use ? w * y[0].x : 0.0, ay = use ? w * y[0].y : 0.0, bx = use ? y[0].x : 0.0, by = use ? y[0].y : 0.0;
+                    if (!(p.ablate & 64)) {
+                        acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
+                        acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
+                        acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
+                    }
                 }
                 remaining &= ~__ballot(mine);
             }
+#pragma unroll
+            for (int v = 0; v + 1 < U; ++v) { y[v] = y[v + 1]; a_[v] = a_[v + 1]; }
         }
+    };
+    load_records(0, xA);
+    for (int off = 0; off < len; off += 16 * U) {
+        lookup(off, xA);                       // issued BEFORE B's record loads: memory operations return in order, so waiting
+        const bool haveB = off + 8 * U < len;  // for the lookups later leaves B's loads in flight
+        if (haveB) load_records(off + 8 * U, xB);
+        consume(off, xA);
+        if (!haveB) break;
+        lookup(off + 8 * U, xB);
+        if (off + 16 * U < len) load_records(off + 16 * U, xA);
+        consume(off + 8 * U, xB);
     }
-    if (dirty) gram_flush(acc, cur_key, p, s_tag, s_tile);
+    if (dirty) flush();
     }  // have_work
     __syncthreads();
     // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
         const uint32_t key = s_tag[i >> 8];
-        if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p);
+        if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
     }
 }
 

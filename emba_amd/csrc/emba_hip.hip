@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -65,7 +66,10 @@ struct emba_ctx {
     int* d_err = nullptr;
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
-    int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P
+    int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P [3] step sequence number
+    int seq = 0;                    // sequence number of the last step whose post-warp kernels publish [3]
+    bool seq_armed = false;         // the pending counts come from kernels that publish the sequence number
+    bool spun = false;              // counts were taken by polling: later kernels of the stream may still be running
     int* h_pinned_dev = nullptr;    // the same memory through its device pointer
     double* h_knots_dev = nullptr;  // device pointer of the pinned control-pose staging buffer
 
@@ -283,12 +287,31 @@ emba_status launch_ep_compaction(emba_ctx* c)
 
 // Synchronize the stream and turn the counters that were read back asynchronously (inlier count, device error
 // word, active-pixel count) into host state.  Called only where the host really needs a value.
-emba_status resolve_pending(emba_ctx* c)
+// counts_only: the caller needs the inlier / active-pixel counts and nothing else from the device.  When they were produced by
+// the fused post-warp kernels, the host polls the sequence word those kernels publish after the counts instead of waiting for
+// the whole stream: it returns while the later kernels of the step (active-set gather, Gram) still run, so the next step's
+// launches queue up behind them and the GPU never idles for a host round trip.  Everything that reads device data on the
+// host goes through the full form (counts_only = false), which drains the stream.
+emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
 {
     { emba_status st = launch_ep_compaction(c); if (st) return st; }
-    if (!c->inl_pending && !c->P_pending) return EMBA_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->knots_in_flight = false;
+    if (!c->inl_pending && !c->P_pending) {
+        if (c->spun && !counts_only) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->spun = false; c->knots_in_flight = false; }
+        return EMBA_OK;
+    }
+    bool polled = false;
+    if (counts_only && c->seq_armed && c->inl_pending && c->P_pending) {
+        volatile int* w = c->h_pinned + 3;
+        for (long spin = 0; spin < 50000000L; ++spin) {      // bounded: a faulted kernel never publishes; fall back to the stream
+            if (*w == c->seq) { polled = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (polled) std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (polled) c->spun = true;
+    else { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->spun = false; }
+    c->seq_armed = false;
+    c->knots_in_flight = false;   // (the prep kernel that reads the pinned knot buffer precedes the post-warp kernels)
     if (c->inl_pending) {
         c->inl_pending = false;
         if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
@@ -732,6 +755,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.blk_cnt = c->d_blk_cnt; q.grp_cnt = c->d_grp_cnt; q.grp_off = c->d_grp_off; q.ngrp = c->ngrp; q.nblk = c->nblk; q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.n_sorted = (long)c->n_sorted; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
+        q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)c->n_ablk + 1), dim3(256), 0, s, q);
         hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3((unsigned)c->ngrp + 1), dim3(1024), 0, s, q);
         c->inl_pending = true;
@@ -822,8 +846,10 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
                                c->d_total + 1, alpha, c->d_Gx, c->d_Gy);
     }
     HIP_TRY(c, hipGetLastError());
-    emba_status st = resolve_pending(c);   // the step's one host synchronization when nothing was resolved earlier
+    const bool download = A11 || b1 || active_idx || A22 || b2 || A12_dense;
+    emba_status st = resolve_pending(c, !download);   // the step's one host wait when nothing was resolved earlier
     if (st) return st;
+    if (!download) { c->finish_done = true; return EMBA_OK; }
     const size_t P = c->P;
     const int dim = 3 * c->K;
     if ((A22 || b2 || A12_dense || active_idx) && cap_P < P) return fail(c, EMBA_ERR_CAPACITY, "cap_P=%zu < P=%zu", cap_P, P);
@@ -1019,7 +1045,7 @@ emba_status emba_last_counts(emba_ctx* c, size_t* n_inliers, size_t* P)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    emba_status st = resolve_pending(c);
+    emba_status st = resolve_pending(c, true);
     if (st) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
     if (P) *P = c->P;
@@ -1033,6 +1059,7 @@ emba_status emba_sync(emba_ctx* c)
     emba_status st = resolve_pending(c);
     if (st) return st;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->spun = false;
     return EMBA_OK;
 }
 

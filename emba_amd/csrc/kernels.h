@@ -581,6 +581,7 @@ struct PostWarpParams {
     const int32_t* count; long npix; int thres; uint32_t* ablk_cnt; uint32_t* ablk_off; long n_ablk; uint32_t* total_P; int* total_P_host;
     const uint32_t* blk_cnt; const uint32_t* grp_cnt; uint32_t* grp_off; long ngrp; long nblk; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
     const double* e_sorted; const uint8_t* flag; long n_sorted; double* ep; int32_t* inl_idx;
+    int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts: the host may poll it instead of waiting for the stream
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
@@ -591,7 +592,13 @@ __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 
 __global__ __launch_bounds__(1024) void emba_post_warp_b_kernel(PostWarpParams p)
 {
-    if (blockIdx.x == 0) block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
+    if (blockIdx.x == 0) {
+        block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
+        if (threadIdx.x == 0 && p.seq_host) {   // same thread as the count stores of block_scan_256: fence, then publish
+            __threadfence_system();
+            __hip_atomic_store(p.seq_host, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     else compact_ep_block((long)blockIdx.x - 1, p.e_sorted, p.flag, p.blk_cnt, p.grp_off, p.n_sorted, p.nblk, p.ep, p.inl_idx);
 }
 

@@ -18,6 +18,7 @@
 
 #include "kernels.h"
 #include "solve_kernels.h"
+#include "poisson_kernels.h"
 
 using namespace emba;
 
@@ -109,6 +110,8 @@ struct emba_ctx {
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
     struct { void* p = nullptr; size_t bytes = 0; } ws[16];
+    // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
+    double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
 };
 
 namespace {
@@ -424,7 +427,8 @@ void emba_destroy(emba_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_window(c);
     dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own); dev_free(c->d_Gx_trial); dev_free(c->d_Gy_trial); dev_free(c->d_x2);
-    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_compact); dev_free(c->d_active_bits); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
+    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_SH); dev_free(c->d_SW); dev_free(c->d_lamH); dev_free(c->d_lamW); dev_free(c->d_pF); dev_free(c->d_pT); dev_free(c->d_pGx); dev_free(c->d_pGy);
+    dev_free(c->d_compact); dev_free(c->d_active_bits); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
     dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
@@ -1222,5 +1226,56 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
 #undef SOLVE_TRY
 #undef SOLVE_HIP
     if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    return EMBA_OK;
+}
+
+// ---- f3: intensity panorama from the gradient map ---------------------------------------------------------------------------
+extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_host, const double* Gy_host, double* M_host)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if ((Gx_host == nullptr) != (Gy_host == nullptr)) return fail(c, EMBA_ERR_INVALID_ARG, "pass both Gx and Gy, or neither");
+    if (!Gx_host && !c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int H = c->H, W = c->W;
+    const size_t npix = c->npix;
+    emba_status st;
+    if (!c->d_SH) {   // first use: S_H, S_W, eigenvalues, two scratch planes
+        if ((st = dev_alloc(c, &c->d_SH, (size_t)H * H)) || (st = dev_alloc(c, &c->d_SW, (size_t)W * W)) || (st = dev_alloc(c, &c->d_lamH, (size_t)H)) ||
+            (st = dev_alloc(c, &c->d_lamW, (size_t)W)) || (st = dev_alloc(c, &c->d_pF, npix)) || (st = dev_alloc(c, &c->d_pT, npix))) {
+            dev_free(c->d_SH); dev_free(c->d_SW); dev_free(c->d_lamH); dev_free(c->d_lamW); dev_free(c->d_pF); dev_free(c->d_pT);
+            return st;
+        }
+        hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, s, H, c->d_SH);
+        hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)W * W + 255) / 256)), dim3(256), 0, s, W, c->d_SW);
+        hipLaunchKernelGGL(emba_dirichlet_eigen_kernel, dim3((H + 255) / 256), dim3(256), 0, s, H, c->d_lamH);
+        hipLaunchKernelGGL(emba_dirichlet_eigen_kernel, dim3((W + 255) / 256), dim3(256), 0, s, W, c->d_lamW);
+    }
+    const double *gx = c->d_Gx, *gy = c->d_Gy;
+    if (Gx_host) {
+        if (!c->d_pGx) { if ((st = dev_alloc(c, &c->d_pGx, npix)) || (st = dev_alloc(c, &c->d_pGy, npix))) { dev_free(c->d_pGx); return st; } }
+        HIP_TRY(c, hipMemcpyAsync(c->d_pGx, Gx_host, npix * sizeof(double), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->d_pGy, Gy_host, npix * sizeof(double), hipMemcpyHostToDevice, s));
+        gx = c->d_pGx; gy = c->d_pGy;
+    }
+    hipLaunchKernelGGL(emba_divergence_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, gx, gy, H, W, c->d_pF);
+    auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue) {
+        GemmParams p{};
+        p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N;
+        p.epilogue = epilogue; p.inv_norm = 1.0 / (4.0 * ((double)(H + 1) * (double)(W + 1)));   // fft_norm, laplace.cpp:648
+        p.lam1 = c->d_lamH; p.lam2 = c->d_lamW;
+        p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
+        const long tiles = (long)((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
+        hipLaunchKernelGGL(emba_dgemm_kernel, dim3((unsigned)grid8(tiles)), dim3(256), 0, s, p);
+    };
+    // rhs -> eigenvector space, solve, back (laplace.cpp:633-758):  M = S_H ((S_H F S_W) o C) S_W
+    gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0);      // T = F S_W
+    gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 1);      // U = (S_H T / fft_norm) / (lambda1 + lambda2)
+    gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0);      // T = U S_W
+    gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 0);      // M = S_H T
+    HIP_TRY(c, hipGetLastError());
+    if (M_host) HIP_TRY(c, hipMemcpyAsync(M_host, c->d_pF, npix * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->spun = false; c->knots_in_flight = false;
     return EMBA_OK;
 }

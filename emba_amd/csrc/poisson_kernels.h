@@ -1,0 +1,173 @@
+// emba_amd/csrc/poisson_kernels.h — SURVEY §8 f3: intensity panorama from the gradient map (gfx950, fp64 matrix cores).
+//
+// Reference: poisson_reconstruction::reconstructFromGradient (src/image_rec/poisson_reconstruction.cpp:9-50) +
+// pde::poisolve, Dirichlet branch (src/image_rec/laplace.cpp:587-797):
+//     F[i][j] = gx[i][j+1] - gx[i][j] + gy[i+1][j] - gy[i][j]   (i < H-1, j < W-1; last row and column 0)
+//     R  = DST-I_2D(F) / (4 (H+1)(W+1))                          (FFTW RODFT00, unnormalised: factor 2 per dimension)
+//     U  = R[i][j] / (lambda1[i] + lambda2[j]),  lambda_d[k] = -4 sin^2(pi (k+1) / (2 (n_d+1)))
+//     M  = DST-I_2D(U)
+// FFTW is not part of the reference tree; the transform is the published RODFT00 definition
+//     Y[k] = 2 sum_j X[j] sin(pi (j+1)(k+1) / (n+1)).
+// The transform lengths 2(n+1) = 2050 / 4098 have large prime factors (41, 683), so an FFT is the wrong tool here: the DST is
+// applied as a dense product with the symmetric sine matrix S_n[k][j] = 2 sin(pi (j+1)(k+1)/(n+1)) — a GEMM-shaped fp64 job,
+// the one place on this code path where MFMA is the bound:  M = S_H ((S_H F S_W) o C) S_W,  25.8 GFLOP at 1024 x 2048.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace emba {
+
+typedef double pdouble4_t __attribute__((ext_vector_type(4)));
+
+// F = d gx/dx + d gy/dy with forward differences (poisson_reconstruction.cpp:21-29); row-major H x W.
+__global__ void emba_divergence_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, int H, int W, double* __restrict__ F)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)H * W) return;
+    const int i = (int)(idx / W), j = (int)(idx % W);
+    double f = 0.0;
+    if (i < H - 1 && j < W - 1) f = Gx[idx + 1] - Gx[idx] + Gy[idx + W] - Gy[idx];   // same association as the reference
+    F[idx] = f;
+}
+
+// S[k][j] = 2 sin(pi (j+1)(k+1) / (n+1)), row-major n x n (symmetric).  The argument is reduced in exact integer arithmetic
+// (period 2(n+1)) and folded to [0, (n+1)/2] before the sine, so every entry is accurate to the last bits.
+__global__ void emba_sine_matrix_kernel(int n, double* __restrict__ S)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)n * n) return;
+    const long k = idx / n, j = idx % n, m = n + 1;
+    long r = ((j + 1) * (k + 1)) % (2 * m);
+    double sgn = 2.0;
+    if (r >= m) { r -= m; sgn = -2.0; }          // sin(x + pi) = -sin(x)
+    if (2 * r > m) r = m - r;                     // sin(pi - x) = sin(x)
+    S[idx] = sgn * sin(3.14159265358979323846 * (double)r / (double)m);
+}
+
+// lambda[k] = -4 sin^2(pi (k+1) / (2 (n+1)))   (laplace.cpp:700-704)
+__global__ void emba_dirichlet_eigen_kernel(int n, double* __restrict__ lam)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double s = sin((3.14159265358979323846 * (double)(k + 1)) / (2.0 * (double)(n + 1)));
+    lam[k] = -4.0 * (s * s);
+}
+
+// C (M x N) = A (M x K) * B (K x N), all row-major fp64, on v_mfma_f64_16x16x4_f64.
+// Block tile 64 x 128 x 16, 256 threads = 4 waves in a 2 x 2 arrangement, each wave 32 x 64 = 2 x 4 MFMA tiles (32 accumulator
+// doubles per lane).  A and B tiles go global -> registers -> LDS (k-major, so that the operand reads of the MFMA layout — lane l
+// holds element (l&15) at k = l>>4 — are consecutive 8-B words), double-buffered: the next tile's global loads are in flight
+// while the current tile's 4 k-steps x 8 MFMAs run.  12 FLOP per byte loaded from L2; MFMA-bound (fp64 matrix peak 78.6 TFLOP/s).
+// epilogue: 0 plain; 1 Poisson eigen-solve  C = (acc * inv_norm) / (lam1[row] + lam2[col])   (laplace.cpp:667-731)
+struct GemmParams {
+    const double* A; const double* B; double* C; int M, N, K; long lda, ldb, ldc;
+    int epilogue; double inv_norm; const double* lam1; const double* lam2;
+    int vec;   // lda, ldb even and A, B 16-B aligned: interior tiles use 16-B loads
+};
+
+constexpr int kGemmBM = 64, kGemmBN = 128, kGemmBK = 16;
+constexpr int kGemmLdA = kGemmBM + 16, kGemmLdB = kGemmBN + 16;   // k-major rows padded to 16 (mod 32) words: the 4 k-slices of an
+                                                                  // MFMA operand read fall on disjoint bank halves
+
+__global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) double sA[2][kGemmBK * kGemmLdA];
+    __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int el = lane & 15, kk = lane >> 4;
+    // XCD-aware tile order: the 8 XCDs take contiguous runs of tile rows, so the B panels an XCD streams stay in its own L2
+    const int tiles_n = (p.N + kGemmBN - 1) / kGemmBN, tiles_m = (p.M + kGemmBM - 1) / kGemmBM;
+    const long n_tiles = (long)tiles_m * tiles_n;
+    long bid = blockIdx.x;
+    {
+        const long per = (n_tiles + 7) / 8;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= n_tiles) return;   // (whole block; before any barrier)
+    }
+    const int m0 = (int)(bid / tiles_n) * kGemmBM, n0 = (int)(bid % tiles_n) * kGemmBN;
+    const int wm = (wv & 1) * 32, wn = (wv >> 1) * 64;
+
+    // global -> register staging: A tile 64 x 16 (4 doubles per thread: row t/4, k (t%4)*4..+3), B tile 16 x 128 (8 per thread: k t/16, cols (t%16)*8..+7)
+    const int a_row = t >> 2, a_k = (t & 3) * 4;
+    const int b_k = t >> 4, b_col = (t & 15) * 8;
+    double ra[4], rb[8];
+    auto load_tile = [&](int k0) {
+        const int gr = m0 + a_row;
+        if (p.vec && gr < p.M && k0 + a_k + 3 < p.K) {           // interior: 16-B loads
+            const double2* q2 = reinterpret_cast<const double2*>(p.A + (size_t)p.lda * gr + k0 + a_k);
+            const double2 v0 = q2[0], v1 = q2[1];
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gk = k0 + a_k + q;
+                ra[q] = (gr < p.M && gk < p.K) ? p.A[(size_t)p.lda * gr + gk] : 0.0;
+            }
+        }
+        const int gk = k0 + b_k;
+        if (p.vec && gk < p.K && n0 + b_col + 7 < p.N) {
+            const double2* q2 = reinterpret_cast<const double2*>(p.B + (size_t)p.ldb * gk + n0 + b_col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const double2 v = q2[q]; rb[2 * q] = v.x; rb[2 * q + 1] = v.y; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int gc = n0 + b_col + q;
+                rb[q] = (gk < p.K && gc < p.N) ? p.B[(size_t)p.ldb * gk + gc] : 0.0;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sA[buf][(a_k + q) * kGemmLdA + a_row] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sB[buf][b_k * kGemmLdB + b_col + q] = rb[q];
+    };
+
+    pdouble4_t acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = pdouble4_t{0.0, 0.0, 0.0, 0.0};
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += kGemmBK) {
+        const bool more = k0 + kGemmBK < p.K;
+        if (more) load_tile(k0 + kGemmBK);            // in flight behind the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < kGemmBK; ks += 4) {
+            double av[2], bv[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = sA[buf][(ks + kk) * kGemmLdA + wm + 16 * a + el];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = sB[buf][(ks + kk) * kGemmLdB + wn + 16 * b + el];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);                // the other buffer: its readers finished before the previous barrier
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // C/D layout of v_mfma_f64_16x16x4_f64: lane l owns rows (l>>4) + 4r, column l&15 of each 16 x 16 tile
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + 16 * a + kk + 4 * r, col = n0 + wn + 16 * b + el;
+                if (row < p.M && col < p.N) {
+                    double v = acc[a][b][r];
+                    if (p.epilogue == 1) v = (v * p.inv_norm) / (p.lam1[row] + p.lam2[col]);
+                    p.C[(size_t)p.ldc * row + col] = v;
+                }
+            }
+}
+
+}  // namespace emba

@@ -10,6 +10,8 @@
   incremental_update             LinearTrajectory::incrementalUpdate :296-304                     (left perturbation exp(x)*knot)
   bearing_lut_from_calibration   EventWarper::precomputeBearingVectors src/utils/event_pano_warper.cpp:27-41 (image_geometry rectifyPoint +
                                                                       projectPixelTo3dRay for a monocular plumb_bob camera)
+  normalize_robust / save_pgm    image_util::normalizeRobust          src/utils/image_utils.cpp:13-38   (8-bit display images of maps and of the
+                                                                      Poisson-reconstructed panorama, solver.cpp:417-425; PGM instead of PNG)
   save_events / load_events      a flat .npz replacing the rosbag of src/utils/rosbag_loading.cpp (x, y u16; polarity u8; t_ns i64, sorted)
 
 Host-side, O(K) or file-sized work; the per-event path is emba_amd.LEGM.
@@ -145,6 +147,27 @@ def bearing_lut_from_calibration(K, D, width, height, iters=5):
         x = (x0 - dx) * icdist
         y = (y0 - dy) * icdist
     return np.ascontiguousarray(np.stack([x, y, np.ones_like(x)], axis=-1).reshape(-1, 3))
+
+
+# ---- display images ---------------------------------------------------------------------------------------------------------
+def normalize_robust(img, percentage_pixels_to_discard=0.1):
+    """image_util::normalizeRobust: scale [robust min, robust max] (order statistics after discarding the given percentage of
+    pixels, float32 index arithmetic like the reference) to [0, 255]; cv::Mat::convertTo(CV_8UC1) = round half to even, saturate."""
+    a = np.asarray(img, dtype=np.float64)
+    srt = np.sort(a, axis=None)
+    n = a.size
+    i_min = int(np.float32(np.float32(0.5) * np.float32(percentage_pixels_to_discard) / np.float32(100.0)) * np.float32(n))
+    i_max = int(np.float32(np.float32(1.0) - np.float32(0.5) * np.float32(percentage_pixels_to_discard) / np.float32(100.0)) * np.float32(n))
+    rmin, rmax = srt[i_min], srt[min(i_max, n - 1)]
+    scale = 255.0 / (rmax - rmin) if rmax != rmin else 1.0
+    return np.clip(np.rint(scale * (a - rmin)), 0, 255).astype(np.uint8)
+
+
+def save_pgm(path, img_u8):
+    img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (img_u8.shape[1], img_u8.shape[0]))
+        f.write(img_u8.tobytes())
 
 
 # ---- events ---------------------------------------------------------------------------------------------------------------

@@ -217,6 +217,19 @@ class LEGM:
         self._check(self._L.emba_download_map(self._ctx, _p(Gx, _dp), _p(Gy, _dp)))
         return Gx, Gy
 
+    def reconstructIntensity(self, Gx=None, Gy=None, download=True):
+        """poisson_reconstruction::reconstructFromGradient (poisson_reconstruction.cpp:9-50; solver.cpp:417,471): the intensity
+        panorama whose gradient is (Gx, Gy) — or the device-resident map when both are None."""
+        if (Gx is None) != (Gy is None):
+            raise ValueError("pass both Gx and Gy, or neither")
+        if Gx is not None:
+            Gx = np.ascontiguousarray(Gx, dtype=np.float64); Gy = np.ascontiguousarray(Gy, dtype=np.float64)
+            if Gx.shape != (self.H, self.W) or Gy.shape != (self.H, self.W):
+                raise ValueError("Gx/Gy must be pano_height x pano_width float64")
+        M = np.empty((self.H, self.W)) if download else None
+        self._check(self._L.emba_reconstruct_intensity(self._ctx, _p(Gx, _dp), _p(Gy, _dp), _p(M, _dp)))
+        return M
+
     def A12_sparse(self):
         """Rank-1 factors of A12 (one per measurement candidate; pix == -1 marks outliers/inactive)."""
         _, M = self.event_counts()

@@ -7,7 +7,7 @@
 
 Inputs: events (.npz: x, y u16; polarity u8; t_ns i64), initial poses ("t tx ty tz qx qy qz qw" per line), initial map
 (Gx.bin / Gy.bin raw float64, H x 2H), calibration (.npz: K [3,3], D [<=5] plumb_bob, width, height).
-Outputs: <out>/refined_traj.txt, <out>/Gx.bin, <out>/Gy.bin (the files emba.cpp:300-330 writes)."""
+Outputs: <out>/refined_traj.txt, <out>/Gx.bin, <out>/Gy.bin (the files emba.cpp:300-330 writes), <out>/map_poisson_opt.pgm."""
 import argparse
 import os
 import sys
@@ -78,6 +78,8 @@ def main():
         print(f"mean control-pose error vs ground truth: {err(traj):.4f} deg -> {err(res.traj):.4f} deg")
     eio.write_trajectory(os.path.join(a.out, "refined_traj.txt"), res.traj)
     eio.save_map(a.out, *model.downloadMap())
+    # intensity panorama from the refined gradient map (solver.cpp:417-425 / 471-479), reconstructed on the device
+    eio.save_pgm(os.path.join(a.out, "map_poisson_opt.pgm"), eio.normalize_robust(model.reconstructIntensity(), 0.1))
 
 
 if __name__ == "__main__":

@@ -161,6 +161,15 @@ emba_status emba_map_accept(emba_ctx* ctx);
 emba_status emba_map_reject(emba_ctx* ctx);
 emba_status emba_download_map(emba_ctx* ctx, double* Gx_host, double* Gy_host);
 
+/* Intensity panorama from the gradient map: poisson_reconstruction::reconstructFromGradient,
+ * src/image_rec/poisson_reconstruction.cpp:9-50 + pde::poisolve (Dirichlet, zero boundary), src/image_rec/laplace.cpp:587-797,
+ * as the reference calls it for its map images (solver.cpp:417,471).  Gx_host/Gy_host: pano_h x pano_w row-major doubles, or
+ * both NULL to use the map resident on the device (the one the next evaluation would use).  M_host: pano_h x pano_w doubles,
+ * or NULL to leave the result in the context's device buffer (timing).  The 2-D DST-I is applied as products with the sine
+ * matrix on the fp64 matrix cores (the transform lengths 2(n+1) have large prime factors); the matrices are built on first
+ * use and kept (8 (H^2 + W^2) bytes). */
+emba_status emba_reconstruct_intensity(emba_ctx* ctx, const double* Gx_host, const double* Gy_host, double* M_host);
+
 /* Schur-complement solve: LEGM::solveNormalEq(A11, A12, A22_blocks, b1, b2, lambda, x1, x2), model.cpp:721-792,
  * on the device-resident normal equations of the last emba_form_finish (so after applyL2Reg, as in solver.cpp:130,190-202),
  * consuming the SPARSE A12 factors: S = A11m - A12 A22m^-1 A12^T is formed chunk-wise from per-pixel column pairs built from the

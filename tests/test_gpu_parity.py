@@ -499,3 +499,24 @@ def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw, resident):
     assert rg.cost_min < rg.log[0][2]
     if ba.alpha == 0.0:
         assert knot_errors(rg.traj, w.traj).mean() < knot_errors(init, w.traj).mean()
+
+
+@pytest.mark.parametrize("pano_h", [75, 256, 1024])
+def test_poisson_reconstruction_matches_oracle(gpu, pano_h):
+    """reconstructFromGradient (poisson_reconstruction.cpp:9-50, laplace.cpp:587-797) on the fp64 matrix cores against
+    the numpy restatement; 75 x 150 exercises the ragged tiles and the unaligned loads, 1024 x 2048 is the BASELINE panorama."""
+    from oracle import poisson as OP
+    w = small_workload(n_events=2000, pano_h=pano_h)
+    m = make_legm(w)
+    rng = np.random.default_rng(pano_h)
+    Gx, Gy = rng.normal(size=(w.pano_h, w.pano_w)), rng.normal(size=(w.pano_h, w.pano_w))
+    M = m.reconstructIntensity(Gx, Gy)
+    Mo = OP.reconstruct_from_gradient(Gx, Gy)
+    assert_close(M, Mo, "intensity panorama", tight=1e-10)
+    # the device result solves the discrete equation it is defined by
+    P = np.pad(M, 1)
+    lap = P[2:, 1:-1] + P[:-2, 1:-1] + P[1:-1, 2:] + P[1:-1, :-2] - 4.0 * M
+    assert np.abs(lap - OP.divergence(Gx, Gy)).max() < 1e-9 * np.abs(Gx).max() * w.pano_w
+    # resident map: same result as passing it
+    m.upload_map(Gx, Gy)
+    assert np.array_equal(m.reconstructIntensity(), M)

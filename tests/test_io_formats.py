@@ -129,3 +129,18 @@ def test_bearing_lut_from_calibration():
     yd = y * rad + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
     v, u = np.meshgrid(np.arange(180.0), np.arange(240.0), indexing="ij")
     assert np.abs(xd * 200 + 120 - u.ravel()).max() < 1e-6 and np.abs(yd * 200 + 90 - v.ravel()).max() < 1e-6
+
+
+def test_normalize_robust_and_pgm(tmp_path):
+    rng = np.random.default_rng(4)
+    img = rng.normal(size=(40, 50)); img[0, 0] = 1e6; img[1, 1] = -1e6          # outliers must not set the range
+    u8 = eio.normalize_robust(img, 1.0)
+    assert u8.dtype == np.uint8 and u8.min() == 0 and u8.max() == 255 and 100 < np.median(u8) < 160
+    srt = np.sort(img, axis=None)
+    lo, hi = srt[int(0.005 * 2000)], srt[int(0.995 * 2000)]
+    k = (5, 7)
+    assert u8[k] == np.clip(np.rint(255.0 / (hi - lo) * (img[k] - lo)), 0, 255)
+    assert (eio.normalize_robust(np.full((4, 4), 3.0)) == 0).all()            # rmax == rmin: scale 1
+    eio.save_pgm(tmp_path / "a.pgm", u8)
+    raw = open(tmp_path / "a.pgm", "rb").read()
+    assert raw.startswith(b"P5\n50 40\n255\n") and len(raw) == len(b"P5\n50 40\n255\n") + 2000

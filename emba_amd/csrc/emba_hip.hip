@@ -1265,8 +1265,9 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         p.epilogue = epilogue; p.inv_norm = 1.0 / (4.0 * ((double)(H + 1) * (double)(W + 1)));   // fft_norm, laplace.cpp:648
         p.lam1 = c->d_lamH; p.lam2 = c->d_lamW;
         p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
-        const long tiles = (long)((M + kGemmBM - 1) / kGemmBM) * ((N + kGemmBN - 1) / kGemmBN);
-        hipLaunchKernelGGL(emba_dgemm_kernel, dim3((unsigned)grid8(tiles)), dim3(256), 0, s, p);
+        const long tm = (M + kGemmBM - 1) / kGemmBM, wide = tm * ((N + 127) / 128), narrow = tm * ((N + 63) / 64);
+        if (wide >= 2L * c->n_cu) hipLaunchKernelGGL(emba_dgemm_kernel<128>, dim3((unsigned)grid8(wide)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(emba_dgemm_kernel<64>, dim3((unsigned)grid8(narrow)), dim3(256), 0, s, p);
     };
     // rhs -> eigenvector space, solve, back (laplace.cpp:633-758):  M = S_H ((S_H F S_W) o C) S_W
     gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0);      // T = F S_W

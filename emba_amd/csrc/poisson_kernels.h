@@ -65,12 +65,15 @@ struct GemmParams {
     int vec;   // lda, ldb even and A, B 16-B aligned: interior tiles use 16-B loads
 };
 
-constexpr int kGemmBM = 64, kGemmBN = 128, kGemmBK = 16;
-constexpr int kGemmLdA = kGemmBM + 16, kGemmLdB = kGemmBN + 16;   // k-major rows padded to 16 (mod 32) words: the 4 k-slices of an
+constexpr int kGemmBM = 64, kGemmBK = 16;
+constexpr int kGemmLdA = kGemmBM + 16;   // k-major rows padded to 16 (mod 32) words: the 4 k-slices of an
                                                                   // MFMA operand read fall on disjoint bank halves
 
+// BN = 128 (wave tile 32 x 64) or 64 (wave tile 32 x 32: twice the blocks, for outputs too small to give every CU two of the wide ones)
+template <int kGemmBN>
 __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
 {
+    constexpr int kGemmLdB = kGemmBN + 16, NB = kGemmBN / 32, BQ = kGemmBN / 16;   // MFMA column tiles per wave; B doubles staged per thread
     __shared__ __attribute__((aligned(16))) double sA[2][kGemmBK * kGemmLdA];
     __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * kGemmLdB];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -85,12 +88,12 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
         if (bid >= n_tiles) return;   // (whole block; before any barrier)
     }
     const int m0 = (int)(bid / tiles_n) * kGemmBM, n0 = (int)(bid % tiles_n) * kGemmBN;
-    const int wm = (wv & 1) * 32, wn = (wv >> 1) * 64;
+    const int wm = (wv & 1) * 32, wn = (wv >> 1) * (kGemmBN / 2);
 
     // global -> register staging: A tile 64 x 16 (4 doubles per thread: row t/4, k (t%4)*4..+3), B tile 16 x 128 (8 per thread: k t/16, cols (t%16)*8..+7)
     const int a_row = t >> 2, a_k = (t & 3) * 4;
-    const int b_k = t >> 4, b_col = (t & 15) * 8;
-    double ra[4], rb[8];
+    const int b_k = t >> 4, b_col = (t & 15) * BQ;
+    double ra[4], rb[BQ];
     auto load_tile = [&](int k0) {
         const int gr = m0 + a_row;
         if (p.vec && gr < p.M && k0 + a_k + 3 < p.K) {           // interior: 16-B loads
@@ -105,13 +108,13 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
             }
         }
         const int gk = k0 + b_k;
-        if (p.vec && gk < p.K && n0 + b_col + 7 < p.N) {
+        if (p.vec && gk < p.K && n0 + b_col + BQ - 1 < p.N) {
             const double2* q2 = reinterpret_cast<const double2*>(p.B + (size_t)p.ldb * gk + n0 + b_col);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const double2 v = q2[q]; rb[2 * q] = v.x; rb[2 * q + 1] = v.y; }
+            for (int q = 0; q < BQ / 2; ++q) { const double2 v = q2[q]; rb[2 * q] = v.x; rb[2 * q + 1] = v.y; }
         } else {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < BQ; ++q) {
                 const int gc = n0 + b_col + q;
                 rb[q] = (gk < p.K && gc < p.N) ? p.B[(size_t)p.ldb * gk + gc] : 0.0;
             }
@@ -121,14 +124,14 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
 #pragma unroll
         for (int q = 0; q < 4; ++q) sA[buf][(a_k + q) * kGemmLdA + a_row] = ra[q];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) sB[buf][b_k * kGemmLdB + b_col + q] = rb[q];
+        for (int q = 0; q < BQ; ++q) sB[buf][b_k * kGemmLdB + b_col + q] = rb[q];
     };
 
-    pdouble4_t acc[2][4];
+    pdouble4_t acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = pdouble4_t{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NB; ++b) acc[a][b] = pdouble4_t{0.0, 0.0, 0.0, 0.0};
 
     load_tile(0);
     store_tile(0);
@@ -139,15 +142,15 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
         if (more) load_tile(k0 + kGemmBK);            // in flight behind the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < kGemmBK; ks += 4) {
-            double av[2], bv[4];
+            double av[2], bv[NB];
 #pragma unroll
             for (int a = 0; a < 2; ++a) av[a] = sA[buf][(ks + kk) * kGemmLdA + wm + 16 * a + el];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) bv[b] = sB[buf][(ks + kk) * kGemmLdB + wn + 16 * b + el];
+            for (int b = 0; b < NB; ++b) bv[b] = sB[buf][(ks + kk) * kGemmLdB + wn + 16 * b + el];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
         if (more) store_tile(buf ^ 1);                // the other buffer: its readers finished before the previous barrier
         __syncthreads();
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + wm + 16 * a + kk + 4 * r, col = n0 + wn + 16 * b + el;

@@ -817,9 +817,11 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
-        // slots per wave: one 16-wave block per CU with equal shares when that gives between kGramChunkMin and kGramChunk slots
-        // (1 M events: 236), else the fixed chunk and several rounds
-        long chunk = ((long)c->n_cand + (long)c->n_cu * (kGramBlock / 64) - 1) / ((long)c->n_cu * (kGramBlock / 64));
+        // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),
+        // between kGramChunkMin and kGramChunk slots
+        const long per_round = (long)c->n_cu * (kGramBlock / 64);
+        const long rounds = std::max<long>(1, ((long)c->n_cand + per_round * kGramChunk - 1) / (per_round * kGramChunk));
+        long chunk = ((long)c->n_cand + per_round * rounds - 1) / (per_round * rounds);
         chunk = (chunk + 7) & ~7L;
         chunk = std::min<long>(std::max<long>(chunk, kGramChunkMin), kGramChunk);
         p.chunk = (int)chunk;

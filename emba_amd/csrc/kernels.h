@@ -23,7 +23,10 @@ namespace emba {
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kInvalidPix = 0xFFFFFFFFu;
 constexpr int kPoseStride = 14;    // doubles per pose record: q[4] J1[9] cp  (112 B = 7 x 16-B gathers per event)
-constexpr int kTexelStride = 6;    // doubles per texel
+#ifndef TEXEL_STRIDE
+#define TEXEL_STRIDE 6
+#endif
+constexpr int kTexelStride = TEXEL_STRIDE;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
 constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: no barriers, neighbours talk through DPP
 constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
@@ -35,7 +38,7 @@ constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
 #endif
 constexpr int kGramPad = 256;     // record slots allocated past the last one: the Gram kernel's stages read whole 8-record groups
 constexpr int kGramChunkMin = 64; // smallest share of record slots a wave of the Gram kernel is given
-constexpr int kGramChunk = 256;    // record slots per wave in the Gram (A11/b1) kernel; multiple of 4
+constexpr int kGramChunk = 1024;   // most record slots a wave of the Gram (A11/b1) kernel is given (multiple of 8)
 constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table)
 constexpr int kGramKeys = 4;       // control-pose pairs the block-level LDS table can hold before falling back to global atomics
 
@@ -841,14 +844,21 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long wave_id = (long)blockIdx.x * (kGramBlock / 64) + wv;
-    const long start = wave_id * p.chunk;
-    const bool have_work = start < p.n_slots;   // wave-uniform
-    const long end = (start + p.chunk < p.n_slots) ? start + p.chunk : p.n_slots;
+    // The block's 16 waves walk ONE contiguous range of 16 x chunk record slots together, stage by stage (wave w takes stages
+    // w, w+16, ...): at any moment the block reads a compact window of the stream, as a grid-stride loop would, instead of 16
+    // separate streams 128 KB apart (4096 concurrent streams chip-wide cost DRAM page locality once the records exceed the
+    // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
+    constexpr int U = GRAM_U;   // independent 1-KiB loads (8 records each) per wave and stage
+    constexpr int kStage = 8 * U, kStride = (kGramBlock / 64) * kStage;
+    const long start = (long)blockIdx.x * (kGramBlock / 64) * p.chunk;
+    const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
+    const int len = (int)(end - start);                              // <= 16 * kGramChunk: stage offsets are 32-bit
+    const int off0 = wv * kStage;
+    const bool have_work = off0 < len;   // wave-uniform
     const int m = lane & 7, R = lane >> 3;
     if (have_work) {
 
-    uint32_t cur_key = p.slot_key[start];
+    uint32_t cur_key = p.slot_key[start + off0];
     bool dirty = false;
     double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
     auto flush = [&]() {
@@ -856,14 +866,12 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
     };
-    constexpr int U = GRAM_U;   // independent 1-KiB loads (8 records each) per wave and stage
     // One fully coalesced 16-B-per-lane load per 8 records is ALL the fast path reads: the residual and the pixel index of a
     // record come from its last lane (ds_swizzle), the pair key is wave-uniform (slots are sorted by pair, so equal first and
     // last keys of a stage mean one pair), and activity comes from a 1-bit map that stays in L2.  Two stages in flight: B's
     // records are on their way while A's activity lookups and MFMAs run.
     double2 xA[U], xB[U];
     uint32_t act[U], k_first = 0, k_last = 0;
-    const int len = (int)(end - start);                              // <= kGramChunk: stage offsets are 32-bit
     const double2* rec0 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * start) + lane;
     const uint32_t* key0 = p.slot_key + start;
     auto load_records = [&](int off, double2* x) {   // may run up to 8 U records past `end`: the record buffer is padded
@@ -948,16 +956,16 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
             for (int v = 0; v + 1 < U; ++v) { y[v] = y[v + 1]; a_[v] = a_[v + 1]; }
         }
     };
-    load_records(0, xA);
-    for (int off = 0; off < len; off += 16 * U) {
-        lookup(off, xA);                       // issued BEFORE B's record loads: memory operations return in order, so waiting
-        const bool haveB = off + 8 * U < len;  // for the lookups later leaves B's loads in flight
-        if (haveB) load_records(off + 8 * U, xB);
+    load_records(off0, xA);
+    for (int off = off0; off < len; off += 2 * kStride) {
+        lookup(off, xA);                        // issued BEFORE B's record loads: memory operations return in order, so waiting
+        const bool haveB = off + kStride < len;  // for the lookups later leaves B's loads in flight
+        if (haveB) load_records(off + kStride, xB);
         consume(off, xA);
         if (!haveB) break;
-        lookup(off + 8 * U, xB);
-        if (off + 16 * U < len) load_records(off + 16 * U, xA);
-        consume(off + 8 * U, xB);
+        lookup(off + kStride, xB);
+        if (off + 2 * kStride < len) load_records(off + 2 * kStride, xA);
+        consume(off + kStride, xB);
     }
     if (dirty) flush();
     }  // have_work

@@ -778,7 +778,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->thres = thres;
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
-    emba_status st = resolve_pending(c);
+    emba_status st = resolve_pending(c, true);   // counts only: a sharded host sizes exchange 2 from P while the gather still runs
     if (st) return st;
     if (P) *P = c->P;
     if (pack_len) *pack_len = c->pack_len;

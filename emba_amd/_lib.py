@@ -52,6 +52,7 @@ SIGNATURES = {
     "emba_map_accept": (C.c_int, [C.c_void_p]),
     "emba_map_reject": (C.c_int, [C.c_void_p]),
     "emba_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_reconstruct_intensity": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "emba_count_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

@@ -94,6 +94,8 @@ struct emba_ctx {
     bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
     size_t n_inliers = 0, P = 0, pack_len = 0;
     bool compact_valid = false;   // d_compact matches the current active set (built on demand)
+    int cost_irls = 0; double cost_eta = 0.0;   // robust cost declared with emba_set_cost: what the NEXT evaluation weights its per-pixel sums with
+    int acc_irls = 0; double acc_eta = 0.0;     // ... and what the per-pixel sums of the LAST evaluation were weighted with
     double fused_alpha = 0.0; bool l2_fused = false;   // emba_step on one GPU folds applyL2Reg into the active-set gather
     bool ep_deferred = false;   // residual compaction not launched yet (it rides along with the active-set kernels)
     bool inl_pending = false, P_pending = false;   // counters enqueued for readback but not yet resolved (no host sync yet)
@@ -706,11 +708,13 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
         p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.grp_cnt = c->d_grp_cnt;
         p.ablate = c->ablate;
+        p.irls = c->cost_irls; p.eta = c->cost_eta;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
     }
     HIP_TRY(c, hipGetLastError());
+    c->acc_irls = c->cost_irls; c->acc_eta = c->cost_eta;
     c->eval_launched = true;
     return EMBA_OK;
 }
@@ -792,7 +796,9 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    const bool generic_a22 = (irls != 0) || (ep_host != nullptr);
+    // the per-pixel sums of the evaluation already carry this cost's weights (emba_set_cost / emba_step)?  Then they ARE A22/b2.
+    const bool acc_matches = (irls == c->acc_irls) && (irls == 0 || eta == c->acc_eta);
+    const bool generic_a22 = !acc_matches || (ep_host != nullptr);
     if (generic_a22) { emba_status st = resolve_pending(c); if (st) return st; }   // needs n_inliers / P on the host (rare path)
     if (ep_host && c->n_inliers) {
         HIP_TRY(c, hipMemcpyAsync(c->d_ep, ep_host, c->n_inliers * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1035,15 +1041,31 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
 emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, int32_t thres, int32_t irls, double eta,
                       double alpha, size_t* n_inliers, size_t* P)
 {
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
     emba_status st;
-    if ((st = emba_eval_launch(c, knots, K, t0_ns, dt_ns))) return st;
+    {   // the evaluation weights its per-pixel sums with THIS step's cost (whatever emba_set_cost declared for other callers)
+        const int keep_irls = c->cost_irls; const double keep_eta = c->cost_eta;
+        c->cost_irls = irls; c->cost_eta = irls ? eta : 0.0;
+        st = emba_eval_launch(c, knots, K, t0_ns, dt_ns);
+        c->cost_irls = keep_irls; c->cost_eta = keep_eta;
+        if (st) return st;
+    }
     if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
-    c->fused_alpha = (irls == 0) ? alpha : 0.0;   // quadratic cost: A22/b2 come from the per-pixel accumulator, L2 rides along
+    c->fused_alpha = alpha;   // A22/b2 come from the accumulator, so applyL2Reg rides along with the gather
     if ((st = emba_form_active(c, thres, nullptr, nullptr))) return st;
     if ((st = emba_form_accumulate(c, nullptr, irls, eta))) return st;
     if ((st = emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr))) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
     if (P) *P = c->P;
+    return EMBA_OK;
+}
+
+emba_status emba_set_cost(emba_ctx* c, int32_t irls, double eta)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
+    c->cost_irls = irls; c->cost_eta = irls ? eta : 0.0;
     return EMBA_OK;
 }
 

@@ -209,6 +209,7 @@ struct WarpParams {
     int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt; uint32_t* grp_cnt;
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
+    int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
 };
 
 // lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
@@ -368,6 +369,13 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     // whatever it carries, so runs of adjacent lanes with equal pixel are summed first (segmented inclusive scan over the wave,
     // heads where the pixel changes) and only the last lane of a run emits: one int add of the run length, five fp64 adds.
     double v0 = dpx * dpx, v1 = dpx * dpy, v2 = dpy * dpy, v3 = dpx * e, v4 = dpy * e;   // zero unless inlier (dpx,dpy,e are)
+    if (p.irls) {   // IRLS weight of the declared robust cost (same expressions as the Gram and A22-from-records kernels)
+        double w;
+        if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);                               // cauchy, model.cpp:603
+        else { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }            // huber, :608-616
+        const double ew = w * e;
+        v0 = w * v0; v1 = w * v1; v2 = w * v2; v3 = dpx * ew; v4 = dpy * ew;             // A22 += w dp dp^T, b2 += dp (w e), :620-636
+    }
     if (!inl) { v0 = 0; v1 = 0; v2 = 0; v3 = 0; v4 = 0; }
     int run_n = inl ? 1 : 0;
     const uint32_t key = inl ? pi : (kInvalidPix - (uint32_t)t);                     // non-inliers never join a run

@@ -217,6 +217,11 @@ class LEGM:
         self._check(self._L.emba_download_map(self._ctx, _p(Gx, _dp), _p(Gy, _dp)))
         return Gx, Gy
 
+    def set_cost(self, cost_type="quadratic", a=0.0):
+        """Declare the robust cost of the formNormalEqIRLS calls to come, so that evaluations accumulate the IRLS-weighted
+        per-pixel sums directly (speed only; see emba_set_cost)."""
+        self._check(self._L.emba_set_cost(self._ctx, COST_TYPES[cost_type], float(a)))
+
     def reconstructIntensity(self, Gx=None, Gy=None, download=True):
         """poisson_reconstruction::reconstructFromGradient (poisson_reconstruction.cpp:9-50; solver.cpp:417,471): the intensity
         panorama whose gradient is (Gx, Gy) — or the device-resident map when both are None."""

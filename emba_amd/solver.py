@@ -79,6 +79,8 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
     it, count_tol, decreased = 0, 0, True
     ph = _Phases(model, ba, resident)
     model.set_events(events)
+    if hasattr(model, "set_cost"):   # evaluations accumulate the IRLS-weighted sums directly (speed only)
+        model.set_cost(ph.cost_type, ba.eta if ba.use_IRLS else 0.0)
     log = []
     while it <= lm.max_num_iter and cost_min > 1e-16 and lam_min <= lam <= lam_max:   # solver.cpp:63-64
         if decreased:

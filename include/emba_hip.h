@@ -221,6 +221,14 @@ emba_status emba_form_finish(emba_ctx* ctx, double alpha, double* A11, double* b
 emba_status emba_step(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns, int64_t dt_ns,
                       int32_t thres_valid_pixel, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
 
+/* Declare the robust cost of the formNormalEq[IRLS] calls that will follow the next evaluations (irls: 0 quadratic, 1 huber,
+ * 2 cauchy; eta as in formNormalEqIRLS, model.cpp:493-687).  The reference applies the IRLS weight w(e) to A22/b2 in
+ * formNormalEqIRLS (model.cpp:599-636); the weight only depends on the residual, which the evaluation has in hand, so an
+ * evaluation that knows the cost accumulates the WEIGHTED per-pixel sums directly and the following emba_form_accumulate with the
+ * same (irls, eta) takes A22/b2 from them instead of a second pass over the records.  Purely a speed hint: results are the same
+ * with any declaration (a mismatch falls back to the records).  emba_step declares its own cost for its own evaluation. */
+emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
+
 /* Inlier count of the last evaluation and active-pixel count of the last emba_form_active, once resolved
  * (after any synchronizing call, e.g. emba_form_finish or emba_sync). */
 emba_status emba_last_counts(emba_ctx* ctx, size_t* n_inliers, size_t* P);

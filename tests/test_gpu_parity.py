@@ -521,3 +521,24 @@ def test_poisson_reconstruction_matches_oracle(gpu, pano_h):
     # resident map: same result as passing it
     m.upload_map(Gx, Gy)
     assert np.array_equal(m.reconstructIntensity(), M)
+
+
+@pytest.mark.parametrize("declared,used", [(("huber", 0.1), ("huber", 0.1)), (("huber", 0.1), ("cauchy", 1.0)), (("cauchy", 1.0), ("quadratic", 0.0)),
+                                           (("quadratic", 0.0), ("huber", 0.1)), (("huber", 0.1), ("huber", 0.2))])
+def test_declared_cost_is_a_pure_speed_hint(gpu, oracle_mod, declared, used):
+    """emba_set_cost lets the evaluation accumulate IRLS-weighted A22/b2 directly (model.cpp:599-636); whatever was declared,
+    formNormalEq[IRLS] must return the normal equations of the cost it is CALLED with (a mismatch falls back to the records)."""
+    w = small_workload(n_events=30000)
+    m = make_legm(w)
+    m.set_cost(*declared)
+    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+    ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, w.events, True, nem)
+    if used[0] == "quadratic":
+        m.formNormalEq(ep, w.K, nem, w.thres_valid_pixel)
+    else:
+        m.formNormalEqIRLS(ep, w.K, nem, w.thres_valid_pixel, used[0], used[1])
+    ne = m.applyL2Reg(w.alpha)
+    irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[used[0]]
+    o = oracle_run(oracle_mod, w, irls=irls, a=used[1])
+    assert np.array_equal(nem, o["num_ev_map"])
+    compare_normal_eq(ne, o["ne"])

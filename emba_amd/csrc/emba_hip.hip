@@ -1214,7 +1214,8 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
         sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.direct = (nks == 1);
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
         if (nks > 1)
-            hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256)), dim3(256), 0, s, d_slab, nks, nbp, na, d_S, lds_);
+            hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256), (unsigned)((nks + kSyrkReduceGroup - 1) / kSyrkReduceGroup)),
+                               dim3(256), 0, s, d_slab, nks, nbp, na, d_S, lds_);
     }
     hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);
 
@@ -1223,7 +1224,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
         double* Sm = d_S + (size_t)lds_ * skip + skip;
         for (int jb = 0; jb < m; jb += 64) {
             const int nb = std::min(64, m - jb);
-            hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(256), 0, s, Sm, lds_, jb, nb, d_info);
+            hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
             const int below = m - jb - nb;
             if (below > 0) {
                 hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 255) / 256), dim3(256), 0, s, Sm, lds_, m, jb, nb);

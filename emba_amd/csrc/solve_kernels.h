@@ -220,6 +220,10 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     }
 }
 
+// C -= sum over the split-K slabs.  blockIdx.y takes a group of kSyrkReduceGroup slabs, so the reduction of a small matrix
+// (K = 21: ONE 64 x 64 tile but 1024 slabs) is spread over hundreds of blocks instead of 16; groups meet through fp64 atomics
+// (4096 x groups adds: far below the atomic rate).
+constexpr int kSyrkReduceGroup = 16;
 __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks, int nbp, int n, double* __restrict__ C, long ldc)
 {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -229,34 +233,44 @@ __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks
     syrk_block_pair(bp, I, J);
     const int row = 64 * I + (i & 63), col = 64 * J + (i >> 6);
     if (row >= n || col >= n || row < col) return;
+    const int k0 = blockIdx.y * kSyrkReduceGroup, k1 = (k0 + kSyrkReduceGroup < nks) ? k0 + kSyrkReduceGroup : nks;
     double acc = 0.0;
-    for (int ks = 0; ks < nks; ++ks) acc += slab[((size_t)ks * nbp + bp) * 4096 + i];
-    C[(size_t)ldc * col + row] -= acc;
+    for (int ks = k0; ks < k1; ++ks) acc += slab[((size_t)ks * nbp + bp) * 4096 + i];
+    if (gridDim.y == 1) C[(size_t)ldc * col + row] -= acc;
+    else atomicAdd(&C[(size_t)ldc * col + row], -acc);
 }
 
 // ---- blocked Cholesky (lower, column-major), panels of 64 ---------------------------------------------------------------
 // (1) factor the diagonal block in LDS
-__global__ __launch_bounds__(256) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
+// ONE wave, left-looking: lane r owns row r; column j is  L[r][j] = (A[r][j] - sum_{k<j} L[r][k] L[j][k]) / L[j][j]  with the
+// matrix in LDS (own row: stride-1 across lanes, row j: a broadcast).  No inter-wave barriers on the 64-step critical path
+// (the 256-thread right-looking version spent ~1.2 us per column in them: 76 us per panel; this one ~15).
+__global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
 {
-    __shared__ double s[64 * 65];
-    const int t = threadIdx.x;
-    for (int i = t; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = A[(size_t)ld * (jb + c) + jb + r]; }
+    __shared__ double s[64 * 65];   // s[c * 65 + r] = element (r, c)
+    const int r = threadIdx.x;
+    for (int c = 0; c < nb; ++c) s[c * 65 + r] = (r < nb) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0;
     __syncthreads();
+    bool bad = false;
     for (int j = 0; j < nb; ++j) {
-        const double d = s[j * 65 + j];
-        __syncthreads();
-        if (t == 0) { if (!(d > 0.0)) atomicOr(info, 2); s[j * 65 + j] = sqrt(d); }
-        __syncthreads();
-        const double piv = s[j * 65 + j];
-        if (t > j && t < nb) s[j * 65 + t] /= piv;
-        __syncthreads();
-        for (int i = t; i < (nb - j - 1) * (nb - j - 1); i += 256) {
-            const int c = j + 1 + i / (nb - j - 1), r = j + 1 + i % (nb - j - 1);
-            if (r >= c) s[c * 65 + r] -= s[j * 65 + r] * s[j * 65 + c];
+        double v = s[j * 65 + r], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int k = 0;
+        for (; k + 4 <= j; k += 4) {   // four independent LDS read pairs in flight per trip
+            v -= s[k * 65 + r] * s[k * 65 + j];
+            v1 -= s[(k + 1) * 65 + r] * s[(k + 1) * 65 + j];
+            v2 -= s[(k + 2) * 65 + r] * s[(k + 2) * 65 + j];
+            v3 -= s[(k + 3) * 65 + r] * s[(k + 3) * 65 + j];
         }
-        __syncthreads();
+        for (; k < j; ++k) v -= s[k * 65 + r] * s[k * 65 + j];
+        v += (v1 + v2) + v3;
+        const double d = __shfl(v, j);
+        bad |= !(d > 0.0);
+        const double piv = sqrt(d);
+        if (r >= j) s[j * 65 + r] = (r == j) ? piv : v / piv;
+        __syncthreads();            // one wave: orders the LDS write before the next column's reads
     }
-    for (int i = t; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; if (r >= c) A[(size_t)ld * (jb + c) + jb + r] = s[c * 65 + r]; }
+    if (bad && r == 0) atomicOr(info, 2);
+    for (int c = 0; c < nb; ++c) if (r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = s[c * 65 + r];
 }
 
 // (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)

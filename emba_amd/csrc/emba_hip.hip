@@ -1159,7 +1159,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     const size_t nblk = (P + 2047) / 2048;
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
     const int nb64 = (na + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
-    const int nks_max = std::max(1, 1024 / nbp);
+    const int nks_max = std::max(1, (4 * c->n_cu + nbp - 1) / nbp);   // enough (tile pair, K slab) blocks to fill the chip ...
     auto cleanup = [&]() {};
     auto ws_get = [&](int slot, size_t bytes, void** out) -> emba_status {
         auto& w = c->ws[slot];
@@ -1209,7 +1209,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
         bp.p0 = (long)p0; bp.p1 = (long)p1;
         hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
         const long kc = (long)(2 * (p1 - p0));
-        const int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 64));
+        const int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
         SyrkParams sp{};
         sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.direct = (nks == 1);
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);

@@ -5,8 +5,8 @@ A "step" is one pass of the hot path over the resident workload: evaluateDataErr
 applyL2Reg (reference solver.cpp:75/251 + :114-130) with events, map planes and LUT already in HBM when the timed region
 starts.  N=1: the BASELINE configuration (synthetic shapes-like: 1 M events, 240x180 sensor, 1024x2048 panorama, K=21,
 seed 20240907).  N>1 (launched by torch.distributed.run, one rank per GPU): weak scaling — N x 1 M events over the same
-1 s window, sharded by time range with a per-pixel halo, int32 count-map all-reduce + fp64 normal-equation-pack all-reduce
-per step over RCCL (emba_amd/sharded.py).
+1 s window, sharded by time range with a per-pixel halo; per step one all-reduce of the count map (as saturated bytes) and one
+of the fp64 normal-equation pack over RCCL (emba_amd/sharded.py).
 
 Prints ONE JSON line on rank 0.  The `roofline` object prices the dominant kernel (emba_warp_residual_kernel) with
 SURVEY §8d's 244 algorithmic bytes per event against the 8 TB/s HBM3E peak, its duration measured live with HIP events on
@@ -142,12 +142,13 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    # Kernel durations by HIP events on the kernels' stream, sampled on every 4th step of the timed region: each event record
-    # opens a ~6 us bubble in front of the next kernel, four records per step would distort the very throughput being measured.
+    # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region: each event record
+    # opens a ~6 us bubble in front of the next kernel and reading the events back makes the host wait for the Gram kernel,
+    # so timing every step would distort the very throughput being measured.
     warp_ms, accum_ms = [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timed = (i % 4 == 0)
+        timed = (i % 8 == 0)
         m.enable_kernel_timing(timed)
         n_inl, _ = step()
         if timed:

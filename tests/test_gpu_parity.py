@@ -542,3 +542,34 @@ def test_declared_cost_is_a_pure_speed_hint(gpu, oracle_mod, declared, used):
     o = oracle_run(oracle_mod, w, irls=irls, a=used[1])
     assert np.array_equal(nem, o["num_ev_map"])
     compare_normal_eq(ne, o["ne"])
+
+
+def test_run_ba_command_line_on_files(gpu, tmp_path):
+    """examples/run_ba.py on data from disk: event file, pose file, Gx.bin/Gy.bin, calibration -> refined trajectory,
+    refined map and the Poisson-reconstructed panorama, in the reference's formats."""
+    import subprocess, sys, os
+    from emba_amd import io as eio, synth
+    w = synth.make_scene_workload(n_steps=800)
+    eio.save_events(tmp_path / "ev.npz", w.events)
+    eio.save_map(tmp_path / "map", w.Gx, w.Gy)
+    # initial poses: the ground-truth spline sampled densely (the front-end's trajectory), in the pose-file format
+    from emba_amd import so3
+    t0, dt, K = w.traj.t0_ns * 1e-9, w.traj.dt_ns * 1e-9, w.K
+    with open(tmp_path / "poses.txt", "w") as f:
+        for t in np.linspace(t0, t0 + dt * (K - 1), 120):
+            i = min(int((t - t0) / dt), K - 2); u = (t - t0 - i * dt) / dt
+            q = so3.mul(w.traj.knots_xyzw[i], so3.exp(u * so3.log(so3.mul(so3.inverse(w.traj.knots_xyzw[i]), w.traj.knots_xyzw[i + 1]))))
+            f.write("%.9f 0 0 0 %.17g %.17g %.17g %.17g\n" % (t, q[0], q[1], q[2], q[3]))
+    np.savez(tmp_path / "calib.npz", K=np.array([[60.0, 0, 32.0], [0, 60.0, 24.0], [0, 0, 1.0]]), D=np.zeros(5), width=64, height=48)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_ba.py"), str(out), "--events", str(tmp_path / "ev.npz"),
+                        "--poses", str(tmp_path / "poses.txt"), "--map-dir", str(tmp_path / "map"), "--calib", str(tmp_path / "calib.npz"),
+                        "--dt-knots", "0.05", "--t-beg", "0.1", "--t-end", "0.35", "--alpha", "0.0", "--max-iter", "10"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    t, qs = eio.load_poses(out / "refined_traj.txt")
+    assert qs.shape == (6, 4) and np.allclose(t, 0.1 + 0.05 * np.arange(6), atol=1e-6)
+    gx, gy = eio.load_map(out)
+    assert gx.shape == w.Gx.shape and np.isfinite(gx).all()
+    assert (out / "map_poisson_opt.pgm").stat().st_size > w.pano_h * w.pano_w

@@ -573,3 +573,47 @@ def test_run_ba_command_line_on_files(gpu, tmp_path):
     gx, gy = eio.load_map(out)
     assert gx.shape == w.Gx.shape and np.isfinite(gx).all()
     assert (out / "map_poisson_opt.pgm").stat().st_size > w.pano_h * w.pano_w
+
+
+def test_randomised_small_configurations(gpu, oracle_mod):
+    """A seeded sweep over odd shapes — sensor and panorama sizes that are not multiples of anything, K from 2 up, event counts with
+    ragged tails, every threshold/cost — through the one-shot interface, the solve and a second evaluation on the same context
+    (so the lazily cleared per-pixel state and the texel rectangle of the previous footprint are exercised as well)."""
+    rng = np.random.default_rng(20240907)
+    for case in range(14):
+        sw, sh = int(rng.integers(5, 70)), int(rng.integers(5, 50))
+        pano_h = int(rng.integers(20, 200))
+        K = int(rng.integers(2, 12))
+        n = int(rng.integers(100, 30000))
+        cost = [("quadratic", 0.0), ("huber", 0.1), ("cauchy", 1.0)][case % 3]
+        thres = int(rng.integers(1, 5))
+        w = small_workload(n_events=n, pano_h=pano_h, K=K, sensor=(sw, sh), focal=float(rng.uniform(0.6, 1.5) * sw), seed=100 + case,
+                           dt_knots=float(rng.choice([0.01, 0.05])), thres_valid_pixel=thres, alpha=float(rng.choice([0.0, 5.0])))
+        irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
+        tag = f"case {case}: {w.describe()} cost={cost} thres={thres} alpha={w.alpha}"
+        o = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
+        g = gpu_run(w, cost_type=cost[0], a=cost[1], dense_A12=True)
+        assert np.array_equal(g["num_ev_map"], o["num_ev_map"]), tag
+        assert g["ep"].shape == o["ep"].shape, tag
+        if o["ep"].size:
+            assert_close(g["ep"], o["ep"], "ep " + tag)
+        compare_normal_eq(g["ne"], o["ne"], dense=True)
+        m = g["legm"]
+        if o["ne"]["P"] and K >= 2:
+            try:
+                ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], 1e-2, True)
+            except ValueError:
+                ox1 = None
+            if ox1 is not None and K > 1 and np.isfinite(ox1).all():
+                x1, x2 = m.solveNormalEq(1e-2, fix_first_pose=True)
+                assert np.allclose(x1, ox1, rtol=1e-6, atol=1e-8 * max(np.abs(ox1).max(), 1e-30)), tag
+                assert np.allclose(x2, ox2, rtol=1e-6, atol=1e-8 * max(np.abs(ox2).max(), 1e-30)), tag
+        # second evaluation on the same context with a slightly different trajectory
+        knots = w.traj.knots_xyzw.copy(); knots[-1] = knots[-1] + 1e-3; knots[-1] /= np.linalg.norm(knots[-1])
+        w.traj = type(w.traj)(knots, w.traj.t0_ns, w.traj.dt_ns)
+        o2 = oracle_run(oracle_mod, w, irls=irls, a=cost[1])
+        nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+        ep2 = m.evaluateDataError(w.traj, None, None, None, True, nem)
+        assert np.array_equal(nem, o2["num_ev_map"]), tag + " (second evaluation)"
+        if o2["ep"].size:
+            assert_close(ep2, o2["ep"], "ep2 " + tag)

@@ -242,35 +242,36 @@ __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks
 
 // ---- blocked Cholesky (lower, column-major), panels of 64 ---------------------------------------------------------------
 // (1) factor the diagonal block in LDS
-// ONE wave, left-looking: lane r owns row r; column j is  L[r][j] = (A[r][j] - sum_{k<j} L[r][k] L[j][k]) / L[j][j]  with the
-// matrix in LDS (own row: stride-1 across lanes, row j: a broadcast).  No inter-wave barriers on the 64-step critical path
-// (the 256-thread right-looking version spent ~1.2 us per column in them: 76 us per panel; this one ~15).
+// ONE wave, left-looking, the whole block in registers: lane r owns row r (64 doubles); column j is
+//     L[r][j] = (A[r][j] - sum_{k<j} L[r][k] L[j][k]) / L[j][j],
+// where L[j][k] is lane j's register k, broadcast with v_readlane (j is uniform).  Both loops are fully unrolled so that every
+// register index is static; no LDS and no barrier on the 64-step critical path (the 256-thread right-looking version spent
+// ~1.2 us per column in barriers: 76 us per panel; the LDS left-looking one 56; this one ~12).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
 __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
 {
-    __shared__ double s[64 * 65];   // s[c * 65 + r] = element (r, c)
     const int r = threadIdx.x;
-    for (int c = 0; c < nb; ++c) s[c * 65 + r] = (r < nb) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0;
-    __syncthreads();
+    double row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
     bool bad = false;
-    for (int j = 0; j < nb; ++j) {
-        double v = s[j * 65 + r], v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int k = 0;
-        for (; k + 4 <= j; k += 4) {   // four independent LDS read pairs in flight per trip
-            v -= s[k * 65 + r] * s[k * 65 + j];
-            v1 -= s[(k + 1) * 65 + r] * s[(k + 1) * 65 + j];
-            v2 -= s[(k + 2) * 65 + r] * s[(k + 2) * 65 + j];
-            v3 -= s[(k + 3) * 65 + r] * s[(k + 3) * 65 + j];
-        }
-        for (; k < j; ++k) v -= s[k * 65 + r] * s[k * 65 + j];
-        v += (v1 + v2) + v3;
-        const double d = __shfl(v, j);
-        bad |= !(d > 0.0);
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        double v = row[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v -= row[k] * readlane_f64(row[k], j);
+        const double d = readlane_f64(v, j);
+        bad |= (j < nb) && !(d > 0.0);
         const double piv = sqrt(d);
-        if (r >= j) s[j * 65 + r] = (r == j) ? piv : v / piv;
-        __syncthreads();            // one wave: orders the LDS write before the next column's reads
+        row[j] = (r == j) ? piv : v / piv;     // rows above the diagonal hold garbage that is never read (k < j <= r below)
     }
     if (bad && r == 0) atomicOr(info, 2);
-    for (int c = 0; c < nb; ++c) if (r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = s[c * 65 + r];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
 
 // (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)

@@ -683,10 +683,10 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
                        c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect, c->d_grp_cnt, (int)c->ngrp);
     c->knots_in_flight = true;   // cleared by the next host synchronisation (an event here would cost a ~6 us bubble per step)
 
-    // Hessian source: with more events than panorama pixels the full texel pack (one 48-B gather per measurement instead of
-    // an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
+    // Hessian source: with several events per panorama pixel (measured break-even: ~4) the full texel pack (one 48-B gather per
+    // measurement instead of an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
     // evaluation touched, and the warp kernel falls back to the stencil outside it.
-    c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > c->npix ? 1 : 3);
+    c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > 4 * c->npix ? 1 : 3);
     {   // pose table and (rectangle mode) texels in ONE launch: both depend only on the prep kernel
         const int nb = (int)c->n_batch;
         const int n_pose_blk = (nb + 63) / 64;

@@ -55,6 +55,7 @@ SIGNATURES = {
     "emba_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_reconstruct_intensity": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "emba_count_map_ready": (C.c_int, [C.c_void_p]),
     "emba_count_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "emba_count_expand": (C.c_int, [C.c_void_p, C.c_void_p]),
     "emba_eval_launch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64]),

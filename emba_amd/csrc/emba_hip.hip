@@ -53,6 +53,7 @@ struct emba_ctx {
     double* d_Gx_trial = nullptr; double* d_Gy_trial = nullptr; bool map_is_trial = false;
     double* d_x2 = nullptr; size_t x2_cap = 0;
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
+    bool counts_raw = false;   // the count map holds the warp kernel's markers, not yet the counts (see ensure_counts)
     double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
     int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (EMBA_TEXEL=auto|pack|fly|rect)
     int use_texel = 0;    // what the current evaluation uses: 0 fly, 1 full pack, 3 rectangle
@@ -265,6 +266,18 @@ emba_status ensure_compact(emba_ctx* c)
         hipLaunchKernelGGL(emba_compact_map_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, s, c->d_active, c->d_total + 1, c->d_compact);
     HIP_TRY(c, hipGetLastError());
     c->compact_valid = true;
+    return EMBA_OK;
+}
+
+// The warp kernel only MARKS touched pixels in the int32 count map (the count itself is accumulated next to the A22/b2 sums, one
+// atomic request per measurement).  The first post-warp launch of the resident step turns the markers into counts as a side
+// effect of its dense pass; whoever needs num_ev_map before that (download, exchange 1, the non-fused active-set path) calls this.
+emba_status ensure_counts(emba_ctx* c)
+{
+    if (!c->counts_raw) return EMBA_OK;
+    c->counts_raw = false;
+    hipLaunchKernelGGL(emba_count_materialise_kernel, dim3((unsigned)((c->npix + 2047) / 2048)), dim3(256), 0, c->stream, c->d_count, c->d_pixacc, (long)c->npix);
+    HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }
 
@@ -631,6 +644,7 @@ emba_status emba_count_compress(emba_ctx* c, uint8_t* u8_dev, int32_t cap)
 {
     if (!c || !u8_dev || cap < 1 || cap > 255) return c ? fail(c, EMBA_ERR_INVALID_ARG, "count_compress: bad arguments") : EMBA_ERR_INVALID_ARG;
     if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    { emba_status st0 = ensure_counts(c); if (st0) return st0; }
     hipLaunchKernelGGL(emba_count_compress_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, c->d_count, (long)c->npix, (int)cap, u8_dev);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
@@ -712,6 +726,9 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
+        c->counts_raw = true;
+    } else {
+        c->counts_raw = false;
     }
     HIP_TRY(c, hipGetLastError());
     c->acc_irls = c->cost_irls; c->acc_eta = c->cost_eta;
@@ -730,7 +747,11 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     if (st) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
     if (ep_out && c->n_inliers) HIP_TRY(c, hipMemcpy(ep_out, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
-    if (num_ev_map_out) HIP_TRY(c, hipMemcpy(num_ev_map_out, c->d_count, c->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (num_ev_map_out) {
+        { emba_status st0 = ensure_counts(c); if (st0) return st0; }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipMemcpy(num_ev_map_out, c->d_count, c->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     return EMBA_OK;
 }
 
@@ -764,11 +785,13 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.n_sorted = (long)c->n_sorted; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
+        if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)c->n_ablk + 1), dim3(256), 0, s, q);
         hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3((unsigned)c->ngrp + 1), dim3(1024), 0, s, q);
         c->inl_pending = true;
     } else {
         { emba_status st0 = launch_ep_compaction(c); if (st0) return st0; }
+        { emba_status st0 = ensure_counts(c); if (st0) return st0; }
         hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1,
                            c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
@@ -1059,6 +1082,13 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     if (n_inliers) *n_inliers = c->n_inliers;
     if (P) *P = c->P;
     return EMBA_OK;
+}
+
+emba_status emba_count_map_ready(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return ensure_counts(c);
 }
 
 emba_status emba_set_cost(emba_ctx* c, int32_t irls, double eta)

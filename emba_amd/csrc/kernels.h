@@ -232,7 +232,7 @@ template <bool DUMP>
 __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
 {
     __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
-    __shared__ double s_acc[64 * 5];                                        // per-run sums {xx xy yy bx by} of the wave's emitting lanes, compacted
+    __shared__ double s_acc[64 * 6];                                        // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted
     __shared__ uint32_t s_q[64];                                            // ... and their panorama pixels
 
     const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -393,24 +393,27 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     const int head_next = dpp_shl1(head ? 1 : 0);                                    // (cross-lane reads stay in uniform control flow)
     const bool emit = inl && ((t == 63) || (head_next != 0));                        // last lane of its run
     const unsigned long long emit_mask = __ballot(emit);
-    // Atomics cost per wave-INSTRUCTION at the memory side (measured: the same adds in fewer instructions run faster), so they
-    // are issued in as few as possible: the count add straight from the emitting lanes (one instruction per wave), the five
-    // accumulator doubles of the emitting lanes compacted through LDS and sent 12 pixels (60 lanes, 12 lines) per instruction.
-    if (emit && !(p.ablate & 1)) atomicAdd(p.count + pi, run_n);                       // model.cpp:227, run length at once
+    // The warp kernel runs at the chip's memory-side atomic REQUEST rate (rocprofv3: TCC_EA0_ATOMIC x 64 B / kernel time was
+    // 1.0 of the ~1.3 TB/s the chip sustains), so every measurement costs exactly ONE atomic request: the count of a pixel
+    // (model.cpp:227) rides as a sixth double in the same 64-B accumulator line as its five A22/b2 sums.  The int32 count map
+    // only receives a plain store of a non-zero MARKER here ("this pixel was touched"); emba_post_warp_a_kernel (or
+    // emba_count_materialise_kernel when someone needs the map earlier) replaces markers by the counts from the lines.
+    // Run sums are compacted through LDS and sent 10 pixels = 60 lanes per atomic instruction.
+    if (emit && !(p.ablate & 1)) p.count[pi] = 1;
     {
         const int n_emit = __popcll(emit_mask);
         if (emit) {
             const int rk = __popcll(emit_mask & ((1ull << t) - 1ull));
-            double* a = s_acc + rk * 5;
-            a[0] = v0; a[1] = v1; a[2] = v2; a[3] = v3; a[4] = v4;
+            double* a = s_acc + rk * 6;
+            a[0] = v0; a[1] = v1; a[2] = v2; a[3] = v3; a[4] = v4; a[5] = (double)run_n;
             s_q[rk] = pi;
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
-        const int r12 = t / 5, comp = t - 5 * r12;
-        for (int g = 0; g < n_emit; g += 12) {                           // wave-uniform trip count
-            const int k = g + r12;
+        const int r10 = t / 6, comp = t - 6 * r10;
+        for (int g = 0; g < n_emit; g += 10) {                           // wave-uniform trip count
+            const int k = g + r10;
             if (t < 60 && k < n_emit && !(p.ablate & 8))
-                atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[5 * k + comp]);
+                atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[6 * k + comp]);
         }
     }
 
@@ -577,12 +580,50 @@ __device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ cou
     return m;
 }
 
+// The same over a RAW count map (markers left by the warp kernel): a touched pixel's count is the sixth double of its accumulator
+// line; the counts are written back, which turns the map into the num_ev_map of model.cpp:227 for everyone downstream.
+__device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ count, const double* __restrict__ pixacc, long p0, long npix, int thres)
+{
+    int c[8];
+    const bool full = p0 + 8 <= npix;
+    if (full) {
+        const int4 a = *reinterpret_cast<const int4*>(count + p0), b = *reinterpret_cast<const int4*>(count + p0 + 4);
+        c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = (p0 + k < npix) ? count[p0 + k] : 0;
+    }
+    int any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) any |= c[k];
+    if (any) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (c[k]) c[k] = (int)pixacc[(size_t)kPixAccStride * (p0 + k) + 5];
+        if (full) {
+            *reinterpret_cast<int4*>(count + p0) = make_int4(c[0], c[1], c[2], c[3]);
+            *reinterpret_cast<int4*>(count + p0 + 4) = make_int4(c[4], c[5], c[6], c[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (p0 + k < npix) count[p0 + k] = c[k];
+        }
+    }
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m |= (uint32_t)(c[k] >= thres) << k;
+    return m;
+}
+
+__global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __restrict__ count, const double* __restrict__ pixacc, long npix)
+{
+    (void)materialise_mask8(count, pixacc, ((long)blockIdx.x * 256 + threadIdx.x) * 8, npix, 1);
+}
+
 __device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
-                                                   uint32_t* __restrict__ blk_cnt)
+                                                   uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr)
 {
     __shared__ uint32_t s_w[4];
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
-    uint32_t c = __popc(active_mask8(count, p0, npix, thres));
+    uint32_t c = __popc(raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres) : active_mask8(count, p0, npix, thres));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -604,11 +645,12 @@ struct PostWarpParams {
     const uint32_t* blk_cnt; const uint32_t* grp_cnt; uint32_t* grp_off; long ngrp; long nblk; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
     const double* e_sorted; const uint8_t* flag; long n_sorted; double* ep; int32_t* inl_idx;
     int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts: the host may poll it instead of waiting for the stream
+    int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
-    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt);
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc);
     else block_scan_256(p.grp_cnt, p.grp_off, p.ngrp, p.total_inl, p.total_inl_host, p.err_dev, p.err_host);
 }
 

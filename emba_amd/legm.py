@@ -267,6 +267,10 @@ class LEGM:
         self._check(self._L.emba_bind_exchange_buffers(self._ctx, C.c_void_p(count_ptr) if count_ptr else None,
                                                        C.c_void_p(pack_ptr) if pack_ptr else None, int(pack_cap)))
 
+    def count_map_ready(self):
+        """Make the device count map hold the counts of the last evaluation (call before reading / all-reducing a bound map)."""
+        self._check(self._L.emba_count_map_ready(self._ctx))
+
     def count_compress(self, u8_ptr, cap):
         self._check(self._L.emba_count_compress(self._ctx, C.c_void_p(u8_ptr), int(cap)))
 

@@ -119,6 +119,8 @@ class ShardedLEGM:
                 dist.all_reduce(self.count_u8)                # X1 (SUM) on a quarter of the bytes; cannot overflow: world * cap <= 255
                 e.count_expand(self.count_u8)                 # saturated global counts back into the int32 map
             else:
+                if hasattr(e, "count_map_ready"):
+                    e.count_map_ready()                       # the evaluation leaves markers; the counts come from the accumulator lines
                 dist.all_reduce(self.count)                   # X1 (SUM), exact counts
         e.eval_finish()                                       # E2 (enqueue only)
         # F1: a single GPU never needs P on the host mid-step; with several ranks the host needs the pack length for X2
@@ -161,6 +163,9 @@ class HipEngine:
 
     def step(self, traj, thres, alpha, cost_type, a):
         return self.m.step(traj, thres, alpha, cost_type, a)
+
+    def count_map_ready(self):
+        self.m.count_map_ready()
 
     def count_compress(self, u8_tensor, cap):
         self.m.count_compress(u8_tensor.data_ptr(), cap)

@@ -187,6 +187,13 @@ emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first
 emba_status emba_bind_exchange_buffers(emba_ctx* ctx, int32_t* count_map_dev, double* pack_dev,
                                        size_t pack_cap);
 
+/* Enqueue whatever is still needed for the device count map (own or bound with emba_bind_exchange_buffers) to hold num_ev_map of the
+ * last evaluation (model.cpp:227).  The evaluation itself only marks touched pixels there — the count of a pixel is accumulated
+ * next to its A22/b2 sums, one atomic request per measurement — and the markers become counts in the first dense pass that follows
+ * (emba_form_active, emba_count_compress, a map download).  A host that reads or all-reduces a BOUND count map directly, before
+ * any of those, calls this first. */
+emba_status emba_count_map_ready(emba_ctx* ctx);
+
 /* Exchange-1 compression for multi-GPU hosts: the merged count map only decides `count >= thres` (model.cpp:333,409), so each rank
  * may send min(count, cap) as ONE BYTE per pixel (cap * world_size <= 255, thres <= cap) — a quarter of the int32 volume on the
  * xGMI links.  emba_count_compress writes the saturated bytes of the context's count map to u8_dev (pano_h*pano_w bytes);

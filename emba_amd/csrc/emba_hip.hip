@@ -83,7 +83,7 @@ struct emba_ctx {
     std::vector<int64_t> h_batch_t;
     uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;
-    double* d_rec = nullptr; uint32_t* d_slot_key = nullptr;
+    double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
     uint32_t* d_blk_cnt = nullptr; uint32_t* d_grp_cnt = nullptr; uint32_t* d_grp_off = nullptr; long ngrp = 0;
     double* d_ep = nullptr;
@@ -723,6 +723,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.grp_cnt = c->d_grp_cnt;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
+        p.stamp = ++c->rec_stamp;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
@@ -838,12 +839,12 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));
         if (c->n_cand)
             hipLaunchKernelGGL(emba_a22_from_records_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec,
-                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c));
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c), c->rec_stamp);
     }
     if (c->n_cand) {
         GramParams p{};
         p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
-        p.irls = irls; p.eta = eta; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
+        p.irls = irls; p.eta = eta; p.stamp = c->rec_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
         // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),
@@ -905,7 +906,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
         (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
         if (c->n_cand)
             hipLaunchKernelGGL(emba_dense_a12_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key,
-                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, c->irls, c->eta, dim, d_A12);
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, c->irls, c->eta, dim, d_A12, c->rec_stamp);
         (void)hipMemcpyAsync(A12_dense, d_A12, n12 * sizeof(double), hipMemcpyDeviceToHost, s);
     }
     hipError_t e = hipStreamSynchronize(s);
@@ -946,7 +947,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     hipStream_t s = c->stream;
     if ((st = ensure_compact(c))) { dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp); return st; }
     hipLaunchKernelGGL(emba_export_a12_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, (long)M,
-                       c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp);
+                       c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp, c->rec_stamp);
     if (cp_c) (void)hipMemcpyAsync(cp_c, d_c, M * 4, hipMemcpyDeviceToHost, s);
     if (cp_p) (void)hipMemcpyAsync(cp_p, d_p, M * 4, hipMemcpyDeviceToHost, s);
     if (pix) (void)hipMemcpyAsync(pix, d_x, M * 4, hipMemcpyDeviceToHost, s);
@@ -1222,7 +1223,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
         hipLaunchKernelGGL(emba_csr_scan3_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_off, (long)P, d_blk_off, d_tot);
         if (M)
             hipLaunchKernelGGL(emba_csr_fill_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, (long)M, c->d_count, c->d_compact,
-                               c->thres, d_off, d_cursor, d_bucket);
+                               c->thres, d_off, d_cursor, d_bucket, c->rec_stamp);
     }
     hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
     SOLVE_HIP(hipGetLastError());

@@ -22,6 +22,14 @@ namespace emba {
 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kInvalidPix = 0xFFFFFFFFu;
+
+// A factor record is valid for the CURRENT evaluation iff its tail word carries this evaluation's stamp: the warp kernel only
+// writes the records of inliers (full 128-B lines), an outlier's slot keeps whatever an earlier evaluation left there.
+__device__ __forceinline__ bool record_valid(double tail_y, uint32_t stamp, uint32_t& pano_idx)
+{
+    pano_idx = (uint32_t)__double2loint(tail_y);
+    return (uint32_t)__double2hiint(tail_y) == stamp && pano_idx != kInvalidPix;
+}
 constexpr int kPoseStride = 14;    // doubles per pose record: q[4] J1[9] cp  (112 B = 7 x 16-B gathers per event)
 #ifndef TEXEL_STRIDE
 #define TEXEL_STRIDE 6
@@ -210,6 +218,7 @@ struct WarpParams {
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
+    uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
 };
 
 // lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
             w2[0] = make_double2(jc[0], jc[1]); w2[1] = make_double2(jc[2], jc[3]); w2[2] = make_double2(jc[4], jc[5]);
             w2[3] = make_double2(jp[0], jp[1]); w2[4] = make_double2(jp[2], jp[3]); w2[5] = make_double2(jp[4], jp[5]);
             w2[6] = make_double2(dpx, dpy);
-            w2[7] = make_double2(e, __hiloint2double(0, (int)pi));     // outliers: pi == kInvalidPix marks the slot invalid
+            w2[7] = make_double2(e, __hiloint2double((int)p.stamp, (int)pi));
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
 #pragma unroll
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
             const bool is_c = (cand_mask >> src) & 1ull, is_i = (inl_mask >> src) & 1ull;
             const uint32_t slot_r = (uint32_t)__shfl((int)slot, src);
             const double2* rd = reinterpret_cast<const double2*>(s_tile + rr * kRecLds);
-            if (is_c && (is_i || c8 == 7) && !(p.ablate & 2))
+            if (is_c && is_i && !(p.ablate & 2))       // inliers only: an outlier's slot is simply not stamped
                 reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * slot_r)[c8] = rd[c8];
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it
@@ -825,6 +834,7 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 struct GramParams {
     const double* rec; const uint32_t* slot_key; long n_slots; int chunk;   // chunk: record slots per wave (multiple of 8)
     const uint32_t* active_bits; int irls; double eta;                    // active_bits: count >= thres per pixel (model.cpp:333,409)
+    uint32_t stamp;                                                       // records of the current evaluation (record_valid)
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
 };
@@ -895,6 +905,10 @@ __device__ __forceinline__ uint32_t rec_elem15_lo(double2 v)
 {
     return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2loint(v.y), (7 << 5) | 0x18);
 }
+__device__ __forceinline__ uint32_t rec_elem15_hi(double2 v)
+{
+    return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2hiint(v.y), (7 << 5) | 0x18);
+}
 
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
 {
@@ -948,7 +962,8 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
         for (int u = 0; u < U; ++u) {
             const uint32_t pi = rec_elem15_lo(x[u]);
             const bool in = off + 8 * u + R < len;
-            act[u] = (in && pi != kInvalidPix) ? ((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31) : 0u;
+            const bool valid = in && rec_elem15_hi(x[u]) == p.stamp && pi != kInvalidPix;
+            act[u] = valid ? ((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31) : 0u;
         }
     };
     auto weight = [&](const double2& x) {
@@ -1042,14 +1057,14 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.
 __global__ void emba_a22_from_records_kernel(const double* __restrict__ rec, long n_slots, const int32_t* __restrict__ count,
                                              const int32_t* __restrict__ compact, int thres, int irls, double eta,
-                                             double* __restrict__ A22b2)
+                                             double* __restrict__ A22b2, uint32_t stamp)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const double2* r2 = reinterpret_cast<const double2*>(rec + (size_t)kRecStride * s);
     const double2 tail = r2[7];
-    const uint32_t pi = (uint32_t)__double2loint(tail.y);
-    if (pi == kInvalidPix || count[pi] < thres) return;
+    uint32_t pi;
+    if (!record_valid(tail.y, stamp, pi) || count[pi] < thres) return;
     const double e = tail.x;
     double w = 1.0;
     if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
@@ -1102,11 +1117,11 @@ __global__ void emba_unpack_kernel(const double* __restrict__ A22b2, long P, dou
 
 // Weight and compact pixel of a record (shared by the dense-A12 and export kernels).
 __device__ __forceinline__ bool record_active(const double* rec, const int32_t* count, const int32_t* compact, int thres,
-                                              int irls, double eta, int32_t* cidx, double* w)
+                                              int irls, double eta, uint32_t stamp, int32_t* cidx, double* w)
 {
     const double2 tail = reinterpret_cast<const double2*>(rec)[7];
-    const uint32_t pi = (uint32_t)__double2loint(tail.y);
-    if (pi == kInvalidPix || count[pi] < thres) return false;
+    uint32_t pi;
+    if (!record_valid(tail.y, stamp, pi) || count[pi] < thres) return false;
     const double e = tail.x;
     double ww = 1.0;
     if (irls == 2) ww = 1.0 / (1.0 + eta * e * e);
@@ -1119,13 +1134,13 @@ __device__ __forceinline__ bool record_active(const double* rec, const int32_t* 
 // Dense A12 (3K x 2P col-major) for the legacy interface (model.cpp:358,483-487); small sizes only.
 __global__ void emba_dense_a12_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key, long n_slots,
                                       const int32_t* __restrict__ count, const int32_t* __restrict__ compact, int thres,
-                                      int irls, double eta, int dim, double* __restrict__ A12)
+                                      int irls, double eta, int dim, double* __restrict__ A12, uint32_t stamp)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const double* r = rec + (size_t)kRecStride * s;
     int32_t cidx; double w;
-    if (!record_active(r, count, compact, thres, irls, eta, &cidx, &w)) return;
+    if (!record_active(r, count, compact, thres, irls, eta, stamp, &cidx, &w)) return;
     const uint32_t key = slot_key[s];
     const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
     double* c0 = A12 + (size_t)dim * (2 * (size_t)cidx);
@@ -1143,7 +1158,7 @@ __global__ void emba_export_a12_kernel(const double* __restrict__ rec, const uin
                                        const int32_t* __restrict__ count, const int32_t* __restrict__ compact, int thres,
                                        int irls, double eta, int32_t* __restrict__ cp_c, int32_t* __restrict__ cp_p,
                                        int32_t* __restrict__ pix, double* __restrict__ w_out, double* __restrict__ jc,
-                                       double* __restrict__ jp, double* __restrict__ dp)
+                                       double* __restrict__ jp, double* __restrict__ dp, uint32_t stamp)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
@@ -1152,7 +1167,7 @@ __global__ void emba_export_a12_kernel(const double* __restrict__ rec, const uin
     cp_c[s] = (int32_t)(key >> 16);
     cp_p[s] = (int32_t)(key & 0xFFFFu);
     int32_t cidx = -1; double w = 0.0;
-    const bool ok = record_active(r, count, compact, thres, irls, eta, &cidx, &w);
+    const bool ok = record_active(r, count, compact, thres, irls, eta, stamp, &cidx, &w);
     pix[s] = ok ? cidx : -1;
     w_out[s] = ok ? w : 0.0;
     for (int i = 0; i < 6; ++i) { jc[6 * s + i] = ok ? r[i] : 0.0; jp[6 * s + i] = ok ? r[6 + i] : 0.0; }

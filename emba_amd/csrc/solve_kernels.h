@@ -55,13 +55,13 @@ __global__ void emba_csr_scan3_kernel(uint32_t* __restrict__ off, long P, const 
 // bucket fill: every active record takes a ticket in its pixel's list
 __global__ void emba_csr_fill_kernel(const double* __restrict__ rec, long n_slots, const int32_t* __restrict__ count,
                                      const int32_t* __restrict__ compact, int thres, const uint32_t* __restrict__ off,
-                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ bucket)
+                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ bucket, uint32_t stamp)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const double2 tail = reinterpret_cast<const double2*>(rec + (size_t)kRecStride * s)[7];
-    const uint32_t pi = (uint32_t)__double2loint(tail.y);
-    if (pi == kInvalidPix || count[pi] < thres) return;
+    uint32_t pi;
+    if (!record_valid(tail.y, stamp, pi) || count[pi] < thres) return;
     const int32_t k = compact[pi];
     const uint32_t pos = off[k] + atomicAdd(cursor + k, 1u);
     bucket[pos] = (uint32_t)s;

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
     __shared__ double s_acc[64 * 6];                                        // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted
     __shared__ uint32_t s_q[64];                                            // ... and their panorama pixels
+    __shared__ uint32_t s_slot[32];                                         // record slots of the staged half's inliers
 
     const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
     if (b >= p.nblk) return;  // the whole wave exits together
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     int run_n = inl ? 1 : 0;
     const uint32_t key = inl ? pi : (kInvalidPix - (uint32_t)t);                     // non-inliers never join a run
     const bool head = (t == 0) || (key != (uint32_t)dpp_shr1((int)key));
-    {
+    if (__ballot(inl && !head)) {   // (wave-uniform) some lane continues its neighbour's run: otherwise every run is one lane long
         int flag = head ? 1 : 0;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -426,31 +427,30 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         }
     }
 
-    // Record stores, issued COOPERATIVELY: a 128-B record
-    // is one contiguous line in HBM, so eight adjacent lanes write one record per wave-instruction (8 full lines per
-    // instruction) instead of every lane writing into its own line (64 partial lines per instruction, store-issue bound).
-    // Records pass through a per-wave LDS tile, half a wave at a time.
-    const uint32_t slot = cand ? p.ev_slot[i] : kNoSlot;
+    // Record stores, issued COOPERATIVELY: a 128-B record is one contiguous line in HBM, so eight adjacent lanes write one record
+    // per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial lines per
+    // instruction, store-issue bound).  Only inliers have a record; they pass through a per-wave LDS tile, half a wave at a
+    // time, COMPACTED (rank among the half's inliers), so that every store instruction but the last of a half is full.
+    const uint32_t slot = inl ? p.ev_slot[i] : kNoSlot;
     const int c8 = t & 7;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        if ((t >> 5) == half && cand) {
-            double2* w2 = reinterpret_cast<double2*>(s_tile + (t & 31) * kRecLds);
+        const uint32_t hmask = (uint32_t)(inl_mask >> (32 * half));
+        const int n_rec = __popc(hmask);
+        if ((t >> 5) == half && inl) {
+            const int rk = __popc(hmask & ((1u << (t & 31)) - 1u));
+            double2* w2 = reinterpret_cast<double2*>(s_tile + rk * kRecLds);
             w2[0] = make_double2(jc[0], jc[1]); w2[1] = make_double2(jc[2], jc[3]); w2[2] = make_double2(jc[4], jc[5]);
             w2[3] = make_double2(jp[0], jp[1]); w2[4] = make_double2(jp[2], jp[3]); w2[5] = make_double2(jp[4], jp[5]);
             w2[6] = make_double2(dpx, dpy);
             w2[7] = make_double2(e, __hiloint2double((int)p.stamp, (int)pi));
+            s_slot[rk] = slot;
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = 8 * r + (t >> 3);
-            const int src = 32 * half + rr;
-            const bool is_c = (cand_mask >> src) & 1ull, is_i = (inl_mask >> src) & 1ull;
-            const uint32_t slot_r = (uint32_t)__shfl((int)slot, src);
-            const double2* rd = reinterpret_cast<const double2*>(s_tile + rr * kRecLds);
-            if (is_c && is_i && !(p.ablate & 2))       // inliers only: an outlier's slot is simply not stamped
-                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * slot_r)[c8] = rd[c8];
+        for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
+            const int rr = r0 + (t >> 3);
+            if (rr < n_rec && !(p.ablate & 2))
+                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * s_slot[rr])[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it
     }

@@ -193,13 +193,18 @@ __device__ __forceinline__ void project_chain(const double* rb, double fx, doubl
     const double phi = atan2(x, z);
     const double r2 = x * x + y * y + z * z;
     const double theta = asin(y / sqrt(r2));
+    // The Jacobian row formulas of equirectangular_camera.h:28-41 with their seven divisions folded into three reciprocals
+    // (fp64 division is ~25 VALU instructions here and this kernel's arithmetic is not free):
+    //   tmp1 = fx / ((1 + (x/z)^2) z) = fx z / (x^2 + z^2),   tmp1 * (x/z) = fx x / (x^2 + z^2),
+    //   tmp2 = -fy / sqrt(1 - (y/rho)^2),  tmp3 = (y/rho) / rho^2  with 1/rho taken once.
+    // Only the Jacobian is affected (last-bit differences); phi and theta — the rounded pixel — use the reference's expressions.
     const double rho = sqrt(sum3(x * x, y * y, z * z));
-    const double Ydivrho = y / rho;
-    const double XdivZ = x / z;
-    const double tmp1 = fx / ((1 + XdivZ * XdivZ) * z);
+    const double inv_rho = 1.0 / rho;
+    const double Ydivrho = y * inv_rho;
+    const double inv_d = fx / (x * x + z * z);
     const double tmp2 = -fy / sqrt(1 - Ydivrho * Ydivrho);
-    const double tmp3 = Ydivrho / (rho * rho);
-    const double Jp[6] = {tmp1, 0.0, -tmp1 * XdivZ, tmp2 * tmp3 * x, tmp2 * (tmp3 * y - 1 / rho), tmp2 * tmp3 * z};
+    const double tmp3 = Ydivrho * inv_rho * inv_rho;
+    const double Jp[6] = {z * inv_d, 0.0, -x * inv_d, tmp2 * tmp3 * x, tmp2 * (tmp3 * y - inv_rho), tmp2 * tmp3 * z};
     const double M[9] = {0, rb[2], -rb[1], -rb[2], 0, rb[0], rb[1], -rb[0], 0};
 #pragma unroll
     for (int i = 0; i < 2; ++i)

@@ -7,10 +7,12 @@
 //             event_pano_warper.cpp:55; J0 = I - J1)
 //   texel     per panorama pixel {Gx Gy Gxx Gxy Gyy pad} = 48 B   (one gather per measurement)
 //   records   one 128-B factor record per measurement candidate, stored in (cp_c,cp_p)-sorted slots:
-//             jc[6] jp[6] dp[2] e {u32 pano_idx, u32 aux}  — the sparse A12 factor + what A11/A22 need
-//   pixacc    per panorama pixel 64 B {sum dx*dx, dx*dy, dy*dy, dx*e, dy*e, pad x3}: the UNWEIGHTED A22/b2 sums of every
-//             inlier measurement, accumulated in the warp kernel next to the int32 count map; only touched lines are
-//             ever non-zero and they are cleared again by emba_clear_kernel at the start of the next evaluation
+//             jc[6] jp[6] dp[2] e {u32 pano_idx, u32 evaluation stamp}  — the sparse A12 factor + what A11/A22 need; only inliers
+//             are written, a slot is valid iff its stamp is the current evaluation's (record_valid)
+//   pixacc    per panorama pixel 64 B {sum w dx*dx, w dx*dy, w dy*dy, dx*we, dy*we, n, pad x2}: the A22/b2 sums (IRLS-weighted when
+//             the cost is declared) and the COUNT of every inlier measurement — one atomic request per measurement; the int32
+//             count map only gets a marker from the warp kernel and is materialised from these lines by the next dense pass;
+//             only touched lines are ever non-zero and they are cleared again by emba_prep_kernel at the start of the next evaluation
 //   pack      [A11 (3K)^2 col-major | b1 3K | per active pixel {xx xy yy bx by}]  (one all-reduce)
 #pragma once
 #include <hip/hip_runtime.h>

@@ -392,6 +392,10 @@ def test_lm_loop_map_residency(gpu, oracle_mod):
     (dict(n_events=20000), 10.0, False, ("quadratic", 0.0)),
     (dict(n_events=30000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01), 1e-2, True, ("huber", 0.1)),
     (dict(n_events=8000, pano_h=64, K=4, sensor=(16, 12), focal=12.0), 1e-3, True, ("cauchy", 1.0)),
+    # 3K - 3 = 219 unknown pose rows: four 64-wide tiles, so the multi-tile SYRK, the panel TRSM and the trailing updates of the
+    # blocked Cholesky all run (K <= 22 fits one tile)
+    (dict(n_events=60000, pano_h=256, K=74, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3), 1e-2, True, ("quadratic", 0.0)),
+    (dict(n_events=40000, pano_h=128, K=45, sensor=(32, 24), focal=30.0, dt_knots=0.01, thres_valid_pixel=3), 1e-1, False, ("huber", 0.1)),
 ])
 def test_schur_solve_parity(gpu, oracle_mod, cfg, lam, fix, cost):
     """SURVEY §8f1: LEGM::solveNormalEq (model.cpp:721-792) on the device from the sparse A12 factors, against the dense CPU

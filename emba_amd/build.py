@@ -6,8 +6,8 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "emba_hip.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "kernels.h"), os.path.join(_HERE, "csrc", "solve_kernels.h"), os.path.join(_HERE, "csrc", "device_math.h"),
-        os.path.join(ROOT, "include", "emba_hip.h")]
+import glob
+DEPS = [SRC, os.path.join(ROOT, "include", "emba_hip.h")] + sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")))   # every header the .hip includes
 OUT = os.path.join(_HERE, "libemba_hip.so")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]

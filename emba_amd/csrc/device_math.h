@@ -8,6 +8,13 @@
 
 namespace emba {
 
+// Everything in this header up to the "Jacobian only" part of project_chain feeds an INTEGER the reference computes — the
+// control-pose index and the rounded panorama pixel round(pm) (model.cpp:209-211) — so it is compiled WITHOUT floating-point
+// contraction: the oracle is built -ffp-contract=off (oracle/Makefile) and a fused multiply-add here would make the two
+// disagree in the last bit of pm, i.e. leave bit-exact indexing to luck.  With contraction off every operation below is the
+// same IEEE operation in the same order as in the oracle; what remains is libm (ocml vs glibc atan2/asin/sin/cos/atan).
+#pragma clang fp contract(off)
+
 constexpr double kSophusEps = 1e-10;  // Sophus::Constants<double>::epsilon(), sophus/common.hpp:94
 constexpr double kPi = 3.14159265358979323846;
 
@@ -184,6 +191,8 @@ __device__ __forceinline__ void spline2_eval(const double* p0, const double* p1,
     q_out[0] = res[0]; q_out[1] = res[1]; q_out[2] = res[2]; q_out[3] = res[3];
 }
 
+__device__ __forceinline__ void project_jacobian(const double* rb, double fx, double fy, double* J23);
+
 // EquirectangularCamera::projectToImage (include/utils/equirectangular_camera.h:18-45) chained with
 // -[rb]x (event_pano_warper.cpp:62-65): pm (2) and J23 = dpm_drb * drb_ddrot (row-major 2x3).
 __device__ __forceinline__ void project_chain(const double* rb, double fx, double fy, double cx, double cy,
@@ -193,6 +202,16 @@ __device__ __forceinline__ void project_chain(const double* rb, double fx, doubl
     const double phi = atan2(x, z);
     const double r2 = x * x + y * y + z * z;
     const double theta = asin(y / sqrt(r2));
+    pm[0] = cx + phi * fx;
+    pm[1] = cy + theta * fy;
+    project_jacobian(rb, fx, fy, J23);
+}
+
+// Jacobian only from here on: contraction is allowed again (last-bit differences, tolerance 1e-5 relative in the north star).
+#pragma clang fp contract(fast)
+__device__ __forceinline__ void project_jacobian(const double* rb, double fx, double fy, double* J23)
+{
+    const double x = rb[0], y = rb[1], z = rb[2];
     // The Jacobian row formulas of equirectangular_camera.h:28-41 with their seven divisions folded into three reciprocals
     // (fp64 division is ~25 VALU instructions here and this kernel's arithmetic is not free):
     //   tmp1 = fx / ((1 + (x/z)^2) z) = fx z / (x^2 + z^2),   tmp1 * (x/z) = fx x / (x^2 + z^2),
@@ -215,8 +234,6 @@ __device__ __forceinline__ void project_chain(const double* rb, double fx, doubl
             for (int k = 0; k < 3; ++k) s += Jp[3 * i + k] * M[3 * k + j];
             J23[3 * i + j] = s;
         }
-    pm[0] = cx + phi * fx;
-    pm[1] = cy + theta * fy;
 }
 
 }  // namespace emba

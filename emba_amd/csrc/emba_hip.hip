@@ -798,7 +798,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
                            c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
     }
     hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy, c->d_active_bits);
+                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy, c->d_active_bits,
+                       (long)((c->pack_cap - (size_t)head) / 5));
     HIP_TRY(c, hipGetLastError());
     c->compact_valid = false;
     c->l2_fused = (c->fused_alpha != 0.0);
@@ -1009,15 +1010,20 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     const size_t ns = c->n_sorted, n = c->n_in;
     if (!ns) return EMBA_OK;
     hipStream_t s = c->stream;
+    // device and host staging only for what was asked for (a 100 M-event pm dump is 1.6 GB, the full state 17 GB)
+    const bool w_pm = pm, w_D = D, w_dp = dp, w_G = Gpm, w_t = temp, w_pi = pm_int, w_inl = inlier_idx, w_flag = inlier_idx || pm_int || Gpm || temp;
     double *d_pm = nullptr, *d_D = nullptr, *d_dp = nullptr, *d_G = nullptr, *d_t = nullptr; int32_t* d_pi = nullptr;
-    emba_status st;
-    if ((st = dev_alloc(c, &d_pm, 2 * ns)) || (st = dev_alloc(c, &d_D, 12 * ns)) || (st = dev_alloc(c, &d_dp, 2 * ns)) ||
-        (st = dev_alloc(c, &d_G, 2 * ns)) || (st = dev_alloc(c, &d_t, 2 * ns)) || (st = dev_alloc(c, &d_pi, 2 * ns))) {
-        dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi);
+    auto free_all = [&]() { dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi); };
+    emba_status st = EMBA_OK;
+    if ((w_pm && (st = dev_alloc(c, &d_pm, 2 * ns))) || (w_D && (st = dev_alloc(c, &d_D, 12 * ns))) || (w_dp && (st = dev_alloc(c, &d_dp, 2 * ns))) ||
+        (w_G && (st = dev_alloc(c, &d_G, 2 * ns))) || (w_t && (st = dev_alloc(c, &d_t, 2 * ns))) || (w_pi && (st = dev_alloc(c, &d_pi, 2 * ns)))) {
+        free_all();
         return st;
     }
-    (void)hipMemsetAsync(d_dp, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_G, 0, 2 * ns * 8, s);
-    (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s); (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
+    if (w_dp) (void)hipMemsetAsync(d_dp, 0, 2 * ns * 8, s);
+    if (w_G) (void)hipMemsetAsync(d_G, 0, 2 * ns * 8, s);
+    if (w_t) (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s);
+    if (w_pi) (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
     p.pose = c->d_pose; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
@@ -1025,27 +1031,31 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
     hipLaunchKernelGGL(emba_warp_residual_kernel<true>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
-    std::vector<double> h_pm(2 * ns), h_D(12 * ns), h_dp(2 * ns), h_G(2 * ns), h_t(2 * ns), h_pose(c->n_batch * kPoseStride);
-    std::vector<int32_t> h_pi(2 * ns), h_inl(ns);
-    std::vector<uint8_t> h_flag(ns);
-    (void)hipMemcpyAsync(h_pm.data(), d_pm, 2 * ns * 8, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_D.data(), d_D, 12 * ns * 8, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_dp.data(), d_dp, 2 * ns * 8, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_G.data(), d_G, 2 * ns * 8, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_t.data(), d_t, 2 * ns * 8, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_pi.data(), d_pi, 2 * ns * 4, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, ns * 4, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_flag.data(), c->d_flag, ns, hipMemcpyDeviceToHost, s);
-    (void)hipMemcpyAsync(h_pose.data(), c->d_pose, h_pose.size() * 8, hipMemcpyDeviceToHost, s);
+    std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
+        h_pose(cp_idx ? c->n_batch * kPoseStride : 0);
+    std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? ns : 0);
+    std::vector<uint8_t> h_flag(w_flag ? ns : 0);
+    if (w_pm) (void)hipMemcpyAsync(h_pm.data(), d_pm, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    if (w_D) (void)hipMemcpyAsync(h_D.data(), d_D, 12 * ns * 8, hipMemcpyDeviceToHost, s);
+    if (w_dp) (void)hipMemcpyAsync(h_dp.data(), d_dp, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    if (w_G) (void)hipMemcpyAsync(h_G.data(), d_G, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    if (w_t) (void)hipMemcpyAsync(h_t.data(), d_t, 2 * ns * 8, hipMemcpyDeviceToHost, s);
+    if (w_pi) (void)hipMemcpyAsync(h_pi.data(), d_pi, 2 * ns * 4, hipMemcpyDeviceToHost, s);
+    if (w_inl) (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, ns * 4, hipMemcpyDeviceToHost, s);
+    if (w_flag) (void)hipMemcpyAsync(h_flag.data(), c->d_flag, ns, hipMemcpyDeviceToHost, s);
+    if (cp_idx) (void)hipMemcpyAsync(h_pose.data(), c->d_pose, h_pose.size() * 8, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
-    dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi);
+    free_all();
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "dump_state: %s", hipGetErrorString(e));
     // pure re-indexing (pixel-major -> original time order); no arithmetic on the host
     if (cp_idx) for (size_t k = 0; k < n; ++k) cp_idx[k] = -1;
     if (inlier_idx) for (size_t k = 0; k < n; ++k) inlier_idx[k] = -2;
     if (pm_int) for (size_t k = 0; k < 2 * n; ++k) pm_int[k] = -1;
-    if (pm) memset(pm, 0, 2 * n * 8); if (D) memset(D, 0, 12 * n * 8); if (dp) memset(dp, 0, 2 * n * 8);
-    if (Gpm) memset(Gpm, 0, 2 * n * 8); if (temp) memset(temp, 0, 2 * n * 8);
+    if (pm) memset(pm, 0, 2 * n * 8);
+    if (D) memset(D, 0, 12 * n * 8);
+    if (dp) memset(dp, 0, 2 * n * 8);
+    if (Gpm) memset(Gpm, 0, 2 * n * 8);
+    if (temp) memset(temp, 0, 2 * n * 8);
     for (size_t i = 0; i < ns; ++i) {
         const uint32_t k = c->h_orig[i];
         if (k == 0xFFFFFFFFu) continue;  // halo

@@ -275,8 +275,11 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         const double* bv = p.lut + 3 * (size_t)pix;
         const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
         double rb[3];
+        {   // feeds round(pm): no contraction (device_math.h), the oracle's three products and two sums
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) rb[r] = sum3(R[3 * r] * b0, R[3 * r + 1] * b1, R[3 * r + 2] * b2);
+            for (int r = 0; r < 3; ++r) rb[r] = sum3(R[3 * r] * b0, R[3 * r + 1] * b1, R[3 * r + 2] * b2);
+        }
         double J23[6];
         project_chain(rb, p.fx, p.fy, p.cx, p.cy, pm, J23);
         // dpm_ddrot_cp = J23 * [I - J1 | J1]   (model.cpp:156; J0 = I - J1, so3_spline.h:261-270)
@@ -295,10 +298,12 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
                 D[6 * r + c] = s0;
                 D[6 * r + c + 3] = s1;
             }
-        if (DUMP) {
-            p.d_pm[2 * i] = pm[0]; p.d_pm[2 * i + 1] = pm[1];
+        if (DUMP) {   // (any dump pointer may be null: only what the caller asked for is produced)
+            if (p.d_pm) { p.d_pm[2 * i] = pm[0]; p.d_pm[2 * i + 1] = pm[1]; }
+            if (p.d_D) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) p.d_D[12 * i + k] = D[k];
+                for (int k = 0; k < 12; ++k) p.d_D[12 * i + k] = D[k];
+            }
         }
     }
 
@@ -317,13 +322,17 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     if (cand) {
         dpx = pm[0] - pmp0;
         dpy = pm[1] - pmp1;
-        const double dp_norm = sqrt(dpx * dpx + dpy * dpy);   // Eigen norm(), model.cpp:199
+        double dp_norm;
+        {   // the outlier decision is an index-level result (who is counted in num_ev_map): no contraction, like the oracle
+#pragma clang fp contract(off)
+            dp_norm = sqrt(dpx * dpx + dpy * dpy);            // Eigen norm(), model.cpp:199
+        }
         const double rx = round(pm[0]), ry = round(pm[1]);    // std::round, model.cpp:209-210
         // Outlier iff dp_norm > 10 (model.cpp:200).  Where the reference is undefined (non-finite dp, or a
         // rounded pixel outside the panorama read unchecked at model.cpp:213,227) the measurement is an
         // outlier as well (DESIGN.md "Defined behaviour").
         inl = (dp_norm <= p.outlier_px) && (rx >= 0.0) && (rx < (double)p.W) && (ry >= 0.0) && (ry < (double)p.H);
-        if (DUMP) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
+        if (DUMP && p.d_dp) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
         if (inl) {
             const int pmx = (int)rx, pmy = (int)ry;
             pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
@@ -349,9 +358,9 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
             const double t0 = gx + (dpx * gxx + dpy * gxy);            // temp = Gpm + dp^T*G2, model.cpp:238
             const double t1 = gy + (dpx * gxy + dpy * gyy);
             if (DUMP) {
-                p.d_Gpm[2 * i] = gx; p.d_Gpm[2 * i + 1] = gy;
-                p.d_temp[2 * i] = t0; p.d_temp[2 * i + 1] = t1;
-                p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy;
+                if (p.d_Gpm) { p.d_Gpm[2 * i] = gx; p.d_Gpm[2 * i + 1] = gy; }
+                if (p.d_temp) { p.d_temp[2 * i] = t0; p.d_temp[2 * i + 1] = t1; }
+                if (p.d_pm_int) { p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy; }
             } else {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
@@ -683,8 +692,9 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
                                                                 const double* __restrict__ pixacc, double* __restrict__ A22b2,
                                                                 double* __restrict__ pack_head, long head_len, double alpha,
                                                                 const double* __restrict__ Gx, const double* __restrict__ Gy,
-                                                                uint8_t* __restrict__ active_bits)
-{   // active_bits: one bit per panorama pixel (pixel p = bit p&31 of 32-bit word p>>5), the Gram kernel's activity lookup
+                                                                uint8_t* __restrict__ active_bits, long max_P)
+{   // max_P: rows of A22b2 the (possibly caller-bound) pack has room for — rows past it are not written, the host reports
+    // EMBA_ERR_CAPACITY once it has read P.   active_bits: one bit per panorama pixel (pixel p = bit p&31 of 32-bit word p>>5), the Gram kernel's activity lookup
     // compact == nullptr: the pano->compact index map is not needed by this step's consumers (it is produced on demand);
     // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU).
     __shared__ uint32_t s_w[4];
@@ -720,7 +730,7 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
         if (m & (1u << j)) {
             if (compact && p0 + 8 > npix) compact[i] = (int32_t)k;
             active_idx[k] = (uint32_t)i;
-            if (A22b2) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
+            if (A22b2 && (long)k < max_P) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
                 const double2* a = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
                 const double2 a0 = a[0], a1 = a[1];
                 const double a4 = pixacc[(size_t)kPixAccStride * i + 4];

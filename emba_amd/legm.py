@@ -73,6 +73,7 @@ class LEGM:
         if st != _lib.OK:
             self._ctx = C.c_void_p()
             raise EmbaError(st, self._L.emba_last_error(None).decode())
+        self.stream = int(stream) if stream else None   # the caller's HIP stream (None: the library made its own)
         self.n_events = 0
         self.K = 0
         self._P = 0
@@ -244,14 +245,17 @@ class LEGM:
                                                 _p(out["w"], _dp), _p(out["jc"], _dp), _p(out["jp"], _dp), _p(out["dp"], _dp)))
         return out
 
-    def dump_state(self):
-        """Per-event State_LEGM (state.h:56-83) in original event order, for parity tests."""
+    def dump_state(self, fields=None):
+        """Per-event State_LEGM (state.h:56-83) in original event order, for parity tests.  fields: subset of
+        (pm, D, cp_idx, inlier_idx, pm_int, dp, Gpm, temp) — only those are produced (a 100 M-event pm dump is 1.6 GB, all of it 17 GB)."""
         n = self.n_events
-        d = dict(pm=np.zeros((n, 2)), D=np.zeros((n, 2, 6)), cp_idx=np.zeros(n, np.int32), inlier_idx=np.zeros(n, np.int32),
-                 pm_int=np.zeros((n, 2), np.int32), dp=np.zeros((n, 2)), Gpm=np.zeros((n, 2)), temp=np.zeros((n, 2)))
-        self._check(self._L.emba_dump_state(self._ctx, _p(d["pm"], _dp), _p(d["D"], _dp), _p(d["cp_idx"], _i32p),
-                                            _p(d["inlier_idx"], _i32p), _p(d["pm_int"], _i32p), _p(d["dp"], _dp), _p(d["Gpm"], _dp),
-                                            _p(d["temp"], _dp)))
+        shapes = dict(pm=((n, 2), np.float64), D=((n, 2, 6), np.float64), cp_idx=((n,), np.int32), inlier_idx=((n,), np.int32),
+                      pm_int=((n, 2), np.int32), dp=((n, 2), np.float64), Gpm=((n, 2), np.float64), temp=((n, 2), np.float64))
+        want = list(shapes) if fields is None else list(fields)
+        d = {k: np.zeros(shapes[k][0], shapes[k][1]) for k in want}
+        g = lambda k, ty: _p(d[k], ty) if k in d else None
+        self._check(self._L.emba_dump_state(self._ctx, g("pm", _dp), g("D", _dp), g("cp_idx", _i32p), g("inlier_idx", _i32p),
+                                            g("pm_int", _i32p), g("dp", _dp), g("Gpm", _dp), g("temp", _dp)))
         return d
 
     # -- phase-level, HBM-resident interface (bench.py, sharded host) -------------------------------

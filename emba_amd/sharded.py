@@ -136,11 +136,21 @@ class ShardedLEGM:
 class HipEngine:
     """Adapter: emba_amd.LEGM phase calls + torch CUDA tensors as the exchange buffers (product path)."""
 
-    def __init__(self, legm):
+    def __init__(self, legm, check_stream=True):
+        """check_stream: the collectives of torch.distributed run on torch's CURRENT stream, the kernels on the LEGM's stream; unless
+        the two are the same stream nothing orders a kernel against the all-reduce that follows it.  Pass False only with a `dist`
+        that synchronises by itself (the thread stand-in of tests/test_gpu_sharded.py drains the engine's stream first)."""
         self.m = legm
+        self.check_stream = check_stream
 
     def bind_exchange(self, count_tensor, pack_tensor):
         assert count_tensor.is_cuda and pack_tensor.is_cuda and count_tensor.is_contiguous() and pack_tensor.is_contiguous()
+        if self.check_stream:
+            import torch
+            cur = torch.cuda.current_stream(count_tensor.device).cuda_stream
+            if getattr(self.m, "stream", None) != cur:
+                raise RuntimeError("HipEngine: create the LEGM with stream=torch.cuda.current_stream().cuda_stream (a non-default "
+                                   "torch stream): kernels and RCCL collectives must share one stream")
         self.m.bind_exchange_buffers(count_tensor.data_ptr(), pack_tensor.data_ptr(), pack_tensor.numel())
 
     def set_events(self, events, halo):

@@ -8,6 +8,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import io as emba_io
+from ._lib import ERR_NUMERIC as _ERR_NUMERIC
 
 
 @dataclass
@@ -26,6 +27,7 @@ class BASettings:               # include/emba/params.h:14-61, values of launch/
     alpha: float = 5.0
     damping_factor: float = 1.0
     first_time_window: bool = True      # the first control pose is held fixed (solver.cpp:156-165, 227-230)
+    use_CG: bool = False                # solveNormalEqCG instead of the Schur solve (solver.cpp:190-202; launch default false)
 
 
 @dataclass
@@ -87,7 +89,23 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             if it == 0:                                                              # :69-91, uploads the initial map once
                 cost_min = ph.evaluate(traj, Gx, Gy)
             ph.form(traj.size())                                                     # :93-131
-        x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)       # :190-202
+        try:
+            if ba.use_CG:
+                x1, x2 = model.solveNormalEqCG(lam, fix_first_pose=ba.first_time_window)[:2]   # :196-202
+            else:
+                x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)         # :190-194
+        except Exception as e:   # noqa: BLE001
+            # The reference factors S with Eigen's pivoted ldlt (model.cpp:789), which also returns for a semi-definite S (e.g. a control
+            # pose no event constrains: its rows of A11 + lambda*diag(A11) stay zero), and then accepts or rejects the step on its cost.
+            # The device factorisation is a Cholesky and reports a vanishing pivot (EMBA_ERR_NUMERIC): treat the step as rejected.
+            if getattr(e, "status", None) != _ERR_NUMERIC and "singular" not in str(e):
+                raise
+            it += 1
+            log.append((it, float(np.log10(lam)), cost_min, float("inf"), False))
+            decreased = False
+            lam *= 10
+            count_tol = 0
+            continue
         traj_new = emba_io.incremental_update(traj, x1, ba.first_time_window)        # :226-234
         model.updateMap(x2, ba.damping_factor)                                       # :237-240 (trial map, on the device)
         cost_new = ph.evaluate(traj_new)                                             # :251-268

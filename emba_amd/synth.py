@@ -58,13 +58,14 @@ class Workload:
     events: EventPacket
     thres_valid_pixel: int = 5
     alpha: float = 5.0
+    kind: str = "synthetic"      # "synthetic": i.i.d. uniform events; "scene": simulated from an analytic scene
 
     @property
     def K(self):
         return self.traj.size()
 
     def describe(self):
-        return (f"synthetic N={self.events.size()} sensor={self.sensor_w}x{self.sensor_h} pano={self.pano_h}x{self.pano_w} "
+        return (f"{self.kind} N={self.events.size()} sensor={self.sensor_w}x{self.sensor_h} pano={self.pano_h}x{self.pano_w} "
                 f"K={self.K} seed={SEED}")
 
 
@@ -176,12 +177,27 @@ def simulate_events(scene, traj, lut, sensor, C_th, n_steps=4000):
 
 
 def make_scene_workload(pano_h=256, K=6, sensor=(64, 48), focal=60.0, C_th=0.2, dt_knots=0.05, t_beg=0.1, yaw_rate=0.5, amp=8.0,
-                        n_steps=4000, seed=3, thres_valid_pixel=5, alpha=5.0):
+                        n_steps=4000, seed=3, thres_valid_pixel=5, alpha=5.0, n_terms=12, max_freq=(14, 7)):
     """Ground-truth trajectory + analytic scene + the events that motion produces; Gx, Gy are the TRUE gradient map."""
     sw, sh = sensor
     lut = pinhole_bearing_lut(sw, sh, focal, focal, sw / 2.0, sh / 2.0)
-    scene = SinusoidScene(pano_h, amp=amp, seed=seed)
+    scene = SinusoidScene(pano_h, n_terms=n_terms, max_freq=max_freq, amp=amp, seed=seed)
     Gx, Gy = scene.gradient_map()
     traj = make_trajectory(K, dt_knots, t_beg, yaw_rate)
     ev = simulate_events(scene, traj, lut, sensor, C_th, n_steps)
-    return Workload(sw, sh, 2 * pano_h, pano_h, lut, C_th, Gx, Gy, traj, ev, thres_valid_pixel, alpha)
+    return Workload(sw, sh, 2 * pano_h, pano_h, lut, C_th, Gx, Gy, traj, ev, thres_valid_pixel, alpha, "scene")
+
+
+def make_scene_stream(n_target, pano_h=1024, K=21, sensor=(240, 180), focal=200.0, C_th=0.2, n_steps=400, seed=3, **kw):
+    """A scene-driven event stream of about n_target events (bench.py --data scene): events cluster where the scene has contrast,
+    every sensor pixel fires at its own rate and polarities follow the sign of the brightness change — unlike the i.i.d. uniform
+    workload of SURVEY §8d.  The scene amplitude is calibrated on a coarse run so that the count lands near the target."""
+    sw, sh = sensor
+    lut = pinhole_bearing_lut(sw, sh, focal, focal, sw / 2.0, sh / 2.0)
+    traj = make_trajectory(K)
+    probe = SinusoidScene(pano_h, n_terms=8, max_freq=(40, 20), amp=1.0, seed=seed)
+    c = simulate_events(probe, traj, lut, sensor, C_th, max(n_steps // 8, 20)).size()
+    amp = float(n_target) / max(c, 1)
+    w = make_scene_workload(pano_h=pano_h, K=K, sensor=sensor, focal=focal, C_th=C_th, amp=amp, n_steps=n_steps, seed=seed,
+                            n_terms=8, max_freq=(40, 20), **kw)
+    return w

@@ -8,6 +8,25 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* Two modes: "ref" = ONE thread, the reference's own evaluation order (the reference is single-threaded: no
+ * `#pragma omp` anywhere despite -fopenmp in CMakeLists.txt:7) — this is the checker; "omp" = the same per-measurement
+ * arithmetic spread over the host's cores, order-relaxed where sums meet (A11/b1 per-thread then merged in thread order,
+ * A22/b2 by atomic adds) — only bench.py's cpu_baseline leg and the test that compares the two modes switch it on. */
+static int g_threads = 1;
+void emba_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int emba_oracle_get_threads(void) { return g_threads; }
+int emba_oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
 
 #define SOPHUS_EPS 1e-10 /* Sophus::Constants<double>::epsilon(), sophus/common.hpp:94 */
 #define EVENT_BATCH 100  /* model.cpp:78 (hard-coded, quirk Q2) */
@@ -298,6 +317,8 @@ struct emba_oracle {
     int32_t* inl;       /* inlier_idx per event */
     uint8_t* polv;
     double* dp; double* Gpm; double* temp; /* 2 per event */
+    size_t first_counted; /* events before this index are warped and can be predecessors but form no measurement of their own
+                           * (how a time shard sees the events in front of it, SURVEY.md §8e "halo"); 0 = the reference */
 };
 
 emba_oracle* emba_oracle_create(int sensor_w, int sensor_h, int pano_w, int pano_h,
@@ -320,6 +341,8 @@ static void free_state(emba_oracle* o)
     o->order = NULL; o->pix = NULL; o->pm = o->D = o->dp = o->Gpm = o->temp = NULL;
     o->cp = o->inl = NULL; o->polv = NULL; o->cap = 0;
 }
+
+void emba_oracle_set_first_counted(emba_oracle* o, size_t k0) { o->first_counted = k0; }
 
 void emba_oracle_destroy(emba_oracle* o)
 {
@@ -390,6 +413,7 @@ static void sobel(const double* src, int H, int W, int dx, double* dst)
 {
     /* dx=1: d/dx (rows: [-1 0 1], cols: [1 2 1]); dx=0: d/dy (rows: [1 2 1], cols: [-1 0 1]) */
     double* tmp = (double*)malloc((size_t)H * W * sizeof(double));
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int y = 0; y < H; ++y) {
         const double* s = src + (size_t)y * W;
         double* t = tmp + (size_t)y * W;
@@ -398,6 +422,7 @@ static void sobel(const double* src, int H, int W, int dx, double* dst)
             t[x] = dx ? (r - l) : (l + r + 2 * c);
         }
     }
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (int y = 0; y < H; ++y) {
         const double* u = tmp + (size_t)reflect101(y - 1, H) * W;
         const double* c = tmp + (size_t)y * W;
@@ -416,6 +441,7 @@ void emba_oracle_hessian(const double* Gx, const double* Gy, int H, int W, doubl
     sobel(Gx, H, W, 0, Gxy);
     sobel(Gy, H, W, 1, Gyx);
     sobel(Gy, H, W, 0, Gyy);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t i = 0; i < n; ++i) {
         Gxx[i] = 0.125 * Gxx[i];
         Gxy[i] = 0.125 * Gxy[i];
@@ -424,6 +450,45 @@ void emba_oracle_hessian(const double* Gx, const double* Gy, int H, int W, doubl
         Gxy[i] = 0.5 * (Gxy[i] + Gyx[i]);
     }
     free(Gyx);
+}
+
+/* One measurement of the pairing loop, model.cpp:186-242: event kc against its predecessor kp at the same sensor pixel.
+ * Returns 0 for an outlier; otherwise the residual (:221), the panorama pixel index (:209-211) and the stored dp/Gpm/temp. */
+/* The index-level half of a measurement (model.cpp:194-211): displacement, outlier test, rounded panorama pixel. */
+static inline int pair_index(const double* pm_c, const double* pm_p, int W, int H, double* dpx_o, double* dpy_o, size_t* pi_out)
+{
+    const double dpx = pm_c[0] - pm_p[0];
+    const double dpy = pm_c[1] - pm_p[1];
+    const double dp_norm = sqrt(dpx * dpx + dpy * dpy);
+    *dpx_o = dpx; *dpy_o = dpy;
+    if (dp_norm > OUTLIER_PX) return 0; /* :200-205 */
+    const double rx = round(pm_c[0]), ry = round(pm_c[1]); /* :209-210 */
+    /* DEFINED BEHAVIOUR where the reference is UB: a non-finite dp or a rounded
+     * pixel outside [0,W)x[0,H) is an outlier (cv::Mat::at is unchecked at model.cpp:213,227). */
+    if (!(dp_norm <= OUTLIER_PX) || !(rx >= 0 && rx < W && ry >= 0 && ry < H)) return 0;
+    const int pm_x = (int)rx, pm_y = (int)ry;
+    *pi_out = (size_t)pm_y * W + pm_x;
+    return 1;
+}
+
+static inline int pair_measure(emba_oracle* o, uint32_t kc, uint32_t kp, const double* Gx, const double* Gy,
+                               const double* Gxx, const double* Gxy, const double* Gyy, double* e_out, size_t* pi_out)
+{
+    double dpx, dpy;
+    size_t pi = 0;
+    const int inl = pair_index(o->pm + 2 * kc, o->pm + 2 * kp, o->W, o->H, &dpx, &dpy, &pi);
+    o->dp[2 * kc] = dpx; o->dp[2 * kc + 1] = dpy;
+    if (!inl) return 0;
+    const double gx = Gx[pi], gy = Gy[pi];
+    const double C_pred = gx * dpx + gy * dpy;               /* :217 */
+    const double C_meas = 2 * (o->polv[kc] - 0.5) * o->C_th;   /* :219 */
+    *e_out = C_meas - C_pred;                                /* :221 */
+    *pi_out = pi;
+    /* temp = Gpm + dp^T * G2pm, :233-238 */
+    o->Gpm[2 * kc] = gx; o->Gpm[2 * kc + 1] = gy;
+    o->temp[2 * kc] = gx + (dpx * Gxx[pi] + dpy * Gxy[pi]);
+    o->temp[2 * kc + 1] = gy + (dpx * Gxy[pi] + dpy * Gyy[pi]);
+    return 1;
 }
 
 /* a1-a7 — LEGM::evaluateDataError, src/emba/model.cpp:72-258 (eval_deriv = true) */
@@ -448,28 +513,58 @@ long emba_oracle_eval_data_error(emba_oracle* o, const double* knots, int K, int
     emba_oracle_hessian(Gx, Gy, H, W, Gxx, Gxy, Gyy); /* :88-97 */
 
     /* event_map_.addEvent order == stable counting sort by sensor pixel (event_map.h:34-37) */
-    memset(o->pix_start, 0, (S + 1) * sizeof(uint32_t));
-    for (size_t k = 0; k < n_used; ++k) {
-        o->pix[k] = (uint32_t)ey[k] * (uint32_t)o->sw + ex[k];
-        o->pix_start[o->pix[k] + 1]++;
-    }
-    for (size_t p = 0; p < S; ++p) o->pix_start[p + 1] += o->pix_start[p];
-    {
+    if (g_threads <= 1) {
+        memset(o->pix_start, 0, (S + 1) * sizeof(uint32_t));
+        for (size_t k = 0; k < n_used; ++k) {
+            o->pix[k] = (uint32_t)ey[k] * (uint32_t)o->sw + ex[k];
+            o->pix_start[o->pix[k] + 1]++;
+        }
+        for (size_t p = 0; p < S; ++p) o->pix_start[p + 1] += o->pix_start[p];
         uint32_t* cur = (uint32_t*)malloc(S * sizeof(uint32_t));
         memcpy(cur, o->pix_start, S * sizeof(uint32_t));
         for (size_t k = 0; k < n_used; ++k) o->order[cur[o->pix[k]]++] = (uint32_t)k;
         free(cur);
+    } else {
+        /* omp mode: the same stable order from per-chunk histograms (chunk c of the time-sorted events precedes chunk c+1 inside every pixel) */
+        const int T = g_threads < 32 ? g_threads : 32;
+        uint32_t* hist = (uint32_t*)calloc((size_t)T * S, sizeof(uint32_t));
+        const size_t per = (n_used + T - 1) / T;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int c = 0; c < T; ++c) {
+            uint32_t* h = hist + (size_t)c * S;
+            const size_t k0 = per * c, k1 = (k0 + per < n_used) ? k0 + per : n_used;
+            for (size_t k = k0; k < k1; ++k) {
+                o->pix[k] = (uint32_t)ey[k] * (uint32_t)o->sw + ex[k];
+                h[o->pix[k]]++;
+            }
+        }
+        uint32_t run = 0;
+        for (size_t p = 0; p < S; ++p) {
+            o->pix_start[p] = run;
+            for (int c = 0; c < T; ++c) { const uint32_t v = hist[(size_t)c * S + p]; hist[(size_t)c * S + p] = run; run += v; }
+        }
+        o->pix_start[S] = run;
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int c = 0; c < T; ++c) {
+            uint32_t* h = hist + (size_t)c * S;
+            const size_t k0 = per * c, k1 = (k0 + per < n_used) ? k0 + per : n_used;
+            for (size_t k = k0; k < k1; ++k) o->order[h[o->pix[k]]++] = (uint32_t)k;
+        }
+        free(hist);
     }
 
-    /* batches :102-172 */
+    /* batches :102-172 (independent of each other: in omp mode they are dealt to the threads as they stand) */
+    int spline_err = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
     for (size_t b = 0; b < num_batches; ++b) {
         const size_t bgn = EVENT_BATCH * b, end = EVENT_BATCH * (b + 1);
         const int64_t t_batch = emba_oracle_batch_mid_ns(t_ns[bgn], t_ns[end - 1]); /* :116-119 */
         double q[4], R[9], J36[18];
         int cp_idx;
         if (emba_oracle_spline_eval(knots, K, t0_ns, dt_ns, t_batch, q, R, &cp_idx, J36)) { /* :130 */
-            free(Gxx); free(Gxy); free(Gyy);
-            return -1;
+#pragma omp atomic write
+            spline_err = 1;
+            continue;
         }
         for (size_t k = bgn; k < end; ++k) {
             double J23[6];
@@ -486,36 +581,54 @@ long emba_oracle_eval_data_error(emba_oracle* o, const double* knots, int K, int
             o->inl[k] = -2;
         }
     }
+    if (spline_err) { free(Gxx); free(Gxy); free(Gyy); return -1; }
     for (size_t k = n_used; k < n; ++k) { o->inl[k] = -2; o->cp[k] = -1; }
 
     /* pairing + residual, :176-246 */
     size_t inlier_count = 0;
-    for (size_t p = 0; p < S; ++p) {
-        for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
-            const uint32_t kc = o->order[i], kp = o->order[i - 1];
-            const double dpx = o->pm[2 * kc] - o->pm[2 * kp];
-            const double dpy = o->pm[2 * kc + 1] - o->pm[2 * kp + 1];
-            const double dp_norm = sqrt(dpx * dpx + dpy * dpy);
-            o->dp[2 * kc] = dpx; o->dp[2 * kc + 1] = dpy;
-            if (dp_norm > OUTLIER_PX) { o->inl[kc] = -1; continue; } /* :200-205 */
-            const double rx = round(o->pm[2 * kc]), ry = round(o->pm[2 * kc + 1]); /* :209-210 */
-            /* DEFINED BEHAVIOUR where the reference is UB: a non-finite dp or a rounded
-             * pixel outside [0,W)x[0,H) is an outlier (cv::Mat::at is unchecked at model.cpp:213,227). */
-            if (!(dp_norm <= OUTLIER_PX) || !(rx >= 0 && rx < W && ry >= 0 && ry < H)) { o->inl[kc] = -1; continue; }
-            const int pm_x = (int)rx, pm_y = (int)ry;
-            const size_t pi = (size_t)pm_y * W + pm_x;
-            const double gx = Gx[pi], gy = Gy[pi];
-            const double C_pred = gx * dpx + gy * dpy;               /* :217 */
-            const double C_meas = 2 * (o->polv[kc] - 0.5) * o->C_th;   /* :219 */
-            ep_out[inlier_count] = C_meas - C_pred;                  /* :221 */
-            o->inl[kc] = (int32_t)inlier_count;
-            inlier_count += 1;
-            num_ev_map[pi] += 1;                                     /* :227 */
-            /* temp = Gpm + dp^T * G2pm, :233-238 */
-            o->Gpm[2 * kc] = gx; o->Gpm[2 * kc + 1] = gy;
-            o->temp[2 * kc] = gx + (dpx * Gxx[pi] + dpy * Gxy[pi]);
-            o->temp[2 * kc + 1] = gy + (dpx * Gxy[pi] + dpy * Gyy[pi]);
+    if (g_threads <= 1) {
+        for (size_t p = 0; p < S; ++p) {
+            for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
+                const uint32_t kc = o->order[i], kp = o->order[i - 1];
+                double e; size_t pi;
+                if (kc < o->first_counted) continue;   /* shard lead-in: inl stays -2 */
+                if (!pair_measure(o, kc, kp, Gx, Gy, Gxx, Gxy, Gyy, &e, &pi)) { o->inl[kc] = -1; continue; }
+                ep_out[inlier_count] = e;                                /* :221 */
+                o->inl[kc] = (int32_t)inlier_count;
+                inlier_count += 1;
+                num_ev_map[pi] += 1;                                     /* :227 */
+            }
         }
+    } else {
+        /* omp mode: the same measurements, numbered in the same (sensor pixel, time) order by a prefix sum over pixels */
+        uint32_t* cnt = (uint32_t*)calloc(S + 1, sizeof(uint32_t));
+        double* etmp = (double*)malloc((n_used ? n_used : 1) * sizeof(double));
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+        for (size_t p = 0; p < S; ++p) {
+            uint32_t c = 0;
+            for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
+                const uint32_t kc = o->order[i], kp = o->order[i - 1];
+                double e; size_t pi;
+                if (kc < o->first_counted) continue;
+                if (!pair_measure(o, kc, kp, Gx, Gy, Gxx, Gxy, Gyy, &e, &pi)) { o->inl[kc] = -1; continue; }
+                etmp[kc] = e; o->inl[kc] = 0; ++c;
+#pragma omp atomic
+                num_ev_map[pi] += 1;
+            }
+            cnt[p + 1] = c;
+        }
+        for (size_t p = 0; p < S; ++p) cnt[p + 1] += cnt[p];
+        inlier_count = cnt[S];
+#pragma omp parallel for schedule(dynamic, 64) num_threads(g_threads)
+        for (size_t p = 0; p < S; ++p) {
+            uint32_t idx = cnt[p];
+            for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
+                const uint32_t kc = o->order[i];
+                if (o->inl[kc] < 0) continue;
+                ep_out[idx] = etmp[kc]; o->inl[kc] = (int32_t)idx; ++idx;
+            }
+        }
+        free(cnt); free(etmp);
     }
     free(Gxx); free(Gxy); free(Gyy);
 
@@ -544,6 +657,134 @@ long emba_oracle_eval_data_error(emba_oracle* o, const double* knots, int K, int
     return (long)inlier_count;
 }
 
+/* Lean pass (index-level results only) for flip-rate measurements at sizes where the full per-event state (177 B/event) does
+ * not fit the host: pm of every event (same leaf functions as emba_oracle_eval_data_error), then the pairing rule of
+ * model.cpp:179-211 applied in TIME order with a last-event-per-sensor-pixel table — the same pairs as the pixel-major walk.
+ * pm_out (2n doubles) and pm_int_out (2n, -1 where the event is not an inlier measurement) may be NULL.  Returns the inlier
+ * count or -1 (batch outside the spline). */
+long emba_oracle_count_map(const emba_oracle* o, const double* knots, int K, int64_t t0_ns, int64_t dt_ns,
+                           const uint16_t* ex, const uint16_t* ey, const int64_t* t_ns, size_t n, double* pm_out,
+                           int32_t* num_ev_map, int32_t* pm_int_out)
+{
+    const int W = o->W, H = o->H;
+    const size_t S = (size_t)o->sw * o->sh, npix = (size_t)W * H;
+    const size_t num_batches = n / EVENT_BATCH, n_used = num_batches * EVENT_BATCH;
+    double* pm = pm_out ? pm_out : (double*)malloc((n_used ? n_used : 1) * 2 * sizeof(double));
+    memset(num_ev_map, 0, npix * sizeof(int32_t));
+    int spline_err = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+    for (size_t b = 0; b < num_batches; ++b) {
+        const size_t bgn = EVENT_BATCH * b, end = EVENT_BATCH * (b + 1);
+        const int64_t t_batch = emba_oracle_batch_mid_ns(t_ns[bgn], t_ns[end - 1]);
+        double q[4], R[9], J36[18];
+        int cp_idx;
+        if (emba_oracle_spline_eval(knots, K, t0_ns, dt_ns, t_batch, q, R, &cp_idx, J36)) {
+#pragma omp atomic write
+            spline_err = 1;
+            continue;
+        }
+        for (size_t k = bgn; k < end; ++k) warp_with_R(o, ex[k], ey[k], R, pm + 2 * k, NULL);
+    }
+    long inliers = -1;
+    if (!spline_err) {
+        int64_t* last = (int64_t*)malloc(S * sizeof(int64_t));
+        for (size_t p = 0; p < S; ++p) last[p] = -1;
+        inliers = 0;
+        for (size_t k = 0; k < n_used; ++k) {
+            const size_t p = (size_t)ey[k] * o->sw + ex[k];
+            if (pm_int_out) { pm_int_out[2 * k] = -1; pm_int_out[2 * k + 1] = -1; }
+            if (last[p] >= 0) {
+                double dpx, dpy; size_t pi = 0;
+                if (pair_index(pm + 2 * k, pm + 2 * (size_t)last[p], W, H, &dpx, &dpy, &pi)) {
+                    num_ev_map[pi] += 1;
+                    ++inliers;
+                    if (pm_int_out) { pm_int_out[2 * k] = (int32_t)(pi % (size_t)W); pm_int_out[2 * k + 1] = (int32_t)(pi / (size_t)W); }
+                }
+            }
+            last[p] = (int64_t)k;
+        }
+        free(last);
+    }
+    if (!pm_out) free(pm);
+    return inliers;
+}
+
+/* One measurement of the accumulation loop of formNormalEq[IRLS], model.cpp:396-487 / :575-684. */
+static inline void accumulate_measure(const emba_oracle* o, uint32_t kc, uint32_t kp, const double* ep, const int32_t* num_ev_map,
+                                      const int32_t* compact, int thres, int irls, double a, int dim, double* A11, double* b1,
+                                      double* A22, double* b2, double* A12, int shared)
+{
+    const int W = o->W;
+    if (o->inl[kc] < 0) return; /* :396 */
+    const int pm_x = (int)round(o->pm[2 * kc]), pm_y = (int)round(o->pm[2 * kc + 1]);
+    const size_t pi = (size_t)pm_y * W + pm_x;
+    if (num_ev_map[pi] < thres) return; /* :409 */
+    const size_t ai = (size_t)compact[pi];
+    const double ep_k = ep[o->inl[kc]]; /* :421 */
+    double Yi = 1.0;
+    if (irls == 2) Yi = 1.0 / (1.0 + a * ep_k * ep_k);             /* :603 */
+    else if (irls == 1) { const double e = fabs(ep_k); Yi = (e < a) ? 1.0 : a / e; } /* :608-616 */
+    const double ep_w = Yi * ep_k;
+
+    const double gx = o->dp[2 * kc], gy = o->dp[2 * kc + 1]; /* dM_dGx, dM_dGy :426-427 */
+    if (!shared) {
+        A22[4 * ai + 0] += Yi * (gx * gx);
+        A22[4 * ai + 1] += Yi * (gx * gy);
+        A22[4 * ai + 2] += Yi * (gx * gy);
+        A22[4 * ai + 3] += Yi * (gy * gy);
+        b2[2 * ai] += gx * ep_w;
+        b2[2 * ai + 1] += gy * ep_w;
+    } else {   /* omp mode: a panorama pixel is fed by several threads */
+#pragma omp atomic
+        A22[4 * ai + 0] += Yi * (gx * gx);
+#pragma omp atomic
+        A22[4 * ai + 1] += Yi * (gx * gy);
+#pragma omp atomic
+        A22[4 * ai + 2] += Yi * (gx * gy);
+#pragma omp atomic
+        A22[4 * ai + 3] += Yi * (gy * gy);
+#pragma omp atomic
+        b2[2 * ai] += gx * ep_w;
+#pragma omp atomic
+        b2[2 * ai + 1] += gy * ep_w;
+    }
+
+    double jc[6], jp[6];
+    const double* Dc = o->D + 12 * (size_t)kc;
+    const double* Dp = o->D + 12 * (size_t)kp;
+    for (int j = 0; j < 6; ++j) {
+        jc[j] = o->temp[2 * kc] * Dc[j] + o->temp[2 * kc + 1] * Dc[6 + j];          /* :449 */
+        jp[j] = (-o->Gpm[2 * kc]) * Dp[j] + (-o->Gpm[2 * kc + 1]) * Dp[6 + j];     /* :459 */
+    }
+    const size_t sc = 3 * (size_t)o->cp[kc], sp = 3 * (size_t)o->cp[kp];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            A11[(sc + r) + (size_t)dim * (sc + c)] += Yi * jc[r] * jc[c]; /* :454 */
+        }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            A11[(sp + r) + (size_t)dim * (sp + c)] += Yi * jp[r] * jp[c]; /* :463 */
+        }
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) {
+            const double cross = Yi * jc[r] * jp[c];                      /* :467 */
+            A11[(sc + r) + (size_t)dim * (sp + c)] += cross;              /* :468 */
+            A11[(sp + c) + (size_t)dim * (sc + r)] += cross;              /* :469 */
+        }
+    for (int r = 0; r < 6; ++r) {
+        b1[sc + r] += jc[r] * ep_w; /* :475 */
+        b1[sp + r] += jp[r] * ep_w; /* :477 */
+    }
+    if (A12) {
+        double* c0 = A12 + (size_t)dim * (2 * ai);
+        double* c1 = A12 + (size_t)dim * (2 * ai + 1);
+        for (int r = 0; r < 6; ++r) {
+            c0[sc + r] += Yi * jc[r] * gx; c1[sc + r] += Yi * jc[r] * gy; /* :483-484 */
+            c0[sp + r] += Yi * jp[r] * gx; c1[sp + r] += Yi * jp[r] * gy; /* :486-487 (dense A12: ref mode only) */
+        }
+    }
+}
+
 /* a8-a10 — LEGM::formNormalEq (model.cpp:316-491) / formNormalEqIRLS (:493-687) */
 long emba_oracle_form_normal_eq(emba_oracle* o, const double* ep, int K, const int32_t* num_ev_map,
                                 int thres, int irls, double a, double* A11, double* b1,
@@ -567,63 +808,36 @@ long emba_oracle_form_normal_eq(emba_oracle* o, const double* ep, int K, const i
     memset(b2, 0, P * 2 * sizeof(double));
     if (A12) memset(A12, 0, (size_t)dim * 2 * P * sizeof(double));
 
-    for (size_t p = 0; p < S; ++p) {
-        for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
-            const uint32_t kc = o->order[i], kp = o->order[i - 1];
-            if (o->inl[kc] < 0) continue; /* :396 */
-            const int pm_x = (int)round(o->pm[2 * kc]), pm_y = (int)round(o->pm[2 * kc + 1]);
-            const size_t pi = (size_t)pm_y * W + pm_x;
-            if (num_ev_map[pi] < thres) continue; /* :409 */
-            const size_t ai = (size_t)compact[pi];
-            const double ep_k = ep[o->inl[kc]]; /* :421 */
-            double Yi = 1.0;
-            if (irls == 2) Yi = 1.0 / (1.0 + a * ep_k * ep_k);             /* :603 */
-            else if (irls == 1) { const double e = fabs(ep_k); Yi = (e < a) ? 1.0 : a / e; } /* :608-616 */
-            const double ep_w = Yi * ep_k;
-
-            const double gx = o->dp[2 * kc], gy = o->dp[2 * kc + 1]; /* dM_dGx, dM_dGy :426-427 */
-            A22[4 * ai + 0] += Yi * (gx * gx);
-            A22[4 * ai + 1] += Yi * (gx * gy);
-            A22[4 * ai + 2] += Yi * (gx * gy);
-            A22[4 * ai + 3] += Yi * (gy * gy);
-            b2[2 * ai] += gx * ep_w;
-            b2[2 * ai + 1] += gy * ep_w;
-
-            double jc[6], jp[6];
-            const double* Dc = o->D + 12 * (size_t)kc;
-            const double* Dp = o->D + 12 * (size_t)kp;
-            for (int j = 0; j < 6; ++j) {
-                jc[j] = o->temp[2 * kc] * Dc[j] + o->temp[2 * kc + 1] * Dc[6 + j];          /* :449 */
-                jp[j] = (-o->Gpm[2 * kc]) * Dp[j] + (-o->Gpm[2 * kc + 1]) * Dp[6 + j];     /* :459 */
-            }
-            const size_t sc = 3 * (size_t)o->cp[kc], sp = 3 * (size_t)o->cp[kp];
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) {
-                    A11[(sc + r) + (size_t)dim * (sc + c)] += Yi * jc[r] * jc[c]; /* :454 */
-                }
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) {
-                    A11[(sp + r) + (size_t)dim * (sp + c)] += Yi * jp[r] * jp[c]; /* :463 */
-                }
-            for (int r = 0; r < 6; ++r)
-                for (int c = 0; c < 6; ++c) {
-                    const double cross = Yi * jc[r] * jp[c];                      /* :467 */
-                    A11[(sc + r) + (size_t)dim * (sp + c)] += cross;              /* :468 */
-                    A11[(sp + c) + (size_t)dim * (sc + r)] += cross;              /* :469 */
-                }
-            for (int r = 0; r < 6; ++r) {
-                b1[sc + r] += jc[r] * ep_w; /* :475 */
-                b1[sp + r] += jp[r] * ep_w; /* :477 */
-            }
-            if (A12) {
-                double* c0 = A12 + (size_t)dim * (2 * ai);
-                double* c1 = A12 + (size_t)dim * (2 * ai + 1);
-                for (int r = 0; r < 6; ++r) {
-                    c0[sc + r] += Yi * jc[r] * gx; c1[sc + r] += Yi * jc[r] * gy; /* :483-484 */
-                    c0[sp + r] += Yi * jp[r] * gx; c1[sp + r] += Yi * jp[r] * gy; /* :486-487 */
-                }
-            }
+    if (g_threads <= 1 || A12) {
+        for (size_t p = 0; p < S; ++p)
+            for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i)
+                accumulate_measure(o, o->order[i], o->order[i - 1], ep, num_ev_map, compact, thres, irls, a, dim, A11, b1, A22, b2, A12, 0);
+    } else {
+        /* omp mode: per-thread A11 / b1, merged in thread order; A22 / b2 by atomic adds */
+        const int T = g_threads;
+        const size_t blk = (size_t)dim * dim + dim;
+        double* priv = (double*)calloc((size_t)T * blk, sizeof(double));
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            const int tid = omp_get_thread_num();
+#else
+            const int tid = 0;
+#endif
+            double* a11 = priv + (size_t)tid * blk;
+            double* bb1 = a11 + (size_t)dim * dim;
+#pragma omp for schedule(dynamic, 64)
+            for (size_t p = 0; p < S; ++p)
+                for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i)
+                    accumulate_measure(o, o->order[i], o->order[i - 1], ep, num_ev_map, compact, thres, irls, a, dim, a11, bb1, A22, b2, NULL, 1);
         }
+#pragma omp parallel for schedule(static) num_threads(T)
+        for (size_t j = 0; j < blk; ++j) {
+            double acc = 0;
+            for (int t = 0; t < T; ++t) acc += priv[(size_t)t * blk + j];
+            if (j < (size_t)dim * dim) A11[j] = acc; else b1[j - (size_t)dim * dim] = acc;
+        }
+        free(priv);
     }
     free(compact);
     return (long)P;
@@ -723,6 +937,246 @@ int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double
     }
     free(Binv); free(W); free(S); free(rhs);
     return bad;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The same two solvers on the SPARSE form of A12 — one rank-1 factor Yi [j_c @3cp_k ; j_p @3cp_{k-1}] (x) dp per measurement
+ * (model.cpp:483-487) — for sizes where the reference's dense 3K x 2P matrix (model.cpp:358) does not fit the test host.
+ * Mathematically the reference's expressions; only the order in which the sums over measurements are taken differs from the
+ * dense route above (tests/test_oracle_pinned.py checks the two against each other at small sizes).
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t ai; int sc, sp; double jc[6], jp[6], dx, dy; } factor_t;   /* jc, jp carry the IRLS weight Yi */
+
+/* the factors of the measurements formNormalEq[IRLS] accumulates (model.cpp:396,409), grouped by active pixel; off[P+1] */
+static factor_t* build_factors(const emba_oracle* o, const double* ep, const int32_t* num_ev_map, int thres, int irls, double a,
+                               size_t P, const uint32_t* active, uint32_t** off_out, size_t* M_out)
+{
+    const int W = o->W;
+    const size_t S = (size_t)o->sw * o->sh, npix = (size_t)o->W * o->H;
+    int32_t* compact = (int32_t*)malloc(npix * sizeof(int32_t));
+    for (size_t i = 0; i < npix; ++i) compact[i] = -1;
+    for (size_t i = 0; i < P; ++i) compact[active[i]] = (int32_t)i;
+    uint32_t* off = (uint32_t*)calloc(P + 2, sizeof(uint32_t));
+    for (int pass = 0; pass < 2; ++pass) {
+        factor_t* F = NULL;
+        uint32_t* cur = NULL;
+        if (pass == 1) {
+            for (size_t i = 0; i < P; ++i) off[i + 1] += off[i];
+            F = (factor_t*)malloc((off[P] ? off[P] : 1) * sizeof(factor_t));
+            cur = (uint32_t*)malloc((P ? P : 1) * sizeof(uint32_t));
+            memcpy(cur, off, P * sizeof(uint32_t));
+        }
+        for (size_t p = 0; p < S; ++p)
+            for (uint32_t i = o->pix_start[p] + 1; i < o->pix_start[p + 1]; ++i) {
+                const uint32_t kc = o->order[i], kp = o->order[i - 1];
+                if (o->inl[kc] < 0) continue;
+                const int pm_x = (int)round(o->pm[2 * kc]), pm_y = (int)round(o->pm[2 * kc + 1]);
+                const size_t pi = (size_t)pm_y * W + pm_x;
+                if (num_ev_map[pi] < thres || compact[pi] < 0) continue;
+                const uint32_t ai = (uint32_t)compact[pi];
+                if (pass == 0) { off[ai + 1]++; continue; }
+                const double ep_k = ep[o->inl[kc]];
+                double Yi = 1.0;
+                if (irls == 2) Yi = 1.0 / (1.0 + a * ep_k * ep_k);
+                else if (irls == 1) { const double e = fabs(ep_k); Yi = (e < a) ? 1.0 : a / e; }
+                factor_t* f = F + cur[ai]++;
+                f->ai = ai; f->sc = 3 * o->cp[kc]; f->sp = 3 * o->cp[kp];
+                f->dx = o->dp[2 * kc]; f->dy = o->dp[2 * kc + 1];
+                const double* Dc = o->D + 12 * (size_t)kc;
+                const double* Dp = o->D + 12 * (size_t)kp;
+                for (int j = 0; j < 6; ++j) {
+                    f->jc[j] = Yi * (o->temp[2 * kc] * Dc[j] + o->temp[2 * kc + 1] * Dc[6 + j]);
+                    f->jp[j] = Yi * ((-o->Gpm[2 * kc]) * Dp[j] + (-o->Gpm[2 * kc + 1]) * Dp[6 + j]);
+                }
+            }
+        if (pass == 1) { free(cur); free(compact); *off_out = off; *M_out = off[P]; return F; }
+    }
+    return NULL;
+}
+
+/* unpivoted LDL^T solve of the m x m column-major system in place (the dense route's code) */
+static int ldlt_solve(double* S, int n, const double* rhs, double* x1)
+{
+    for (int j = 0; j < n; ++j) {
+        double d = S[j + (size_t)n * j];
+        for (int k = 0; k < j; ++k) d -= S[j + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
+        if (d == 0.0) return 1;
+        S[j + (size_t)n * j] = d;
+        for (int r = j + 1; r < n; ++r) {
+            double v = S[r + (size_t)n * j];
+            for (int k = 0; k < j; ++k) v -= S[r + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
+            S[r + (size_t)n * j] = v / d;
+        }
+    }
+    for (int r = 0; r < n; ++r) { double v = rhs[r]; for (int k = 0; k < r; ++k) v -= S[r + (size_t)n * k] * x1[k]; x1[r] = v; }
+    for (int r = 0; r < n; ++r) x1[r] /= S[r + (size_t)n * r];
+    for (int r = n - 1; r >= 0; --r) { double v = x1[r]; for (int k = r + 1; k < n; ++k) v -= S[k + (size_t)n * r] * x1[k]; x1[r] = v; }
+    return 0;
+}
+
+/* column pair (c0, c1) of A12 for one active pixel from its factors, as sparse 6-row bands written into dense scratch of length n */
+static void pixel_columns(const factor_t* F, uint32_t f0, uint32_t f1, double* c0, double* c1, int* bands, int* nb_out, uint8_t* mark)
+{
+    int nb = 0;
+    for (uint32_t f = f0; f < f1; ++f) {
+        const factor_t* q = F + f;
+        for (int h = 0; h < 2; ++h) {
+            const int base = h ? q->sp : q->sc;
+            const double* j = h ? q->jp : q->jc;
+            for (int r = 0; r < 6; ++r) {
+                if (!mark[base + r]) { mark[base + r] = 1; bands[nb++] = base + r; c0[base + r] = 0; c1[base + r] = 0; }
+                c0[base + r] += j[r] * q->dx;
+                c1[base + r] += j[r] * q->dy;
+            }
+        }
+    }
+    for (int k = 0; k < nb; ++k) mark[bands[k]] = 0;
+    *nb_out = nb;
+}
+
+/* f1 on the sparse factors — LEGM::solveNormalEq, model.cpp:721-792.  A11 n x n col-major and b1 (n = 3K, UNtrimmed), A22 P x
+ * [xx xy; xy yy], b2 2P: the blocks formNormalEq + applyL2Reg produced; skip = 3 drops the first control pose like
+ * solver.cpp:156-165 (x1 comes back with zeros there).  Uses the state of the last evaluateDataError.  Returns 0 / 1 (zero pivot). */
+int emba_oracle_solve_sparse(emba_oracle* o, const double* ep, int K, const int32_t* num_ev_map, int thres, int irls, double a,
+                             const double* A11, const double* b1, size_t P, const uint32_t* active, const double* A22,
+                             const double* b2, double lambda, int skip, double* x1, double* x2)
+{
+    const int n = 3 * K, m = n - skip;
+    uint32_t* off; size_t M;
+    factor_t* F = build_factors(o, ep, num_ev_map, thres, irls, a, P, active, &off, &M);
+    double* S = (double*)malloc((size_t)m * m * sizeof(double));
+    double* rhs = (double*)malloc((size_t)n * sizeof(double));
+    double* c0 = (double*)calloc(n, sizeof(double)); double* c1 = (double*)calloc(n, sizeof(double));
+    double* w0 = (double*)calloc(n, sizeof(double)); double* w1 = (double*)calloc(n, sizeof(double));
+    int* bands = (int*)malloc((size_t)n * sizeof(int)); uint8_t* mark = (uint8_t*)calloc(n, 1);
+    double* Binv = (double*)malloc((P ? P : 1) * 4 * sizeof(double));
+    for (int c = 0; c < m; ++c)
+        for (int r = 0; r < m; ++r) {
+            const double v = A11[(r + skip) + (size_t)n * (c + skip)];
+            S[r + (size_t)m * c] = v + ((r == c) ? lambda * v : 0.0);                       /* :728-730 */
+        }
+    for (int r = 0; r < n; ++r) rhs[r] = b1[r];
+    for (size_t i = 0; i < P; ++i) {
+        const double aa = A22[4 * i] + lambda * A22[4 * i], bb = A22[4 * i + 1], cc = A22[4 * i + 2], dd = A22[4 * i + 3] + lambda * A22[4 * i + 3];
+        const double det = aa * dd - bb * cc;
+        Binv[4 * i] = dd / det; Binv[4 * i + 1] = -bb / det; Binv[4 * i + 2] = -cc / det; Binv[4 * i + 3] = aa / det;   /* :743-759 */
+        int nb;
+        pixel_columns(F, off[i], off[i + 1], c0, c1, bands, &nb, mark);
+        for (int k = 0; k < nb; ++k) {                                                       /* W = A12 * A22m_inv, :784 */
+            const int r = bands[k];
+            w0[r] = c0[r] * Binv[4 * i] + c1[r] * Binv[4 * i + 2];
+            w1[r] = c0[r] * Binv[4 * i + 1] + c1[r] * Binv[4 * i + 3];
+        }
+        for (int k = 0; k < nb; ++k) {
+            const int r = bands[k];
+            rhs[r] -= w0[r] * b2[2 * i] + w1[r] * b2[2 * i + 1];                             /* b1 - W*b2, :789 */
+            if (r < skip) continue;
+            for (int l = 0; l < nb; ++l) {
+                const int c = bands[l];
+                if (c < skip) continue;
+                S[(r - skip) + (size_t)m * (c - skip)] -= w0[r] * c0[c] + w1[r] * c1[c];     /* S = A11m - W*A12^T, :786 */
+            }
+        }
+    }
+    for (int r = 0; r < n; ++r) x1[r] = 0.0;
+    const int bad = ldlt_solve(S, m, rhs + skip, x1 + skip);                                 /* :789 */
+    if (!bad)
+        for (size_t i = 0; i < P; ++i) {                                                     /* x2 = A22m_inv (b2 - A12^T x1), :791 */
+            int nb;
+            pixel_columns(F, off[i], off[i + 1], c0, c1, bands, &nb, mark);
+            double t0 = b2[2 * i], t1 = b2[2 * i + 1];
+            for (int k = 0; k < nb; ++k) { const int r = bands[k]; t0 -= c0[r] * x1[r]; t1 -= c1[r] * x1[r]; }
+            x2[2 * i] = Binv[4 * i] * t0 + Binv[4 * i + 1] * t1;
+            x2[2 * i + 1] = Binv[4 * i + 2] * t0 + Binv[4 * i + 3] * t1;
+        }
+    free(F); free(off); free(S); free(rhs); free(c0); free(c1); free(w0); free(w1); free(bands); free(mark); free(Binv);
+    return bad;
+}
+
+/* LEGM::solveNormalEqCG, model.cpp:794-840: Eigen::ConjugateGradient<SpMat, Lower|Upper> (default DiagonalPreconditioner,
+ * max 100 iterations, tolerance 1e-6, zero initial guess) on [A11m A12; A12^T A22m] with A?m = A? + lambda*diag(A?); the
+ * iteration is thirdparty/basalt-headers/thirdparty/eigen/Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-88 restated,
+ * the matrix applied through the sparse factors.  skip as above.  iters_out / err_out = cg.iterations() / cg.error(). */
+int emba_oracle_solve_cg_sparse(emba_oracle* o, const double* ep, int K, const int32_t* num_ev_map, int thres, int irls, double a,
+                                const double* A11, const double* b1, size_t P, const uint32_t* active, const double* A22,
+                                const double* b2, double lambda, int skip, int max_iter, double tol, double* x1, double* x2,
+                                int* iters_out, double* err_out)
+{
+    const int n = 3 * K, m = n - skip;
+    const size_t N = (size_t)m + 2 * P;
+    uint32_t* off; size_t M;
+    factor_t* F = build_factors(o, ep, num_ev_map, thres, irls, a, P, active, &off, &M);
+    double* x = (double*)calloc(N, sizeof(double)); double* r = (double*)malloc(N * sizeof(double));
+    double* p = (double*)malloc(N * sizeof(double)); double* z = (double*)malloc(N * sizeof(double));
+    double* t = (double*)malloc(N * sizeof(double)); double* invd = (double*)malloc(N * sizeof(double));
+    double* full = (double*)calloc(n, sizeof(double));
+    /* y = A v with v = [v1 (m); v2 (2P)] */
+#define APPLY(v, y)                                                                                                      \
+    do {                                                                                                                 \
+        for (int rr = 0; rr < m; ++rr) {                                                                                 \
+            double acc = 0;                                                                                              \
+            for (int cc = 0; cc < m; ++cc) { const double e_ = A11[(rr + skip) + (size_t)n * (cc + skip)]; acc += (rr == cc ? e_ + lambda * e_ : e_) * (v)[cc]; } \
+            (y)[rr] = acc;                                                                                               \
+        }                                                                                                                \
+        for (int rr = 0; rr < n; ++rr) full[rr] = 0;                                                                     \
+        for (size_t i = 0; i < P; ++i) {                                                                                 \
+            const double v0 = (v)[m + 2 * i], v1 = (v)[m + 2 * i + 1];                                                   \
+            double s0 = 0, s1 = 0;                                                                                       \
+            for (uint32_t f = off[i]; f < off[i + 1]; ++f) {                                                             \
+                const factor_t* q = F + f;                                                                               \
+                const double dv = q->dx * v0 + q->dy * v1;                                                               \
+                double jv = 0;                                                                                           \
+                for (int k = 0; k < 6; ++k) {                                                                            \
+                    full[q->sc + k] += q->jc[k] * dv; full[q->sp + k] += q->jp[k] * dv;                                  \
+                    if (q->sc + k >= skip) jv += q->jc[k] * (v)[q->sc + k - skip];                                       \
+                    if (q->sp + k >= skip) jv += q->jp[k] * (v)[q->sp + k - skip];                                       \
+                }                                                                                                        \
+                s0 += q->dx * jv; s1 += q->dy * jv;                                                                      \
+            }                                                                                                            \
+            const double a00 = A22[4 * i], a01 = A22[4 * i + 1], a10 = A22[4 * i + 2], a11 = A22[4 * i + 3];             \
+            (y)[m + 2 * i] = s0 + (a00 + lambda * a00) * v0 + a01 * v1;                                                  \
+            (y)[m + 2 * i + 1] = s1 + a10 * v0 + (a11 + lambda * a11) * v1;                                              \
+        }                                                                                                                \
+        for (int rr = 0; rr < m; ++rr) (y)[rr] += full[rr + skip];                                                       \
+    } while (0)
+    for (int rr = 0; rr < m; ++rr) { const double d = A11[(rr + skip) + (size_t)n * (rr + skip)]; const double dm_ = d + lambda * d; invd[rr] = dm_ != 0 ? 1.0 / dm_ : 1.0; r[rr] = b1[rr + skip]; }
+    for (size_t i = 0; i < P; ++i) {
+        const double d0 = A22[4 * i] + lambda * A22[4 * i], d1 = A22[4 * i + 3] + lambda * A22[4 * i + 3];
+        invd[m + 2 * i] = d0 != 0 ? 1.0 / d0 : 1.0; invd[m + 2 * i + 1] = d1 != 0 ? 1.0 / d1 : 1.0;
+        r[m + 2 * i] = b2[2 * i]; r[m + 2 * i + 1] = b2[2 * i + 1];
+    }
+    double rhs2 = 0; for (size_t k = 0; k < N; ++k) rhs2 += r[k] * r[k];
+    int it = 0; double err = 0;
+    if (rhs2 != 0) {
+        const double thr = fmax(tol * tol * rhs2, 2.2250738585072014e-308);
+        double rn2 = rhs2;                                   /* x = 0: residual = rhs */
+        if (rn2 >= thr) {
+            for (size_t k = 0; k < N; ++k) p[k] = invd[k] * r[k];
+            double absNew = 0; for (size_t k = 0; k < N; ++k) absNew += r[k] * p[k];
+            while (it < max_iter) {
+                APPLY(p, t);
+                double pt = 0; for (size_t k = 0; k < N; ++k) pt += p[k] * t[k];
+                const double alpha = absNew / pt;
+                for (size_t k = 0; k < N; ++k) { x[k] += alpha * p[k]; r[k] -= alpha * t[k]; }
+                rn2 = 0; for (size_t k = 0; k < N; ++k) rn2 += r[k] * r[k];
+                if (rn2 < thr) break;
+                for (size_t k = 0; k < N; ++k) z[k] = invd[k] * r[k];
+                const double absOld = absNew;
+                absNew = 0; for (size_t k = 0; k < N; ++k) absNew += r[k] * z[k];
+                const double beta = absNew / absOld;
+                for (size_t k = 0; k < N; ++k) p[k] = z[k] + beta * p[k];
+                ++it;
+            }
+        }
+        err = sqrt(rn2 / rhs2);
+    }
+#undef APPLY
+    for (int rr = 0; rr < n; ++rr) x1[rr] = rr < skip ? 0.0 : x[rr - skip];
+    for (size_t k = 0; k < 2 * P; ++k) x2[k] = x[m + k];
+    if (iters_out) *iters_out = it;
+    if (err_out) *err_out = err;
+    free(F); free(off); free(x); free(r); free(p); free(z); free(t); free(invd); free(full);
+    return 0;
 }
 
 /* a12 — 0.5*ep.dot(ep) (solver.cpp:88,265) or evaluateRobustDataCost (model.cpp:279-314) */

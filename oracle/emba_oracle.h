@@ -34,6 +34,11 @@ emba_oracle* emba_oracle_create(int sensor_w, int sensor_h, int pano_w, int pano
                                 const double* bearing_lut, double C_th);
 void emba_oracle_destroy(emba_oracle* o);
 
+/* Shard view: events [0, k0) of the next evaluateDataError are warped and serve as predecessors but form no
+ * measurement themselves — what a time shard's halo does.  k0 = 0 (default) is the reference.  Used by the tests that check one
+ * rank's shard of a 40 M / 100 M-event stream without evaluating the whole stream on the CPU. */
+void emba_oracle_set_first_counted(emba_oracle* o, size_t k0);
+
 /* a2: t_batch = t_bgn + (t_end - t_bgn) * 0.5 in ros::Time / ros::Duration arithmetic
  * (src/emba/model.cpp:116-119; rostime semantics per SURVEY.md Appendix A). */
 int64_t emba_oracle_batch_mid_ns(int64_t t_first_ns, int64_t t_last_ns);
@@ -82,6 +87,19 @@ long emba_oracle_eval_data_error(emba_oracle* o, const double* knots_xyzw, int K
                                  const int64_t* t_ns, size_t n, double* ep_out,
                                  int32_t* num_ev_map, const emba_oracle_dump* dump);
 
+/* Index-level results only (pm, rounded pixels, num_ev_map, inlier count) with O(sensor pixels) working memory: used to
+ * measure the pm_int / num_ev_map flip rate of the device path at 10 M - 100 M events.  pm_out, pm_int_out: 2n each or NULL. */
+long emba_oracle_count_map(const emba_oracle* o, const double* knots_xyzw, int K, int64_t t0_ns, int64_t dt_ns,
+                           const uint16_t* x, const uint16_t* y, const int64_t* t_ns, size_t n, double* pm_out,
+                           int32_t* num_ev_map, int32_t* pm_int_out);
+
+/* Threading mode of evaluateDataError / formNormalEq / count_map.  1 (default) = "ref": one thread, the reference's order —
+ * the checker.  n > 1 = "omp": the same per-measurement arithmetic on n host threads, order-relaxed where sums meet
+ * (SURVEY.md §8d asks for both as CPU baselines).  Only bench.py's cpu_baseline leg and tests switch it on. */
+void emba_oracle_set_threads(int n);
+int emba_oracle_get_threads(void);
+int emba_oracle_max_threads(void);
+
 /* a8-a10: LEGM::formNormalEq / formNormalEqIRLS (model.cpp:316-491 / 493-687), using the state
  * left by the last emba_oracle_eval_data_error.  irls: 0 quadratic, 1 huber, 2 cauchy.
  * A11 3K*3K col-major, b1 3K; active_idx capacity H*W (ascending pano index);
@@ -105,6 +123,18 @@ void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, c
  * rounding).  Returns 0, or 1 if a pivot vanishes. */
 int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double* A12, const double* A22, const double* b1,
                                 const double* b2, double lambda, double* x1, double* x2);
+
+/* f1 on the sparse form of A12 (one rank-1 factor per measurement, taken from the state of the last evaluateDataError): the same
+ * LEGM::solveNormalEq / solveNormalEqCG (model.cpp:721-792 / 794-840) for sizes where the dense 3K x 2P matrix does not fit.
+ * A11 (3K)^2 col-major, b1 3K (untrimmed); A22 P x [xx xy; xy yy], b2 2P after applyL2Reg; skip = 3 holds the first control pose
+ * fixed (solver.cpp:156-165).  x1[3K], x2[2P]. */
+int emba_oracle_solve_sparse(emba_oracle* o, const double* ep, int K, const int32_t* num_ev_map, int thres, int irls, double a,
+                             const double* A11, const double* b1, size_t P, const uint32_t* active, const double* A22,
+                             const double* b2, double lambda, int skip, double* x1, double* x2);
+int emba_oracle_solve_cg_sparse(emba_oracle* o, const double* ep, int K, const int32_t* num_ev_map, int thres, int irls, double a,
+                                const double* A11, const double* b1, size_t P, const uint32_t* active, const double* A22,
+                                const double* b2, double lambda, int skip, int max_iter, double tol, double* x1, double* x2,
+                                int* iters_out, double* err_out);
 
 /* a12: cost terms.  0.5*ep.ep (src/emba/solver.cpp:88); evaluateRobustDataCost (model.cpp:279-314);
  * 0.5*alpha*|evaluateRegError|^2 (model.cpp:260-277, solver.cpp:90). */

@@ -42,12 +42,14 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
+        srcs = [os.path.join(_HERE, f) for f in ("emba_oracle.c", "emba_oracle.h", "Makefile")]
+        if not os.path.exists(_LIB) or any(os.path.getmtime(f) > os.path.getmtime(_LIB) for f in srcs):
             build()
         L = C.CDLL(_LIB)
         L.emba_oracle_create.restype = C.c_void_p
         L.emba_oracle_create.argtypes = [C.c_int] * 4 + [_dp, C.c_double]
         L.emba_oracle_destroy.argtypes = [C.c_void_p]
+        L.emba_oracle_set_first_counted.argtypes = [C.c_void_p, C.c_size_t]
         L.emba_oracle_batch_mid_ns.restype = C.c_int64
         L.emba_oracle_batch_mid_ns.argtypes = [C.c_int64, C.c_int64]
         L.emba_oracle_spline_eval.restype = C.c_int
@@ -76,6 +78,18 @@ def lib():
         L.emba_oracle_data_cost.argtypes = [_dp, C.c_size_t, C.c_int, C.c_double]
         L.emba_oracle_reg_cost.restype = C.c_double
         L.emba_oracle_reg_cost.argtypes = [_dp, _dp, C.c_size_t, C.c_double]
+        _sp = [C.c_void_p, _dp, C.c_int, _i32p, C.c_int, C.c_int, C.c_double, _dp, _dp, C.c_size_t, C.POINTER(C.c_uint32), _dp, _dp,
+               C.c_double, C.c_int]
+        L.emba_oracle_solve_sparse.restype = C.c_int
+        L.emba_oracle_solve_sparse.argtypes = _sp + [_dp, _dp]
+        L.emba_oracle_solve_cg_sparse.restype = C.c_int
+        L.emba_oracle_solve_cg_sparse.argtypes = _sp + [C.c_int, C.c_double, _dp, _dp, C.POINTER(C.c_int), _dp]
+        L.emba_oracle_count_map.restype = C.c_long
+        L.emba_oracle_count_map.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16),
+                                            C.POINTER(C.c_uint16), C.POINTER(C.c_int64), C.c_size_t, _dp, _i32p, _i32p]
+        L.emba_oracle_set_threads.argtypes = [C.c_int]
+        L.emba_oracle_get_threads.restype = C.c_int
+        L.emba_oracle_max_threads.restype = C.c_int
         _lib = L
     return _lib
 
@@ -104,6 +118,15 @@ def ref():
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def set_threads(n):
+    """1 = "ref" mode (one thread, the reference's order: the checker); n > 1 = "omp" CPU-baseline mode."""
+    lib().emba_oracle_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().emba_oracle_max_threads())
 
 
 def spline_eval(knots_xyzw, t0_ns, dt_ns, t_ns, use_ref=False):
@@ -208,7 +231,9 @@ class OracleLEGM:
         lib().emba_oracle_warp(self._o, int(x), int(y), _ptr(q, _dp), _ptr(pm, _dp), _ptr(J, _dp))
         return pm, J.reshape(2, 3)
 
-    def evaluate_data_error(self, knots_xyzw, t0_ns, dt_ns, Gx, Gy, x, y, pol, t_ns, dump=False):
+    def evaluate_data_error(self, knots_xyzw, t0_ns, dt_ns, Gx, Gy, x, y, pol, t_ns, dump=False, first_counted=0):
+        """first_counted: shard view — events before this index only serve as predecessors (emba_oracle_set_first_counted)."""
+        lib().emba_oracle_set_first_counted(self._o, int(first_counted))
         knots = _f64(knots_xyzw).reshape(-1, 4)
         Gx = _f64(Gx); Gy = _f64(Gy)
         x = np.ascontiguousarray(x, dtype=np.uint16); y = np.ascontiguousarray(y, dtype=np.uint16)
@@ -237,6 +262,27 @@ class OracleLEGM:
         ep = ep[:m].copy()
         return (ep, num_ev_map, d) if dump else (ep, num_ev_map)
 
+    def count_map(self, knots_xyzw, t0_ns, dt_ns, x, y, t_ns, want_pm=False, want_pm_int=False):
+        """Index-level results only (emba_oracle_count_map): (n_inliers, num_ev_map[, pm][, pm_int])."""
+        knots = _f64(knots_xyzw).reshape(-1, 4)
+        x = np.ascontiguousarray(x, dtype=np.uint16); y = np.ascontiguousarray(y, dtype=np.uint16)
+        t_ns = np.ascontiguousarray(t_ns, dtype=np.int64)
+        n = x.size
+        nem = np.zeros((self.H, self.W), dtype=np.int32)
+        pm = np.zeros((n, 2)) if want_pm else None
+        pmi = np.zeros((n, 2), dtype=np.int32) if want_pm_int else None
+        m = lib().emba_oracle_count_map(self._o, _ptr(knots, _dp), knots.shape[0], int(t0_ns), int(dt_ns),
+                                        _ptr(x, C.POINTER(C.c_uint16)), _ptr(y, C.POINTER(C.c_uint16)),
+                                        _ptr(t_ns, C.POINTER(C.c_int64)), n, _ptr(pm, _dp), _ptr(nem, _i32p), _ptr(pmi, _i32p))
+        if m < 0:
+            raise ValueError("batch time outside the spline's knots")
+        out = [int(m), nem]
+        if want_pm:
+            out.append(pm)
+        if want_pm_int:
+            out.append(pmi)
+        return tuple(out)
+
     def form_normal_eq(self, ep, K, num_ev_map, thres, irls=0, a=0.0, dense_A12=False):
         ep = _f64(ep)
         nem = np.ascontiguousarray(num_ev_map, dtype=np.int32)
@@ -251,6 +297,29 @@ class OracleLEGM:
                                              _ptr(A22, _dp), _ptr(b2, _dp), _ptr(A12, _dp))
         assert P == P_guess
         return dict(A11=A11, b1=b1, active=active[:P].copy(), A22=A22[:P], b2=b2[:2 * P], A12=A12, P=P)
+
+    def _sparse_args(self, ne, ep, K, num_ev_map, thres, irls, a, lam, fix_first_pose):
+        ep = _f64(ep); nem = np.ascontiguousarray(num_ev_map, dtype=np.int32)
+        A11 = np.asfortranarray(ne["A11"]); b1 = _f64(ne["b1"]); A22 = _f64(ne["A22"]); b2 = _f64(ne["b2"])
+        act = np.ascontiguousarray(ne["active"], dtype=np.uint32)
+        keep = (ep, nem, A11, b1, A22, b2, act)
+        return keep, [self._o, _ptr(ep, _dp), K, _ptr(nem, _i32p), int(thres), int(irls), float(a), _ptr(A11, _dp), _ptr(b1, _dp),
+                      ne["P"], _ptr(act, C.POINTER(C.c_uint32)), _ptr(A22, _dp), _ptr(b2, _dp), float(lam), 3 if fix_first_pose else 0]
+
+    def solve_sparse(self, ne, ep, K, num_ev_map, thres, irls=0, a=0.0, lam=1e-3, fix_first_pose=False):
+        """LEGM::solveNormalEq (model.cpp:721-792) from the sparse A12 factors of the last evaluate_data_error (after apply_l2)."""
+        keep, args = self._sparse_args(ne, ep, K, num_ev_map, thres, irls, a, lam, fix_first_pose)
+        x1 = np.zeros(3 * K); x2 = np.zeros(2 * max(ne["P"], 1))
+        if lib().emba_oracle_solve_sparse(*args, _ptr(x1, _dp), _ptr(x2, _dp)):
+            raise ValueError("singular system")
+        return x1, x2[:2 * ne["P"]]
+
+    def solve_cg_sparse(self, ne, ep, K, num_ev_map, thres, irls=0, a=0.0, lam=1e-3, fix_first_pose=False, max_iter=100, tol=1e-6):
+        """LEGM::solveNormalEqCG (model.cpp:794-840): returns (x1, x2, iterations, error)."""
+        keep, args = self._sparse_args(ne, ep, K, num_ev_map, thres, irls, a, lam, fix_first_pose)
+        x1 = np.zeros(3 * K); x2 = np.zeros(2 * max(ne["P"], 1)); it = C.c_int(0); err = np.zeros(1)
+        lib().emba_oracle_solve_cg_sparse(*args, int(max_iter), float(tol), _ptr(x1, _dp), _ptr(x2, _dp), C.byref(it), _ptr(err, _dp))
+        return x1, x2[:2 * ne["P"]], it.value, float(err[0])
 
     def apply_l2(self, ne, alpha, Gx, Gy):
         Gx = _f64(Gx); Gy = _f64(Gy)

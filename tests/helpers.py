@@ -47,8 +47,11 @@ class OracleModel:
     """The CPU oracle behind the method names emba_amd.solver.solve_time_window drives, so the SAME LM loop can run on the
     oracle and on the device path and their iteration logs compared (test infrastructure only)."""
 
-    def __init__(self, O, w):
+    def __init__(self, O, w, sparse=False, use_cg=False):
+        """sparse: solve from the sparse A12 factors (sizes where the dense 3K x 2P matrix does not fit); use_cg: solveNormalEqCG."""
         self.O = O
+        self.sparse, self.use_cg = sparse or use_cg, use_cg
+        self.irls, self.a, self.thres = 0, 0.0, 5
         self.o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
         self.H, self.W = w.pano_h, w.pano_w
         self.cur = self.trial = None
@@ -75,16 +78,25 @@ class OracleModel:
         return self.O.reg_cost(self.used[0], self.used[1], alpha)
 
     def formNormalEq(self, ep, K, nem, thres):
-        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, 0, 0.0, True)
+        self.irls, self.a, self.thres = 0, 0.0, thres
+        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, 0, 0.0, not self.sparse)
 
     def formNormalEqIRLS(self, ep, K, nem, thres, cost_type, a):
-        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a, True)
+        self.irls, self.a, self.thres = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a, thres
+        self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, self.irls, a, not self.sparse)
 
     def applyL2Reg(self, alpha):
         self.o.apply_l2(self.ne, alpha, self.used[0], self.used[1])
 
     def solveNormalEq(self, lam, fix_first_pose=False):
+        if self.use_cg:
+            return self.o.solve_cg_sparse(self.ne, self.ep, self.K, self.nem, self.thres, self.irls, self.a, lam, fix_first_pose)[:2]
+        if self.sparse:
+            return self.o.solve_sparse(self.ne, self.ep, self.K, self.nem, self.thres, self.irls, self.a, lam, fix_first_pose)
         return self.O.solve_normal_eq(self.ne, lam, fix_first_pose)
+
+    def solveNormalEqCG(self, lam, fix_first_pose=False):
+        return self.o.solve_cg_sparse(self.ne, self.ep, self.K, self.nem, self.thres, self.irls, self.a, lam, fix_first_pose)
 
     def updateMap(self, x2, damping):
         self.trial = self.O.update_map(self.ne["active"], x2, damping, self.cur[0], self.cur[1])

@@ -59,7 +59,7 @@ def _rank_main(shared, rank, w, results, compressed=False):
         pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
         torch.cuda.synchronize()
         cu8 = torch.zeros(npix, dtype=torch.uint8, device=dev) if compressed else None
-        sh = ShardedLEGM(HipEngine(m), _ThreadDist(shared, rank, m.sync), count, pack, w.sensor_w, cu8)
+        sh = ShardedLEGM(HipEngine(m, check_stream=False), _ThreadDist(shared, rank, m.sync), count, pack, w.sensor_w, cu8)
         local = sh.set_events(w.events)
         m.upload_map(w.Gx, w.Gy)
         out = None

@@ -318,3 +318,60 @@ def test_solve_normal_eq_solves_the_damped_system(oracle_mod):
         assert np.allclose(got, x, rtol=1e-8, atol=1e-10 * np.abs(x).max())
         if fix:
             assert (x1[:3] == 0).all()
+
+
+@pytest.mark.parametrize("irls,a,fix", [(0, 0.0, False), (1, 0.1, True), (2, 1.0, True)])
+def test_sparse_oracle_solvers_match_the_dense_route(oracle_mod, irls, a, fix):
+    """The oracle's Schur solve on the sparse A12 factors (what the full-size device tests are checked with) must agree with its
+    dense restatement of LEGM::solveNormalEq (model.cpp:721-792); its restatement of solveNormalEqCG (model.cpp:794-840, Eigen's
+    ConjugateGradient loop) must converge to the same solution when allowed to, and stop after max_iter like Eigen does."""
+    from helpers import small_workload
+    O = oracle_mod
+    w = small_workload(n_events=20000)
+    o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+    ev = w.events
+    ep, nem = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns)
+    ne = o.apply_l2(o.form_normal_eq(ep, w.K, nem, 5, irls, a, True), w.alpha, w.Gx, w.Gy)
+    for lam in (1e-3, 10.0):
+        x1d, x2d = O.solve_normal_eq(ne, lam, fix)
+        x1s, x2s = o.solve_sparse(ne, ep, w.K, nem, 5, irls, a, lam, fix)
+        assert np.abs(x1s - x1d).max() <= 1e-9 * np.abs(x1d).max() and np.abs(x2s - x2d).max() <= 1e-9 * np.abs(x2d).max()
+        x1c, x2c, it, err = o.solve_cg_sparse(ne, ep, w.K, nem, 5, irls, a, lam, fix, max_iter=5000, tol=1e-13)
+        assert err < 1e-12 and np.abs(x1c - x1d).max() <= 1e-6 * np.abs(x1d).max() and np.abs(x2c - x2d).max() <= 1e-6 * np.abs(x2d).max()
+    _, _, it, err = o.solve_cg_sparse(ne, ep, w.K, nem, 5, irls, a, 1e-3, fix)       # the reference's settings: 100 iterations, 1e-6
+    assert it <= 100 and (it == 100 or err < 1e-6)
+    if fix:
+        assert np.all(x1s[:3] == 0) and np.all(x1c[:3] == 0)
+
+
+def test_omp_mode_and_lean_count_map_agree_with_the_reference_order_pass(oracle_mod):
+    """The "omp" CPU-baseline mode (bench.py) runs the same per-measurement arithmetic as the one-thread checker: identical ep
+    (values and order), identical count map and active set, blocks equal to rounding; the lean index-level pass used for the
+    flip-rate measurement gives the same count map, inlier count, pm and rounded pixels as the full pass."""
+    from helpers import small_workload
+    O = oracle_mod
+    w = small_workload(n_events=30000)
+    ev = w.events
+
+    def run(threads):
+        O.set_threads(threads)
+        try:
+            o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+            ep, nem, d = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns, dump=True)
+            ne = o.apply_l2(o.form_normal_eq(ep, w.K, nem, 5, 1, 0.1), w.alpha, w.Gx, w.Gy)
+            lean = o.count_map(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, ev.x, ev.y, ev.t_ns, want_pm=True, want_pm_int=True)
+        finally:
+            O.set_threads(1)
+        return ep, nem, d, ne, lean
+
+    ep1, nem1, d1, ne1, lean1 = run(1)
+    ep4, nem4, d4, ne4, lean4 = run(4)
+    assert np.array_equal(ep1, ep4) and np.array_equal(nem1, nem4) and np.array_equal(ne1["active"], ne4["active"])
+    assert np.array_equal(d1["inlier_idx"], d4["inlier_idx"]) and np.array_equal(d1["pm"], d4["pm"])
+    for k in ("A11", "b1", "A22", "b2"):
+        assert np.abs(ne1[k] - ne4[k]).max() <= 1e-12 * np.abs(ne1[k]).max(), k
+    for lean in (lean1, lean4):
+        n_inl, nem_l, pm_l, pmi_l = lean
+        n_used = (ev.size() // 100) * 100
+        assert n_inl == ep1.size and np.array_equal(nem_l, nem1)
+        assert np.array_equal(pm_l[:n_used], d1["pm"][:n_used]) and np.array_equal(pmi_l[:n_used], d1["pm_int"][:n_used])

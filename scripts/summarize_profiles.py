@@ -10,22 +10,26 @@ src = os.path.join("gpurun_out", f"prof_{tag}")
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for name in ("fetch", "write"):
-    for r in csv.DictReader(open(glob.glob(f"{src}/{name}/*/*_counter_collection.csv")[0])):
+for name in ("fetch", "write", "atomic"):
+    fs = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
+    if not fs:
+        continue
+    for r in csv.DictReader(open(fs[0])):
         vals[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
 for k, d in vals.items():
     f = sum(d["FETCH_SIZE"]) / max(len(d["FETCH_SIZE"]), 1); w = sum(d["WRITE_SIZE"]) / max(len(d["WRITE_SIZE"]), 1)
-    rows.append((k, len(d["FETCH_SIZE"]), f, w, (2 * f + w) * 1024))
+    at = sum(d["TCC_EA0_ATOMIC_sum"]) / max(len(d["TCC_EA0_ATOMIC_sum"]), 1)
+    rows.append((k, len(d["FETCH_SIZE"]), f, w, (2 * f + w) * 1024, at))
 rows.sort(key=lambda r: -r[4])
 with open(f"profiles/{tag}_pmc_summary.csv", "w") as fo:
-    fo.write("kernel,launches,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean,hbm_bytes_per_launch_corrected(2*FETCH+WRITE)*1024\n")
+    fo.write("kernel,launches,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean,hbm_bytes_per_launch_corrected(2*FETCH+WRITE)*1024,TCC_EA0_ATOMIC_requests_mean\n")
     for r in rows:
-        fo.write('"%s",%d,%.1f,%.1f,%.0f\n' % r)
-dom = [r for r in rows if "emba_warp_residual_kernel<false>" in r[0]][0]
+        fo.write('"%s",%d,%.1f,%.1f,%.0f,%.0f\n' % r)
+dom = [r for r in rows if "emba_warp_residual_kernel" in r[0] and "true" not in r[0]][0]
 bench = json.loads([l for l in open(f"{src}/bench_trace.log") if l.startswith("{")][-1])
 json.dump({"kernel": "emba_warp_residual_kernel", "hbm_bytes_per_launch": dom[4], "FETCH_SIZE_KiB": dom[2], "WRITE_SIZE_KiB": dom[3],
-           "correction": "gfx950: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "workload": bench["config"]["workload"], "tag": tag},
+           "atomic_requests_per_launch": dom[5], "correction": "gfx950: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "workload": bench["config"]["workload"], "tag": tag},
           open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 json.dump(bench, open(f"profiles/{tag}_bench_profiled.json", "w"))
 print(open(f"profiles/{tag}_pmc_summary.csv").read())

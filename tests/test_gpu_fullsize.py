@@ -42,7 +42,7 @@ def test_city_shape_10M_events_one_evaluation_and_form(gpu, oracle_mod):
     """Config 3 at full size: 10 M events, 640x480, K = 97, 1024x2048 — count map / inlier numbering bit-exact, blocks <= 1e-9."""
     from emba_amd.synth import make_workload
     O = oracle_mod
-    w = make_workload(n_events=10_000_000, pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240)
+    w = make_workload(n_events=10_000_000, pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240, yaw_rate=0.1)   # ~5 px between events of a pixel
     ev = w.events
     m = _legm(w)
     nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
@@ -54,6 +54,7 @@ def test_city_shape_10M_events_one_evaluation_and_form(gpu, oracle_mod):
     o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
     ep_o, nem_o, d_o = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns, dump=True)
     assert np.array_equal(nem, nem_o), "num_ev_map differs at 10 M events"
+    assert ep_o.size > 5_000_000, "the workload is meant to be mostly inliers"
     assert np.array_equal(d["inlier_idx"], d_o["inlier_idx"]) and np.array_equal(d["pm_int"], d_o["pm_int"])
     del d, d_o
     assert_close(ep, ep_o, "ep")
@@ -119,7 +120,7 @@ def test_city_shape_lm_to_convergence_and_poisson(gpu, oracle_mod):
     from helpers import OracleModel
     from oracle import poisson as OP
     from test_lm_solver_cpu import perturbed
-    w = synth.make_scene_workload(pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240, n_steps=200, amp=0.55, n_terms=6)
+    w = synth.make_scene_workload(pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240, n_steps=200, amp=3.0, n_terms=6, yaw_rate=0.02, max_freq=(40, 20))
     assert w.events.size() >= 2_000_000, w.events.size()
     init = perturbed(w)
     ba, lm = BASettings(), LMSettings(max_num_iter=8)

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "order_kernels.h"
 #include "solve_kernels.h"
 #include "poisson_kernels.h"
 
@@ -75,20 +77,25 @@ struct emba_ctx {
     int* h_pinned_dev = nullptr;    // the same memory through its device pointer
     double* h_knots_dev = nullptr;  // device pointer of the pinned control-pose staging buffer
 
-    // per-window (set_events) state
+    // per-window (set_events) state — all of it lives on the device (order_kernels.h)
     bool have_events = false, have_map = false;
-    size_t n_in = 0, n_used = 0, n_halo = 0, n_sorted = 0, n_batch = 0, n_cand = 0;
+    size_t n_in = 0, n_used = 0, n_halo = 0, n_pm = 0, n_sorted = 0, n_batch = 0, n_cand = 0;   // n_pm: pm-order entries (events + halo); n_sorted: entries of the device order
     long nblk = 0;
-    std::vector<uint32_t> h_pix, h_batch, h_orig;   // pixel-major
-    std::vector<int64_t> h_batch_t;
-    uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;
+    uint32_t* d_pm_pix = nullptr; uint32_t* d_pm_batch = nullptr; uint32_t* d_pm_orig = nullptr;   // pm-order = (sensor pixel, time): the reference's per-pixel vectors laid end to end
+    uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;    // device order (== pm-order arrays in pixel order; own arrays in tile order)
+    uint32_t* d_ev_pm = nullptr; uint32_t* d_perm = nullptr;                                        // tile order only: entry -> pm index, pm index -> entry
+    uint16_t* d_cp = nullptr;                                                                       // control-pose index per batch
+    ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
+    bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
+    size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
-    uint32_t* d_blk_cnt = nullptr; uint32_t* d_grp_cnt = nullptr; uint32_t* d_grp_off = nullptr; long ngrp = 0;
+    uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
     double* d_ep = nullptr;
-    // key order cache
+    // order / key cache
     bool keys_ready = false; int64_t key_t0 = 0, key_dt = 0; int key_K = 0;
+    double set_events_ms = 0, prepare_ms = 0;   // wall time of the last emba_set_events[_dev] / order preparation (diagnostics)
 
     // per-iteration state
     int K = 0;
@@ -112,7 +119,7 @@ struct emba_ctx {
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
-    struct { void* p = nullptr; size_t bytes = 0; } ws[16];
+    struct { void* p = nullptr; size_t bytes = 0; } ws[32];   // 0-15 Schur solve, 16-31 sort / order preparation
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
     double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
 };
@@ -156,11 +163,15 @@ void dev_free(T*& p)
 
 void free_window(emba_ctx* c)
 {
-    dev_free(c->d_ev_pix); dev_free(c->d_ev_batch); dev_free(c->d_ev_slot); dev_free(c->d_batch_t);
+    if (c->d_ev_pix != c->d_pm_pix) dev_free(c->d_ev_pix);
+    if (c->d_ev_batch != c->d_pm_batch) dev_free(c->d_ev_batch);
+    c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
+    dev_free(c->d_pm_pix); dev_free(c->d_pm_batch); dev_free(c->d_pm_orig); dev_free(c->d_ev_slot); dev_free(c->d_ev_pm); dev_free(c->d_perm);
+    dev_free(c->d_cp); dev_free(c->d_chunks); dev_free(c->d_batch_t);
     dev_free(c->d_pose); dev_free(c->d_rec); dev_free(c->d_slot_key); dev_free(c->d_e_sorted);
-    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_blk_cnt); dev_free(c->d_grp_cnt); dev_free(c->d_grp_off);
+    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_fblk_cnt); dev_free(c->d_fblk_off);
     dev_free(c->d_ep);
-    c->have_events = false; c->keys_ready = false;
+    c->have_events = false; c->keys_ready = false; c->tile_order = false; c->n_chunks = 0; c->n_lead = 0;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
 }
 
@@ -179,53 +190,227 @@ int64_t batch_mid_ns(int64_t t_first, int64_t t_last)
     return t_first + hsec * 1000000000LL + hnsec;
 }
 
-// Assign every measurement candidate a record slot, sorted by (cp_c, cp_p): the control-pose pair is a
-// function of the batch midpoint times and the spline's (t0, dt) only, i.e. pose-independent.
-emba_status prepare_keys(emba_ctx* c, int64_t t0, int64_t dt, int K)
+// ---- device-side helpers of the once-per-window structure (order_kernels.h) ----------------------------------------------------
+emba_status ws_get(emba_ctx* c, int slot, size_t bytes, void** out)
+{
+    auto& w = c->ws[slot];
+    if (w.bytes < bytes || !w.p) {
+        if (w.p) (void)hipFree(w.p);
+        w.p = nullptr; w.bytes = 0;
+        if (hipMalloc(&w.p, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(c, EMBA_ERR_HIP, "hipMalloc of %zu bytes failed (workspace %d)", bytes, slot);
+        w.bytes = std::max<size_t>(bytes, 8);
+    }
+    *out = w.p;
+    return EMBA_OK;
+}
+
+void ws_release(emba_ctx* c, int first, int last)
+{
+    for (int i = first; i <= last; ++i) { if (c->ws[i].p) (void)hipFree(c->ws[i].p); c->ws[i].p = nullptr; c->ws[i].bytes = 0; }
+}
+
+inline unsigned nblocks(size_t n, unsigned per = 256) { return (unsigned)std::max<size_t>((n + per - 1) / per, 1); }
+
+// out[i] = sum_{j<i} in[j]; total_dev[0] = sum of all (may be nullptr).  Workspaces 16, 17.
+emba_status dev_scan(emba_ctx* c, const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_dev)
+{
+    hipStream_t s = c->stream;
+    const size_t ntiles = (n + kScanTile - 1) / kScanTile;
+    uint32_t *sums = nullptr, *offs = nullptr, *tot = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 16, (ntiles + 1) * 4, (void**)&sums)) || (st = ws_get(c, 17, (ntiles + 2) * 4, (void**)&offs))) return st;
+    tot = total_dev ? total_dev : offs + ntiles + 1;
+    if (!n) { HIP_TRY(c, hipMemsetAsync(tot, 0, 4, s)); return EMBA_OK; }
+    hipLaunchKernelGGL(emba_scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, in, (long)n, sums);
+    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, sums, offs, (long)ntiles, tot, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(emba_scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, in, (long)n, offs, out);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+// Stable LSD radix sort of (keys, vals) on the low `bits` bits of the keys; the sorted arrays end up in (*keys, *vals), the other
+// pair of buffers is scratch (pointers are swapped per pass).  Workspace 18 (+ 16, 17 through dev_scan).
+emba_status dev_sort(emba_ctx* c, uint32_t** keys, uint32_t** vals, uint32_t** keys_alt, uint32_t** vals_alt, size_t n, int bits)
+{
+    if (n < 2 || bits <= 0) return EMBA_OK;
+    hipStream_t s = c->stream;
+    const size_t ntiles = (n + kSortTile - 1) / kSortTile;
+    uint32_t* hist = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 18, 256 * ntiles * 4, (void**)&hist))) return st;
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(emba_sort_hist_kernel, dim3(nblocks(ntiles, 4)), dim3(256), 0, s, *keys, (long)n, shift, (long)ntiles, hist);
+        if ((st = dev_scan(c, hist, hist, 256 * ntiles, nullptr))) return st;
+        hipLaunchKernelGGL(emba_sort_scatter_kernel, dim3(nblocks(ntiles, 4)), dim3(256), 0, s, *keys, *vals, (long)n, shift, (long)ntiles, hist, *keys_alt, *vals_alt);
+        std::swap(*keys, *keys_alt); std::swap(*vals, *vals_alt);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+int bits_for(size_t n_values) { int b = 1; while (((size_t)1 << b) < n_values) ++b; return b; }
+
+// At the first evaluation of a window (and again whenever the spline timing changes): the control-pose pair of every measurement,
+// the device order (pixel order, or tile order from the panorama positions the given control poses predict) and the record slots
+// sorted by pair.  Pose-independent except for the tile binning, which only affects speed.
+emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int64_t dt, int K)
 {
     if (c->keys_ready && c->key_t0 == t0 && c->key_dt == dt && c->key_K == K) return EMBA_OK;
     if (dt <= 0 || K < 2 || K > 65535) return fail(c, EMBA_ERR_INVALID_ARG, "bad spline: dt_ns=%lld K=%d", (long long)dt, K);
-    std::vector<uint16_t> cp(c->n_batch ? c->n_batch : 1, 0);
-    for (size_t b = 0; b < c->n_batch; ++b) {
-        const int64_t st = c->h_batch_t[b] - t0;
-        const int64_t s = (st >= 0) ? st / dt : -1;
-        if (st < 0 || s + 2 > (int64_t)K)
-            return fail(c, EMBA_ERR_TIME_RANGE, "batch %zu midpoint %lld ns outside spline [%lld, %lld) (K=%d)", b,
-                        (long long)c->h_batch_t[b], (long long)t0, (long long)(t0 + dt * (K - 1)), K);
-        cp[b] = (uint16_t)s;
+    const auto t_begin = std::chrono::steady_clock::now();
+    hipStream_t s = c->stream;
+    emba_status st;
+    const size_t ns = c->n_pm, nbatch = c->n_batch;
+    // (a previous order of this window goes away)
+    if (c->d_ev_pix != c->d_pm_pix) dev_free(c->d_ev_pix);
+    if (c->d_ev_batch != c->d_pm_batch) dev_free(c->d_ev_batch);
+    c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
+    dev_free(c->d_ev_slot); dev_free(c->d_ev_pm); dev_free(c->d_perm); dev_free(c->d_chunks); dev_free(c->d_e_sorted); dev_free(c->d_flag); dev_free(c->d_inl_idx);
+    c->tile_order = false; c->n_chunks = 0; c->n_lead = 0;
+
+    // control-pose index per batch; a batch outside the knots is an error (BASALT_ASSERT_STREAM at so3_spline.h:221-229)
+    uint32_t* d_err = nullptr;
+    if ((st = ws_get(c, 19, 64, (void**)&d_err))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_err, 0xFF, 64, s));
+    if (!c->d_cp && (st = dev_alloc(c, &c->d_cp, nbatch))) return st;
+    if (nbatch) hipLaunchKernelGGL(emba_batch_cp_kernel, dim3(nblocks(nbatch)), dim3(256), 0, s, c->d_batch_t, (long)nbatch, t0, dt, K, c->d_cp, d_err);
+    uint32_t h_err[16];
+    HIP_TRY(c, hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (h_err[0] != 0xFFFFFFFFu) {
+        int64_t tb = 0;
+        (void)hipMemcpy(&tb, c->d_batch_t + h_err[0], 8, hipMemcpyDeviceToHost);
+        return fail(c, EMBA_ERR_TIME_RANGE, "batch %u midpoint %lld ns outside spline [%lld, %lld) (K=%d)", h_err[0], (long long)tb, (long long)t0,
+                    (long long)(t0 + dt * (K - 1)), K);
     }
-    const size_t n = c->n_sorted, M = c->n_cand;
-    std::vector<uint32_t> cand(M), key(M);
-    {
-        size_t m = 0;
-        for (size_t i = 1; i < n; ++i)
-            if ((c->h_pix[i] & 0x7FFFFFFFu) == (c->h_pix[i - 1] & 0x7FFFFFFFu)) {
-                cand[m] = (uint32_t)i;
-                key[m] = ((uint32_t)cp[c->h_batch[i]] << 16) | (uint32_t)cp[c->h_batch[i - 1]];
-                ++m;
+
+    // ---- which order?  Tile order pays when many events share a panorama pixel (the per-pixel sums are then combined in LDS) and the
+    // chains of a sensor pixel stay in a tile for a while (every tile entry costs one extra warp of the predecessor).
+    BinGeom g{};
+    g.W = c->W; g.H = c->H; g.bw = kTileW - 2 * kTileMargin; g.bh = kTileH - 2 * kTileMargin;
+    g.nbx = (c->W + g.bw - 1) / g.bw; g.nby = (c->H + g.bh - 1) / g.bh;
+    const size_t nbins = (size_t)g.nbx * g.nby + 1;
+    uint32_t *d_bin = nullptr, *d_emit = nullptr, *d_pos = nullptr; uint8_t* d_used = nullptr; unsigned long long* d_breaks = nullptr;
+    bool tile = false;
+    size_t n_break = 0, n_used_bins = 0;
+    if (c->order_mode != 1 && ns && knots_host) {
+        if ((st = ws_get(c, 20, ns * 4, (void**)&d_bin)) || (st = ws_get(c, 21, ns * 4, (void**)&d_emit)) || (st = ws_get(c, 22, ns * 4, (void**)&d_pos)) ||
+            (st = ws_get(c, 23, nbins + 8, (void**)&d_used)))
+            return st;
+        d_breaks = reinterpret_cast<unsigned long long*>(d_err + 8);
+        HIP_TRY(c, hipMemsetAsync(d_used, 0, nbins, s));
+        HIP_TRY(c, hipMemsetAsync(d_breaks, 0, 8, s));
+        // the poses the caller starts from (staged through the pinned buffer like every evaluation's)
+        HIP_TRY(c, hipMemcpyAsync(c->d_knots, knots_host, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(emba_pose_kernel, dim3(nblocks(nbatch, 64)), dim3(64), 0, s, c->d_batch_t, (int)nbatch, c->d_knots, K, t0, dt, c->d_pose, c->d_err);
+        hipLaunchKernelGGL(emba_predict_bin_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, c->d_pm_batch, (long)ns, c->d_pose, kPoseStride, c->d_lut,
+                           c->fx, c->fy, c->cx, c->cy, g, d_bin, d_used);
+        hipLaunchKernelGGL(emba_expand_count_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, (long)ns, d_emit);
+        hipLaunchKernelGGL(emba_count_breaks_kernel, dim3((unsigned)std::min<size_t>(nblocks(ns), 1024)), dim3(256), 0, s, d_emit, (long)ns, d_breaks);
+        std::vector<uint8_t> h_used(nbins);
+        unsigned long long hb = 0;
+        HIP_TRY(c, hipMemcpyAsync(h_used.data(), d_used, nbins, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(&hb, d_breaks, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        n_break = (size_t)hb;
+        for (size_t b = 0; b + 1 < nbins; ++b) n_used_bins += h_used[b];
+        const double per_px = n_used_bins ? (double)c->n_used / ((double)n_used_bins * g.bw * g.bh) : 0.0;     // events per panorama pixel of the occupied tiles
+        const double lead_frac = c->n_used ? (double)n_break / (double)c->n_used : 1.0;
+        tile = (c->order_mode == 2) || (per_px >= 8.0 && lead_frac <= 0.35);
+    }
+
+    if (!tile) {
+        c->d_ev_pix = c->d_pm_pix; c->d_ev_batch = c->d_pm_batch;
+        c->n_sorted = ns;
+    } else {
+        // expanded list: every event, plus a lead-in copy of its predecessor where its chain enters a tile -> stable sort by tile
+        uint32_t* d_tot = d_err + 4;
+        if ((st = dev_scan(c, d_emit, d_pos, ns, d_tot))) return st;
+        uint32_t nd32 = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nd32, d_tot, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const size_t nd = nd32;
+        uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *d_bin_start = nullptr;
+        if ((st = ws_get(c, 24, nd * 4, (void**)&k0)) || (st = ws_get(c, 25, nd * 4, (void**)&v0)) || (st = ws_get(c, 26, nd * 4, (void**)&k1)) ||
+            (st = ws_get(c, 27, nd * 4, (void**)&v1)) || (st = ws_get(c, 28, (nbins + 1) * 4, (void**)&d_bin_start)))
+            return st;
+        hipLaunchKernelGGL(emba_expand_write_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, d_emit, d_pos, (long)ns, k0, v0);
+        if ((st = dev_sort(c, &k0, &v0, &k1, &v1, nd, bits_for(nbins)))) return st;
+        if ((st = dev_alloc(c, &c->d_ev_pix, nd)) || (st = dev_alloc(c, &c->d_ev_batch, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd)) ||
+            (st = dev_alloc(c, &c->d_perm, ns)))
+            return st;
+        HIP_TRY(c, hipMemsetAsync(c->d_perm, 0xFF, std::max<size_t>(ns, 1) * 4, s));
+        HIP_TRY(c, hipMemsetAsync(d_bin_start, 0xFF, (nbins + 1) * 4, s));
+        uint32_t* d_cf = d_emit;    // (emit is dead: its buffer now takes the candidate flags of the device order — nd <= 2 ns may exceed it)
+        if (nd > ns && (st = ws_get(c, 21, nd * 4, (void**)&d_cf))) return st;
+        hipLaunchKernelGGL(emba_dev_gather_kernel, dim3(nblocks(nd)), dim3(256), 0, s, k0, v0, (long)nd, c->d_pm_pix, c->d_pm_batch, c->d_ev_pix, c->d_ev_batch,
+                           c->d_ev_pm, c->d_perm, d_cf, d_bin_start);
+        // chunks: every occupied tile is cut into workgroup-sized pieces (host: <= 32 k tiles)
+        std::vector<uint32_t> h_start(nbins + 1);
+        HIP_TRY(c, hipMemcpyAsync(h_start.data(), d_bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        std::vector<std::pair<uint32_t, uint32_t>> occ;   // (bin, start)
+        for (size_t b = 0; b < nbins; ++b) if (h_start[b] != 0xFFFFFFFFu) occ.emplace_back((uint32_t)b, h_start[b]);
+        // chunk size: enough workgroups for ~8 rounds of the chip, at most 16 groups of 63 entries per wave
+        const size_t slots = (size_t)c->n_cu * 2;
+        size_t chunk = (nd + slots * 8 - 1) / (slots * 8);
+        chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves), (size_t)kWarpNew * kTileWaves * 16);
+        std::vector<ChunkDesc> h_chunks;
+        for (size_t k = 0; k < occ.size(); ++k) {
+            const uint32_t b = occ[k].first, b0 = occ[k].second, b1 = (k + 1 < occ.size()) ? occ[k + 1].second : (uint32_t)nd;
+            const size_t cnt = b1 - b0, nch = (cnt + chunk - 1) / chunk, per = (cnt + nch - 1) / nch;
+            const int bx = (int)(b % (uint32_t)g.nbx), by = (int)(b / (uint32_t)g.nbx);
+            for (size_t q = 0; q < nch; ++q) {
+                ChunkDesc d;
+                d.begin = b0 + (uint32_t)(q * per); d.end = (uint32_t)std::min<size_t>(b0 + (q + 1) * per, b1);
+                d.x0 = bx * g.bw - kTileMargin; d.y0 = by * g.bh - kTileMargin;
+                if (d.begin < d.end) h_chunks.push_back(d);
             }
-        if (m != M) return fail(c, EMBA_ERR_STATE, "candidate recount mismatch %zu vs %zu", m, M);
+        }
+        c->n_chunks = (long)h_chunks.size();
+        if ((st = dev_alloc(c, &c->d_chunks, h_chunks.size()))) return st;
+        HIP_TRY(c, hipMemcpyAsync(c->d_chunks, h_chunks.data(), h_chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        c->n_sorted = nd; c->n_lead = nd - c->n_used; c->tile_order = true;
+        d_emit = d_cf;
     }
-    // stable LSD counting sort on the two 16-bit halves of the key
-    std::vector<uint32_t> ord(M), tmp(M);
-    for (size_t m = 0; m < M; ++m) ord[m] = (uint32_t)m;
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<size_t> cnt(65537, 0);
-        const int sh = pass * 16;
-        for (size_t m = 0; m < M; ++m) cnt[((key[ord[m]] >> sh) & 0xFFFFu) + 1]++;
-        for (size_t k = 0; k < 65536; ++k) cnt[k + 1] += cnt[k];
-        for (size_t m = 0; m < M; ++m) tmp[cnt[(key[ord[m]] >> sh) & 0xFFFFu]++] = ord[m];
-        ord.swap(tmp);
+    const size_t nd = c->n_sorted;
+    c->nblk = (long)((nd + kWarpNew - 1) / kWarpNew);
+
+    // record slots sorted by control-pose pair: candidates of the device order -> (key, entry) -> stable sort -> slot
+    {
+        const size_t M = c->n_cand;
+        uint32_t *d_cf = nullptr, *d_cpos = nullptr, *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr;
+        if ((st = ws_get(c, 22, std::max<size_t>(nd, 1) * 4, (void**)&d_cpos))) return st;
+        if (tile) d_cf = d_emit;
+        else {
+            if ((st = ws_get(c, 21, std::max<size_t>(nd, 1) * 4, (void**)&d_cf))) return st;
+            if (nd) hipLaunchKernelGGL(emba_cand_flag_kernel, dim3(nblocks(nd)), dim3(256), 0, s, c->d_ev_pix, (long)nd, d_cf);
+        }
+        if ((st = dev_scan(c, d_cf, d_cpos, nd, nullptr))) return st;
+        if ((st = ws_get(c, 24, std::max<size_t>(M, 1) * 4, (void**)&k0)) || (st = ws_get(c, 25, std::max<size_t>(M, 1) * 4, (void**)&v0)) ||
+            (st = ws_get(c, 26, std::max<size_t>(M, 1) * 4, (void**)&k1)) || (st = ws_get(c, 27, std::max<size_t>(M, 1) * 4, (void**)&v1)))
+            return st;
+        if ((st = dev_alloc(c, &c->d_ev_slot, nd))) return st;
+        HIP_TRY(c, hipMemsetAsync(c->d_ev_slot, 0xFF, std::max<size_t>(nd, 1) * 4, s));
+        if (nd) hipLaunchKernelGGL(emba_cand_keys_kernel, dim3(nblocks(nd)), dim3(256), 0, s, c->d_ev_pix, c->d_ev_batch, c->d_cp, (long)nd, d_cpos, k0, v0);
+        // the key's low half is cp_p, the high half cp_c, both < K: sort on the bits they really use
+        const int kb = bits_for((size_t)K);
+        if (kb <= 8) {   // fold the two halves into one 16-bit key for the sort (two passes instead of four)
+            if (M) hipLaunchKernelGGL(emba_fold_keys_kernel, dim3(nblocks(M)), dim3(256), 0, s, k0, (long)M, 1);
+            if ((st = dev_sort(c, &k0, &v0, &k1, &v1, M, 16))) return st;
+            if (M) hipLaunchKernelGGL(emba_fold_keys_kernel, dim3(nblocks(M)), dim3(256), 0, s, k0, (long)M, 0);
+        } else if ((st = dev_sort(c, &k0, &v0, &k1, &v1, M, 32))) return st;
+        if (M) hipLaunchKernelGGL(emba_slot_assign_kernel, dim3(nblocks(M)), dim3(256), 0, s, k0, v0, (long)M, c->d_ev_slot, c->d_slot_key);
     }
-    std::vector<uint32_t> slot(n ? n : 1, kNoSlot), slot_key(M ? M : 1, 0);
-    for (size_t s = 0; s < M; ++s) {
-        slot[cand[ord[s]]] = (uint32_t)s;
-        slot_key[s] = key[ord[s]];
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_ev_slot, slot.data(), std::max<size_t>(n, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_slot_key, slot_key.data(), std::max<size_t>(M, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+    // per-entry outputs of the evaluations
+    if ((st = dev_alloc(c, &c->d_e_sorted, nd)) || (st = dev_alloc(c, &c->d_flag, nd)) || (st = dev_alloc(c, &c->d_inl_idx, nd))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, std::max<size_t>(nd, 1), s));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));
+    ws_release(c, 16, 31);   // hundreds of MB at 100 M events: not kept around
     c->keys_ready = true; c->key_t0 = t0; c->key_dt = dt; c->key_K = K;
+    c->prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return EMBA_OK;
 }
 
@@ -288,11 +473,12 @@ emba_status launch_ep_compaction(emba_ctx* c)
     if (!c->ep_deferred) return EMBA_OK;
     c->ep_deferred = false;
     hipStream_t s = c->stream;
-    if (c->n_sorted) {
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_grp_cnt, c->d_grp_off, c->ngrp, c->d_total,
+    if (c->n_pm) {
+        hipLaunchKernelGGL(emba_flag_count_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_flag, c->d_perm, (long)c->n_pm, c->d_fblk_cnt);
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total,
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
-        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->ngrp), dim3(1024), 0, s, c->d_e_sorted, c->d_flag,
-                           c->d_blk_cnt, c->d_grp_off, (long)c->n_sorted, c->nblk, c->d_ep, c->d_inl_idx);
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, c->d_perm, c->d_fblk_off,
+                           (long)c->n_pm, c->d_ep, c->d_inl_idx);
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
@@ -319,9 +505,9 @@ emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
     }
     bool polled = false;
     if (counts_only && c->seq_armed && c->inl_pending && c->P_pending) {
-        volatile int* w = c->h_pinned + 3;
+        volatile int* w = c->h_pinned + 3;                   // [3] behind the active-pixel count, [4] behind the inlier count
         for (long spin = 0; spin < 50000000L; ++spin) {      // bounded: a faulted kernel never publishes; fall back to the stream
-            if (*w == c->seq) { polled = true; break; }
+            if (w[0] == c->seq && w[1] == c->seq) { polled = true; break; }
             __builtin_ia32_pause();
         }
         if (polled) std::atomic_thread_fence(std::memory_order_acquire);
@@ -390,6 +576,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
     if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
+    if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
 #define CREATE_TRY(call)                                                                                  \
@@ -456,6 +643,71 @@ void emba_destroy(emba_ctx* c)
     delete c;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Shared by emba_set_events (host arrays: uploaded first) and emba_set_events_dev (arrays already in HBM).  x, y, pol, hx, hy, hbt are
+// DEVICE pointers; t_dev (device) or batch_t_host (the nb midpoints, computed by the caller) supplies the times.
+emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, const uint8_t* pol, const int64_t* t_dev, const int64_t* batch_t_host,
+                            size_t n, const uint16_t* hx, const uint16_t* hy, const int64_t* hbt, size_t n_halo)
+{
+    hipStream_t s = c->stream;
+    const size_t n_used = (n / 100) * 100;   // quirk Q1: std::ceil of an integer division (model.cpp:79)
+    const size_t nb = n_used / 100;
+    if (n_used + n_halo >= 0x3FFFFFFFull) return fail(c, EMBA_ERR_INVALID_ARG, "too many events for 32-bit indices");
+    c->n_in = n; c->n_used = n_used; c->n_halo = n_halo; c->n_batch = nb + n_halo;
+    const size_t ns = n_used + n_halo;
+    c->n_pm = ns; c->n_sorted = ns;
+    emba_status st;
+    uint32_t* d_err = nullptr;
+    if ((st = ws_get(c, 19, 64, (void**)&d_err))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_err, 0xFF, 64, s));
+    hipLaunchKernelGGL(emba_validate_events_kernel, dim3(nblocks(std::max(n_used, n_halo))), dim3(256), 0, s, x, y, t_dev, (long)n_used, c->sw, c->sh, hx, hy,
+                       (long)n_halo, d_err);
+    if ((st = dev_alloc(c, &c->d_batch_t, c->n_batch))) return st;
+    if (t_dev) { if (nb) hipLaunchKernelGGL(emba_batch_mid_kernel, dim3(nblocks(nb)), dim3(256), 0, s, t_dev, (long)nb, c->d_batch_t); }
+    else if (nb) HIP_TRY(c, hipMemcpyAsync(c->d_batch_t, batch_t_host, nb * 8, hipMemcpyHostToDevice, s));
+    if (n_halo) HIP_TRY(c, hipMemcpyAsync(c->d_batch_t + nb, hbt, n_halo * 8, hipMemcpyDeviceToDevice, s));
+
+    // pm-order: stable sort by sensor pixel == the per-pixel vectors of EventMap::addEvent (event_map.h:34-37), halo entries in front
+    uint32_t *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *d_cf = nullptr, *d_cpos = nullptr;
+    if ((st = ws_get(c, 24, std::max<size_t>(ns, 1) * 4, (void**)&k0)) || (st = ws_get(c, 25, std::max<size_t>(ns, 1) * 4, (void**)&v0)) ||
+        (st = ws_get(c, 26, std::max<size_t>(ns, 1) * 4, (void**)&k1)) || (st = ws_get(c, 27, std::max<size_t>(ns, 1) * 4, (void**)&v1)) ||
+        (st = ws_get(c, 21, std::max<size_t>(ns, 1) * 4, (void**)&d_cf)) || (st = ws_get(c, 22, std::max<size_t>(ns, 1) * 4, (void**)&d_cpos)))
+        return st;
+    if (ns) hipLaunchKernelGGL(emba_pixel_keys_kernel, dim3(nblocks(ns)), dim3(256), 0, s, x, y, (long)n_used, c->sw, hx, hy, (long)n_halo, k0, v0);
+    if ((st = dev_sort(c, &k0, &v0, &k1, &v1, ns, bits_for(c->S)))) return st;
+    if ((st = dev_alloc(c, &c->d_pm_pix, ns)) || (st = dev_alloc(c, &c->d_pm_batch, ns)) || (st = dev_alloc(c, &c->d_pm_orig, ns))) return st;
+    if (ns) hipLaunchKernelGGL(emba_pm_gather_kernel, dim3(nblocks(ns)), dim3(256), 0, s, k0, v0, (long)ns, pol, (long)nb, c->d_pm_pix, c->d_pm_batch, c->d_pm_orig, d_cf);
+    uint32_t* d_tot = d_err + 4;
+    if ((st = dev_scan(c, d_cf, d_cpos, ns, d_tot))) return st;    // (only the total is used: the number of measurement candidates)
+    uint32_t h_err[16];
+    HIP_TRY(c, hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (h_err[0] != 0xFFFFFFFFu) return fail(c, EMBA_ERR_INVALID_ARG, "event %u lies outside the %dx%d sensor", h_err[0], c->sw, c->sh);
+    if (h_err[1] != 0xFFFFFFFFu) return fail(c, EMBA_ERR_INVALID_ARG, "timestamps not sorted at event %u", h_err[1]);
+    if (h_err[2] != 0xFFFFFFFFu) return fail(c, EMBA_ERR_INVALID_ARG, "halo event %u outside the sensor", h_err[2]);
+    c->n_cand = ns ? h_err[4] : 0;
+    const size_t n_cand = c->n_cand;
+
+    if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
+    if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride))) return st;
+    if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
+    c->n_fblk = (long)std::max<size_t>((ns + kFlagBlk - 1) / kFlagBlk, 1);
+    if ((st = dev_alloc(c, &c->d_fblk_cnt, (size_t)c->n_fblk)) || (st = dev_alloc(c, &c->d_fblk_off, (size_t)c->n_fblk))) return st;
+    if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, std::max<size_t>(n_cand, 1) * kRecStride * sizeof(double), s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->nblk = (long)((ns + kWarpNew - 1) / kWarpNew);
+    c->have_events = true;
+    return EMBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, const uint8_t* pol, const int64_t* t_ns,
                             size_t n, const uint16_t* hx, const uint16_t* hy, const int64_t* hbt, size_t n_halo)
 {
@@ -464,71 +716,63 @@ emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     if (n_halo && (!hx || !hy || !hbt)) return fail(c, EMBA_ERR_INVALID_ARG, "halo arrays are NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const auto t_begin = std::chrono::steady_clock::now();
     free_window(c);
-
-    const size_t n_used = (n / 100) * 100;   // quirk Q1: std::ceil of an integer division (model.cpp:79)
-    const size_t nb = n_used / 100;
-    if (n_used + n_halo >= 0x7FFFFFFFull) return fail(c, EMBA_ERR_INVALID_ARG, "too many events for 32-bit indices");
-    for (size_t k = 0; k < n_used; ++k) {
-        if (x[k] >= c->sw || y[k] >= c->sh) return fail(c, EMBA_ERR_INVALID_ARG, "event %zu pixel (%u,%u) outside the sensor", k, x[k], y[k]);
-        if (k && t_ns[k] < t_ns[k - 1]) return fail(c, EMBA_ERR_INVALID_ARG, "timestamps not sorted at event %zu", k);
-    }
-    for (size_t h = 0; h < n_halo; ++h)
-        if (hx[h] >= c->sw || hy[h] >= c->sh) return fail(c, EMBA_ERR_INVALID_ARG, "halo event %zu outside the sensor", h);
-
-    c->n_in = n; c->n_used = n_used; c->n_halo = n_halo; c->n_batch = nb + n_halo;
-    c->n_sorted = n_used + n_halo;
-    c->h_batch_t.assign(c->n_batch ? c->n_batch : 1, 0);
-    for (size_t b = 0; b < nb; ++b) c->h_batch_t[b] = batch_mid_ns(t_ns[100 * b], t_ns[100 * b + 99]);
-    for (size_t h = 0; h < n_halo; ++h) c->h_batch_t[nb + h] = hbt[h];
-
-    // stable counting sort by sensor pixel == the per-pixel vectors of EventMap::addEvent (event_map.h:34-37)
-    const size_t S = c->S, ns = c->n_sorted;
-    std::vector<uint32_t> start(S + 1, 0);
-    for (size_t h = 0; h < n_halo; ++h) start[(size_t)hy[h] * c->sw + hx[h] + 1]++;
-    for (size_t k = 0; k < n_used; ++k) start[(size_t)y[k] * c->sw + x[k] + 1]++;
-    size_t n_cand = 0;
-    for (size_t p = 0; p < S; ++p) { if (start[p + 1] > 1) n_cand += start[p + 1] - 1; start[p + 1] += start[p]; }
-    c->n_cand = n_cand;
-    c->h_pix.assign(ns ? ns : 1, 0); c->h_batch.assign(ns ? ns : 1, 0); c->h_orig.assign(ns ? ns : 1, 0);
-    {
-        std::vector<uint32_t> cur(start.begin(), start.end() - 1);
-        for (size_t h = 0; h < n_halo; ++h) {
-            const uint32_t p = (uint32_t)hy[h] * c->sw + hx[h];
-            const uint32_t i = cur[p]++;
-            c->h_pix[i] = p; c->h_batch[i] = (uint32_t)(nb + h); c->h_orig[i] = 0xFFFFFFFFu;
-        }
-        for (size_t k = 0; k < n_used; ++k) {
-            const uint32_t p = (uint32_t)y[k] * c->sw + x[k];
-            const uint32_t i = cur[p]++;
-            c->h_pix[i] = p | ((pol[k] ? 1u : 0u) << 31); c->h_batch[i] = (uint32_t)(k / 100); c->h_orig[i] = (uint32_t)k;
-        }
-    }
-    c->nblk = (long)((ns + kWarpNew - 1) / kWarpNew);
-
+    const size_t n_used = (n / 100) * 100, nb = n_used / 100;
+    // The host only touches the timestamps: sortedness and the batch midpoints (model.cpp:116-119) need two reads per batch plus one
+    // pass of comparisons; shipping 8 B per event over PCIe for that would cost more than the pass.
+    for (size_t k = 1; k < n_used; ++k)
+        if (t_ns[k] < t_ns[k - 1]) return fail(c, EMBA_ERR_INVALID_ARG, "timestamps not sorted at event %zu", k);
+    std::vector<int64_t> bt(nb ? nb : 1);
+    for (size_t b = 0; b < nb; ++b) bt[b] = batch_mid_ns(t_ns[100 * b], t_ns[100 * b + 99]);
+    // x, y, polarity (5 B per event) and the halo go to the device as they are
+    hipStream_t s = c->stream;
+    uint16_t *dx = nullptr, *dy = nullptr, *dhx = nullptr, *dhy = nullptr; uint8_t* dp = nullptr; int64_t* dhb = nullptr;
     emba_status st;
-    if ((st = dev_alloc(c, &c->d_ev_pix, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_ev_batch, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_ev_slot, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_batch_t, c->n_batch))) return st;
-    if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
-    if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride))) return st;
-    if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
-    if ((st = dev_alloc(c, &c->d_e_sorted, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_flag, ns))) return st;
-    if ((st = dev_alloc(c, &c->d_inl_idx, ns))) return st;
-    c->ngrp = (c->nblk + kEpGroup - 1) / kEpGroup;
-    if ((st = dev_alloc(c, &c->d_blk_cnt, (size_t)c->ngrp * kEpGroup))) return st;
-    if ((st = dev_alloc(c, &c->d_grp_cnt, (size_t)c->ngrp))) return st;
-    if ((st = dev_alloc(c, &c->d_grp_off, (size_t)c->ngrp))) return st;
-    HIP_TRY(c, hipMemset(c->d_blk_cnt, 0, std::max<size_t>((size_t)c->ngrp * kEpGroup, 1) * sizeof(uint32_t)));
-    if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
-    HIP_TRY(c, hipMemcpy(c->d_ev_pix, c->h_pix.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_ev_batch, c->h_batch.data(), std::max<size_t>(ns, 1) * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->d_batch_t, c->h_batch_t.data(), std::max<size_t>(c->n_batch, 1) * 8, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemset(c->d_flag, 0, std::max<size_t>(ns, 1)));
-    HIP_TRY(c, hipMemset(c->d_rec, 0, std::max<size_t>(n_cand, 1) * kRecStride * sizeof(double)));
-    c->have_events = true;
+    if ((st = ws_get(c, 28, std::max<size_t>(n_used, 1) * 2, (void**)&dx)) || (st = ws_get(c, 29, std::max<size_t>(n_used, 1) * 2, (void**)&dy)) ||
+        (st = ws_get(c, 30, std::max<size_t>(n_used, 1), (void**)&dp)) || (st = ws_get(c, 31, std::max<size_t>(n_halo, 1) * 12, (void**)&dhb)))
+        return st;
+    dhx = reinterpret_cast<uint16_t*>(dhb + n_halo); dhy = dhx + n_halo;
+    if (n_used) {
+        HIP_TRY(c, hipMemcpyAsync(dx, x, n_used * 2, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(dy, y, n_used * 2, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(dp, pol, n_used, hipMemcpyHostToDevice, s));
+    }
+    if (n_halo) {
+        HIP_TRY(c, hipMemcpyAsync(dhb, hbt, n_halo * 8, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(dhx, hx, n_halo * 2, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(dhy, hy, n_halo * 2, hipMemcpyHostToDevice, s));
+    }
+    st = set_events_core(c, dx, dy, dp, nullptr, bt.data(), n, dhx, dhy, dhb, n_halo);
+    ws_release(c, 16, 31);
+    c->set_events_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return st;
+}
+
+emba_status emba_set_events_dev(emba_ctx* c, const uint16_t* x_dev, const uint16_t* y_dev, const uint8_t* pol_dev, const int64_t* t_ns_dev, size_t n,
+                                const uint16_t* hx_dev, const uint16_t* hy_dev, const int64_t* hbt_dev, size_t n_halo)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (n && (!x_dev || !y_dev || !pol_dev || !t_ns_dev)) return fail(c, EMBA_ERR_INVALID_ARG, "event arrays are NULL");
+    if (n_halo && (!hx_dev || !hy_dev || !hbt_dev)) return fail(c, EMBA_ERR_INVALID_ARG, "halo arrays are NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const auto t_begin = std::chrono::steady_clock::now();
+    free_window(c);
+    emba_status st = set_events_core(c, x_dev, y_dev, pol_dev, t_ns_dev, nullptr, n, hx_dev, hy_dev, hbt_dev, n_halo);
+    ws_release(c, 16, 31);
+    c->set_events_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    return st;
+}
+
+emba_status emba_last_setup_ms(const emba_ctx* c, double* set_events_ms, double* prepare_ms, int32_t* tile_order, size_t* n_entries, size_t* n_chunks)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (set_events_ms) *set_events_ms = c->set_events_ms;
+    if (prepare_ms) *prepare_ms = c->prepare_ms;
+    if (tile_order) *tile_order = c->tile_order ? 1 : 0;
+    if (n_entries) *n_entries = c->n_sorted;
+    if (n_chunks) *n_chunks = (size_t)c->n_chunks;
     return EMBA_OK;
 }
 
@@ -667,14 +911,14 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map: call emba_upload_map or emba_bind_map_dev");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st;
-    if ((st = prepare_keys(c, t0_ns, dt_ns, K))) return st;
-    c->K = K;
-    if ((st = ensure_pack(c, K))) return st;
     if (c->knots_cap < K) {
         dev_free(c->d_knots);
         if ((st = dev_alloc(c, &c->d_knots, (size_t)4 * K))) return st;
         c->knots_cap = K;
     }
+    if ((st = prepare_order(c, knots, t0_ns, dt_ns, K))) return st;
+    c->K = K;
+    if ((st = ensure_pack(c, K))) return st;
     if (c->h_knots_cap < K) {
         if (c->h_knots) (void)hipHostFree(c->h_knots);
         HIP_TRY(c, hipHostMalloc((void**)&c->h_knots, (size_t)4 * K * sizeof(double), hipHostMallocMapped));
@@ -694,7 +938,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     int* rect_cur = c->d_rect;
     const int n_prep_blk = (int)((c->npix + 1023) / 1024);
     hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)n_prep_blk), dim3(256), 0, s, c->d_count, (long)c->npix,
-                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect, c->d_grp_cnt, (int)c->ngrp);
+                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect);
     c->knots_in_flight = true;   // cleared by the next host synchronisation (an event here would cost a ~6 us bubble per step)
 
     // Hessian source: with several events per panorama pixel (measured break-even: ~4) the full texel pack (one 48-B gather per
@@ -720,12 +964,14 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
-        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.grp_cnt = c->d_grp_cnt;
+        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp;
+        p.chunks = c->d_chunks; p.n_chunks = c->n_chunks;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
-        hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+        if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
+        else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
         c->counts_raw = true;
     } else {
@@ -776,19 +1022,25 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     hipStream_t s = c->stream;
     const long npix = (long)c->npix;
     const long head = (long)9 * c->K * c->K + (long)3 * c->K;
+    ActiveWriteParams aw{};
+    aw.count = c->d_count; aw.npix = npix; aw.thres = thres; aw.blk_off = c->d_ablk_off; aw.compact = nullptr; aw.active_idx = c->d_active; aw.pixacc = c->d_pixacc;
+    aw.A22b2 = pack_A22b2(c); aw.pack_head = c->d_pack; aw.head_len = head; aw.alpha = c->fused_alpha; aw.Gx = c->d_Gx; aw.Gy = c->d_Gy;
+    aw.active_bits = c->d_active_bits; aw.max_P = (long)((c->pack_cap - (size_t)head) / 5); aw.n_ablk = (long)c->n_ablk;
     if (c->ep_deferred && c->n_sorted) {
-        // residual compaction (scan -> compact) and active set (count -> scan) share two launches
+        // residual compaction (count -> scan -> compact) and active set (count -> scan -> write) share three launches
         c->ep_deferred = false;
         PostWarpParams q{};
         q.count = c->d_count; q.npix = npix; q.thres = thres; q.ablk_cnt = c->d_ablk_cnt; q.ablk_off = c->d_ablk_off; q.n_ablk = (long)c->n_ablk;
         q.total_P = c->d_total + 1; q.total_P_host = c->h_pinned_dev + 2;
-        q.blk_cnt = c->d_blk_cnt; q.grp_cnt = c->d_grp_cnt; q.grp_off = c->d_grp_off; q.ngrp = c->ngrp; q.nblk = c->nblk; q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
+        q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = c->d_perm; q.n_pm = (long)c->n_pm;
+        q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
-        q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.n_sorted = (long)c->n_sorted; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
+        q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
-        hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)c->n_ablk + 1), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3((unsigned)c->ngrp + 1), dim3(1024), 0, s, q);
+        hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3(2), dim3(256), 0, s, q);
+        hipLaunchKernelGGL(emba_post_warp_c_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, aw, q);
         c->inl_pending = true;
     } else {
         { emba_status st0 = launch_ep_compaction(c); if (st0) return st0; }
@@ -796,10 +1048,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         hipLaunchKernelGGL(emba_active_count_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres, c->d_ablk_cnt);
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_ablk_cnt, c->d_ablk_off, (long)c->n_ablk, c->d_total + 1,
                            c->h_pinned_dev + 2, (const int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
     }
-    hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, c->d_count, npix, (int)thres,
-                       c->d_ablk_off, (int32_t*)nullptr, c->d_active, c->d_pixacc, pack_A22b2(c), c->d_pack, head, c->fused_alpha, c->d_Gx, c->d_Gy, c->d_active_bits,
-                       (long)((c->pack_cap - (size_t)head) / 5));
     HIP_TRY(c, hipGetLastError());
     c->compact_valid = false;
     c->l2_fused = (c->fused_alpha != 0.0);
@@ -1029,7 +1279,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     p.pose = c->d_pose; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
-    p.flag = c->d_flag; p.blk_cnt = c->d_blk_cnt; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
+    p.flag = c->d_flag; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
     hipLaunchKernelGGL(emba_warp_residual_kernel<true>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
         h_pose(cp_idx ? c->n_batch * kPoseStride : 0);
@@ -1056,13 +1306,20 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (dp) memset(dp, 0, 2 * n * 8);
     if (Gpm) memset(Gpm, 0, 2 * n * 8);
     if (temp) memset(temp, 0, 2 * n * 8);
+    // entry of the device order -> pm-order index -> original event (lead-in copies and halo entries map to nothing)
+    std::vector<uint32_t> h_evpix(ns), h_evbatch(cp_idx ? ns : 0), h_evpm(c->d_ev_pm ? ns : 0), h_pmorig(c->n_pm);
+    HIP_TRY(c, hipMemcpy(h_evpix.data(), c->d_ev_pix, ns * 4, hipMemcpyDeviceToHost));
+    if (cp_idx) HIP_TRY(c, hipMemcpy(h_evbatch.data(), c->d_ev_batch, ns * 4, hipMemcpyDeviceToHost));
+    if (c->d_ev_pm) HIP_TRY(c, hipMemcpy(h_evpm.data(), c->d_ev_pm, ns * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(h_pmorig.data(), c->d_pm_orig, c->n_pm * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < ns; ++i) {
-        const uint32_t k = c->h_orig[i];
-        if (k == 0xFFFFFFFFu) continue;  // halo
-        const bool cand = i > 0 && ((c->h_pix[i] & 0x7FFFFFFFu) == (c->h_pix[i - 1] & 0x7FFFFFFFu));
+        if (h_evpix[i] & kEvLead) continue;                        // lead-in copy / halo
+        const uint32_t k = h_pmorig[c->d_ev_pm ? h_evpm[i] : i];
+        if (k == 0xFFFFFFFFu) continue;
+        const bool cand = (h_evpix[i] & kEvHasPred) != 0;
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
         if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
-        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)c->h_batch[i] * kPoseStride + 13];
+        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)h_evbatch[i] * kPoseStride + 13];
         if (inlier_idx) inlier_idx[k] = cand ? (h_flag[i] ? h_inl[i] : -1) : -2;
         if (pm_int && h_flag[i]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
         if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }

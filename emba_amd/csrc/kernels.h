@@ -40,7 +40,6 @@ constexpr int kTexelStride = TEXEL_STRIDE;    // doubles per texel
 constexpr int kRecStride = 16;     // doubles per factor record
 constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: no barriers, neighbours talk through DPP
 constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
-constexpr int kEpGroup = 16;       // waves per residual-compaction block (1024 threads); the inlier scan runs over these groups
 constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
 #ifndef GRAM_U
@@ -87,6 +86,12 @@ __device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ b
 #pragma unroll
     for (int i = 0; i < 9; ++i) o[4 + i] = J1[i];
     o[13] = (double)s;
+}
+
+__global__ __launch_bounds__(64) void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots, int K,
+                                                       int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
+{
+    pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,24 +208,36 @@ __global__ __launch_bounds__(256) void emba_pose_texel_kernel(const int64_t* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// a4-a7 (+ the per-measurement half of a9): the dominant kernel.
-// One thread per pixel-major event: gather the batch pose, warp (event_pano_warper.cpp:43-74 +
-// equirectangular_camera.h:18-45), chain the Jacobian (model.cpp:155-157), hand pm and the 2x6
-// Jacobian to the next thread through LDS (the predecessor at the same sensor pixel is the previous
-// array element), then pairing/outlier test/rounding/texel gather/residual/count (model.cpp:186-242)
-// and the two 1x6 rows j_c = temp*D_k, j_p = -Gpm*D_{k-1} (model.cpp:449,459) written as one 128-B record.
+// a4-a7 (+ the per-measurement half of a9): the dominant kernel, in two forms that share every per-event expression.
+// One lane per entry of the device-order event array: gather the batch pose, warp (event_pano_warper.cpp:43-74 +
+// equirectangular_camera.h:18-45), chain the Jacobian (model.cpp:155-157), hand pm to the next lane (the predecessor at the
+// same sensor pixel is the previous array element whenever the entry's kEvHasPred bit says so), then pairing / outlier test /
+// rounding / texel gather / residual / count (model.cpp:186-242) and the two 1x6 rows j_c = temp*D_k, j_p = -Gpm*D_{k-1}
+// (model.cpp:449,459) written as one 128-B record.
+//   emba_warp_residual_kernel  pixel order: one-wave workgroups, per-pixel sums straight to HBM (one atomic request per run)
+//   emba_warp_tiled_kernel     tile order (order_kernels.h): a workgroup owns one panorama tile's worth of events and keeps the
+//                              per-pixel sums of the tile (+ margin) in LDS; one atomic request per touched pixel at the end
 // ------------------------------------------------------------------------------------------------
+struct ChunkDesc { uint32_t begin, end; int32_t x0, y0; };   // entries [begin, end) of the device order; LDS tile origin (panorama px)
+
+constexpr int kTileW = 48, kTileH = 24;         // LDS accumulator tile: a 32 x 8 bin plus a margin of 8 px on every side
+constexpr int kTileMargin = 8;
+constexpr int kTilePx = kTileW * kTileH;
+constexpr int kTileWaves = 10;                  // waves per workgroup of the tiled kernel (two workgroups per CU: 2 x 79 KB of LDS)
+constexpr int kTileRecStage = 16;               // records staged per wave at a time in the tiled kernel (a quarter of a wave)
+
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
     const double* pose; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
-    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag; uint32_t* blk_cnt; uint32_t* grp_cnt;
+    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag;
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
-    int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count atomic, 2 no record store, 4 no texel gather, 8 no pixacc atomics
+    int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count marker, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
     uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
+    const ChunkDesc* chunks; long n_chunks;   // tiled kernel only
 };
 
 // lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
@@ -236,32 +253,27 @@ __device__ __forceinline__ double dpp_shl1(double v)
     return __hiloint2double(dpp_shl1(__double2hiint(v)), dpp_shl1(__double2loint(v)));
 }
 
-#ifndef WARP_OCC
-#define WARP_OCC
-#endif
+// What one lane knows about its measurement after the shared part.
+struct LaneOut {
+    bool inl; uint32_t pi; int pmx, pmy;
+    double jc[6], jp[6], dpx, dpy, e;
+    double v0, v1, v2, v3, v4;   // the lane's terms of the per-pixel sums {w dx dx, w dx dy, w dy dy, dx we, dy we} (0 unless inlier)
+};
+
+// The per-event part shared by both kernels.  Every lane of the wave must call it (cross-lane moves inside); lane 0 of a wave
+// re-warps the entry in front of the wave's 63 new ones and takes no other part.
 template <bool DUMP>
-__global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
+__device__ __forceinline__ void warp_lane(const WarpParams& p, long i, bool valid, int t, LaneOut& o)
 {
-    __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
-    __shared__ double s_acc[64 * 6];                                        // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted
-    __shared__ uint32_t s_q[64];                                            // ... and their panorama pixels
-    __shared__ uint32_t s_slot[32];                                         // record slots of the staged half's inliers
-
-    const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    if (b >= p.nblk) return;  // the whole wave exits together
-    const int t = threadIdx.x;   // == lane
-    const long i = b * kWarpNew + t - 1;
-    const bool valid = (i >= 0) && (i < p.n_sorted);
-
     double pm[2] = {0, 0};
     double D[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) D[k] = 0;
-    uint32_t pix = kInvalidPix, pol = 0;
+    uint32_t pw = 0, pol = 0;
 
     if (valid) {
-        const uint32_t pw = p.ev_pix[i];
-        pix = pw & 0x7FFFFFFFu;
+        pw = p.ev_pix[i];
+        const uint32_t pix = pw & 0x1FFFFFFFu;
         pol = pw >> 31;
         const uint32_t bi = (p.ablate & 16) ? (p.ev_batch[i] & 1u) : p.ev_batch[i];   // 16: static camera (diagnostic)
         const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
@@ -307,18 +319,18 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         }
     }
 
-    // The predecessor at the same sensor pixel is the previous array element = the previous lane.
-    // (Only pm and the pixel id travel forward now; the predecessor's 2x6 Jacobian stays where it is and the two map gradients
+    // The predecessor at the same sensor pixel is the previous array element = the previous lane (kEvHasPred).
+    // (Only pm travels forward; the predecessor's 2x6 Jacobian stays where it is and the two map gradients
     // travel BACKWARD instead — see j_p below — which keeps 24 VGPRs free across the long-latency texel gather.)
     const double pmp0 = dpp_shr1(pm[0]), pmp1 = dpp_shr1(pm[1]);
-    const uint32_t pix_prev = (uint32_t)dpp_shr1((int)pix);
 
     bool inl = false;
-    const bool cand = valid && (t >= 1) && (pix_prev == pix);
+    const bool cand = valid && (t >= 1) && (pw & 0x20000000u);   // kEvHasPred (never set on lead-in / halo entries)
     uint32_t pi = kInvalidPix;
-    double jc[6], jp[6], dpx = 0, dpy = 0, e = 0, ngx = 0, ngy = 0;   // ngx, ngy = -Gpm of an inlier (0 otherwise)
+    int pmx = 0, pmy = 0;
+    double dpx = 0, dpy = 0, e = 0, ngx = 0, ngy = 0;   // ngx, ngy = -Gpm of an inlier (0 otherwise)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) { jc[j] = 0; jp[j] = 0; }
+    for (int j = 0; j < 6; ++j) { o.jc[j] = 0; o.jp[j] = 0; }
     if (cand) {
         dpx = pm[0] - pmp0;
         dpy = pm[1] - pmp1;
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         inl = (dp_norm <= p.outlier_px) && (rx >= 0.0) && (rx < (double)p.W) && (ry >= 0.0) && (ry < (double)p.H);
         if (DUMP && p.d_dp) { p.d_dp[2 * i] = dpx; p.d_dp[2 * i + 1] = dpy; }
         if (inl) {
-            const int pmx = (int)rx, pmy = (int)ry;
+            pmx = (int)rx; pmy = (int)ry;
             pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
             double gx = 0.01, gy = 0.02, gxx = 0.001, gxy = 0.002, gyy = 0.003;
             if (!(p.ablate & 4)) {
@@ -363,33 +375,24 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
                 if (p.d_pm_int) { p.d_pm_int[2 * i] = pmx; p.d_pm_int[2 * i + 1] = pmy; }
             } else {
 #pragma unroll
-                for (int j = 0; j < 6; ++j) jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
+                for (int j = 0; j < 6; ++j) o.jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
                 ngx = -gx; ngy = -gy;
                 p.e_sorted[i] = e;
             }
         }
     }
+    o.inl = inl; o.pi = pi; o.pmx = pmx; o.pmy = pmy; o.dpx = dpx; o.dpy = dpy; o.e = e;
     if (DUMP) return;
 
     {   // j_p = -Gpm_k * D_{k-1} (model.cpp:459): lane k-1 owns D_{k-1}; it receives -Gpm_k from lane k, forms the 1x6 row
         // with the same two products and one sum as before, and hands the row forward.
         const double gxn = dpp_shl1(ngx), gyn = dpp_shl1(ngy);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) jp[j] = dpp_shr1(gxn * D[j] + gyn * D[6 + j]);
+        for (int j = 0; j < 6; ++j) o.jp[j] = dpp_shr1(gxn * D[j] + gyn * D[6 + j]);
     }
-
     if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
-    const unsigned long long cand_mask = __ballot(cand), inl_mask = __ballot(inl);
-    if (t == 0) {   // inliers of this wave, and of its group of kEpGroup waves (what the single-tile scan runs over)
-        const uint32_t n_inl = (uint32_t)__popcll(inl_mask);
-        p.blk_cnt[b] = n_inl;
-        if (n_inl) atomicAdd(p.grp_cnt + (b / kEpGroup), n_inl);
-    }
 
-    // Per-pixel sums (model.cpp:227 count, :426-439 A22/b2).  Consecutive events of a sensor pixel often land on the SAME panorama
-    // pixel (dense streams: the camera moves a fraction of a pixel between them), and every atomic costs one memory-side request
-    // whatever it carries, so runs of adjacent lanes with equal pixel are summed first (segmented inclusive scan over the wave,
-    // heads where the pixel changes) and only the last lane of a run emits: one int add of the run length, five fp64 adds.
+    // the lane's terms of the per-pixel sums (model.cpp:227 count, :426-439 A22/b2), IRLS-weighted when the cost is declared
     double v0 = dpx * dpx, v1 = dpx * dpy, v2 = dpy * dpy, v3 = dpx * e, v4 = dpy * e;   // zero unless inlier (dpx,dpy,e are)
     if (p.irls) {   // IRLS weight of the declared robust cost (same expressions as the Gram and A22-from-records kernels)
         double w;
@@ -399,6 +402,69 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         v0 = w * v0; v1 = w * v1; v2 = w * v2; v3 = dpx * ew; v4 = dpy * ew;             // A22 += w dp dp^T, b2 += dp (w e), :620-636
     }
     if (!inl) { v0 = 0; v1 = 0; v2 = 0; v3 = 0; v4 = 0; }
+    o.v0 = v0; o.v1 = v1; o.v2 = v2; o.v3 = v3; o.v4 = v4;
+}
+
+// Record stores, issued COOPERATIVELY: a 128-B record is one contiguous line in HBM, so eight adjacent lanes write one record
+// per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial lines per
+// instruction, store-issue bound).  Only inliers have a record; they pass through a per-wave LDS tile, STAGE lanes at a time,
+// COMPACTED (rank among the stage's inliers), so that every store instruction but the last of a stage is full.
+template <int STAGE>
+__device__ __forceinline__ void store_records(const WarpParams& p, int t, const LaneOut& o, uint32_t slot, unsigned long long inl_mask,
+                                              double* s_tile /* STAGE * kRecLds doubles */, uint32_t* s_slot /* STAGE */)
+{
+    const int c8 = t & 7;
+#pragma unroll
+    for (int st = 0; st < 64 / STAGE; ++st) {
+        const unsigned long long smask = (STAGE == 64) ? inl_mask : ((inl_mask >> (STAGE * st)) & ((1ull << (STAGE & 63)) - 1ull));
+        const int n_rec = __popcll(smask);
+        if ((t / STAGE) == st && o.inl) {
+            const int rk = __popcll(smask & ((1ull << (t % STAGE)) - 1ull));
+            double2* w2 = reinterpret_cast<double2*>(s_tile + rk * kRecLds);
+            w2[0] = make_double2(o.jc[0], o.jc[1]); w2[1] = make_double2(o.jc[2], o.jc[3]); w2[2] = make_double2(o.jc[4], o.jc[5]);
+            w2[3] = make_double2(o.jp[0], o.jp[1]); w2[4] = make_double2(o.jp[2], o.jp[3]); w2[5] = make_double2(o.jp[4], o.jp[5]);
+            w2[6] = make_double2(o.dpx, o.dpy);
+            w2[7] = make_double2(o.e, __hiloint2double((int)p.stamp, (int)o.pi));
+            s_slot[rk] = slot;
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
+        for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
+            const int rr = r0 + (t >> 3);
+            if (rr < n_rec && !(p.ablate & 2))
+                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * s_slot[rr])[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the next stage overwrites it
+    }
+}
+
+#ifndef WARP_OCC
+#define WARP_OCC
+#endif
+template <bool DUMP>
+__global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
+{
+    __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
+    __shared__ double s_acc[64 * 6];                                        // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted
+    __shared__ uint32_t s_q[64];                                            // ... and their panorama pixels
+    __shared__ uint32_t s_slot[32];                                         // record slots of the staged half's inliers
+
+    const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (b >= p.nblk) return;  // the whole wave exits together
+    const int t = threadIdx.x;   // == lane
+    const long i = b * kWarpNew + t - 1;
+    const bool valid = (i >= 0) && (i < p.n_sorted);
+    LaneOut o;
+    warp_lane<DUMP>(p, i, valid, t, o);
+    if (DUMP) return;
+    const bool inl = o.inl;
+    const uint32_t pi = o.pi;
+    const unsigned long long inl_mask = __ballot(inl);
+
+    // Per-pixel sums.  Consecutive events of a sensor pixel often land on the SAME panorama
+    // pixel (dense streams: the camera moves a fraction of a pixel between them), and every atomic costs one memory-side request
+    // whatever it carries, so runs of adjacent lanes with equal pixel are summed first (segmented inclusive scan over the wave,
+    // heads where the pixel changes) and only the last lane of a run emits: one int add of the run length, five fp64 adds.
+    double v0 = o.v0, v1 = o.v1, v2 = o.v2, v3 = o.v3, v4 = o.v4;
     int run_n = inl ? 1 : 0;
     const uint32_t key = inl ? pi : (kInvalidPix - (uint32_t)t);                     // non-inliers never join a run
     const bool head = (t == 0) || (key != (uint32_t)dpp_shr1((int)key));
@@ -437,33 +503,77 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
                 atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[6 * k + comp]);
         }
     }
-
-    // Record stores, issued COOPERATIVELY: a 128-B record is one contiguous line in HBM, so eight adjacent lanes write one record
-    // per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial lines per
-    // instruction, store-issue bound).  Only inliers have a record; they pass through a per-wave LDS tile, half a wave at a
-    // time, COMPACTED (rank among the half's inliers), so that every store instruction but the last of a half is full.
     const uint32_t slot = inl ? p.ev_slot[i] : kNoSlot;
-    const int c8 = t & 7;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const uint32_t hmask = (uint32_t)(inl_mask >> (32 * half));
-        const int n_rec = __popc(hmask);
-        if ((t >> 5) == half && inl) {
-            const int rk = __popc(hmask & ((1u << (t & 31)) - 1u));
-            double2* w2 = reinterpret_cast<double2*>(s_tile + rk * kRecLds);
-            w2[0] = make_double2(jc[0], jc[1]); w2[1] = make_double2(jc[2], jc[3]); w2[2] = make_double2(jc[4], jc[5]);
-            w2[3] = make_double2(jp[0], jp[1]); w2[4] = make_double2(jp[2], jp[3]); w2[5] = make_double2(jp[4], jp[5]);
-            w2[6] = make_double2(dpx, dpy);
-            w2[7] = make_double2(e, __hiloint2double((int)p.stamp, (int)pi));
-            s_slot[rk] = slot;
+    store_records<32>(p, t, o, slot, inl_mask, s_tile, s_slot);
+}
+
+// Tile order: blockIdx -> chunk of one panorama bin's events (ChunkDesc).  The workgroup's waves take the chunk's 63-entry groups
+// round-robin; inlier measurements whose pixel lies inside the LDS tile (the bin plus kTileMargin pixels on every side: trial poses
+// of an LM loop move events by a few pixels) add their six terms with LDS atomics, the few outside go to HBM directly; at the end
+// every touched pixel of the tile costs ONE atomic request to its 64-B accumulator line and one marker store.
+__global__ __launch_bounds__(kTileWaves * 64) void emba_warp_tiled_kernel(WarpParams p)
+{
+    __shared__ double s_sum[6][kTilePx];                                                  // SoA: plane k = k-th term of every tile pixel
+    __shared__ __attribute__((aligned(16))) double s_tile[kTileWaves][kTileRecStage * kRecLds];
+    __shared__ uint32_t s_slot[kTileWaves][kTileRecStage];
+    __shared__ uint16_t s_list[kTileWaves][64];
+
+    const long c = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tid = threadIdx.x, t = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = tid; k < 6 * kTilePx; k += kTileWaves * 64) (&s_sum[0][0])[k] = 0.0;
+    __syncthreads();
+    if (c < p.n_chunks) {   // (block-uniform)
+        const ChunkDesc ch = p.chunks[c];
+        const long begin = ch.begin, end = ch.end;
+        for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += (long)kWarpNew * kTileWaves) {   // wave-uniform
+            const long i = g0 + t - 1;
+            const bool valid = (i >= 0) && (i < end);
+            LaneOut o;
+            warp_lane<false>(p, i, valid, t, o);
+            const unsigned long long inl_mask = __ballot(o.inl);
+            if (o.inl) {
+                const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
+                if (lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH) {
+                    const int q = ly * kTileW + lx;
+                    if (!(p.ablate & 8)) {
+                        atomicAdd(&s_sum[0][q], o.v0); atomicAdd(&s_sum[1][q], o.v1); atomicAdd(&s_sum[2][q], o.v2);
+                        atomicAdd(&s_sum[3][q], o.v3); atomicAdd(&s_sum[4][q], o.v4); atomicAdd(&s_sum[5][q], 1.0);
+                    }
+                } else {   // moved out of the tile since the order was built: still correct, just not aggregated
+                    double* a = p.pixacc + (size_t)kPixAccStride * o.pi;
+                    p.count[o.pi] = 1;
+                    atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
+                }
+            }
+            const uint32_t slot = o.inl ? p.ev_slot[i] : kNoSlot;
+            store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);
         }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
-        for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
-            const int rr = r0 + (t >> 3);
-            if (rr < n_rec && !(p.ablate & 2))
-                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * s_slot[rr])[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
+    }
+    __syncthreads();
+    if (c >= p.n_chunks) return;
+    const ChunkDesc ch = p.chunks[c];
+    // flush: wave by wave over the tile's pixels; touched ones are listed (LDS) and sent 10 pixels = 60 lanes per atomic instruction
+    for (int q0 = wv * 64; q0 < kTilePx; q0 += kTileWaves * 64) {
+        const int q = q0 + t;
+        const bool touched = q < kTilePx && s_sum[5][q] > 0.0;
+        const unsigned long long m = __ballot(touched);
+        if (!m) continue;
+        if (touched) s_list[wv][__popcll(m & ((1ull << t) - 1ull))] = (uint16_t)q;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n_emit = __popcll(m);
+        const int r10 = t / 6, comp = t - 6 * r10;
+        for (int g = 0; g < n_emit; g += 10) {
+            const int k = g + r10;
+            if (t < 60 && k < n_emit) {
+                const int qq = s_list[wv][k];
+                const int gy = ch.y0 + qq / kTileW, gx = ch.x0 + qq % kTileW;
+                const size_t pi = (size_t)gy * p.W + gx;
+                if (comp == 0 && !(p.ablate & 1)) p.count[pi] = 1;
+                if (!(p.ablate & 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
+            }
         }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the other half overwrites it
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
 
@@ -536,36 +646,74 @@ __device__ __forceinline__ uint32_t block_rank_256(bool f, uint32_t* s_w /*[4]*/
     return off + within;
 }
 
-// Residual compaction into the reference's order (model.cpp:221,256): pixel-major array order.
-__device__ __forceinline__ void compact_ep_block(long blk, const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
-                                                 const uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ grp_off, long n_sorted,
-                                                 long nblk, double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+// Residual compaction into the reference's order (model.cpp:221,256): sensor pixel major, then time = "pm-order".  The warp
+// kernels leave residual and inlier flag per entry of the DEVICE order; perm maps a pm-order index to its device entry
+// (nullptr: the device order IS the pm-order; 0xFFFFFFFF: a halo entry, never a measurement).  Blocks of kFlagBlk pm entries,
+// four consecutive ones per thread: count -> scan over blocks -> compact.
+constexpr int kFlagBlk = 1024;
+
+__device__ __forceinline__ uint32_t flag_quad(long i0, long n_pm, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ perm, uint32_t* j_out)
 {
-    // same partition as the warp kernel: wave-blocks of kWarpNew events, kEpGroup of them per 1024-thread block; the block's
-    // offset comes from the scan over groups, the wave's from the <= 15 per-wave counts before it, the lane's from a ballot
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long i = i0 + k;
+        uint32_t j = 0xFFFFFFFFu;
+        if (i < n_pm) j = perm ? perm[i] : (uint32_t)i;
+        j_out[k] = j;
+        if (j != 0xFFFFFFFFu && flag[j]) m |= 1u << k;
+    }
+    return m;
+}
+
+__device__ __forceinline__ void flag_count_block(long blk, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ perm, long n_pm,
+                                                 uint32_t* __restrict__ fblk_cnt)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t j[4];
+    uint32_t c = __popc(flag_quad(blk * kFlagBlk + 4 * threadIdx.x, n_pm, flag, perm, j));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) fblk_cnt[blk] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__device__ __forceinline__ void compact_ep_block(long blk, const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                 const uint32_t* __restrict__ perm, const uint32_t* __restrict__ fblk_off, long n_pm,
+                                                 double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+{
+    __shared__ uint32_t s_w[4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long wb = blk * kEpGroup + wv;
-    const long i = wb * kWarpNew + lane;
-    const bool in = (lane < kWarpNew) && (wb < nblk) && (i < n_sorted);
-    const bool f = in && flag[i];
-    const unsigned long long m = __ballot(f);
-    if (!m && !in) return;
-    uint32_t off = grp_off[blk];
-    for (int j = 0; j < wv; ++j) off += blk_cnt[blk * kEpGroup + j];
-    if (f) {
-        const uint32_t k = off + __popcll(m & ((1ull << lane) - 1ull));
-        ep[k] = e_sorted[i];
-        inl_idx[i] = (int32_t)k;
-    } else if (in) {
-        inl_idx[i] = -1;
+    uint32_t j[4];
+    const uint32_t m = flag_quad(blk * kFlagBlk + 4 * threadIdx.x, n_pm, flag, perm, j);
+    const uint32_t mine = __popc(m);
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint32_t k = fblk_off[blk] + x - mine;
+    for (int w = 0; w < wv; ++w) k += s_w[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (j[q] == 0xFFFFFFFFu) continue;
+        if (m & (1u << q)) { ep[k] = e_sorted[j[q]]; inl_idx[j[q]] = (int32_t)k; ++k; }
+        else inl_idx[j[q]] = -1;
     }
 }
 
-__global__ __launch_bounds__(1024) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
-                                                               const uint32_t* __restrict__ blk_cnt, const uint32_t* __restrict__ grp_off,
-                                                               long n_sorted, long nblk, double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+__global__ __launch_bounds__(256) void emba_flag_count_kernel(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ perm, long n_pm,
+                                                              uint32_t* __restrict__ fblk_cnt)
 {
-    compact_ep_block(blockIdx.x, e_sorted, flag, blk_cnt, grp_off, n_sorted, nblk, ep, inl_idx);
+    flag_count_block(blockIdx.x, flag, perm, n_pm, fblk_cnt);
+}
+
+__global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
+                                                              const uint32_t* __restrict__ perm, const uint32_t* __restrict__ fblk_off,
+                                                              long n_pm, double* __restrict__ ep, int32_t* __restrict__ inl_idx)
+{
+    compact_ep_block(blockIdx.x, e_sorted, flag, perm, fblk_off, n_pm, ep, inl_idx);
 }
 
 // Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
@@ -657,53 +805,53 @@ __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* _
     active_count_block(blockIdx.x, count, npix, thres, blk_cnt);
 }
 
-// The two small post-warp chains (residual compaction: scan -> compact; active set: count -> scan -> write) are independent of
-// each other, so their stages share launches ("heterogeneous" kernels): A = {active count blocks | one ep-scan block},
-// B = {one active-scan block | ep-compaction blocks}.  Two launches fewer on the step's critical path.
+// The two small post-warp chains (residual compaction: count -> scan -> compact; active set: count -> scan -> write) are
+// independent of each other, so their stages share launches ("heterogeneous" kernels):
+//   A = {active-count blocks | inlier-flag-count blocks}   B = {active-scan block | flag-scan block}   C = {active-write blocks | compaction blocks}
 struct PostWarpParams {
     const int32_t* count; long npix; int thres; uint32_t* ablk_cnt; uint32_t* ablk_off; long n_ablk; uint32_t* total_P; int* total_P_host;
-    const uint32_t* blk_cnt; const uint32_t* grp_cnt; uint32_t* grp_off; long ngrp; long nblk; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
-    const double* e_sorted; const uint8_t* flag; long n_sorted; double* ep; int32_t* inl_idx;
-    int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts: the host may poll it instead of waiting for the stream
+    uint32_t* fblk_cnt; uint32_t* fblk_off; long n_fblk; const uint32_t* perm; long n_pm; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
+    const double* e_sorted; const uint8_t* flag; double* ep; int32_t* inl_idx;
+    int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts (two words: [0] behind P, [1] behind the inlier count): the host may poll them instead of waiting for the stream
     int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
+};
+
+struct ActiveWriteParams {
+    const int32_t* count; long npix; int thres; const uint32_t* blk_off; int32_t* compact; uint32_t* active_idx; const double* pixacc;
+    double* A22b2; double* pack_head; long head_len; double alpha; const double* Gx; const double* Gy; uint8_t* active_bits; long max_P; long n_ablk;
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
     if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc);
-    else block_scan_256(p.grp_cnt, p.grp_off, p.ngrp, p.total_inl, p.total_inl_host, p.err_dev, p.err_host);
+    else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
 }
 
-__global__ __launch_bounds__(1024) void emba_post_warp_b_kernel(PostWarpParams p)
+__global__ __launch_bounds__(256) void emba_post_warp_b_kernel(PostWarpParams p)
 {
-    if (blockIdx.x == 0) {
-        block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
-        if (threadIdx.x == 0 && p.seq_host) {   // same thread as the count stores of block_scan_256: fence, then publish
-            __threadfence_system();
-            __hip_atomic_store(p.seq_host, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+    if (blockIdx.x == 0) block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
+    else block_scan_256(p.fblk_cnt, p.fblk_off, p.n_fblk, p.total_inl, p.total_inl_host, p.err_dev, p.err_host);
+    if (threadIdx.x == 0 && p.seq_host) {   // same thread as the count stores of block_scan_256: fence, then publish
+        __threadfence_system();
+        __hip_atomic_store(p.seq_host + blockIdx.x, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    else compact_ep_block((long)blockIdx.x - 1, p.e_sorted, p.flag, p.blk_cnt, p.grp_off, p.n_sorted, p.nblk, p.ep, p.inl_idx);
 }
 
-__global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* __restrict__ count, long npix, int thres,
-                                                                const uint32_t* __restrict__ blk_off,
-                                                                int32_t* __restrict__ compact, uint32_t* __restrict__ active_idx,
-                                                                const double* __restrict__ pixacc, double* __restrict__ A22b2,
-                                                                double* __restrict__ pack_head, long head_len, double alpha,
-                                                                const double* __restrict__ Gx, const double* __restrict__ Gy,
-                                                                uint8_t* __restrict__ active_bits, long max_P)
-{   // max_P: rows of A22b2 the (possibly caller-bound) pack has room for — rows past it are not written, the host reports
-    // EMBA_ERR_CAPACITY once it has read P.   active_bits: one bit per panorama pixel (pixel p = bit p&31 of 32-bit word p>>5), the Gram kernel's activity lookup
+__device__ __forceinline__ void active_write_block(long blk, const ActiveWriteParams& a)
+{   // active_bits: one bit per panorama pixel (pixel p = bit p&31 of 32-bit word p>>5), the Gram kernel's activity lookup
     // compact == nullptr: the pano->compact index map is not needed by this step's consumers (it is produced on demand);
-    // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU).
+    // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU);
+    // max_P: rows of A22b2 the (possibly caller-bound) pack has room for — rows past it are not written, the host reports
+    // EMBA_ERR_CAPACITY once it has read P.
     __shared__ uint32_t s_w[4];
+    const int32_t* __restrict__ count = a.count; const double* __restrict__ pixacc = a.pixacc; int32_t* __restrict__ compact = a.compact;
+    const long npix = a.npix;
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < head_len; i += (long)gridDim.x * 256) pack_head[i] = 0.0;
+    for (long i = blk * 256 + threadIdx.x; i < a.head_len; i += a.n_ablk * 256) a.pack_head[i] = 0.0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const long p0 = (long)blockIdx.x * kActivePix + 8 * threadIdx.x;
-    const uint32_t m = active_mask8(count, p0, npix, thres);
-    if (p0 < npix) active_bits[p0 >> 3] = (uint8_t)m;
+    const long p0 = blk * kActivePix + 8 * threadIdx.x;
+    const uint32_t m = active_mask8(count, p0, npix, a.thres);
+    if (p0 < npix) a.active_bits[p0 >> 3] = (uint8_t)m;
     const uint32_t mine = __popc(m);
     uint32_t x = mine;
 #pragma unroll
@@ -713,7 +861,7 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
     }
     if (lane == 63) s_w[wv] = x;
     __syncthreads();
-    uint32_t k = blk_off[blockIdx.x] + x - mine;
+    uint32_t k = a.blk_off[blk] + x - mine;
     for (int w = 0; w < wv; ++w) k += s_w[w];
     if (compact && p0 + 8 <= npix) {   // compact index of 8 consecutive pixels: two 16-B stores
         int cv[8];
@@ -729,13 +877,14 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
         if (i >= npix) break;
         if (m & (1u << j)) {
             if (compact && p0 + 8 > npix) compact[i] = (int32_t)k;
-            active_idx[k] = (uint32_t)i;
-            if (A22b2 && (long)k < max_P) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
-                const double2* a = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
-                const double2 a0 = a[0], a1 = a[1];
+            a.active_idx[k] = (uint32_t)i;
+            if (a.A22b2 && (long)k < a.max_P) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
+                const double2* q2 = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
+                const double2 a0 = q2[0], a1 = q2[1];
                 const double a4 = pixacc[(size_t)kPixAccStride * i + 4];
-                double* q = A22b2 + 5 * (size_t)k;
-                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * Gx[i]; q[4] = a4 - alpha * Gy[i]; }
+                double* q = a.A22b2 + 5 * (size_t)k;
+                const double alpha = a.alpha;
+                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * a.Gx[i]; q[4] = a4 - alpha * a.Gy[i]; }
                 else { q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4; }
             }
             ++k;
@@ -743,6 +892,14 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(const int32_t* _
             compact[i] = -1;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParams a) { active_write_block(blockIdx.x, a); }
+
+__global__ __launch_bounds__(256) void emba_post_warp_c_kernel(ActiveWriteParams a, PostWarpParams p)
+{
+    if ((long)blockIdx.x < a.n_ablk) active_write_block(blockIdx.x, a);
+    else compact_ep_block((long)blockIdx.x - a.n_ablk, p.e_sorted, p.flag, p.perm, p.fblk_off, p.n_pm, p.ep, p.inl_idx);
 }
 
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
@@ -783,9 +940,8 @@ __global__ void emba_compact_map_kernel(const uint32_t* __restrict__ active_idx,
 __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc,
                                                         int* __restrict__ err, const double* __restrict__ knots_host,
                                                         double* __restrict__ knots_dev, int n_knot_doubles, int W,
-                                                        int* __restrict__ blk_rect, uint32_t* __restrict__ grp_cnt, int n_grp)
+                                                        int* __restrict__ blk_rect)
 {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_grp; i += gridDim.x * 256) grp_cnt[i] = 0;   // per-group inlier counters
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) err[0] = 0;
         for (int i = threadIdx.x; i < n_knot_doubles; i += 256) knots_dev[i] = knots_host[i];

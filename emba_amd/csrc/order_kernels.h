@@ -1,0 +1,365 @@
+// emba_amd/csrc/order_kernels.h — once-per-window structure of the event stream, built ON THE DEVICE (gfx950, wave64).
+//
+// Everything the reference's event_map_ rebuilds on every evaluateDataError call except the numbers is pose-independent
+// (event_map.h:34-47: which event follows which at a sensor pixel; model.cpp:116-119: the batch midpoint times), so it is built
+// once per window, here:
+//   * validation of the event arrays and the batch midpoint times (ros::Time / Duration arithmetic, model.cpp:116-119)
+//   * "pm-order": events sorted by (sensor pixel, time) — the per-pixel vectors of EventMap::addEvent laid end to end — by a
+//     stable LSD radix sort (8-bit digits, one wave per 4096-key tile, ranks by wave ballots: no block barriers)
+//   * at the first evaluation of a window (the spline timing and the initial control poses are known then):
+//       - the control-pose pair of every measurement and the record slots sorted by that pair (what the Gram kernel walks)
+//       - optionally the TILE order: events binned by the panorama tile the initial trajectory sends them to, with a copy of the
+//         predecessor ("lead-in") wherever a pixel's chain of events enters a tile, so that a workgroup of the warp kernel owns a
+//         small panorama neighbourhood and sums A22 / b2 / counts in LDS before touching HBM (kernels.h, tiled warp kernel).
+//         Speed only: an event whose pixel has moved out of its workgroup's LDS tile goes to memory directly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+namespace emba {
+
+// flag bits of an event word (sensor pixel index in the low 29 bits)
+constexpr uint32_t kEvPol = 0x80000000u;      // polarity
+constexpr uint32_t kEvLead = 0x40000000u;     // lead-in / halo: warped as somebody's predecessor, no measurement of its own
+constexpr uint32_t kEvHasPred = 0x20000000u;  // the previous entry of the array is this event's predecessor at its sensor pixel
+constexpr uint32_t kEvPixMask = 0x1FFFFFFFu;
+constexpr uint32_t kValHalo = 0x80000000u;    // sort-1 value: halo entry h (else the event's original index)
+constexpr uint32_t kNoBin = 0xFFFFFFFFu;
+
+constexpr int kSortTile = 4096;               // keys per wave-tile of the radix sort
+constexpr int kScanTile = 4096;               // elements per block of the generic scan
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// generic exclusive scan of uint32 (three launches: tile sums, scan of the sums by one block, tile-local scans + offsets)
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void emba_scan_tile_sums_kernel(const uint32_t* __restrict__ in, long n, uint32_t* __restrict__ sums)
+{
+    __shared__ uint32_t s_w[4];
+    const long base = (long)blockIdx.x * kScanTile + 16 * threadIdx.x;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += (base + k < n) ? in[base + k] : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+__global__ __launch_bounds__(256) void emba_scan_apply_kernel(const uint32_t* __restrict__ in, long n, const uint32_t* __restrict__ tile_off,
+                                                              uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_w[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long base = (long)blockIdx.x * kScanTile + 16 * t;
+    uint32_t v[16], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { v[k] = (base + k < n) ? in[base + k] : 0u; mine += v[k]; }
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wv] = x;
+    __syncthreads();
+    uint32_t run = tile_off[blockIdx.x] + x - mine;
+    for (int w = 0; w < wv; ++w) run += s_w[w];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// stable LSD radix sort of (key, value) pairs, 8 bits per pass.  One WAVE owns a tile of kSortTile consecutive keys and needs no
+// block barrier: its digit counters live in its own 1-KiB LDS slice, LDS operations of one wave complete in order.
+//   pass = { histogram (per tile, per digit) -> exclusive scan over [digit][tile] -> scatter }
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(256) void emba_sort_hist_kernel(const uint32_t* __restrict__ keys, long n, int shift, long ntiles,
+                                                             uint32_t* __restrict__ hist /* [256][ntiles] */)
+{
+    __shared__ uint32_t s_cnt[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long tile = (long)blockIdx.x * 4 + wv;
+    uint32_t* cnt = s_cnt[wv];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[lane + 64 * k] = 0;
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (tile < ntiles) {
+        const long base = tile * kSortTile;
+        for (int r = 0; r < kSortTile / 64; ++r) {
+            const long i = base + 64 * r + lane;
+            const bool valid = i < n;
+            const uint32_t d = valid ? (keys[i] >> shift) & 0xFFu : 0u;
+            const unsigned long long peers = match_digit(d, valid);
+            if (valid && (peers & ((1ull << lane) - 1ull)) == 0) cnt[d] += (uint32_t)__popcll(peers);   // one lane per distinct digit
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hist[(size_t)(lane + 64 * k) * ntiles + tile] = cnt[lane + 64 * k];
+    }
+}
+
+__global__ __launch_bounds__(256) void emba_sort_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long n,
+                                                                int shift, long ntiles, const uint32_t* __restrict__ offs /* scanned hist */,
+                                                                uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    __shared__ uint32_t s_cnt[4][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long tile = (long)blockIdx.x * 4 + wv;
+    if (tile >= ntiles) return;
+    uint32_t* cnt = s_cnt[wv];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) cnt[lane + 64 * k] = offs[(size_t)(lane + 64 * k) * ntiles + tile];
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const long base = tile * kSortTile;
+    for (int r = 0; r < kSortTile / 64; ++r) {
+        const long i = base + 64 * r + lane;
+        const bool valid = i < n;
+        const uint32_t k = valid ? keys[i] : 0u, v = valid ? vals[i] : 0u;
+        const uint32_t d = (k >> shift) & 0xFFu;
+        const unsigned long long peers = match_digit(d, valid);
+        const uint32_t rank = (uint32_t)__popcll(peers & ((1ull << lane) - 1ull));
+        const uint32_t b = cnt[d];                                  // every lane of a digit reads the same word: broadcast
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (valid && rank == 0) cnt[d] = b + (uint32_t)__popcll(peers);
+        if (valid) { keys_out[b + rank] = k; vals_out[b + rank] = v; }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// validation + batch midpoints
+// ------------------------------------------------------------------------------------------------------------------------------
+// err[0] = smallest index of an event outside the sensor, err[1] = smallest index of an event earlier than its predecessor,
+// err[2] = smallest index of a halo event outside the sensor (0xFFFFFFFF each when clean)
+__global__ void emba_validate_events_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ y, const int64_t* __restrict__ t,
+                                            long n_used, int sw, int sh, const uint16_t* __restrict__ hx, const uint16_t* __restrict__ hy,
+                                            long n_halo, uint32_t* __restrict__ err)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_used) {
+        if (x[k] >= sw || y[k] >= sh) atomicMin(err + 0, (uint32_t)k);
+        if (t && k > 0 && t[k] < t[k - 1]) atomicMin(err + 1, (uint32_t)k);
+    }
+    if (k < n_halo && (hx[k] >= sw || hy[k] >= sh)) atomicMin(err + 2, (uint32_t)k);
+}
+
+// ros::Time/Duration midpoint of a batch (model.cpp:116-119; rostime semantics per SURVEY Appendix A): the host function
+// batch_mid_ns of emba_hip.hip operation for operation (no contraction: the double scale-and-round must give the same integer).
+#pragma clang fp contract(off)
+__device__ __forceinline__ int64_t batch_mid_ns_dev(int64_t t_first, int64_t t_last)
+{
+    const int64_t d = t_last - t_first;
+    int64_t dsec = d / 1000000000LL, dnsec = d % 1000000000LL;
+    if (dnsec < 0) { dnsec += 1000000000LL; dsec -= 1; }
+    const double half = ((double)dsec + 1e-9 * (double)dnsec) * 0.5;   // Duration::toSec() * 0.5
+    int64_t hsec = (int64_t)floor(half);
+    int64_t hnsec = (int64_t)round((half - (double)hsec) * 1e9);       // Duration::fromSec
+    hsec += hnsec / 1000000000LL;
+    hnsec = hnsec % 1000000000LL;
+    return t_first + hsec * 1000000000LL + hnsec;
+}
+#pragma clang fp contract(fast)
+
+__global__ void emba_batch_mid_kernel(const int64_t* __restrict__ t, long nb, int64_t* __restrict__ batch_t)
+{
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nb) batch_t[b] = batch_mid_ns_dev(t[100 * b], t[100 * b + 99]);
+}
+
+// sort-1 input: halo entries first (a stable sort then keeps them in front of their pixel's events), then the events
+__global__ void emba_pixel_keys_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ y, long n_used, int sw,
+                                       const uint16_t* __restrict__ hx, const uint16_t* __restrict__ hy, long n_halo,
+                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n_halo) { keys[e] = (uint32_t)hy[e] * (uint32_t)sw + hx[e]; vals[e] = kValHalo | (uint32_t)e; }
+    else if (e < n_halo + n_used) { const long k = e - n_halo; keys[e] = (uint32_t)y[k] * (uint32_t)sw + x[k]; vals[e] = (uint32_t)k; }
+}
+
+// pm-order arrays from the sorted (pixel, value) pairs.  pm_pix: pixel | polarity | kEvLead (halo) | kEvHasPred;
+// pm_batch: batch of the event (halo h: nb + h); pm_orig: original index (halo: 0xFFFFFFFF); cand_flag: 1 iff the entry is a
+// measurement candidate (has a predecessor at its pixel and is not a halo entry).
+__global__ void emba_pm_gather_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long ns, const uint8_t* __restrict__ pol,
+                                      long nb, uint32_t* __restrict__ pm_pix, uint32_t* __restrict__ pm_batch, uint32_t* __restrict__ pm_orig,
+                                      uint32_t* __restrict__ cand_flag)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t key = keys[i], v = vals[i];
+    const bool halo = v & kValHalo;
+    const bool has_pred = !halo && i > 0 && keys[i - 1] == key;
+    uint32_t w = key;
+    if (halo) w |= kEvLead;
+    else if (pol[v]) w |= kEvPol;
+    if (has_pred) w |= kEvHasPred;
+    pm_pix[i] = w;
+    pm_batch[i] = halo ? (uint32_t)(nb + (v & ~kValHalo)) : v / 100u;
+    pm_orig[i] = halo ? 0xFFFFFFFFu : v;
+    cand_flag[i] = has_pred ? 1u : 0u;
+}
+
+// control-pose index of every batch (basalt: s = (t - t0) / dt in int64, so3_spline.h:221-229); err = smallest batch outside the knots
+__global__ void emba_batch_cp_kernel(const int64_t* __restrict__ batch_t, long n_batch, int64_t t0, int64_t dt, int K, uint16_t* __restrict__ cp,
+                                     uint32_t* __restrict__ err)
+{
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_batch) return;
+    const int64_t st = batch_t[b] - t0;
+    const int64_t s = (st >= 0) ? st / dt : -1;
+    if (st < 0 || s + 2 > (int64_t)K) { atomicMin(err, (uint32_t)b); cp[b] = 0; return; }
+    cp[b] = (uint16_t)s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// tile order: predicted panorama tile of every pm-order entry under the initial trajectory
+// ------------------------------------------------------------------------------------------------------------------------------
+struct BinGeom { int W, H, bw, bh, nbx, nby; };   // bins of bw x bh panorama pixels, nbx x nby of them
+
+__global__ __launch_bounds__(256) void emba_predict_bin_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pm_batch, long ns,
+                                                               const double* __restrict__ pose, int pose_stride, const double* __restrict__ lut,
+                                                               double fx, double fy, double cx, double cy, BinGeom g,
+                                                               uint32_t* __restrict__ bin, uint8_t* __restrict__ bin_used)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t pix = pm_pix[i] & kEvPixMask;
+    const double* P = pose + (size_t)pose_stride * pm_batch[i];
+    const double q[4] = {P[0], P[1], P[2], P[3]};
+    double R[9];
+    quat_to_matrix(q, R);
+    const double* bv = lut + 3 * (size_t)pix;
+    const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
+    const double x = R[0] * b0 + R[1] * b1 + R[2] * b2, y = R[3] * b0 + R[4] * b1 + R[5] * b2, z = R[6] * b0 + R[7] * b1 + R[8] * b2;
+    const double px = round(cx + atan2(x, z) * fx), py = round(cy + asin(y / sqrt(x * x + y * y + z * z)) * fy);
+    uint32_t b = kNoBin;
+    if (px >= 0.0 && px < (double)g.W && py >= 0.0 && py < (double)g.H) b = (uint32_t)((int)py / g.bh) * (uint32_t)g.nbx + (uint32_t)((int)px / g.bw);
+    else b = (uint32_t)g.nbx * (uint32_t)g.nby;        // one extra bin for whatever falls outside the panorama (never an inlier)
+    bin[i] = b;
+    bin_used[b] = 1;
+}
+
+// how many entries the tile order needs for pm entry i: the event itself (halo entries appear only as lead-ins) plus a lead-in copy
+// of its predecessor when the chain enters a new tile here (or the predecessor is a halo entry)
+__global__ void emba_expand_count_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ bin, long ns, uint32_t* __restrict__ emit)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t w = pm_pix[i];
+    uint32_t e = 0;
+    if (!(w & kEvLead)) {
+        e = 1;
+        if ((w & kEvHasPred) && ((pm_pix[i - 1] & kEvLead) || bin[i - 1] != bin[i])) e = 2;
+    }
+    emit[i] = e;
+}
+
+constexpr uint32_t kValLead = 0x80000000u;    // sort-2 value: lead-in copy of pm entry (v & ~kValLead)
+
+__global__ void emba_expand_write_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ bin, const uint32_t* __restrict__ emit,
+                                         const uint32_t* __restrict__ pos, long ns, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t e = emit[i];
+    if (!e) return;
+    uint32_t p = pos[i];
+    const uint32_t b = bin[i];
+    if (e == 2) { keys[p] = b; vals[p] = kValLead | (uint32_t)(i - 1); ++p; }
+    keys[p] = b; vals[p] = (uint32_t)i;
+}
+
+// device-order arrays of the tile order from the sorted (bin, value) pairs
+__global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long nd, const uint32_t* __restrict__ pm_pix,
+                                       const uint32_t* __restrict__ pm_batch, uint32_t* __restrict__ ev_pix, uint32_t* __restrict__ ev_batch,
+                                       uint32_t* __restrict__ ev_pm /* pm index of the entry */, uint32_t* __restrict__ perm /* pm index -> entry */,
+                                       uint32_t* __restrict__ cand_flag, uint32_t* __restrict__ bin_start)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nd) return;
+    const uint32_t v = vals[j];
+    const bool lead = v & kValLead;
+    const uint32_t i = v & ~kValLead;
+    uint32_t w = pm_pix[i];
+    if (lead) w = (w & ~kEvHasPred) | kEvLead;       // a copy that only serves as the next entry's predecessor
+    ev_pix[j] = w;
+    ev_batch[j] = pm_batch[i];
+    ev_pm[j] = i;
+    if (!lead) perm[i] = (uint32_t)j;
+    cand_flag[j] = (w & kEvHasPred) ? 1u : 0u;
+    if (j == 0 || keys[j - 1] != keys[j]) bin_start[keys[j]] = (uint32_t)j;
+}
+
+// pair key of every measurement candidate of the device order, compacted: cand_pos = exclusive scan of cand_flag
+__global__ void emba_cand_keys_kernel(const uint32_t* __restrict__ ev_pix, const uint32_t* __restrict__ ev_batch, const uint16_t* __restrict__ cp, long nd,
+                                      const uint32_t* __restrict__ cand_pos, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nd || !(ev_pix[j] & kEvHasPred)) return;
+    const uint32_t m = cand_pos[j];
+    keys[m] = ((uint32_t)cp[ev_batch[j]] << 16) | (uint32_t)cp[ev_batch[j - 1]];
+    vals[m] = (uint32_t)j;
+}
+
+__global__ void emba_cand_flag_kernel(const uint32_t* __restrict__ ev_pix, long nd, uint32_t* __restrict__ cand_flag)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nd) cand_flag[j] = (ev_pix[j] & kEvHasPred) ? 1u : 0u;
+}
+
+// (cp_c << 16 | cp_p) <-> (cp_c << 8 | cp_p) when both indices fit a byte: the sort then needs two passes instead of four
+__global__ void emba_fold_keys_kernel(uint32_t* __restrict__ keys, long M, int fold)
+{
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t k = keys[m];
+    keys[m] = fold ? (((k >> 16) << 8) | (k & 0xFFu)) : (((k >> 8) << 16) | (k & 0xFFu));
+}
+
+// after the sort by pair key: slot s holds candidate vals[s]
+__global__ void emba_slot_assign_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long M, uint32_t* __restrict__ ev_slot,
+                                        uint32_t* __restrict__ slot_key)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= M) return;
+    ev_slot[vals[s]] = (uint32_t)s;
+    slot_key[s] = keys[s];
+}
+
+__global__ void emba_fill_u32_kernel(uint32_t* __restrict__ p, long n, uint32_t v)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+__global__ void emba_iota_kernel(uint32_t* __restrict__ p, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (uint32_t)i;
+}
+
+// statistics the host decides the order with: chain breaks (lead-ins the tile order would need)
+__global__ __launch_bounds__(256) void emba_count_breaks_kernel(const uint32_t* __restrict__ emit, long ns, unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ns; i += (long)gridDim.x * 256) acc += (emit[i] == 2) ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])));
+}
+
+}  // namespace emba

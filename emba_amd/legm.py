@@ -115,6 +115,25 @@ class LEGM:
                                             _p(hx, _u16p), _p(hy, _u16p), _p(ht, _i64p), nh))
         self.n_events = x.size
 
+    def set_events_dev(self, x_ptr, y_ptr, pol_ptr, t_ptr, n, halo=None):
+        """The same with the arrays already in HBM: device pointers to uint16 x, uint16 y, uint8 polarity, int64 t_ns (n each);
+        halo = (hx_ptr, hy_ptr, hbt_ptr, n_halo) or None.  Nothing of the per-window structure is built on the host."""
+        hx = hy = ht = None
+        nh = 0
+        if halo is not None and halo[3]:
+            hx, hy, ht, nh = C.c_void_p(halo[0]), C.c_void_p(halo[1]), C.c_void_p(halo[2]), int(halo[3])
+        self._check(self._L.emba_set_events_dev(self._ctx, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(pol_ptr), C.c_void_p(t_ptr), int(n),
+                                                hx, hy, ht, nh))
+        self.n_events = int(n)
+
+    def setup_info(self):
+        """Diagnostics of the once-per-window work (emba_last_setup_ms)."""
+        a, b = C.c_double(0), C.c_double(0)
+        t = C.c_int32(0)
+        ne, nc = C.c_size_t(0), C.c_size_t(0)
+        self._check(self._L.emba_last_setup_ms(self._ctx, C.byref(a), C.byref(b), C.byref(t), C.byref(ne), C.byref(nc)))
+        return dict(set_events_ms=a.value, prepare_ms=b.value, tile_order=bool(t.value), entries=ne.value, chunks=nc.value)
+
     def event_counts(self):
         a, b = C.c_size_t(0), C.c_size_t(0)
         self._check(self._L.emba_event_counts(self._ctx, C.byref(a), C.byref(b)))

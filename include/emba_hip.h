@@ -91,6 +91,22 @@ emba_status emba_set_events(emba_ctx* ctx, const uint16_t* x, const uint16_t* y,
                             const uint16_t* halo_x, const uint16_t* halo_y,
                             const int64_t* halo_batch_t_ns, size_t n_halo);
 
+/* The same with every array already in HBM (device pointers; t_ns is needed here: validation and the batch midpoints run on the
+ * device too).  Nothing of the once-per-window structure is built on the host: the (sensor pixel, time) order is a stable LSD
+ * radix sort, the record slots a second one by control-pose pair (emba_amd/csrc/order_kernels.h).  The arrays may be freed
+ * when the call returns. */
+emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint16_t* y_dev, const uint8_t* pol_dev,
+                                const int64_t* t_ns_dev, size_t n,
+                                const uint16_t* halo_x_dev, const uint16_t* halo_y_dev,
+                                const int64_t* halo_batch_t_ns_dev, size_t n_halo);
+
+/* Diagnostics of the once-per-window work: wall time of the last emba_set_events[_dev] and of the order preparation done by
+ * the first evaluation (control-pose pairs, record slots, optional tile order), whether the tile order is in use (events binned
+ * by the panorama tile the first trajectory sends them to: EMBA_ORDER=auto|pixel|tile), entries of the device order (events +
+ * halo / lead-in copies) and workgroup chunks of the tiled kernel.  Any pointer may be NULL. */
+emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
+                               size_t* n_entries, size_t* n_chunks);
+
 /* Number of events actually used (floor(n/100)*100) and of measurement candidates
  * (events that have a predecessor at their sensor pixel). */
 emba_status emba_event_counts(const emba_ctx* ctx, size_t* n_used, size_t* n_candidates);

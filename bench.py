@@ -221,7 +221,8 @@ def main():
                        "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
                        "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM",
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
-                       "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3)},
+                       "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
+                       "setup": m.setup_info()},
             "roofline": {"bound": "hbm", "kernel": "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_launch"] if tr else None), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",

@@ -193,11 +193,84 @@ __device__ __forceinline__ void spline2_eval(const double* p0, const double* p1,
 
 __device__ __forceinline__ void project_jacobian(const double* rb, double fx, double fy, double* J23);
 
+// Compact form of d_val_d_knot[1] (tile order: the per-batch pose record shrinks from 112 B to one 64-B line).
+// J1 = u R0 Jl(u delta) Jl^-1(delta) R0^T (so3_spline.h:261-270).  Jl(u delta) and Jl^-1(delta) are polynomials in hat(delta)
+// (sophus_utils.hpp:332-414) and R0 hat(a) R0^T = hat(R0 a), so J1 = u I + a1 hat(k) + a2 hat(k)^2 with k = R0 delta/|delta| a
+// property of the spline SEGMENT and (u, a1, a2) of the batch.  a1, a2 are taken by projecting the reference-order J1 of the batch
+// onto hat(k) and hat(k)^2, so the per-event reconstruction returns that J1 to rounding (1e-16 relative: Jacobian tolerance only,
+// nothing index-level depends on J1).  k = 0 for coinciding knots (then J1 = u I).
+__device__ __forceinline__ void segment_axis(const double* p0, const double* p1, double* k)
+{
+    double p0inv[4] = {-p0[0], -p0[1], -p0[2], p0[3]};
+    quat_normalize(p0inv);
+    double r01[4], delta[3], R0[9];
+    so3_mul(p0inv, p1, r01);
+    so3_log(r01, delta);
+    const double th = sqrt(sqn3(delta[0] * delta[0], delta[1] * delta[1], delta[2] * delta[2]));
+    if (!(th > 0.0)) { k[0] = 0; k[1] = 0; k[2] = 0; return; }
+    quat_to_matrix(p0, R0);
+    const double a0 = delta[0] / th, a1 = delta[1] / th, a2 = delta[2] / th;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) k[r] = R0[3 * r] * a0 + R0[3 * r + 1] * a1 + R0[3 * r + 2] * a2;
+}
+
+// (u, a1, a2) of a batch from its exact J1 and the segment axis k
+__device__ __forceinline__ void project_j1(const double* J1, double u, const double* k, double& a1, double& a2)
+{
+    const double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    a1 = 0; a2 = 0;
+    if (!(kk > 0.0)) return;
+    // antisymmetric part = hat(w), w = (J21 - J12, J02 - J20, J10 - J01) / 2  =>  a1 = w.k / k.k
+    const double w0 = 0.5 * (J1[7] - J1[5]), w1 = 0.5 * (J1[2] - J1[6]), w2 = 0.5 * (J1[3] - J1[1]);
+    a1 = (w0 * k[0] + w1 * k[1] + w2 * k[2]) / kk;
+    // symmetric part - u I = a2 N, N = k k^T - (k.k) I
+    double num = 0, den = 0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double n = k[r] * k[c] - ((r == c) ? kk : 0.0);
+            const double m = 0.5 * (J1[3 * r + c] + J1[3 * c + r]) - ((r == c) ? u : 0.0);
+            num += m * n; den += n * n;
+        }
+    a2 = (den > 0.0) ? num / den : 0.0;
+}
+
+// J1 = u I + a1 hat(k) + a2 (k k^T - (k.k) I)
+__device__ __forceinline__ void rebuild_j1(double u, double a1, double a2, const double* k, double* J1)
+{
+    const double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
+    const double d = u - a2 * kk;
+    J1[0] = d + a2 * k[0] * k[0]; J1[1] = a2 * k[0] * k[1] - a1 * k[2]; J1[2] = a2 * k[0] * k[2] + a1 * k[1];
+    J1[3] = a2 * k[1] * k[0] + a1 * k[2]; J1[4] = d + a2 * k[1] * k[1]; J1[5] = a2 * k[1] * k[2] - a1 * k[0];
+    J1[6] = a2 * k[2] * k[0] - a1 * k[1]; J1[7] = a2 * k[2] * k[1] + a1 * k[0]; J1[8] = d + a2 * k[2] * k[2];
+}
+
 // EquirectangularCamera::projectToImage (include/utils/equirectangular_camera.h:18-45) chained with
 // -[rb]x (event_pano_warper.cpp:62-65): pm (2) and J23 = dpm_drb * drb_ddrot (row-major 2x3).
+// The projection alone, as a REAL function (noinline): its atan2 / asin carry ~40 fp64 polynomial constants, which the compiler
+// hoists out of a loop and keeps in registers for the loop's whole life (fp64 literals cannot be encoded in VALU instructions
+// on gfx9: the tiled warp kernel, whose waves loop over event groups, went from 88 to 190 VGPRs that way).  Behind a call the
+// constants are materialised per call and die at the return.  Same expressions, same results as the inline form.
+__device__ __attribute__((noinline)) void project_angles_call(double x, double y, double z, double* phi, double* theta)
+{
+    *phi = atan2(x, z);
+    const double r2 = x * x + y * y + z * z;
+    *theta = asin(y / sqrt(r2));
+}
+
+template <bool CALL = false>
 __device__ __forceinline__ void project_chain(const double* rb, double fx, double fy, double cx, double cy,
                                               double* pm, double* J23)
 {
+    if (CALL) {
+        double phi, theta;
+        project_angles_call(rb[0], rb[1], rb[2], &phi, &theta);
+        pm[0] = cx + phi * fx;
+        pm[1] = cy + theta * fy;
+        project_jacobian(rb, fx, fy, J23);
+        return;
+    }
     const double x = rb[0], y = rb[1], z = rb[2];
     const double phi = atan2(x, z);
     const double r2 = x * x + y * y + z * z;

@@ -88,7 +88,8 @@ struct emba_ctx {
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
     bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
     size_t n_lead = 0;                             // lead-in copies the tile order added
-    int64_t* d_batch_t = nullptr; double* d_pose = nullptr;
+    int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order) or 64 B per batch + d_seg (tile order)
+    double* d_seg = nullptr; int seg_cap = 0;                 // per-segment rotation axis (compact pose form), 4 doubles per control pose
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
@@ -631,7 +632,7 @@ void emba_destroy(emba_ctx* c)
     dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own); dev_free(c->d_Gx_trial); dev_free(c->d_Gy_trial); dev_free(c->d_x2);
     dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_SH); dev_free(c->d_SW); dev_free(c->d_lamH); dev_free(c->d_lamW); dev_free(c->d_pF); dev_free(c->d_pT); dev_free(c->d_pGx); dev_free(c->d_pGy);
     dev_free(c->d_compact); dev_free(c->d_active_bits); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
-    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
+    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_seg); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
     dev_free(c->d_total); dev_free(c->d_scalar);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_knots) (void)hipHostFree(c->h_knots);
@@ -916,6 +917,11 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         if ((st = dev_alloc(c, &c->d_knots, (size_t)4 * K))) return st;
         c->knots_cap = K;
     }
+    if (c->seg_cap < K) {
+        dev_free(c->d_seg);
+        if ((st = dev_alloc(c, &c->d_seg, (size_t)4 * K))) return st;
+        c->seg_cap = K;
+    }
     if ((st = prepare_order(c, knots, t0_ns, dt_ns, K))) return st;
     c->K = K;
     if ((st = ensure_pack(c, K))) return st;
@@ -947,12 +953,12 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > 4 * c->npix ? 1 : 3);
     {   // pose table and (rectangle mode) texels in ONE launch: both depend only on the prep kernel
         const int nb = (int)c->n_batch;
-        const int n_pose_blk = (nb + 63) / 64;
+        const int n_pose_blk = (std::max(nb, c->tile_order ? (int)K - 1 : 0) + 63) / 64;   // (compact form: thread b also fills segment b of the axis table)
         const int n_tex_blk = (c->use_texel == 3) ? 512 : 0;
         if (n_pose_blk + n_tex_blk)
             hipLaunchKernelGGL(emba_pose_texel_kernel, dim3(n_pose_blk + n_tex_blk), dim3(256), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
                                t0_ns, dt_ns, c->d_pose, c->d_err, n_pose_blk, n_tex_blk, c->d_Gx, c->d_Gy, c->H, c->W, c->d_blk_rect,
-                               n_prep_blk, rect_cur, c->d_texel);
+                               n_prep_blk, rect_cur, c->d_texel, c->tile_order ? 1 : 0, c->d_seg);
     }
     if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
@@ -960,7 +966,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
-        p.nblk = c->nblk; p.pose = c->d_pose; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
+        p.nblk = c->nblk; p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
@@ -1276,11 +1282,12 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (w_pi) (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
-    p.pose = c->d_pose; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
+    p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
-    hipLaunchKernelGGL(emba_warp_residual_kernel<true>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+    if (c->tile_order) hipLaunchKernelGGL((emba_warp_residual_kernel<true, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+    else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
         h_pose(cp_idx ? c->n_batch * kPoseStride : 0);
     std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? ns : 0);
@@ -1319,7 +1326,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
         const bool cand = (h_evpix[i] & kEvHasPred) != 0;
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
         if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
-        if (cp_idx) cp_idx[k] = (int32_t)h_pose[(size_t)h_evbatch[i] * kPoseStride + 13];
+        if (cp_idx) cp_idx[k] = (int32_t)(c->tile_order ? h_pose[(size_t)h_evbatch[i] * kPoseStrideCompact + 7] : h_pose[(size_t)h_evbatch[i] * kPoseStride + 13]);
         if (inlier_idx) inlier_idx[k] = cand ? (h_flag[i] ? h_inl[i] : -1) : -2;
         if (pm_int && h_flag[i]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
         if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }

@@ -64,9 +64,20 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long grid)
 // a2/a3: one thread per batch -> pose record.  LinearTrajectory::evaluate (trajectory.cpp:122-147) /
 // So3Spline<2>::evaluate (so3_spline.h:218-274).  s and u use the same int64 arithmetic as the reference.
 // ------------------------------------------------------------------------------------------------
+// compact != 0 (tile order): one 64-B record per batch {q[4], u, a1, a2, cp} instead, plus a per-SEGMENT axis table seg[4 s] =
+// {kx, ky, kz, 0} from which the warp kernel rebuilds J1 (device_math.h: segment_axis / project_j1 / rebuild_j1).
+constexpr int kPoseStrideCompact = 8;
 __device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
-                                            int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
+                                            int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
+                                            int compact = 0, double* __restrict__ seg = nullptr)
 {
+    if (compact && b < K - 1) {
+        double p0[4], p1[4], k[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * b + i]; p1[i] = knots[4 * (b + 1) + i]; }
+        segment_axis(p0, p1, k);
+        seg[4 * b] = k[0]; seg[4 * b + 1] = k[1]; seg[4 * b + 2] = k[2]; seg[4 * b + 3] = 0.0;
+    }
     if (b >= nb) return;
     const int64_t st = batch_t_ns[b] - t0_ns;
     const int64_t s = (st >= 0) ? st / dt_ns : -1;
@@ -80,6 +91,14 @@ __device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ b
     for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * s + i]; p1[i] = knots[4 * (s + 1) + i]; }
     double q[4], J1[9];
     spline2_eval(p0, p1, u, q, J1);
+    if (compact) {
+        double k[3], a1, a2;
+        segment_axis(p0, p1, k);
+        project_j1(J1, u, k, a1, a2);
+        double2* o = reinterpret_cast<double2*>(pose + (size_t)kPoseStrideCompact * b);
+        o[0] = make_double2(q[0], q[1]); o[1] = make_double2(q[2], q[3]); o[2] = make_double2(u, a1); o[3] = make_double2(a2, (double)s);
+        return;
+    }
     double* o = pose + (size_t)kPoseStride * b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = q[i];
@@ -201,9 +220,10 @@ __global__ __launch_bounds__(256) void emba_pose_texel_kernel(const int64_t* __r
                                                               int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
                                                               int n_pose_blk, int n_tex_blk, const double* __restrict__ Gx,
                                                               const double* __restrict__ Gy, int H, int W, const int* __restrict__ blk_rect,
-                                                              int n_blk_rect, int* __restrict__ rect_out, double* __restrict__ texel)
+                                                              int n_blk_rect, int* __restrict__ rect_out, double* __restrict__ texel,
+                                                              int compact, double* __restrict__ seg)
 {
-    if ((int)blockIdx.x < n_pose_blk) { if (threadIdx.x < 64) pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err); }
+    if ((int)blockIdx.x < n_pose_blk) { if (threadIdx.x < 64) pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err, compact, seg); }
     else texel_rect_blocks((long)blockIdx.x - n_pose_blk, n_tex_blk, Gx, Gy, H, W, blk_rect, n_blk_rect, rect_out, texel);
 }
 
@@ -223,12 +243,18 @@ struct ChunkDesc { uint32_t begin, end; int32_t x0, y0; };   // entries [begin, 
 constexpr int kTileW = 48, kTileH = 24;         // LDS accumulator tile: a 32 x 8 bin plus a margin of 8 px on every side
 constexpr int kTileMargin = 8;
 constexpr int kTilePx = kTileW * kTileH;
-constexpr int kTileWaves = 10;                  // waves per workgroup of the tiled kernel (two workgroups per CU: 2 x 79 KB of LDS)
+#ifndef TILE_WAVES
+#define TILE_WAVES 8
+#endif
+#ifndef TILE_OCC
+#define TILE_OCC 4
+#endif
+constexpr int kTileWaves = TILE_WAVES;          // waves per workgroup of the tiled kernel; two workgroups per CU (2 x 74 KB of LDS) = TILE_OCC waves per SIMD
 constexpr int kTileRecStage = 16;               // records staged per wave at a time in the tiled kernel (a quarter of a wave)
 
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
-    const double* pose; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy
+    const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; seg: compact pose only
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
@@ -262,9 +288,29 @@ struct LaneOut {
 
 // The per-event part shared by both kernels.  Every lane of the wave must call it (cross-lane moves inside); lane 0 of a wave
 // re-warps the entry in front of the wave's 63 new ones and takes no other part.
-template <bool DUMP>
-__device__ __forceinline__ void warp_lane(const WarpParams& p, long i, bool valid, int t, LaneOut& o)
+// The event word and (compact form) the batch's pose record of one lane, loaded ahead of their use: the tiled kernel walks its
+// chunk group by group and fetches the NEXT group's words and pose lines while it works on the current one.
+struct LaneIn { uint32_t pw, bi, slot; bool valid; double2 P[4]; };
+
+// (the record slot is fetched here, with the event words, although only inliers use it: loaded where it is needed it would sit
+// behind the lane's own stores in the in-order memory counter and every staging round would wait for the previous round's stores)
+__device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bool valid, LaneIn& in)
 {
+    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot;
+    if (valid) { in.pw = p.ev_pix[i]; in.bi = p.ev_batch[i]; in.slot = p.ev_slot[i]; }
+}
+__device__ __forceinline__ void load_pose_compact(const WarpParams& p, LaneIn& in)
+{
+    if (in.valid) {
+        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStrideCompact * in.bi);
+        in.P[0] = P2[0]; in.P[1] = P2[1]; in.P[2] = P2[2]; in.P[3] = P2[3];
+    }
+}
+
+template <bool DUMP, bool COMPACT = false>
+__device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o)
+{
+    const bool valid = in.valid;
     double pm[2] = {0, 0};
     double D[12];
 #pragma unroll
@@ -272,13 +318,21 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, bool vali
     uint32_t pw = 0, pol = 0;
 
     if (valid) {
-        pw = p.ev_pix[i];
+        pw = in.pw;
         const uint32_t pix = pw & 0x1FFFFFFFu;
         pol = pw >> 31;
-        const uint32_t bi = (p.ablate & 16) ? (p.ev_batch[i] & 1u) : p.ev_batch[i];   // 16: static camera (diagnostic)
-        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
+        const uint32_t bi = in.bi;
         double R[9], J1[9];
-        {
+        if (COMPACT) {   // one 64-B line per batch + the segment's axis (a K-entry table: cache-resident)
+            const double2 a0 = in.P[0], a1 = in.P[1], a2 = in.P[2], a3 = in.P[3];
+            const double q[4] = {a0.x, a0.y, a1.x, a1.y};
+            quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
+            const double2* S2 = reinterpret_cast<const double2*>(p.seg + 4 * (size_t)(int)a3.y);
+            const double2 k01 = S2[0], k2_ = S2[1];
+            const double k[3] = {k01.x, k01.y, k2_.x};
+            rebuild_j1(a2.x, a2.y, a3.x, k, J1);
+        } else {
+            const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
             const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6];
             const double q[4] = {a0.x, a0.y, a1.x, a1.y};
             quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
@@ -293,7 +347,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, bool vali
             for (int r = 0; r < 3; ++r) rb[r] = sum3(R[3 * r] * b0, R[3 * r + 1] * b1, R[3 * r + 2] * b2);
         }
         double J23[6];
-        project_chain(rb, p.fx, p.fy, p.cx, p.cy, pm, J23);
+        project_chain<COMPACT && !DUMP>(rb, p.fx, p.fy, p.cx, p.cy, pm, J23);   // (the tiled kernel loops over groups: see project_angles_call)
         // dpm_ddrot_cp = J23 * [I - J1 | J1]   (model.cpp:156; J0 = I - J1, so3_spline.h:261-270)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
@@ -440,7 +494,7 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
 #ifndef WARP_OCC
 #define WARP_OCC
 #endif
-template <bool DUMP>
+template <bool DUMP, bool COMPACT = false>
 __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
 {
     __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
@@ -454,11 +508,19 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     const long i = b * kWarpNew + t - 1;
     const bool valid = (i >= 0) && (i < p.n_sorted);
     LaneOut o;
-    warp_lane<DUMP>(p, i, valid, t, o);
+    LaneIn in;
+    load_event_words(p, i, valid, in);
+    if (COMPACT) load_pose_compact(p, in);
+    warp_lane<DUMP, COMPACT>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;
     const uint32_t pi = o.pi;
     const unsigned long long inl_mask = __ballot(inl);
+
+    // Records first, per-pixel sums second: loads, stores and atomics share one in-order counter per wave, so anything that waits
+    // for a load issued after the atomics would wait for the atomics' round trip to the memory side too.
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (event words, pose, texels, slot: long done; the residual / flag stores: two small ones)
+    store_records<32>(p, t, o, in.slot, inl_mask, s_tile, s_slot);
 
     // Per-pixel sums.  Consecutive events of a sensor pixel often land on the SAME panorama
     // pixel (dense streams: the camera moves a fraction of a pixel between them), and every atomic costs one memory-side request
@@ -503,15 +565,13 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
                 atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[6 * k + comp]);
         }
     }
-    const uint32_t slot = inl ? p.ev_slot[i] : kNoSlot;
-    store_records<32>(p, t, o, slot, inl_mask, s_tile, s_slot);
 }
 
 // Tile order: blockIdx -> chunk of one panorama bin's events (ChunkDesc).  The workgroup's waves take the chunk's 63-entry groups
 // round-robin; inlier measurements whose pixel lies inside the LDS tile (the bin plus kTileMargin pixels on every side: trial poses
 // of an LM loop move events by a few pixels) add their six terms with LDS atomics, the few outside go to HBM directly; at the end
 // every touched pixel of the tile costs ONE atomic request to its 64-B accumulator line and one marker store.
-__global__ __launch_bounds__(kTileWaves * 64) void emba_warp_tiled_kernel(WarpParams p)
+__global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu(TILE_OCC, TILE_OCC))) void emba_warp_tiled_kernel(WarpParams p)
 {
     __shared__ double s_sum[6][kTilePx];                                                  // SoA: plane k = k-th term of every tile pixel
     __shared__ __attribute__((aligned(16))) double s_tile[kTileWaves][kTileRecStage * kRecLds];
@@ -526,11 +586,30 @@ __global__ __launch_bounds__(kTileWaves * 64) void emba_warp_tiled_kernel(WarpPa
     if (c < p.n_chunks) {   // (block-uniform)
         const ChunkDesc ch = p.chunks[c];
         const long begin = ch.begin, end = ch.end;
-        for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += (long)kWarpNew * kTileWaves) {   // wave-uniform
+        constexpr long kStep = (long)kWarpNew * kTileWaves;
+        // Two-deep software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter
+        // (vmcnt), so a load issued after a store cannot be waited for without waiting for the store's round trip as well.  Each
+        // iteration therefore: (1) issues the pose lines of group g+1 (their batch indices arrived during group g-1) and the event
+        // words + record slots of group g+2; (2) works on group g from registers — its only waits are for its own texel gather,
+        // behind which nothing slow is queued; (3) waits for everything once (the prefetches have had the whole group's arithmetic to
+        // arrive) and rotates the registers; (4) issues the record stores last, so nothing in the next iteration's steps (1)-(2)
+        // depends on them.  Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
+        LaneIn cur, nxt, nn;
+        {
+            const long g0 = begin + (long)kWarpNew * wv;
+            const long i0 = g0 + t - 1, i1 = i0 + kStep;
+            load_event_words(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
+            load_event_words(p, i1, g0 + kStep < end && i1 < end, nxt);
+            load_pose_compact(p, cur);
+        }
+#pragma unroll 1
+        for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += kStep) {   // wave-uniform
             const long i = g0 + t - 1;
-            const bool valid = (i >= 0) && (i < end);
+            load_pose_compact(p, nxt);
+            { const long i2 = i + 2 * kStep; load_event_words(p, i2, g0 + 2 * kStep < end && i2 < end, nn); }
+            __builtin_amdgcn_sched_barrier(0);          // keep the prefetches where they are issued: ahead of this group's work
             LaneOut o;
-            warp_lane<false>(p, i, valid, t, o);
+            warp_lane<false, true>(p, i, cur, t, o);
             const unsigned long long inl_mask = __ballot(o.inl);
             if (o.inl) {
                 const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
@@ -546,8 +625,11 @@ __global__ __launch_bounds__(kTileWaves * 64) void emba_warp_tiled_kernel(WarpPa
                     atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
                 }
             }
-            const uint32_t slot = o.inl ? p.ev_slot[i] : kNoSlot;
-            store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);
+            const uint32_t slot = cur.slot;
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (3): prefetched words / pose lines are in; the compiler sees no pending load below
+            cur = nxt; nxt = nn;
+            __builtin_amdgcn_sched_barrier(0);
+            store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)
         }
     }
     __syncthreads();

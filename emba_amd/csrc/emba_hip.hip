@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -1445,75 +1446,52 @@ emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 
 }  // extern "C"
 
-extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
-{
-    if (!c) return EMBA_ERR_INVALID_ARG;
-    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEq needs formNormalEq + applyL2Reg (emba_form_finish) first");
-    HIP_TRY(c, hipSetDevice(c->device));
-    emba_status st = resolve_pending(c);
-    if (st) return st;
-    hipStream_t s = c->stream;
-    const int n = 3 * c->K;
-    const int skip = fix_first_pose ? 3 : 0, m = n - skip;
-    const size_t P = c->P, M = c->n_cand;
-    if (m <= 0) return fail(c, EMBA_ERR_INVALID_ARG, "nothing to solve for");
-    const int na = n + 1;                              // augmented: row n carries y / the right-hand side
-    const long lds_ = (na + 15) / 16 * 16;             // leading dimension of S_aug and of U
+// ---- f1: the solvers (solve_kernels.h) ------------------------------------------------------------------------------------------
+namespace {
 
-    // grow-only workspaces cached in the context
-    uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr, *d_blk = nullptr, *d_blk_off = nullptr, *d_tot = nullptr;
-    double *d_S = nullptr, *d_rhs = nullptr, *d_U = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_x2 = nullptr, *d_slab = nullptr;
-    int* d_info = nullptr;
-    const size_t nblk = (P + 2047) / 2048;
-    const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(P, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
+struct SolveLists { uint32_t* off = nullptr; uint32_t* bucket = nullptr; };
+
+// per-pixel record lists over `n_pix` pixels of `view` (n_rec records): counts from the records themselves, exclusive scan, fill.
+// Workspaces 0 (off), 1 (cursor), 2 (bucket).
+emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n_pix, SolveLists* out)
+{
+    hipStream_t s = c->stream;
+    uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
+        (st = ws_get(c, 2, (n_rec + 1) * 4, (void**)&d_bucket)))
+        return st;
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
+    if (n_rec) hipLaunchKernelGGL(emba_csr_count_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_cursor);
+    if ((st = dev_scan(c, d_cursor, d_off, n_pix, d_off + n_pix))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
+    if (n_rec) hipLaunchKernelGGL(emba_csr_fill_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_off, d_cursor, d_bucket);
+    HIP_TRY(c, hipGetLastError());
+    out->off = d_off; out->bucket = d_bucket;
+    return EMBA_OK;
+}
+
+// S_aug (lds x (n+1), zero or pre-initialised) -= U_aug U_aug^T over the pixels [0, n_pix) of the lists; A22b2 points at the first of
+// those pixels' {xx xy yy bx by}.  Also leaves y = C^-1 b2 (d_y) and the 2x2 Cholesky factors (d_cf).  Workspaces 8 (U), 12 (slabs).
+emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists& L, size_t n_pix, const double* A22b2, double lambda, int n,
+                             double* d_S, long lds_, double* d_y, double* d_cf, int* d_info)
+{
+    hipStream_t s = c->stream;
+    const int na = n + 1;
+    const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(n_pix, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
     const int nb64 = (na + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
     const int nks_max = std::max(1, (4 * c->n_cu + nbp - 1) / nbp);   // enough (tile pair, K slab) blocks to fill the chip ...
-    auto cleanup = [&]() {};
-    auto ws_get = [&](int slot, size_t bytes, void** out) -> emba_status {
-        auto& w = c->ws[slot];
-        if (w.bytes < bytes || !w.p) {
-            if (w.p) (void)hipFree(w.p);
-            w.p = nullptr; w.bytes = 0;
-            if (hipMalloc(&w.p, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(c, EMBA_ERR_HIP, "hipMalloc of %zu bytes failed in the Schur solve", bytes);
-            w.bytes = std::max<size_t>(bytes, 8);
-        }
-        *out = w.p;
-        return EMBA_OK;
-    };
-#define SOLVE_TRY(expr) do { emba_status st_ = (expr); if (st_) { cleanup(); return st_; } } while (0)
-#define SOLVE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(c, EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } } while (0)
-    SOLVE_TRY(ws_get(0, (P + 1) * 4, (void**)&d_off)); SOLVE_TRY(ws_get(1, P * 4, (void**)&d_cursor)); SOLVE_TRY(ws_get(2, M * 4, (void**)&d_bucket));
-    SOLVE_TRY(ws_get(3, nblk * 4, (void**)&d_blk)); SOLVE_TRY(ws_get(4, nblk * 4, (void**)&d_blk_off)); SOLVE_TRY(ws_get(5, 4, (void**)&d_tot));
-    SOLVE_TRY(ws_get(6, (size_t)lds_ * na * 8, (void**)&d_S)); SOLVE_TRY(ws_get(7, (size_t)n * 8, (void**)&d_rhs));
-    SOLVE_TRY(ws_get(8, (size_t)lds_ * 2 * chunk * 8, (void**)&d_U)); SOLVE_TRY(ws_get(9, 2 * P * 8, (void**)&d_y)); SOLVE_TRY(ws_get(10, 3 * P * 8, (void**)&d_cf));
-    SOLVE_TRY(ws_get(11, 2 * P * 8, (void**)&d_x2)); SOLVE_TRY(ws_get(12, (size_t)nks_max * nbp * 4096 * 8, (void**)&d_slab)); SOLVE_TRY(ws_get(13, 4, (void**)&d_info));
-    SOLVE_TRY(ensure_compact(c));
-    SOLVE_HIP(hipMemsetAsync(d_info, 0, sizeof(int), s));
-    SOLVE_HIP(hipMemsetAsync(d_cursor, 0, std::max<size_t>(P, 1) * sizeof(uint32_t), s));
-    SOLVE_HIP(hipMemsetAsync(d_off, 0, (P + 1) * sizeof(uint32_t), s));
-    SOLVE_HIP(hipMemsetAsync(d_S, 0, (size_t)lds_ * na * sizeof(double), s));
-
-    // per-pixel record lists (CSR over the active pixels)
-    if (P) {
-        hipLaunchKernelGGL(emba_csr_scan1_kernel, dim3((unsigned)nblk), dim3(256), 0, s, c->d_count, c->d_active, (long)P, d_off, d_blk);
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, d_blk, d_blk_off, (long)nblk, d_tot, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
-        hipLaunchKernelGGL(emba_csr_scan3_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, d_off, (long)P, d_blk_off, d_tot);
-        if (M)
-            hipLaunchKernelGGL(emba_csr_fill_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, (long)M, c->d_count, c->d_compact,
-                               c->thres, d_off, d_cursor, d_bucket, c->rec_stamp);
-    }
-    hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
-    SOLVE_HIP(hipGetLastError());
-
-    // S_aug -= U_aug U_aug^T, one chunk of pixels at a time
+    double *d_U = nullptr, *d_slab = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 8, (size_t)lds_ * 2 * chunk * 8, (void**)&d_U)) || (st = ws_get(c, 12, (size_t)nks_max * nbp * 4096 * 8, (void**)&d_slab))) return st;
     SchurBuildParams bp{};
-    bp.rec = c->d_rec; bp.slot_key = c->d_slot_key; bp.off = d_off; bp.bucket = d_bucket; bp.A22b2 = pack_A22b2(c); bp.lambda = lambda;
+    bp.view = view; bp.off = L.off; bp.bucket = L.bucket; bp.A22b2 = A22b2; bp.lambda = lambda;
     bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
     const size_t lds_bytes = (size_t)4 * 2 * n * sizeof(double);
-    if (lds_bytes > 160 * 1024) { cleanup(); return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", c->K); }
-    if (lds_bytes > 64 * 1024) SOLVE_HIP(hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    for (size_t p0 = 0; p0 < P; p0 += chunk) {
-        const size_t p1 = std::min(P, p0 + chunk);
+    if (lds_bytes > 160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", n / 3);
+    if (lds_bytes > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    for (size_t p0 = 0; p0 < n_pix; p0 += chunk) {
+        const size_t p1 = std::min(n_pix, p0 + chunk);
         bp.p0 = (long)p0; bp.p1 = (long)p1;
         hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
         const long kc = (long)(2 * (p1 - p0));
@@ -1525,40 +1503,166 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
             hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256), (unsigned)((nks + kSyrkReduceGroup - 1) / kSyrkReduceGroup)),
                                dim3(256), 0, s, d_slab, nks, nbp, na, d_S, lds_);
     }
-    hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
 
-    // blocked Cholesky of S[skip:n, skip:n] (x1 = S \ rhs; the reference calls Eigen's ldlt, model.cpp:789)
-    {
-        double* Sm = d_S + (size_t)lds_ * skip + skip;
-        for (int jb = 0; jb < m; jb += 64) {
-            const int nb = std::min(64, m - jb);
-            hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
-            const int below = m - jb - nb;
-            if (below > 0) {
-                hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 255) / 256), dim3(256), 0, s, Sm, lds_, m, jb, nb);
-                const int tb = (below + 63) / 64;
-                SyrkParams tp{};
-                tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below; tp.k = nb;
-                tp.C = Sm + (size_t)lds_ * (jb + nb) + (jb + nb); tp.ldc = lds_; tp.slab = nullptr; tp.nbp = tb * (tb + 1) / 2; tp.direct = 1;
-                hipLaunchKernelGGL(emba_syrk_kernel, dim3(tp.nbp, 1), dim3(256), 0, s, tp);
-            }
+// blocked Cholesky of S[skip:n, skip:n] and the two triangular solves: d_rhs <- x1 (zeros in front of skip).  The reference calls
+// Eigen's ldlt (model.cpp:789).
+emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int skip, double* d_rhs, int* d_info)
+{
+    hipStream_t s = c->stream;
+    const int m = n - skip;
+    hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);
+    double* Sm = d_S + (size_t)lds_ * skip + skip;
+    for (int jb = 0; jb < m; jb += 64) {
+        const int nb = std::min(64, m - jb);
+        hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
+        const int below = m - jb - nb;
+        if (below > 0) {
+            hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 255) / 256), dim3(256), 0, s, Sm, lds_, m, jb, nb);
+            const int tb = (below + 63) / 64;
+            SyrkParams tp{};
+            tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below; tp.k = nb;
+            tp.C = Sm + (size_t)lds_ * (jb + nb) + (jb + nb); tp.ldc = lds_; tp.slab = nullptr; tp.nbp = tb * (tb + 1) / 2; tp.direct = 1;
+            hipLaunchKernelGGL(emba_syrk_kernel, dim3(tp.nbp, 1), dim3(256), 0, s, tp);
         }
-        hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
     }
+    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+RecView local_view(emba_ctx* c)
+{
+    RecView v{};
+    v.rec = c->d_rec; v.slot_key = c->d_slot_key; v.compact = c->d_compact; v.stamp = c->rec_stamp; v.packed = 0; v.pix_base = 0;
+    return v;
+}
+
+}  // namespace
+
+extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEq needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    const int n = 3 * c->K;
+    const int skip = fix_first_pose ? 3 : 0;
+    const size_t P = c->P, M = c->n_cand;
+    if (n - skip <= 0) return fail(c, EMBA_ERR_INVALID_ARG, "nothing to solve for");
+    const int na = n + 1;                              // augmented: row n carries y / the right-hand side
+    const long lds_ = (na + 15) / 16 * 16;             // leading dimension of S_aug and of U
+    double *d_S = nullptr, *d_rhs = nullptr, *d_y = nullptr, *d_cf = nullptr, *d_x2 = nullptr;
+    int* d_info = nullptr;
+    if ((st = ws_get(c, 6, (size_t)lds_ * na * 8, (void**)&d_S)) || (st = ws_get(c, 7, (size_t)n * 8, (void**)&d_rhs)) || (st = ws_get(c, 9, 2 * (P + 1) * 8, (void**)&d_y)) ||
+        (st = ws_get(c, 10, 3 * (P + 1) * 8, (void**)&d_cf)) || (st = ws_get(c, 11, 2 * (P + 1) * 8, (void**)&d_x2)) || (st = ws_get(c, 13, 4, (void**)&d_info)))
+        return st;
+    if ((st = ensure_compact(c))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_info, 0, sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(d_S, 0, (size_t)lds_ * na * sizeof(double), s));
+    const RecView view = local_view(c);
+    SolveLists L;
+    if ((st = build_lists(c, view, M, P, &L))) return st;
+    hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
+    if ((st = schur_accumulate(c, view, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info))) return st;
+    if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)
-        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, c->d_rec, c->d_slot_key, d_off, d_bucket, d_y,
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, view, L.off, L.bucket, d_y,
                            d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2);
-    SOLVE_HIP(hipGetLastError());
+    HIP_TRY(c, hipGetLastError());
     int info = 0;
-    SOLVE_HIP(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
-    if (x1_host) SOLVE_HIP(hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-    if (x2_host && P) SOLVE_HIP(hipMemcpyAsync(x2_host, d_x2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
-    SOLVE_HIP(hipStreamSynchronize(s));
-    cleanup();
-#undef SOLVE_TRY
-#undef SOLVE_HIP
+    HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (x2_host && P) HIP_TRY(c, hipMemcpyAsync(x2_host, d_x2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
     if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    return EMBA_OK;
+}
+
+// LEGM::solveNormalEqCG (model.cpp:794-840)
+extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host,
+                                               double* x2_host, int32_t* iterations, double* error)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEqCG needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    hipStream_t s = c->stream;
+    const int n = 3 * c->K, skip = fix_first_pose ? 3 : 0;
+    const size_t P = c->P, M = c->n_cand, N = (size_t)n + 2 * P;
+    if (max_iter <= 0) max_iter = 100;     // model.cpp:823-824
+    if (!(tol > 0)) tol = 1e-6;
+    double *d_x = nullptr, *d_r = nullptr, *d_p = nullptr, *d_z = nullptr, *d_t = nullptr, *d_invd = nullptr, *d_sc = nullptr;
+    if ((st = ws_get(c, 6, N * 8, (void**)&d_x)) || (st = ws_get(c, 7, N * 8, (void**)&d_r)) || (st = ws_get(c, 8, N * 8, (void**)&d_p)) ||
+        (st = ws_get(c, 9, N * 8, (void**)&d_z)) || (st = ws_get(c, 10, N * 8, (void**)&d_t)) || (st = ws_get(c, 11, N * 8, (void**)&d_invd)) ||
+        (st = ws_get(c, 13, 64, (void**)&d_sc)))
+        return st;
+    if ((st = ensure_compact(c))) return st;
+    const RecView view = local_view(c);
+    SolveLists L;
+    if ((st = build_lists(c, view, M, P, &L))) return st;
+    const unsigned gridN = (unsigned)std::min<size_t>(nblocks(N), 1024);
+    auto read2 = [&](double* a, double* b) -> emba_status {   // device scalars d_sc[0], d_sc[1] -> host, then cleared
+        double h[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(h, d_sc, 16, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemsetAsync(d_sc, 0, 16, s));
+        if (a) *a = h[0];
+        if (b) *b = h[1];
+        return EMBA_OK;
+    };
+    CgPixParams pp{};
+    pp.view = view; pp.off = L.off; pp.bucket = L.bucket; pp.A22b2 = pack_A22b2(c); pp.lambda = lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = skip;
+    pp.P = (long)P;
+    auto apply = [&](const double* v, double* y) {   // y = [A11m A12; A12^T A22m] v
+        hipLaunchKernelGGL(emba_cg_a11_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pack_A11(c), n, lambda, skip, v, y);
+        pp.v = v; pp.y = y;
+        if (P) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, (size_t)4 * c->n_cu)), dim3(256), (size_t)n * 8, s, pp);
+    };
+    // Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-88 (zero initial guess: residual = rhs)
+    HIP_TRY(c, hipMemsetAsync(d_sc, 0, 64, s));
+    hipLaunchKernelGGL(emba_cg_init_kernel, dim3(gridN), dim3(256), 0, s, pack_A11(c), pack_b1(c), pack_A22b2(c), n, skip, (long)P, lambda, d_x, d_r, d_p, d_invd, d_sc);
+    double rhs2 = 0, absNew = 0;
+    if ((st = read2(&rhs2, &absNew))) return st;
+    int it = 0;
+    double err = 0;
+    if (rhs2 != 0) {
+        const double thr = std::max(tol * tol * rhs2, std::numeric_limits<double>::min());
+        double rn2 = rhs2;
+        if (rn2 >= thr) {
+            while (it < max_iter) {
+                apply(d_p, d_t);
+                hipLaunchKernelGGL(emba_cg_dot_kernel, dim3(gridN), dim3(256), 0, s, d_p, d_t, (long)N, d_sc);
+                double pt = 0;
+                if ((st = read2(&pt, nullptr))) return st;
+                const double alpha = absNew / pt;
+                hipLaunchKernelGGL(emba_cg_xr_kernel, dim3(gridN), dim3(256), 0, s, alpha, d_p, d_t, (long)N, d_x, d_r, d_sc);
+                hipLaunchKernelGGL(emba_cg_z_kernel, dim3(gridN), dim3(256), 0, s, d_invd, d_r, (long)N, d_z, d_sc + 1);
+                double absNext = 0;
+                if ((st = read2(&rn2, &absNext))) return st;
+                if (rn2 < thr) break;
+                const double beta = absNext / absNew;
+                absNew = absNext;
+                hipLaunchKernelGGL(emba_cg_p_kernel, dim3(nblocks(N)), dim3(256), 0, s, beta, d_z, (long)N, d_p);
+                ++it;
+            }
+        }
+        err = std::sqrt(rn2 / rhs2);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(d_x, 0, N * 8, s));
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (x2_host && P) HIP_TRY(c, hipMemcpyAsync(x2_host, d_x + n, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (iterations) *iterations = it;
+    if (error) *error = err;
     return EMBA_OK;
 }
 

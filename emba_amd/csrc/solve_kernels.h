@@ -22,54 +22,52 @@
 namespace emba {
 
 // ---- per-pixel record lists (CSR over the active pixels, compact order) ------------------------------------------------
-// level 1: per-block exclusive scan of cnt[i] = count[active_idx[i]]
-__global__ __launch_bounds__(256) void emba_csr_scan1_kernel(const int32_t* __restrict__ count, const uint32_t* __restrict__ active_idx,
-                                                             long P, uint32_t* __restrict__ off, uint32_t* __restrict__ blk_tot)
+// Two views of "the records of this solve":
+//   local  : the context's own records (slot order); a record takes part iff its stamp is the current evaluation's and its pixel is
+//            in the active set (compact[pano] >= 0: the active set may come from all-reduced counts, so the count map is NOT consulted
+//            and the list lengths are COUNTED from the records — a pixel can be active without a single local record)
+//   packed : records a sharded solve has re-distributed by pixel owner (emba_solve_shard_pack): all valid, tail word = {compact pixel
+//            index, control-pose pair key}
+struct RecView {
+    const double* rec; const uint32_t* slot_key; const int32_t* compact; uint32_t stamp; int packed; long pix_base;   // pix_base: first compact index of this rank's pixels (packed view)
+};
+
+__device__ __forceinline__ bool rec_pixel(const RecView& v, long s, int32_t& k)
 {
-    __shared__ uint32_t s_w[4];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const long i0 = ((long)blockIdx.x * 256 + t) * 8;
-    uint32_t v[8], mine = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = (i0 + k < P) ? (uint32_t)count[active_idx[i0 + k]] : 0u; mine += v[k]; }
-    uint32_t x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[wv] = x;
-    __syncthreads();
-    uint32_t run = x - mine;
-    for (int w = 0; w < wv; ++w) run += s_w[w];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { if (i0 + k < P) off[i0 + k] = run; run += v[k]; }
-    if (t == 255) blk_tot[blockIdx.x] = run;
+    const double tail = v.rec[(size_t)kRecStride * s + 15];
+    if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(tail) - v.pix_base); return true; }
+    uint32_t pi;
+    if (!record_valid(tail, v.stamp, pi)) return false;
+    k = v.compact[pi];
+    return k >= 0;
+}
+__device__ __forceinline__ uint32_t rec_key(const RecView& v, uint32_t s)
+{
+    return v.packed ? (uint32_t)__double2hiint(v.rec[(size_t)kRecStride * s + 15]) : v.slot_key[s];
 }
 
-// level 3: add the scanned block totals; off[P] = total
-__global__ void emba_csr_scan3_kernel(uint32_t* __restrict__ off, long P, const uint32_t* __restrict__ blk_off, const uint32_t* __restrict__ total)
-{
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < P) off[i] += blk_off[i / 2048];
-    if (i == 0) off[P] = total[0];
-}
-
-// bucket fill: every active record takes a ticket in its pixel's list
-__global__ void emba_csr_fill_kernel(const double* __restrict__ rec, long n_slots, const int32_t* __restrict__ count,
-                                     const int32_t* __restrict__ compact, int thres, const uint32_t* __restrict__ off,
-                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ bucket, uint32_t stamp)
+__global__ void emba_csr_count_kernel(RecView v, long n_rec, uint32_t* __restrict__ cnt)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots) return;
-    const double2 tail = reinterpret_cast<const double2*>(rec + (size_t)kRecStride * s)[7];
-    uint32_t pi;
-    if (!record_valid(tail.y, stamp, pi) || count[pi] < thres) return;
-    const int32_t k = compact[pi];
+    if (s >= n_rec) return;
+    int32_t k;
+    if (rec_pixel(v, s, k)) atomicAdd(cnt + k, 1u);
+}
+
+// bucket fill: every participating record takes a ticket in its pixel's list
+__global__ void emba_csr_fill_kernel(RecView v, long n_rec, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor, uint32_t* __restrict__ bucket)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_rec) return;
+    int32_t k;
+    if (!rec_pixel(v, s, k)) return;
     const uint32_t pos = off[k] + atomicAdd(cursor + k, 1u);
     bucket[pos] = (uint32_t)s;
 }
 
 // ---- U chunk: one wave per active pixel ---------------------------------------------------------------------------------
 struct SchurBuildParams {
-    const double* rec; const uint32_t* slot_key; const uint32_t* off; const uint32_t* bucket;
+    RecView view; const uint32_t* off; const uint32_t* bucket;
     const double* A22b2; long p0, p1;            // pixel chunk [p0, p1) in compact order
     double lambda; int irls; double eta; int n;  // n = 3K
     double* U; long ldu;                         // column-major n x 2(p1-p0)
@@ -99,13 +97,13 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             const uint32_t bb = b + kk;
             const bool in = bb < b1;
             const uint32_t s = in ? p.bucket[bb] : 0u;
-            const double x = in ? p.rec[(size_t)kRecStride * s + el] : 0.0;
+            const double x = in ? p.view.rec[(size_t)kRecStride * s + el] : 0.0;
             const int g = lane & 48;
             const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
             double w = 1.0;
             if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
             else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
-            const uint32_t key = in ? p.slot_key[s] : 0u;
+            const uint32_t key = in ? rec_key(p.view, s) : 0u;
             const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
             const double wx = w * x;                                            // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
 #pragma unroll
@@ -355,7 +353,7 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
 
 // x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,
 // then z = C^-1 (A12_i^T x1)  (since U^T x1 = C^-1 A12^T x1)                                                       model.cpp:791
-__global__ __launch_bounds__(256) void emba_schur_x2_kernel(const double* __restrict__ rec, const uint32_t* __restrict__ slot_key,
+__global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
                                                             const uint32_t* __restrict__ off, const uint32_t* __restrict__ bucket,
                                                             const double* __restrict__ yv, const double* __restrict__ cfac,
                                                             const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
@@ -370,8 +368,8 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(const double* __rest
             const uint32_t bb = b + kk;
             const bool in = bb < b1;
             const uint32_t s = in ? bucket[bb] : 0u;
-            const double x = in ? rec[(size_t)kRecStride * s + el] : 0.0;
-            const uint32_t key = in ? slot_key[s] : 0u;
+            const double x = in ? view.rec[(size_t)kRecStride * s + el] : 0.0;
+            const uint32_t key = in ? rec_key(view, s) : 0u;
             const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
             double d = (in && el < 12) ? x * x1[row] : 0.0;
             d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
@@ -392,6 +390,141 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(const double* __rest
             x2[2 * i] = (t0 - c10 * bq) / c00;
         }
     }
+}
+
+
+// ---- LEGM::solveNormalEqCG (model.cpp:794-840): Eigen::ConjugateGradient on [A11m A12; A12^T A22m], matrix-free ---------------
+// Vectors have n + 2P entries: [pose part (3K, entries of a fixed first pose stay 0) | map part (2 per active pixel)].  One
+// application of the matrix reads every record once (through the per-pixel lists): A12^T v1 per pixel by dot products, A12 v2
+// scattered into a per-block LDS copy of the pose part (<= 6 KB) that is flushed with fp64 atomics.
+__global__ __launch_bounds__(256) void emba_cg_a11_kernel(const double* __restrict__ A11, int n, double lambda, int skip, const double* __restrict__ v,
+                                                          double* __restrict__ y)
+{   // one wave per row r: y[r] = sum_c A11m[r][c] v[c]
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n) return;
+    double acc = 0.0;
+    if (r >= skip)
+        for (int c = skip + lane; c < n; c += 64) { const double a = A11[(size_t)n * c + r]; acc += ((r == c) ? a + lambda * a : a) * v[c]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) y[r] = acc;      // (= : this kernel runs first; the pixel kernel adds A12 v2 on top)
+}
+
+struct CgPixParams {
+    RecView view; const uint32_t* off; const uint32_t* bucket; const double* A22b2; double lambda; int irls; double eta; int n, skip; long P;
+    const double* v; double* y;
+};
+
+__global__ __launch_bounds__(256) void emba_cg_pixel_kernel(CgPixParams p)
+{
+    extern __shared__ double s_y[];      // pose part contributed by this block
+    for (int r = threadIdx.x; r < p.n; r += 256) s_y[r] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4, g = lane & 48;
+    const long nwaves = (long)gridDim.x * 4;
+    const double* v1 = p.v; const double* v2 = p.v + p.n;
+    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < p.P; i += nwaves) {
+        const double vx = v2[2 * i], vy = v2[2 * i + 1];
+        double a0 = 0.0, a1 = 0.0;
+        const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
+        for (uint32_t b = b0; b < b1; b += 4) {
+            const uint32_t bb = b + kk;
+            const bool in = bb < b1;
+            const uint32_t s = in ? p.bucket[bb] : 0u;
+            const double x = in ? p.view.rec[(size_t)kRecStride * s + el] : 0.0;
+            const uint32_t key = in ? rec_key(p.view, s) : 0u;
+            const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
+            const bool live = in && el < 12 && row >= p.skip;
+            double d = live ? x * v1[row] : 0.0;
+            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
+            double w = 1.0;
+            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
+            else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
+            if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
+            if (live) atomicAdd(&s_y[row], w * (dx * vx + dy * vy) * x);     // A12 v2
+        }
+        a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
+        a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+        if (lane == 0) {
+            const double* q = p.A22b2 + 5 * i;
+            p.y[p.n + 2 * i] = a0 + (q[0] + p.lambda * q[0]) * vx + q[1] * vy;
+            p.y[p.n + 2 * i + 1] = a1 + q[1] * vx + (q[2] + p.lambda * q[2]) * vy;
+        }
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < p.n; r += 256) { const double a = s_y[r]; if (a != 0.0) atomicAdd(p.y + r, a); }
+}
+
+// setup: r = b (first-pose rows zeroed), invd = 1/diag (DiagonalPreconditioner: 1 where the diagonal vanishes), x = 0, p = invd.*r;
+// out[0] += r.r, out[1] += r.p
+__global__ __launch_bounds__(256) void emba_cg_init_kernel(const double* __restrict__ A11, const double* __restrict__ b1, const double* __restrict__ A22b2,
+                                                           int n, int skip, long P, double lambda, double* __restrict__ x, double* __restrict__ r,
+                                                           double* __restrict__ pv, double* __restrict__ invd, double* __restrict__ out)
+{
+    __shared__ double s_w[2][4];
+    const long N = n + 2 * P;
+    double rr = 0.0, rp = 0.0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) {
+        double d, b;
+        if (k < n) { const double a = A11[(size_t)n * k + k]; d = a + lambda * a; b = (k >= skip) ? b1[k] : 0.0; }
+        else { const long i = (k - n) >> 1; const int h = (int)((k - n) & 1); const double* q = A22b2 + 5 * i; const double a = h ? q[2] : q[0]; d = a + lambda * a; b = q[3 + h]; }
+        const double iv = (d != 0.0) ? 1.0 / d : 1.0;
+        x[k] = 0.0; r[k] = b; invd[k] = iv; pv[k] = iv * b;
+        rr += b * b; rp += b * iv * b;
+    }
+    rr = wave_sum(rr); rp = wave_sum(rp);
+    if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = rr; s_w[1][threadIdx.x >> 6] = rp; }
+    __syncthreads();
+    if (threadIdx.x == 0) { atomicAdd(out, (s_w[0][0] + s_w[0][1]) + (s_w[0][2] + s_w[0][3])); atomicAdd(out + 1, (s_w[1][0] + s_w[1][1]) + (s_w[1][2] + s_w[1][3])); }
+}
+
+__global__ __launch_bounds__(256) void emba_cg_dot_kernel(const double* __restrict__ a, const double* __restrict__ b, long N, double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0.0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) acc += a[k] * b[k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+// x += alpha p; r -= alpha t; out += r.r
+__global__ __launch_bounds__(256) void emba_cg_xr_kernel(double alpha, const double* __restrict__ pv, const double* __restrict__ t, long N,
+                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0.0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) {
+        x[k] += alpha * pv[k];
+        const double rv = r[k] - alpha * t[k];
+        r[k] = rv; acc += rv * rv;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+// z = invd .* r ; out += r.z
+__global__ __launch_bounds__(256) void emba_cg_z_kernel(const double* __restrict__ invd, const double* __restrict__ r, long N, double* __restrict__ z,
+                                                        double* __restrict__ out)
+{
+    __shared__ double s_w[4];
+    double acc = 0.0;
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) { const double zv = invd[k] * r[k]; z[k] = zv; acc += r[k] * zv; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+}
+
+__global__ void emba_cg_p_kernel(double beta, const double* __restrict__ z, long N, double* __restrict__ pv)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < N) pv[k] = z[k] + beta * pv[k];
 }
 
 }  // namespace emba

@@ -220,6 +220,14 @@ class LEGM:
         self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
         return x1, x2[:2 * self._P]
 
+    def solveNormalEqCG(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6):
+        """model.cpp:794-840 (Eigen ConjugateGradient, 100 iterations, tolerance 1e-6) on the device: returns (x1, x2, iterations, error)."""
+        x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
+        it = C.c_int32(0); err = C.c_double(0)
+        self._check(self._L.emba_solve_normal_eq_cg(self._ctx, float(lam), 1 if fix_first_pose else 0, int(max_iter), float(tol), _p(x1, _dp), _p(x2, _dp),
+                                                    C.byref(it), C.byref(err)))
+        return x1, x2[:2 * self._P], it.value, err.value
+
     def updateMap(self, x2, damping_factor):
         """model.cpp:863-903 on the device-resident map: builds the TRIAL map (active += damping*x2, all other pixels 0) that
         the following evaluateDataError(traj, None, None) uses; report the LM decision with acceptMap() / rejectMap()."""

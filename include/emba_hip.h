@@ -192,8 +192,15 @@ emba_status emba_reconstruct_intensity(emba_ctx* ctx, const double* Gx_host, con
  * records, x1 = S \ (b1 - A12 A22m^-1 b2) by Cholesky, x2 = A22m^-1 (b2 - A12^T x1).  LM damping as the reference:
  * A11m = A11 + lambda*diag(A11), A22m = A22 + lambda*diag(A22).  fix_first_pose != 0 reproduces the first-window trim of
  * solver.cpp:156-165 (rows/cols 0..2 dropped; x1[0..2] = 0 on return).  x1_host: 3K doubles, x2_host: 2P doubles (either may
- * be NULL).  Single GPU only (a sharded Schur step needs the per-pixel A12 columns of all ranks). */
+ * be NULL).  Works on this context's own records: with a sharded window use emba_solve_shard_* (a pixel's A12 columns are sums over all
+ * ranks' records, so the records are first re-distributed by pixel owner). */
 emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
+
+/* LEGM::solveNormalEqCG (model.cpp:794-840; selected by BA_config.use_CG at solver.cpp:190-202): Eigen's ConjugateGradient (default
+ * diagonal preconditioner, zero initial guess; max_iter <= 0 -> 100, tol <= 0 -> 1e-6 as in the reference) on the full system
+ * [A11m A12; A12^T A22m], applied matrix-free through the sparse A12 factors.  iterations / error = cg.iterations() / cg.error(). */
+emba_status emba_solve_normal_eq_cg(emba_ctx* ctx, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol,
+                                    double* x1_host, double* x2_host, int32_t* iterations, double* error);
 
 /* Bind caller-owned device buffers that the caller all-reduces between phases:
  *   count_map_dev : int32 pano_h*pano_w                       (exchange 1)

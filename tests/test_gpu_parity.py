@@ -417,6 +417,38 @@ def test_schur_solve_parity(gpu, oracle_mod, cfg, lam, fix, cost):
     assert np.allclose(x1b, ob1, rtol=1e-7, atol=1e-9 * np.abs(ob1).max()) and np.allclose(x2b, ob2, rtol=1e-7, atol=1e-9 * np.abs(ob2).max())
 
 
+@pytest.mark.parametrize("cfg,lam,fix,cost", [
+    (dict(n_events=20000), 1e-3, True, ("quadratic", 0.0)),
+    (dict(n_events=30000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01), 1e-2, False, ("huber", 0.1)),
+])
+def test_cg_solve_parity(gpu, oracle_mod, cfg, lam, fix, cost):
+    """LEGM::solveNormalEqCG (model.cpp:794-840) on the device against the oracle's restatement of Eigen's ConjugateGradient loop: with the
+    reference's settings (100 iterations, 1e-6) the same stopping behaviour and iterates that agree to the solver's own tolerance; run to
+    convergence, the solution of the direct Schur solve."""
+    w = small_workload(**cfg)
+    irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
+    g = gpu_run(w, cost_type=cost[0], a=cost[1])
+    o = oracle_run(oracle_mod, w, irls=irls, a=cost[1])
+    m, orc = g["legm"], o["oracle"]
+    thres = w.thres_valid_pixel
+    x1, x2, it, err = m.solveNormalEqCG(lam, fix_first_pose=fix)
+    ox1, ox2, oit, oerr = orc.solve_cg_sparse(o["ne"], o["ep"], w.K, o["num_ev_map"], thres, irls, cost[1], lam, fix)
+    # the residual norm crosses the threshold within an iteration or two of the oracle's (different summation order), both below 1e-6
+    assert abs(it - oit) <= 2 and it < 100 and err < 1e-6 and oerr < 1e-6
+    assert np.abs(x1 - ox1).max() <= 1e-4 * np.abs(ox1).max() and np.abs(x2 - ox2).max() <= 1e-4 * np.abs(ox2).max()
+    # same number of iterations -> the same iterate to rounding
+    x1k, x2k, itk, _ = m.solveNormalEqCG(lam, fix_first_pose=fix, max_iter=10, tol=1e-30)
+    o1k, o2k, oitk, _ = orc.solve_cg_sparse(o["ne"], o["ep"], w.K, o["num_ev_map"], thres, irls, cost[1], lam, fix, max_iter=10, tol=1e-30)
+    assert itk == oitk == 10
+    assert np.abs(x1k - o1k).max() <= 1e-8 * np.abs(o1k).max() and np.abs(x2k - o2k).max() <= 1e-8 * np.abs(o2k).max()
+    if fix:
+        assert (x1[:3] == 0).all()
+    # to convergence: the direct solution
+    x1c, x2c, itc, errc = m.solveNormalEqCG(lam, fix_first_pose=fix, max_iter=5000, tol=1e-13)
+    d1, d2 = m.solveNormalEq(lam, fix_first_pose=fix)
+    assert errc < 1e-12 and np.abs(x1c - d1).max() <= 1e-6 * np.abs(d1).max() and np.abs(x2c - d2).max() <= 1e-6 * np.abs(d2).max()
+
+
 def test_lm_iterations_decrease_cost(gpu, oracle_mod):
     """A few full Levenberg-Marquardt iterations entirely through the device path (evaluate -> form -> L2 -> solve -> update map and
     poses -> evaluate), following solver.cpp:63-353: with a good damping the accepted steps must lower the total cost."""

@@ -159,6 +159,8 @@ def main():
         def get_world_size(): return world
         @staticmethod
         def all_reduce(t): dist.all_reduce(t)
+        @staticmethod
+        def all_to_all_single(out, inp, out_splits, in_splits): dist.all_to_all_single(out, inp, out_splits, in_splits)
 
     count_u8 = torch.zeros(npix, dtype=torch.uint8, device=dev)   # exchange 1 travels as saturated bytes (emba_amd/sharded.py)
     sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w, count_u8)

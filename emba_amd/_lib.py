@@ -51,6 +51,11 @@ SIGNATURES = {
     "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "emba_solve_normal_eq": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, _dp, _dp]),
+    "emba_solve_shard_size": (C.c_int, [C.c_void_p, _szp]),
+    "emba_solve_shard_count": (C.c_int, [C.c_void_p, C.c_int32, _szp]),
+    "emba_solve_shard_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "emba_solve_shard_partial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]),
+    "emba_solve_shard_finish": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_void_p, _dp, C.c_void_p]),
     "emba_solve_normal_eq_cg": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _i32p, _dp]),
     "emba_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "emba_map_accept": (C.c_int, [C.c_void_p]),

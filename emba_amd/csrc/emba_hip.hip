@@ -1584,6 +1584,118 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     return EMBA_OK;
 }
 
+// ---- sharded Schur solve (f1 on N GPUs): count / pack / [all-to-all] / partial / [all-reduce] / finish ----------------------------
+extern "C" emba_status emba_solve_shard_size(emba_ctx* c, size_t* s_doubles)
+{
+    if (!c || !s_doubles) return EMBA_ERR_INVALID_ARG;
+    const int na = 3 * c->K + 1;
+    const long lds_ = (na + 15) / 16 * 16;
+    *s_doubles = (size_t)lds_ * na;
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_solve_shard_count(emba_ctx* c, int32_t n_ranks, size_t* counts_host)
+{
+    if (!c || !counts_host || n_ranks < 1 || n_ranks > 1024) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_count: bad arguments") : EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "the sharded solve needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    if ((st = ensure_compact(c))) return st;
+    hipStream_t s = c->stream;
+    unsigned long long* d_cnt = nullptr;
+    if ((st = ws_get(c, 14, (size_t)3 * n_ranks * 8 + 8, (void**)&d_cnt))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, (size_t)3 * n_ranks * 8 + 8, s));
+    if (c->n_cand) hipLaunchKernelGGL(emba_shard_count_kernel, dim3(nblocks(c->n_cand)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt);
+    std::vector<unsigned long long> h(n_ranks);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), d_cnt, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    unsigned long long run = 0;
+    std::vector<unsigned long long> off(n_ranks);
+    for (int r = 0; r < n_ranks; ++r) { counts_host[r] = (size_t)h[r]; off[r] = run; run += h[r]; }
+    HIP_TRY(c, hipMemcpyAsync(d_cnt + n_ranks, off.data(), (size_t)n_ranks * 8, hipMemcpyHostToDevice, s));   // [n, 2n): offsets; [2n, 3n): cursors (zero)
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_solve_shard_pack(emba_ctx* c, int32_t n_ranks, double* send_dev)
+{
+    if (!c || n_ranks < 1) return EMBA_ERR_INVALID_ARG;
+    if (!c->ws[14].p) return fail(c, EMBA_ERR_STATE, "call emba_solve_shard_count first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    unsigned long long* d_cnt = (unsigned long long*)c->ws[14].p;
+    HIP_TRY(c, hipMemsetAsync(d_cnt + 2 * n_ranks, 0, (size_t)n_ranks * 8, s));
+    if (c->n_cand && send_dev)
+        hipLaunchKernelGGL(emba_shard_pack_kernel, dim3(nblocks(c->n_cand)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt + n_ranks,
+                           d_cnt + 2 * n_ranks, send_dev);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+namespace {
+void shard_range(size_t P, int rank, int n_ranks, size_t* lo, size_t* hi) { *lo = (P * (size_t)rank) / n_ranks; *hi = (P * ((size_t)rank + 1)) / n_ranks; }
+}
+
+extern "C" emba_status emba_solve_shard_partial(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda, double* S_part_dev)
+{
+    if (!c || !S_part_dev || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_partial: bad arguments") : EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "the sharded solve needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = 3 * c->K, na = n + 1;
+    const long lds_ = (na + 15) / 16 * 16;
+    size_t lo, hi;
+    shard_range(c->P, rank, n_ranks, &lo, &hi);
+    const size_t n_pix = hi - lo;
+    double *d_y = nullptr, *d_cf = nullptr; int* d_info = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 9, 2 * (n_pix + 1) * 8, (void**)&d_y)) || (st = ws_get(c, 10, 3 * (n_pix + 1) * 8, (void**)&d_cf)) || (st = ws_get(c, 13, 64, (void**)&d_info))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_info, 0, sizeof(int), s));
+    HIP_TRY(c, hipMemsetAsync(S_part_dev, 0, (size_t)lds_ * na * sizeof(double), s));
+    RecView view{};
+    view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
+    SolveLists L;
+    if ((st = build_lists(c, view, n_recv, n_pix, &L))) return st;
+    return schur_accumulate(c, view, L, n_pix, pack_A22b2(c) + 5 * lo, lambda, n, S_part_dev, lds_, d_y, d_cf, d_info);
+}
+
+extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda,
+                                               int32_t fix_first_pose, double* S_dev, double* x1_host, double* x2_full_dev)
+{
+    if (!c || !S_dev || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_finish: bad arguments") : EMBA_ERR_INVALID_ARG;
+    if (!c->ws[0].p || !c->ws[9].p) return fail(c, EMBA_ERR_STATE, "call emba_solve_shard_partial first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = 3 * c->K, na = n + 1, skip = fix_first_pose ? 3 : 0;
+    const long lds_ = (na + 15) / 16 * 16;
+    size_t lo, hi;
+    shard_range(c->P, rank, n_ranks, &lo, &hi);
+    const size_t n_pix = hi - lo;
+    double* d_rhs = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 7, (size_t)n * 8, (void**)&d_rhs))) return st;
+    int* d_info = (int*)c->ws[13].p;
+    double* d_y = (double*)c->ws[9].p; double* d_cf = (double*)c->ws[10].p;
+    hipLaunchKernelGGL(emba_schur_add_a11_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, S_dev, lds_);
+    if ((st = schur_factor_solve(c, S_dev, lds_, n, skip, d_rhs, d_info))) return st;
+    if (x2_full_dev) {
+        HIP_TRY(c, hipMemsetAsync(x2_full_dev, 0, 2 * c->P * sizeof(double), s));
+        RecView view{};
+        view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
+        if (n_pix)
+            hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((n_pix + 3) / 4, 8192)), dim3(256), 0, s, view, (const uint32_t*)c->ws[0].p,
+                               (const uint32_t*)c->ws[2].p, d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo);
+    }
+    HIP_TRY(c, hipGetLastError());
+    int info = 0;
+    HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    return EMBA_OK;
+}
+
 // LEGM::solveNormalEqCG (model.cpp:794-840)
 extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host,
                                                double* x2_host, int32_t* iterations, double* error)

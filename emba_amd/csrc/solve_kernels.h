@@ -527,4 +527,55 @@ __global__ void emba_cg_p_kernel(double beta, const double* __restrict__ z, long
     if (k < N) pv[k] = z[k] + beta * pv[k];
 }
 
+
+// ---- sharded Schur solve: re-distribution of the records by pixel owner --------------------------------------------------------
+// A pixel's two A12 columns are sums over ALL ranks' records of that pixel (its events come from several time shards), and the
+// Schur complement needs the outer product of the SUMMED columns, so the records are first sent to the rank that owns their pixel:
+// rank r of n owns the active pixels [P r / n, P (r+1) / n) in compact (ascending panorama) order.
+__device__ __forceinline__ int pixel_owner(long k, long P, int n_ranks)
+{
+    int r = (int)((k * n_ranks) / (P > 0 ? P : 1));
+    if (r >= n_ranks) r = n_ranks - 1;
+    while (r + 1 < n_ranks && (P * (r + 1)) / n_ranks <= k) ++r;     // boundaries are floor(P r / n)
+    while (r > 0 && (P * r) / n_ranks > k) --r;
+    return r;
+}
+
+__global__ void emba_shard_count_kernel(RecView v, long n_rec, long P, int n_ranks, unsigned long long* __restrict__ cnt)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_rec) return;
+    int32_t k;
+    if (rec_pixel(v, s, k)) atomicAdd(cnt + pixel_owner(k, P, n_ranks), 1ull);
+}
+
+// packed record = the record with its tail word rewritten to {compact pixel index, control-pose pair key}
+__global__ void emba_shard_pack_kernel(RecView v, long n_rec, long P, int n_ranks, const unsigned long long* __restrict__ off,
+                                       unsigned long long* __restrict__ cursor, double* __restrict__ out)
+{
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_rec) return;
+    int32_t k;
+    if (!rec_pixel(v, s, k)) return;
+    const int r = pixel_owner(k, P, n_ranks);
+    const unsigned long long pos = off[r] + atomicAdd(cursor + r, 1ull);
+    const double2* src = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * s);
+    double2* dst = reinterpret_cast<double2*>(out + (size_t)kRecStride * pos);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) dst[q] = src[q];
+    dst[7] = make_double2(src[7].x, __hiloint2double((int)rec_key(v, (uint32_t)s), (int)k));
+}
+
+// S_aug += [A11m, . ; b1^T, 0] (the replicated part, added once after the all-reduce of the partial Schur sums)
+__global__ void emba_schur_add_a11_kernel(const double* __restrict__ A11, const double* __restrict__ b1, int n, double lambda, double* __restrict__ S, long lds)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)n * n) {
+        const int r = (int)(i % n), c = (int)(i / n);
+        const double a = A11[i];
+        S[(size_t)lds * c + r] += (r == c) ? a + lambda * a : a;
+    }
+    if (i < n) S[(size_t)lds * i + n] += b1[i];
+}
+
 }  // namespace emba

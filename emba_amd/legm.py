@@ -220,6 +220,29 @@ class LEGM:
         self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
         return x1, x2[:2 * self._P]
 
+    # -- sharded Schur solve: primitives around the caller's two collectives (emba_amd.sharded.ShardedLEGM.solveNormalEq) --------
+    def solve_shard_size(self):
+        n = C.c_size_t(0)
+        self._check(self._L.emba_solve_shard_size(self._ctx, C.byref(n)))
+        return n.value
+
+    def solve_shard_count(self, n_ranks):
+        counts = np.zeros(n_ranks, dtype=np.uint64)
+        self._check(self._L.emba_solve_shard_count(self._ctx, int(n_ranks), counts.ctypes.data_as(_lib._szp)))
+        return counts.astype(np.int64)
+
+    def solve_shard_pack(self, n_ranks, send_ptr):
+        self._check(self._L.emba_solve_shard_pack(self._ctx, int(n_ranks), C.c_void_p(send_ptr)))
+
+    def solve_shard_partial(self, rank, n_ranks, recv_ptr, n_recv, lam, S_ptr):
+        self._check(self._L.emba_solve_shard_partial(self._ctx, int(rank), int(n_ranks), C.c_void_p(recv_ptr), int(n_recv), float(lam), C.c_void_p(S_ptr)))
+
+    def solve_shard_finish(self, rank, n_ranks, recv_ptr, n_recv, lam, fix_first_pose, S_ptr, x2_ptr):
+        x1 = np.zeros(3 * self.K)
+        self._check(self._L.emba_solve_shard_finish(self._ctx, int(rank), int(n_ranks), C.c_void_p(recv_ptr), int(n_recv), float(lam),
+                                                    1 if fix_first_pose else 0, C.c_void_p(S_ptr), _p(x1, _dp), C.c_void_p(x2_ptr)))
+        return x1
+
     def solveNormalEqCG(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6):
         """model.cpp:794-840 (Eigen ConjugateGradient, 100 iterations, tolerance 1e-6) on the device: returns (x1, x2, iterations, error)."""
         x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))

@@ -133,6 +133,42 @@ class ShardedLEGM:
         return n_inl, out
 
 
+    def solveNormalEq(self, lam, fix_first_pose=False):
+        """LEGM::solveNormalEq (model.cpp:721-792) over all ranks, after iteration(): the sparse A12 factors are time-sharded, a pixel's
+        columns are sums over several ranks' records, so the records are first sent to the rank that owns their pixel (contiguous
+        ranges of the active set), each rank forms the Schur sums of ITS pixels, one all-reduce of the (3K+1)^2 block follows, the
+        Cholesky is replicated and the per-pixel x2 are exchanged.  Three collectives: all-to-all (records), all-reduce (S), all-reduce
+        (x2, disjoint supports).  Returns (x1 [3K], x2 [2P]) — identical on every rank."""
+        import torch
+        e, dist, w, r = self.engine, self.dist, self.world, self.rank
+        dev = self.pack.device
+        counts = e.solve_shard_count(w)                                            # records this rank sends to every owner
+        table = torch.zeros(w * w, dtype=torch.int64, device=dev)
+        table[r * w:(r + 1) * w] = torch.from_numpy(counts).to(dev)
+        if w > 1:
+            dist.all_reduce(table)                                                 # everybody's counts (disjoint rows)
+        table = table.cpu().numpy().reshape(w, w)
+        n_send, recv_counts = int(counts.sum()), table[:, r]
+        n_recv = int(recv_counts.sum())
+        send = torch.empty(max(n_send, 1) * 16, dtype=torch.float64, device=dev)
+        recv = torch.empty(max(n_recv, 1) * 16, dtype=torch.float64, device=dev)
+        e.solve_shard_pack(w, send)
+        if w > 1:
+            dist.all_to_all_single(recv[: n_recv * 16], send[: n_send * 16], [int(v) * 16 for v in recv_counts], [int(v) * 16 for v in counts])
+        else:
+            e.sync(); recv[: n_send * 16] = send[: n_send * 16]; torch.cuda.synchronize(dev)
+        S = torch.zeros(e.solve_shard_size(), dtype=torch.float64, device=dev)
+        e.solve_shard_partial(r, w, recv, n_recv, lam, S)
+        if w > 1:
+            dist.all_reduce(S)
+        x2 = torch.zeros(2 * max(self.P, 1), dtype=torch.float64, device=dev)
+        x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
+        if w > 1:
+            dist.all_reduce(x2)
+        torch.cuda.synchronize(dev)
+        return x1, x2[: 2 * self.P].cpu().numpy()
+
+
 class HipEngine:
     """Adapter: emba_amd.LEGM phase calls + torch CUDA tensors as the exchange buffers (product path)."""
 
@@ -188,3 +224,21 @@ class HipEngine:
 
     def form_finish(self, alpha, download):
         return self.m.form_finish(alpha, download)
+
+    def sync(self):
+        self.m.sync()
+
+    def solve_shard_size(self):
+        return self.m.solve_shard_size()
+
+    def solve_shard_count(self, n_ranks):
+        return self.m.solve_shard_count(n_ranks)
+
+    def solve_shard_pack(self, n_ranks, send):
+        self.m.solve_shard_pack(n_ranks, send.data_ptr())
+
+    def solve_shard_partial(self, rank, n_ranks, recv, n_recv, lam, S):
+        self.m.solve_shard_partial(rank, n_ranks, recv.data_ptr(), n_recv, lam, S.data_ptr())
+
+    def solve_shard_finish(self, rank, n_ranks, recv, n_recv, lam, fix_first_pose, S, x2):
+        return self.m.solve_shard_finish(rank, n_ranks, recv.data_ptr(), n_recv, lam, fix_first_pose, S.data_ptr(), x2.data_ptr())

@@ -196,6 +196,26 @@ emba_status emba_reconstruct_intensity(emba_ctx* ctx, const double* Gx_host, con
  * ranks' records, so the records are first re-distributed by pixel owner). */
 emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
 
+/* The same Schur solve for a window sharded over n_ranks GPUs (events sharded by time, A12 factors stay sharded).
+ * A pixel's A12 columns are sums over ALL ranks' records of that pixel, and S needs the outer products of the summed columns, so the
+ * records are first re-distributed by pixel owner (rank r owns the active pixels [P r / n, P (r+1) / n) in ascending panorama order):
+ *   emba_solve_shard_count   counts_host[n_ranks] = this rank's valid records on active pixels, by owner
+ *   emba_solve_shard_pack    packs them owner-major into send_dev (16 doubles each; tail word = {compact pixel index, pose-pair key})
+ *   -- caller: all-to-all of the records (RCCL send/recv, torch.distributed.all_to_all_single) into recv_dev / n_recv --
+ *   emba_solve_shard_partial S_part_dev (emba_solve_shard_size doubles) = - sum over the OWNED pixels of U_aug U_aug^T
+ *   -- caller: all-reduce(SUM) of S_part_dev --
+ *   emba_solve_shard_finish  adds the replicated [A11m | b1], factors, x1 -> x1_host (identical on every rank); x2 of the owned pixels
+ *                            into x2_full_dev (2P doubles, zero elsewhere: the caller all-reduces it to get every rank's full x2)
+ * Call after emba_form_finish (A22/b2 all-reduced, L2 applied), all on the context's stream.  Tested as rank threads on one GPU
+ * against the single-process oracle (tests/test_gpu_sharded.py). */
+emba_status emba_solve_shard_size(emba_ctx* ctx, size_t* s_doubles);
+emba_status emba_solve_shard_count(emba_ctx* ctx, int32_t n_ranks, size_t* counts_host);
+emba_status emba_solve_shard_pack(emba_ctx* ctx, int32_t n_ranks, double* send_dev);
+emba_status emba_solve_shard_partial(emba_ctx* ctx, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv,
+                                     double lambda, double* S_part_dev);
+emba_status emba_solve_shard_finish(emba_ctx* ctx, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv,
+                                    double lambda, int32_t fix_first_pose, double* S_dev, double* x1_host, double* x2_full_dev);
+
 /* LEGM::solveNormalEqCG (model.cpp:794-840; selected by BA_config.use_CG at solver.cpp:190-202): Eigen's ConjugateGradient (default
  * diagonal preconditioner, zero initial guess; max_iter <= 0 -> 100, tol <= 0 -> 1e-6 as in the reference) on the full system
  * [A11m A12; A12^T A22m], applied matrix-free through the sparse A12 factors.  iterations / error = cg.iterations() / cg.error(). */

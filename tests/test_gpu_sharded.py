@@ -47,7 +47,28 @@ class _ThreadDist:
         self.s.barrier.wait()
 
 
-def _rank_main(shared, rank, w, results, compressed=False):
+    def all_to_all_single(self, out, inp, out_splits, in_splits):
+        """Rank r's j-th input piece goes to rank j, where it becomes the r-th output piece."""
+        import torch
+        self.sync_fn()
+        self.s.slots[self.rank] = (out, inp, list(out_splits), list(in_splits))
+        self.s.barrier.wait()
+        if self.rank == 0:
+            W = self.s.world
+            for src in range(W):
+                _, inp_s, _, ins = self.s.slots[src]
+                ioff = 0
+                for dst in range(W):
+                    out_d, _, outs, _ = self.s.slots[dst]
+                    ooff = sum(outs[:src])
+                    assert outs[src] == ins[dst]
+                    out_d[ooff:ooff + outs[src]].copy_(inp_s[ioff:ioff + ins[dst]])
+                    ioff += ins[dst]
+            torch.cuda.synchronize()
+        self.s.barrier.wait()
+
+
+def _rank_main(shared, rank, w, results, compressed=False, solve=None):
     try:
         import torch
         from emba_amd import LEGM
@@ -65,13 +86,14 @@ def _rank_main(shared, rank, w, results, compressed=False):
         out = None
         for _ in range(2):                    # twice: the per-pixel accumulator must be cleared between evaluations
             n_inl, out = sh.iteration(w.traj, w.thres_valid_pixel, w.alpha, download=True)
+        sol = sh.solveNormalEq(*solve) if solve else None
         d = m.dump_state()
         _, ep, _ = m.eval_finish(want_ep=True)
         pix = local.y.astype(np.int64) * w.sensor_w + local.x
         ep_pix = np.zeros(ep.size, dtype=np.int64)
         sel = d["inlier_idx"] >= 0
         ep_pix[d["inlier_idx"][sel]] = pix[sel]
-        results[rank] = dict(ne=out, count=count.cpu().numpy(), ep=ep.copy(), ep_pix=ep_pix, n_inl=n_inl)
+        results[rank] = dict(ne=out, count=count.cpu().numpy(), ep=ep.copy(), ep_pix=ep_pix, n_inl=n_inl, sol=sol)
     except Exception as e:  # noqa: BLE001
         shared.errors.append((rank, repr(e)))
         shared.barrier.abort()
@@ -106,3 +128,27 @@ def test_two_rank_threads_on_one_gpu(oracle_mod, cfg, compressed):
     ep = merge_ep([results[r]["ep"] for r in range(world)], [results[r]["ep_pix"] for r in range(world)])
     assert_close(ep, o["ep"], "merged ep")
     assert sum(results[r]["n_inl"] for r in range(world)) == o["ep"].size
+
+
+@pytest.mark.parametrize("cfg,world,lam,fix", [
+    (dict(n_events=20000), 2, 1e-3, True),
+    (dict(n_events=40000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01), 3, 1e-2, False),
+])
+def test_sharded_schur_solve(oracle_mod, cfg, world, lam, fix):
+    """f1 under sharding: every rank-thread holds a time shard (+ halo); the records are re-distributed by pixel owner, the Schur sums
+    all-reduced, and every rank ends with the x1 / x2 of the single-process oracle solve (model.cpp:721-792)."""
+    import torch
+    assert torch.cuda.is_available()
+    w = small_workload(**cfg)
+    shared, results = _Shared(world), [None] * world
+    th = [threading.Thread(target=_rank_main, args=(shared, r, w, results, False, (lam, fix))) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=180) for t in th]
+    assert not shared.errors, shared.errors
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+    for r in range(world):
+        x1, x2 = results[r]["sol"]
+        assert x1.shape == ox1.shape and x2.shape == ox2.shape
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()), f"rank {r} x1"
+        assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max()), f"rank {r} x2"

@@ -80,6 +80,23 @@ SIGNATURES = {
     "emba_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int32, _fp]),
     "emba_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "emba_last_kernel_ms": (C.c_int, [C.c_void_p, _fp, _fp]),
+    # single-process multi-GPU host
+    "emba_group_create": (C.c_int, [C.POINTER(EmbaCfg), _i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "emba_group_destroy": (None, [C.c_void_p]),
+    "emba_group_last_error": (C.c_char_p, [C.c_void_p]),
+    "emba_group_size": (C.c_int32, [C.c_void_p]),
+    "emba_group_uses_rccl": (C.c_int32, [C.c_void_p]),
+    "emba_group_ctx": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "emba_group_set_events": (C.c_int, [C.c_void_p, _u16p, _u16p, _u8p, _i64p, C.c_size_t]),
+    "emba_group_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_group_step": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
+    "emba_group_download": (C.c_int, [C.c_void_p, _dp, _dp, _u32p, C.c_size_t, _dp, _dp]),
+    "emba_group_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dp, _dp]),
+    "emba_group_solve": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, _dp, _dp]),
+    "emba_group_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "emba_group_map_accept": (C.c_int, [C.c_void_p]),
+    "emba_group_map_reject": (C.c_int, [C.c_void_p]),
+    "emba_group_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
 }
 
 

@@ -1829,3 +1829,6 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
     c->spun = false; c->knots_in_flight = false;
     return EMBA_OK;
 }
+
+// ---- single-process multi-GPU host (emba_group_*) ----------------------------------------------------------------------------
+#include "group.h"

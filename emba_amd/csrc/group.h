@@ -1,0 +1,438 @@
+// emba_amd/csrc/group.h — single-process multi-GPU host of the hot path, behind the C ABI (emba_group_*).
+//
+// The reference front-end is ONE process that owns ONE LEGM (src/emba/emba.cpp:378, called from solver.cpp:63-353).  An emba_group
+// is its drop-in for a node with several GPUs: N contexts on N devices driven by the caller's single host thread, events sharded by
+// time on the global 100-event batch grid with a per-sensor-pixel halo, and per Gauss-Newton iteration the two exchanges of §8e —
+// X1 (count map, as saturated bytes when the activity threshold allows) and X2 (the fp64 pack [A11 | b1 | A22b2]) — as grouped RCCL
+// all-reduces on the contexts' own HIP streams (ncclCommInitAll: one communicator per device, no extra threads or processes).  The
+// Schur solve re-distributes the sparse A12 factors by pixel owner first (grouped ncclSend / ncclRecv), see emba_solve_shard_*.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1) the first time a group spans DISTINCT devices, so the library carries no link
+// dependency on it and never meets a second copy of it in a process that already has one (PyTorch ships its own).  Ranks that share a
+// device (what a one-GPU test box can run: two contexts, two streams, devices = {0, 0}) and single-rank groups exchange through
+// in-library copies and add kernels ordered by events instead — same protocol, same call sequence, no RCCL.
+#pragma once
+#include <dlfcn.h>
+
+#include <set>
+
+namespace emba {
+
+__global__ void emba_add_f64_kernel(double* __restrict__ dst, const double* __restrict__ src, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+__global__ void emba_add_i32_kernel(int32_t* __restrict__ dst, const int32_t* __restrict__ src, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+__global__ void emba_add_u8_kernel(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, long n)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (uint8_t)(dst[i] + src[i]);
+}
+
+}  // namespace emba
+
+namespace {
+
+// ---- RCCL, bound at run time --------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* h = nullptr;
+    typedef void* comm_t;
+    int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+    int (*CommDestroy)(comm_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    enum { kUint8 = 1, kInt32 = 2, kFloat64 = 8, kSum = 0 };   // rccl.h: ncclDataType_t / ncclRedOp_t
+    bool load(std::string* err)
+    {
+        if (h) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) { *err = std::string("cannot load librccl: ") + dlerror(); return false; }
+#define EMBA_SYM(field, sym) do { *(void**)(&field) = dlsym(h, sym); if (!field) { *err = std::string("librccl lacks ") + sym; return false; } } while (0)
+        EMBA_SYM(CommInitAll, "ncclCommInitAll"); EMBA_SYM(CommDestroy, "ncclCommDestroy"); EMBA_SYM(AllReduce, "ncclAllReduce");
+        EMBA_SYM(Send, "ncclSend"); EMBA_SYM(Recv, "ncclRecv"); EMBA_SYM(GroupStart, "ncclGroupStart"); EMBA_SYM(GroupEnd, "ncclGroupEnd");
+        EMBA_SYM(GetErrorString, "ncclGetErrorString");
+#undef EMBA_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+
+}  // namespace
+
+struct emba_group {
+    int n = 0;
+    std::vector<emba_ctx*> ctx;
+    std::vector<int> dev;
+    bool use_rccl = false;
+    std::vector<Rccl::comm_t> comm;
+    std::vector<hipEvent_t> ev;          // one per rank (local exchange ordering)
+    hipEvent_t ev0 = nullptr;
+    std::string err;
+    size_t npix = 0; int sw = 0;
+    // exchange buffers, per rank, on the rank's device
+    std::vector<int32_t*> count; std::vector<uint8_t*> count_u8; std::vector<double*> pack; size_t pack_cap = 0; int pack_K = 0;
+    // per-iteration results
+    size_t P = 0, n_inliers = 0; int K = 0;
+    std::vector<size_t> n_local;
+};
+
+namespace {
+
+emba_status gfail(emba_group* g, emba_status st, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g->err = buf;
+    return st;
+}
+#define G_TRY(g, r, call) do { emba_status st_ = (call); if (st_) return gfail((g), st_, "rank %d: %s", (r), emba_last_error((g)->ctx[(r)])); } while (0)
+#define G_HIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return gfail((g), EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
+#define G_NCCL(g, call) do { int e_ = (call); if (e_ != 0) return gfail((g), EMBA_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(e_)); } while (0)
+
+enum class XType { U8, I32, F64 };
+inline size_t xsize(XType t) { return t == XType::U8 ? 1 : t == XType::I32 ? 4 : 8; }
+
+// all-reduce(SUM) of bufs[r] (count elements each) over the ranks, in place, on the ranks' streams
+emba_status group_allreduce(emba_group* g, void* const* bufs, size_t count, XType t)
+{
+    if ((g->n == 1 && !g->use_rccl) || count == 0) return EMBA_OK;
+    if (g->use_rccl) {
+        const int dt = t == XType::U8 ? Rccl::kUint8 : t == XType::I32 ? Rccl::kInt32 : Rccl::kFloat64;
+        G_NCCL(g, g_rccl.GroupStart());
+        for (int r = 0; r < g->n; ++r) {
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            G_NCCL(g, g_rccl.AllReduce(bufs[r], bufs[r], count, dt, Rccl::kSum, g->comm[r], g->ctx[r]->stream));
+        }
+        G_NCCL(g, g_rccl.GroupEnd());
+        return EMBA_OK;
+    }
+    // ranks on one device: rank 0's stream sums everybody's buffer into its own once the producers are done, the others copy it back
+    G_HIP(g, hipSetDevice(g->dev[0]));
+    hipStream_t s0 = g->ctx[0]->stream;
+    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(g->ev[r], g->ctx[r]->stream)); G_HIP(g, hipStreamWaitEvent(s0, g->ev[r], 0)); }
+    const unsigned grid = (unsigned)((count + 255) / 256);
+    for (int r = 1; r < g->n; ++r) {
+        if (t == XType::F64) hipLaunchKernelGGL(emba::emba_add_f64_kernel, dim3(grid), dim3(256), 0, s0, (double*)bufs[0], (const double*)bufs[r], (long)count);
+        else if (t == XType::I32) hipLaunchKernelGGL(emba::emba_add_i32_kernel, dim3(grid), dim3(256), 0, s0, (int32_t*)bufs[0], (const int32_t*)bufs[r], (long)count);
+        else hipLaunchKernelGGL(emba::emba_add_u8_kernel, dim3(grid), dim3(256), 0, s0, (uint8_t*)bufs[0], (const uint8_t*)bufs[r], (long)count);
+    }
+    G_HIP(g, hipGetLastError());
+    G_HIP(g, hipEventRecord(g->ev0, s0));
+    for (int r = 1; r < g->n; ++r) {
+        G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev0, 0));
+        G_HIP(g, hipMemcpyAsync(bufs[r], bufs[0], count * xsize(t), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
+    }
+    // rank 0 must not overwrite its buffer before the copies have read it
+    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(g->ev[r], g->ctx[r]->stream)); G_HIP(g, hipStreamWaitEvent(s0, g->ev[r], 0)); }
+    return EMBA_OK;
+}
+
+// all-to-all of doubles: rank src sends cnt[src][dst] elements (from send[src], destination-major) to rank dst, which stores them
+// source-major in recv[dst]
+emba_status group_alltoall(emba_group* g, double* const* send, double* const* recv, const std::vector<std::vector<size_t>>& cnt)
+{
+    const int n = g->n;
+    std::vector<std::vector<size_t>> soff(n, std::vector<size_t>(n, 0)), roff(n, std::vector<size_t>(n, 0));
+    for (int s = 0; s < n; ++s) { size_t run = 0; for (int d = 0; d < n; ++d) { soff[s][d] = run; run += cnt[s][d]; } }
+    for (int d = 0; d < n; ++d) { size_t run = 0; for (int s = 0; s < n; ++s) { roff[d][s] = run; run += cnt[s][d]; } }
+    if (g->use_rccl) {
+        G_NCCL(g, g_rccl.GroupStart());
+        for (int r = 0; r < n; ++r) {
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            for (int q = 0; q < n; ++q) {
+                if (cnt[r][q]) G_NCCL(g, g_rccl.Send(send[r] + soff[r][q], cnt[r][q], Rccl::kFloat64, q, g->comm[r], g->ctx[r]->stream));
+                if (cnt[q][r]) G_NCCL(g, g_rccl.Recv(recv[r] + roff[r][q], cnt[q][r], Rccl::kFloat64, q, g->comm[r], g->ctx[r]->stream));
+            }
+        }
+        G_NCCL(g, g_rccl.GroupEnd());
+        return EMBA_OK;
+    }
+    for (int s = 0; s < n; ++s) G_HIP(g, hipEventRecord(g->ev[s], g->ctx[s]->stream));
+    for (int d = 0; d < n; ++d)
+        for (int s = 0; s < n; ++s) {
+            if (!cnt[s][d]) continue;
+            if (s != d) G_HIP(g, hipStreamWaitEvent(g->ctx[d]->stream, g->ev[s], 0));
+            G_HIP(g, hipMemcpyAsync(recv[d] + roff[d][s], send[s] + soff[s][d], cnt[s][d] * 8, hipMemcpyDeviceToDevice, g->ctx[d]->stream));
+        }
+    // a sender may reuse its buffer only after every receiver has copied from it
+    for (int d = 0; d < n; ++d) G_HIP(g, hipEventRecord(g->ev[d], g->ctx[d]->stream));
+    for (int s = 0; s < n; ++s) for (int d = 0; d < n; ++d) if (s != d) G_HIP(g, hipStreamWaitEvent(g->ctx[s]->stream, g->ev[d], 0));
+    return EMBA_OK;
+}
+
+emba_status group_ensure_buffers(emba_group* g, int K)
+{
+    const size_t need = (size_t)9 * K * K + (size_t)3 * K + 5 * g->npix;
+    if (g->pack_cap >= need && !g->pack.empty()) return EMBA_OK;
+    for (int r = 0; r < g->n; ++r) {
+        G_HIP(g, hipSetDevice(g->dev[r]));
+        G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream));
+        if (g->pack[r]) (void)hipFree(g->pack[r]);
+        g->pack[r] = nullptr;
+        G_HIP(g, hipMalloc((void**)&g->pack[r], need * sizeof(double)));
+        if (!g->count[r]) {
+            G_HIP(g, hipMalloc((void**)&g->count[r], g->npix * sizeof(int32_t)));
+            G_HIP(g, hipMalloc((void**)&g->count_u8[r], g->npix));
+            G_HIP(g, hipMemset(g->count[r], 0, g->npix * sizeof(int32_t)));
+        }
+        G_TRY(g, r, emba_bind_exchange_buffers(g->ctx[r], g->count[r], g->pack[r], need));
+    }
+    g->pack_cap = need; g->pack_K = K;
+    return EMBA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, emba_group** out)
+{
+    if (!out) return EMBA_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!cfg || !devices || n_ranks < 1 || n_ranks > 64) return fail(nullptr, EMBA_ERR_INVALID_ARG, "emba_group_create: bad arguments");
+    emba_group* g = new emba_group();
+    g->n = n_ranks;
+    g->npix = (size_t)cfg->pano_w * cfg->pano_h; g->sw = cfg->sensor_w;
+    g->ctx.assign(n_ranks, nullptr); g->dev.assign(devices, devices + n_ranks); g->comm.assign(n_ranks, nullptr); g->ev.assign(n_ranks, nullptr);
+    g->count.assign(n_ranks, nullptr); g->count_u8.assign(n_ranks, nullptr); g->pack.assign(n_ranks, nullptr); g->n_local.assign(n_ranks, 0);
+    auto bail = [&](emba_status st, const std::string& msg) { fail(nullptr, st, "%s", msg.c_str()); emba_group_destroy(g); return st; };
+    for (int r = 0; r < n_ranks; ++r) {
+        emba_cfg c2 = *cfg;
+        c2.device = devices[r]; c2.stream = nullptr;      // every rank gets a stream of its own
+        const emba_status st = emba_create(&c2, &g->ctx[r]);
+        if (st) return bail(st, std::string("rank ") + std::to_string(r) + ": " + emba_last_error(nullptr));
+        if (hipSetDevice(devices[r]) != hipSuccess || hipEventCreateWithFlags(&g->ev[r], hipEventDisableTiming) != hipSuccess) return bail(EMBA_ERR_HIP, "hipEventCreate failed");
+    }
+    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->ev0, hipEventDisableTiming) != hipSuccess) return bail(EMBA_ERR_HIP, "hipEventCreate failed");
+    const std::set<int> distinct(g->dev.begin(), g->dev.end());
+    // EMBA_GROUP_FORCE_RCCL=1: a one-rank group goes through RCCL as well (what a one-GPU box can rehearse of the RCCL path: the run-time
+    // binding, communicator set-up and every collective call, with world size 1)
+    const bool force = n_ranks == 1 && getenv("EMBA_GROUP_FORCE_RCCL") && atoi(getenv("EMBA_GROUP_FORCE_RCCL"));
+    if ((n_ranks > 1 && (int)distinct.size() == n_ranks) || force) {
+        std::string e;
+        if (!g_rccl.load(&e)) return bail(EMBA_ERR_HIP, e);
+        const int rc = g_rccl.CommInitAll(g->comm.data(), n_ranks, g->dev.data());
+        if (rc != 0) return bail(EMBA_ERR_HIP, std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(rc));
+        g->use_rccl = true;
+    } else if (n_ranks > 1 && distinct.size() != 1) {
+        return bail(EMBA_ERR_INVALID_ARG, "a group's ranks must sit on distinct devices (RCCL) or all on one device (in-library exchange)");
+    }
+    *out = g;
+    return EMBA_OK;
+}
+
+void emba_group_destroy(emba_group* g)
+{
+    if (!g) return;
+    for (int r = 0; r < g->n; ++r) {
+        if (g->ctx[r]) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+        if (g->use_rccl && g->comm[r]) (void)g_rccl.CommDestroy(g->comm[r]);
+        if (g->count[r]) (void)hipFree(g->count[r]);
+        if (g->count_u8[r]) (void)hipFree(g->count_u8[r]);
+        if (g->pack[r]) (void)hipFree(g->pack[r]);
+        if (g->ev[r]) (void)hipEventDestroy(g->ev[r]);
+        emba_destroy(g->ctx[r]);
+    }
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    delete g;
+}
+
+const char* emba_group_last_error(const emba_group* g) { return g ? g->err.c_str() : emba_last_error(nullptr); }
+int32_t emba_group_size(const emba_group* g) { return g ? g->n : 0; }
+int32_t emba_group_uses_rccl(const emba_group* g) { return (g && g->use_rccl) ? 1 : 0; }
+emba_ctx* emba_group_ctx(emba_group* g, int32_t rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[rank] : nullptr; }
+
+// Events sorted by time, the reference's EventPacket.  Rank r gets the whole global batches [nb r / N, nb (r+1) / N) and, per sensor
+// pixel, the last event before its range with the midpoint time of the (global) batch that event belongs to (emba_set_events).
+emba_status emba_group_set_events(emba_group* g, const uint16_t* x, const uint16_t* y, const uint8_t* pol, const int64_t* t_ns, size_t n)
+{
+    if (!g || (n && (!x || !y || !pol || !t_ns))) return g ? gfail(g, EMBA_ERR_INVALID_ARG, "event arrays are NULL") : EMBA_ERR_INVALID_ARG;
+    const size_t nb = n / 100;
+    const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
+    for (size_t k = 0; k < nb * 100; ++k)
+        if (x[k] >= g->ctx[0]->sw || y[k] >= g->ctx[0]->sh) return gfail(g, EMBA_ERR_INVALID_ARG, "event %zu lies outside the sensor", k);
+    std::vector<int64_t> last(S, -1);
+    size_t k = 0, b = 0;
+    for (int r = 0; r < g->n; ++r) {
+        const size_t cnt = nb / g->n + ((size_t)r < nb % g->n ? 1 : 0);
+        const size_t lo = b * 100, hi = (b + cnt) * 100;
+        for (; k < lo; ++k) last[(size_t)y[k] * g->sw + x[k]] = (int64_t)k;      // events before this rank's range
+        std::vector<uint16_t> hx, hy; std::vector<int64_t> hbt;
+        if (lo) {
+            std::vector<int64_t> idx;
+            for (size_t p = 0; p < S; ++p) if (last[p] >= 0) idx.push_back(last[p]);
+            std::sort(idx.begin(), idx.end());                                      // time order
+            for (int64_t i : idx) {
+                const size_t bb = (size_t)i / 100;
+                hx.push_back(x[i]); hy.push_back(y[i]); hbt.push_back(batch_mid_ns(t_ns[100 * bb], t_ns[100 * bb + 99]));
+            }
+        }
+        // the last rank also receives the n % 100 tail the reference drops (quirk Q1): emba_set_events ignores it the same way
+        const size_t n_r = (r == g->n - 1) ? n - lo : hi - lo;
+        G_TRY(g, r, emba_set_events(g->ctx[r], x + lo, y + lo, pol + lo, t_ns + lo, n_r, hx.data(), hy.data(), hbt.data(), hx.size()));
+        g->n_local[r] = hi - lo;
+        b += cnt;
+    }
+    return EMBA_OK;
+}
+
+emba_status emba_group_upload_map(emba_group* g, const double* Gx, const double* Gy)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_upload_map(g->ctx[r], Gx, Gy));
+    return EMBA_OK;
+}
+
+// One evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks (the map must be resident): E1 | X1 | E2, F1 | F2 | X2 | F3.
+emba_status emba_group_step(emba_group* g, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, int32_t thres, int32_t irls, double eta,
+                            double alpha, size_t* n_inliers, size_t* P)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    g->K = K;
+    if (g->n == 1 && !g->use_rccl) {
+        G_TRY(g, 0, emba_step(g->ctx[0], knots, K, t0_ns, dt_ns, thres, irls, eta, alpha, &g->n_inliers, &g->P));
+        if (n_inliers) *n_inliers = g->n_inliers;
+        if (P) *P = g->P;
+        return EMBA_OK;
+    }
+    { emba_status st = group_ensure_buffers(g, K); if (st) return st; }
+    for (int r = 0; r < g->n; ++r) {
+        G_TRY(g, r, emba_set_cost(g->ctx[r], irls, eta));
+        G_TRY(g, r, emba_eval_launch(g->ctx[r], knots, K, t0_ns, dt_ns));                                   // E1
+    }
+    const int cap = 255 / g->n;
+    if (thres <= cap) {   // X1 as saturated bytes: sum_i min(c_i, cap) >= thres <=> sum_i c_i >= thres, and world * cap <= 255 cannot wrap
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_compress(g->ctx[r], g->count_u8[r], cap));
+        { emba_status st = group_allreduce(g, (void* const*)g->count_u8.data(), g->npix, XType::U8); if (st) return st; }
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_expand(g->ctx[r], g->count_u8[r]));
+    } else {
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_map_ready(g->ctx[r]));
+        { emba_status st = group_allreduce(g, (void* const*)g->count.data(), g->npix, XType::I32); if (st) return st; }
+    }
+    size_t Pr = 0, pl = 0;
+    for (int r = 0; r < g->n; ++r) {
+        G_TRY(g, r, emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr));                                   // E2 (enqueue only)
+        G_TRY(g, r, emba_form_active(g->ctx[r], thres, &Pr, &pl));                                              // F1 (global counts: identical everywhere)
+        if (r && Pr != g->P) return gfail(g, EMBA_ERR_STATE, "ranks disagree on the active set (%zu vs %zu pixels)", Pr, g->P);
+        g->P = Pr;
+        G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                                       // F2
+    }
+    { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }   // X2
+    g->n_inliers = 0;
+    for (int r = 0; r < g->n; ++r) {
+        G_TRY(g, r, emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));   // F3: applyL2Reg once, after the reduce
+        size_t ni = 0, pp = 0;
+        G_TRY(g, r, emba_last_counts(g->ctx[r], &ni, &pp));
+        g->n_inliers += ni;
+    }
+    if (n_inliers) *n_inliers = g->n_inliers;
+    if (P) *P = g->P;
+    return EMBA_OK;
+}
+
+// The reduced blocks (identical on every rank; read from rank 0): the out-arguments of formNormalEq + applyL2Reg.
+emba_status emba_group_download(emba_group* g, double* A11, double* b1, uint32_t* active_idx, size_t cap_P, double* A22, double* b2)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    // (alpha = 0 here: the L2 term was applied by the step; form_finish applies it once per set of blocks anyway)
+    G_TRY(g, 0, emba_form_finish(g->ctx[0], 0.0, A11, b1, active_idx, cap_P, A22, b2, nullptr));
+    return EMBA_OK;
+}
+
+// 0.5 * ep.ep (or the robust cost) summed over the ranks' measurements + alpha/2 |G|^2 from the replicated map.
+emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    double d = 0;
+    for (int r = 0; r < g->n; ++r) { double v = 0; G_TRY(g, r, emba_data_cost(g->ctx[r], irls, eta, &v)); d += v; }
+    if (data_cost) *data_cost = d;
+    if (reg_cost) G_TRY(g, 0, emba_reg_cost(g->ctx[0], alpha, reg_cost));
+    return EMBA_OK;
+}
+
+// LEGM::solveNormalEq (model.cpp:721-792) over the group: records to their pixel owners, partial Schur sums, all-reduce, replicated
+// Cholesky, x2 exchanged.  x1_host: 3K, x2_host: 2P (either may be NULL).
+emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    if (g->n == 1 && !g->use_rccl) { G_TRY(g, 0, emba_solve_normal_eq(g->ctx[0], lambda, fix_first_pose, x1_host, x2_host)); return EMBA_OK; }
+    const int n = g->n;
+    std::vector<std::vector<size_t>> cnt(n, std::vector<size_t>(n, 0));
+    for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_count(g->ctx[r], n, cnt[r].data()));
+    std::vector<double*> send(n, nullptr), recv(n, nullptr), S(n, nullptr), x2(n, nullptr);
+    std::vector<size_t> n_recv(n, 0);
+    size_t s_doubles = 0;
+    G_TRY(g, 0, emba_solve_shard_size(g->ctx[0], &s_doubles));
+    auto cleanup = [&]() { for (int r = 0; r < n; ++r) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream);
+                                                         for (double* p : {send[r], recv[r], S[r], x2[r]}) if (p) (void)hipFree(p); } };
+    emba_status st = EMBA_OK;
+    auto run = [&]() -> emba_status {
+        std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
+        for (int r = 0; r < n; ++r) {
+            size_t ns = 0;
+            for (int d = 0; d < n; ++d) { ns += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            G_HIP(g, hipMalloc((void**)&send[r], std::max<size_t>(ns, 1) * 16 * 8));
+            G_TRY(g, r, emba_solve_shard_pack(g->ctx[r], n, send[r]));
+        }
+        for (int r = 0; r < n; ++r) {
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            G_HIP(g, hipMalloc((void**)&recv[r], std::max<size_t>(n_recv[r], 1) * 16 * 8));
+            G_HIP(g, hipMalloc((void**)&S[r], s_doubles * 8));
+            G_HIP(g, hipMalloc((void**)&x2[r], std::max<size_t>(2 * g->P, 2) * 8));
+        }
+        { emba_status s2 = group_alltoall(g, send.data(), recv.data(), cnt16); if (s2) return s2; }
+        for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_partial(g->ctx[r], r, n, recv[r], n_recv[r], lambda, S[r]));
+        { emba_status s2 = group_allreduce(g, (void* const*)S.data(), s_doubles, XType::F64); if (s2) return s2; }
+        for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_finish(g->ctx[r], r, n, recv[r], n_recv[r], lambda, fix_first_pose, S[r], r == 0 ? x1_host : nullptr, x2[r]));
+        { emba_status s2 = group_allreduce(g, (void* const*)x2.data(), 2 * g->P, XType::F64); if (s2) return s2; }
+        if (x2_host && g->P) {
+            G_HIP(g, hipSetDevice(g->dev[0]));
+            G_HIP(g, hipMemcpyAsync(x2_host, x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        }
+        return EMBA_OK;
+    };
+    st = run();
+    cleanup();
+    return st;
+}
+
+// LEGM::updateMap (model.cpp:863-903) and the LM decision on every rank's replica of the map
+emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_update_map(g->ctx[r], x2_host, damping));
+    return EMBA_OK;
+}
+emba_status emba_group_map_accept(emba_group* g)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_map_accept(g->ctx[r]));
+    return EMBA_OK;
+}
+emba_status emba_group_map_reject(emba_group* g)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_map_reject(g->ctx[r]));
+    return EMBA_OK;
+}
+emba_status emba_group_download_map(emba_group* g, double* Gx, double* Gy)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    G_TRY(g, 0, emba_download_map(g->ctx[0], Gx, Gy));
+    return EMBA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// emba_amd/host/legm_sharded.hpp — the reference's measurement model for a node with several GPUs, driven by ONE host thread.
+//
+// The reference front-end is a single process that owns a single `EMBA::LEGM` (reference src/emba/emba.cpp:378) and calls it from
+// `EMBA::solveTimeWindow` (src/emba/solver.cpp:63-353).  `emba_host::ShardedLEGM` keeps that shape: one object, the same call order
+// (evaluate / form / applyL2Reg fused into iterate(), solveNormalEq, updateMap, accept / reject), with the window's events sharded by
+// time over the devices behind it.  All of it is the C ABI's emba_group_* (include/emba_hip.h): N contexts on N
+// devices, the two per-iteration exchanges as grouped RCCL all-reduces on the contexts' streams, the Schur solve on records
+// re-distributed by pixel owner.  No Python, no extra processes or threads.  Free of ROS / OpenCV / Eigen types like legm_host.hpp.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "legm_host.hpp"
+
+namespace emba_host {
+
+class ShardedLEGM {
+public:
+    // devices: one entry per rank.  Distinct devices: RCCL over xGMI.  All equal (e.g. {0, 0}): ranks share a GPU (tests).
+    ShardedLEGM(int sensor_w, int sensor_h, const double* bearing_lut, double C_th, int pano_width, int pano_height, const std::vector<int>& devices)
+        : W_(pano_width), H_(pano_height)
+    {
+        emba_cfg cfg{};
+        cfg.sensor_w = sensor_w; cfg.sensor_h = sensor_h; cfg.pano_w = pano_width; cfg.pano_h = pano_height;
+        cfg.bearing_lut = bearing_lut; cfg.C_th = C_th; cfg.event_batch = 100; cfg.outlier_px = 10.0;
+        std::vector<int32_t> dev(devices.begin(), devices.end());
+        const emba_status st = emba_group_create(&cfg, dev.data(), (int32_t)dev.size(), &g_);
+        if (st != EMBA_OK) throw std::runtime_error("emba_group_create status " + std::to_string((int)st) + ": " + emba_last_error(nullptr));
+    }
+    ~ShardedLEGM() { emba_group_destroy(g_); }
+    ShardedLEGM(const ShardedLEGM&) = delete;
+    ShardedLEGM& operator=(const ShardedLEGM&) = delete;
+
+    int world() const { return emba_group_size(g_); }
+    bool usesRccl() const { return emba_group_uses_rccl(g_) != 0; }
+
+    // the EventPacket argument of evaluateDataError (model.h:83-84), once per window
+    void setEvents(const EventPacket& ev)
+    {
+        std::vector<uint16_t> x(ev.size()), y(ev.size());
+        std::vector<uint8_t> pol(ev.size());
+        std::vector<int64_t> t(ev.size());
+        for (size_t k = 0; k < ev.size(); ++k) { x[k] = ev[k].x; y[k] = ev[k].y; pol[k] = ev[k].polarity ? 1 : 0; t[k] = ev[k].t_ns; }
+        check(emba_group_set_events(g_, x.data(), y.data(), pol.data(), t.data(), ev.size()));
+    }
+    void uploadMap(const double* Gx, const double* Gy) { check(emba_group_upload_map(g_, Gx, Gy)); }
+
+    // evaluateDataError (model.cpp:72-258) + formNormalEq[IRLS] (:316-687) + applyL2Reg (:689-719) on the resident map, over all ranks.
+    // Returns the number of inlier measurements; numActivePixels() afterwards.
+    size_t iterate(const TrajectoryView& traj, int thres_valid_pixel, const std::string& cost_type, double a, double alpha)
+    {
+        K_ = traj.num_ctrl_poses;
+        size_t n_inl = 0;
+        check(emba_group_step(g_, traj.knots_xyzw, traj.num_ctrl_poses, traj.t0_ns, traj.dt_ns, thres_valid_pixel, irls_code(cost_type), a, alpha, &n_inl, &P_));
+        return n_inl;
+    }
+    size_t numActivePixels() const { return P_; }
+
+    // the out-arguments of formNormalEq + applyL2Reg (reduced over the ranks)
+    void download(NormalEquations& ne)
+    {
+        const size_t P = P_, dim = 3 * (size_t)K_;
+        ne.dim_ctrl_poses = (int)dim; ne.num_active_pixels = P;
+        ne.A11.assign(dim * dim, 0.0); ne.b1.assign(dim, 0.0); ne.A22_blocks.assign(4 * P, 0.0); ne.b2.assign(2 * P, 0.0); ne.active_pix_idxes.assign(P, 0);
+        check(emba_group_download(g_, ne.A11.data(), ne.b1.data(), P ? ne.active_pix_idxes.data() : nullptr, P, P ? ne.A22_blocks.data() : nullptr,
+                                  P ? ne.b2.data() : nullptr));
+    }
+
+    // 0.5*ep.dot(ep) / evaluateRobustDataCost (solver.cpp:88, model.cpp:279-314) + alpha*0.5*|evaluateRegError|^2 (model.cpp:260-277)
+    double totalCost(const std::string& cost_type, double a, double alpha)
+    {
+        double d = 0, r = 0;
+        check(emba_group_costs(g_, irls_code(cost_type), a, alpha, &d, &r));
+        return d + r;
+    }
+
+    // solveNormalEq(A11, A12, A22_blocks, b1, b2, lambda, x1, x2)   model.cpp:721-792
+    void solveNormalEq(double lambda, bool fix_first_pose, std::vector<double>& x1, std::vector<double>& x2)
+    {
+        x1.assign(3 * (size_t)K_, 0.0); x2.assign(2 * P_, 0.0);
+        check(emba_group_solve(g_, lambda, fix_first_pose ? 1 : 0, x1.data(), P_ ? x2.data() : nullptr));
+    }
+
+    // updateMap (model.cpp:863-903) into the trial map; the LM decision (solver.cpp:299-352)
+    void updateMap(const std::vector<double>& x2, double damping_factor) { check(emba_group_update_map(g_, x2.data(), damping_factor)); }
+    void acceptMap() { check(emba_group_map_accept(g_)); }
+    void rejectMap() { check(emba_group_map_reject(g_)); }
+    void downloadMap(double* Gx, double* Gy) { check(emba_group_download_map(g_, Gx, Gy)); }
+
+    emba_group* group() { return g_; }
+
+private:
+    static int irls_code(const std::string& t) { return t == "cauchy" ? 2 : t == "huber" ? 1 : 0; }
+    void check(emba_status st)
+    {   // the reference aborts through glog CHECK / LOG(FATAL); callers that link glog can catch and LOG(FATAL)
+        if (st != EMBA_OK) throw std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + emba_group_last_error(g_));
+    }
+    emba_group* g_ = nullptr;
+    int W_, H_, K_ = 0;
+    size_t P_ = 0;
+};
+
+}  // namespace emba_host

@@ -295,6 +295,35 @@ emba_status emba_timer_elapsed_ms(emba_ctx* ctx, int32_t slot, float* ms); /* sy
 emba_status emba_enable_kernel_timing(emba_ctx* ctx, int32_t on);
 emba_status emba_last_kernel_ms(emba_ctx* ctx, float* warp_ms, float* accum_ms);
 
+/* ---- Several GPUs behind ONE host thread ------------------------------------------------------------------------
+ * The reference front-end is one process that owns one LEGM (src/emba/emba.cpp:378; solver.cpp:63-353 calls it).  An emba_group is
+ * that object for a multi-GPU node: n_ranks contexts on devices[0..n_ranks), events sharded by time on the global batch grid with
+ * a per-pixel halo, the two exchanges of an iteration as grouped RCCL all-reduces on the contexts' own streams (ncclCommInitAll,
+ * librccl bound at run time).  All ranks on ONE device (devices = {0, 0}: what a single-GPU box can test) or n_ranks = 1 exchange
+ * through in-library copies and add kernels instead — same protocol, no RCCL.  Same call order as the single-GPU entry points:
+ *   emba_group_set_events -> emba_group_upload_map -> { emba_group_step -> [emba_group_download] -> emba_group_solve ->
+ *   emba_group_update_map -> emba_group_step ... -> emba_group_map_accept / _reject }.  emba_group_ctx gives a rank's context for
+ * anything else (diagnostics, dumps). */
+typedef struct emba_group emba_group;
+emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, emba_group** out);   /* cfg->device, cfg->stream are ignored */
+void        emba_group_destroy(emba_group* g);
+const char* emba_group_last_error(const emba_group* g);
+int32_t     emba_group_size(const emba_group* g);
+int32_t     emba_group_uses_rccl(const emba_group* g);
+emba_ctx*   emba_group_ctx(emba_group* g, int32_t rank);
+emba_status emba_group_set_events(emba_group* g, const uint16_t* x, const uint16_t* y, const uint8_t* pol, const int64_t* t_ns, size_t n);
+emba_status emba_group_upload_map(emba_group* g, const double* Gx, const double* Gy);
+/* evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks; n_inliers = total over the ranks, P = active pixels */
+emba_status emba_group_step(emba_group* g, const double* knots_xyzw, int32_t K, int64_t t0_ns, int64_t dt_ns, int32_t thres_valid_pixel,
+                            int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
+emba_status emba_group_download(emba_group* g, double* A11, double* b1, uint32_t* active_idx, size_t cap_P, double* A22, double* b2);
+emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost);
+emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
+emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping);
+emba_status emba_group_map_accept(emba_group* g);
+emba_status emba_group_map_reject(emba_group* g);
+emba_status emba_group_download_map(emba_group* g, double* Gx_host, double* Gy_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,11 +12,30 @@ from helpers import oracle_run, small_workload
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build(tmp_path, hip_lib):
-    exe = str(tmp_path / "host_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", "host_test.cpp"), "-o", exe,
+def _build(tmp_path, hip_lib, name="host_test"):
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L", os.path.join(ROOT, "emba_amd"), "-lemba_hip", "-Wl,-rpath," + os.path.join(ROOT, "emba_amd")])
     return exe
+
+
+def _write_case(path, w, o, solve=None):
+    ne = o["ne"]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.K, w.thres_valid_pixel))
+        f.write(struct.pack("<3q", w.traj.t0_ns, w.traj.dt_ns, w.events.size()))
+        f.write(struct.pack("<2d", w.C_th, w.alpha))
+        for a, dt in ((w.lut, "<f8"), (w.traj.knots_xyzw, "<f8"), (w.Gx, "<f8"), (w.Gy, "<f8"), (w.events.x, "<u2"), (w.events.y, "<u2"),
+                      (w.events.polarity, "u1"), (w.events.t_ns, "<i8")):
+            f.write(np.ascontiguousarray(a).astype(dt).tobytes())
+        f.write(struct.pack("<q", o["ep"].size)); f.write(o["ep"].astype("<f8").tobytes()); f.write(o["num_ev_map"].astype("<i4").tobytes())
+        f.write(struct.pack("<q", ne["P"]))
+        f.write(np.asfortranarray(ne["A11"]).ravel(order="F").astype("<f8").tobytes()); f.write(ne["b1"].astype("<f8").tobytes())
+        f.write(ne["A22"].astype("<f8").tobytes()); f.write(ne["b2"].astype("<f8").tobytes()); f.write(ne["active"].astype("<u4").tobytes())
+        if solve is not None:
+            lam, fix, x1, x2 = solve
+            f.write(struct.pack("<d", lam)); f.write(struct.pack("<i", 1 if fix else 0))
+            f.write(x1.astype("<f8").tobytes()); f.write(x2.astype("<f8").tobytes())
 
 
 def test_cpp_host_compiles_and_links(tmp_path, hip_lib):
@@ -30,19 +49,35 @@ def test_cpp_host_matches_oracle(tmp_path, hip_lib, oracle_mod):
     exe = _build(tmp_path, hip_lib)
     w = small_workload(n_events=20000)
     o = oracle_run(oracle_mod, w)
-    ne = o["ne"]
     p = tmp_path / "in.bin"
-    with open(p, "wb") as f:
-        f.write(struct.pack("<6i", w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.K, w.thres_valid_pixel))
-        f.write(struct.pack("<3q", w.traj.t0_ns, w.traj.dt_ns, w.events.size()))
-        f.write(struct.pack("<2d", w.C_th, w.alpha))
-        for a, dt in ((w.lut, "<f8"), (w.traj.knots_xyzw, "<f8"), (w.Gx, "<f8"), (w.Gy, "<f8"), (w.events.x, "<u2"), (w.events.y, "<u2"),
-                      (w.events.polarity, "u1"), (w.events.t_ns, "<i8")):
-            f.write(np.ascontiguousarray(a).astype(dt).tobytes())
-        f.write(struct.pack("<q", o["ep"].size)); f.write(o["ep"].astype("<f8").tobytes()); f.write(o["num_ev_map"].astype("<i4").tobytes())
-        f.write(struct.pack("<q", ne["P"]))
-        f.write(np.asfortranarray(ne["A11"]).ravel(order="F").astype("<f8").tobytes()); f.write(ne["b1"].astype("<f8").tobytes())
-        f.write(ne["A22"].astype("<f8").tobytes()); f.write(ne["b2"].astype("<f8").tobytes()); f.write(ne["active"].astype("<u4").tobytes())
+    _write_case(p, w, o)
     r = subprocess.run([exe, str(p)], capture_output=True, text=True, timeout=120)
     print(r.stdout, r.stderr)
     assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+
+
+def test_cpp_sharded_host_compiles_and_links(tmp_path, hip_lib):
+    exe = _build(tmp_path, hip_lib, "sharded_test")
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,force_rccl", [("0", False), ("0,0", False), ("0,0,0", False), ("0", True)])
+def test_cpp_sharded_host_matches_oracle(tmp_path, hip_lib, oracle_mod, devices, force_rccl):
+    """The single-process multi-GPU host (emba_host::ShardedLEGM over emba_group_*): 1, 2 and 3 ranks on one GPU (two / three contexts and
+    streams, in-library exchange), the whole LM-iteration call order incl. the sharded Schur solve, against the single-process oracle."""
+    exe = _build(tmp_path, hip_lib, "sharded_test")
+    w = small_workload(n_events=30000)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    lam, fix = 1e-3, True
+    x1, x2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+    p = tmp_path / "in.bin"
+    _write_case(p, w, o, (lam, fix, x1, x2))
+    env = dict(os.environ)
+    if force_rccl:      # one rank through RCCL itself: run-time binding of librccl, ncclCommInitAll, grouped all-reduce / send / recv calls
+        env["EMBA_GROUP_FORCE_RCCL"] = "1"
+    r = subprocess.run([exe, str(p), devices], capture_output=True, text=True, timeout=180, env=env)
+    print(r.stdout, r.stderr)
+    last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""      # (RCCL prints a version banner first)
+    assert r.returncode == 0 and last.startswith("OK"), r.stdout + r.stderr
+    assert f"world={len(devices.split(','))} rccl={int(force_rccl)}" in last

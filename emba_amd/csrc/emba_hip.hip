@@ -16,6 +16,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.h"
@@ -84,7 +85,10 @@ struct emba_ctx {
     long nblk = 0;
     uint32_t* d_pm_pix = nullptr; uint32_t* d_pm_batch = nullptr; uint32_t* d_pm_orig = nullptr;   // pm-order = (sensor pixel, time): the reference's per-pixel vectors laid end to end
     uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;    // device order (== pm-order arrays in pixel order; own arrays in tile order)
+    uint32_t* d_ev_pix_own = nullptr; uint32_t* d_ev_batch_own = nullptr;                          // tile order: the arrays d_ev_pix / d_ev_batch point to
     uint32_t* d_ev_pm = nullptr; uint32_t* d_perm = nullptr;                                        // tile order only: entry -> pm index, pm index -> entry
+    bool have_ev_pm = false;
+    std::unordered_map<void**, size_t> caps;                                                        // capacities of the grow-only device buffers (dev_alloc)
     uint16_t* d_cp = nullptr;                                                                       // control-pose index per batch
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
     bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
@@ -147,34 +151,46 @@ emba_status fail(emba_ctx* c, emba_status st, const char* fmt, ...)
                         __FILE__, __LINE__);                                                     \
     } while (0)
 
+// Grow-only device buffers: a buffer is re-allocated only when it has to grow, so that registering the next window of a sliding-window
+// run (same sizes) costs kernels, not hipMalloc / hipFree of gigabytes (measured at 100 M events: 270 ms of allocator time around
+// 10 ms of kernels).  `fresh` tells the caller that the memory is new (uninitialised).
 template <typename T>
-emba_status dev_alloc(emba_ctx* c, T** p, size_t count)
+emba_status dev_alloc(emba_ctx* c, T** p, size_t count, bool* fresh = nullptr)
 {
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    void** key = reinterpret_cast<void**>(p);
+    auto it = c->caps.find(key);
+    if (*p && it != c->caps.end() && it->second >= bytes) { if (fresh) *fresh = false; return EMBA_OK; }
+    if (*p) (void)hipFree(*p);
     *p = nullptr;
-    if (count == 0) count = 1;
-    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    c->caps.erase(key);
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(p), bytes));
+    c->caps[key] = bytes;
+    if (fresh) *fresh = true;
     return EMBA_OK;
 }
 
 template <typename T>
-void dev_free(T*& p)
+void dev_free(emba_ctx* c, T*& p)
 {
     if (p) (void)hipFree(p);
+    if (c) c->caps.erase(reinterpret_cast<void**>(&p));
     p = nullptr;
 }
 
 void free_window(emba_ctx* c)
-{
-    if (c->d_ev_pix != c->d_pm_pix) dev_free(c->d_ev_pix);
-    if (c->d_ev_batch != c->d_pm_batch) dev_free(c->d_ev_batch);
+{   // (the buffers stay: the next window reuses them, see dev_alloc)
     c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
-    dev_free(c->d_pm_pix); dev_free(c->d_pm_batch); dev_free(c->d_pm_orig); dev_free(c->d_ev_slot); dev_free(c->d_ev_pm); dev_free(c->d_perm);
-    dev_free(c->d_cp); dev_free(c->d_chunks); dev_free(c->d_batch_t);
-    dev_free(c->d_pose); dev_free(c->d_rec); dev_free(c->d_slot_key); dev_free(c->d_e_sorted);
-    dev_free(c->d_flag); dev_free(c->d_inl_idx); dev_free(c->d_fblk_cnt); dev_free(c->d_fblk_off);
-    dev_free(c->d_ep);
-    c->have_events = false; c->keys_ready = false; c->tile_order = false; c->n_chunks = 0; c->n_lead = 0;
+    c->have_events = false; c->keys_ready = false; c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
+}
+
+void free_all_buffers(emba_ctx* c)
+{
+    std::vector<void**> keys;
+    for (auto& kv : c->caps) keys.push_back(kv.first);
+    for (void** k : keys) { if (*k) (void)hipFree(*k); *k = nullptr; }
+    c->caps.clear();
 }
 
 // ros::Time/Duration midpoint of a batch (model.cpp:116-119; rostime semantics per SURVEY Appendix A):
@@ -263,18 +279,15 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     hipStream_t s = c->stream;
     emba_status st;
     const size_t ns = c->n_pm, nbatch = c->n_batch;
-    // (a previous order of this window goes away)
-    if (c->d_ev_pix != c->d_pm_pix) dev_free(c->d_ev_pix);
-    if (c->d_ev_batch != c->d_pm_batch) dev_free(c->d_ev_batch);
+    // (a previous order of this window goes away; its buffers are reused)
     c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
-    dev_free(c->d_ev_slot); dev_free(c->d_ev_pm); dev_free(c->d_perm); dev_free(c->d_chunks); dev_free(c->d_e_sorted); dev_free(c->d_flag); dev_free(c->d_inl_idx);
-    c->tile_order = false; c->n_chunks = 0; c->n_lead = 0;
+    c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0;
 
     // control-pose index per batch; a batch outside the knots is an error (BASALT_ASSERT_STREAM at so3_spline.h:221-229)
     uint32_t* d_err = nullptr;
     if ((st = ws_get(c, 19, 64, (void**)&d_err))) return st;
     HIP_TRY(c, hipMemsetAsync(d_err, 0xFF, 64, s));
-    if (!c->d_cp && (st = dev_alloc(c, &c->d_cp, nbatch))) return st;
+    if ((st = dev_alloc(c, &c->d_cp, nbatch))) return st;
     if (nbatch) hipLaunchKernelGGL(emba_batch_cp_kernel, dim3(nblocks(nbatch)), dim3(256), 0, s, c->d_batch_t, (long)nbatch, t0, dt, K, c->d_cp, d_err);
     uint32_t h_err[16];
     HIP_TRY(c, hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
@@ -341,9 +354,10 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
             return st;
         hipLaunchKernelGGL(emba_expand_write_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, d_emit, d_pos, (long)ns, k0, v0);
         if ((st = dev_sort(c, &k0, &v0, &k1, &v1, nd, bits_for(nbins)))) return st;
-        if ((st = dev_alloc(c, &c->d_ev_pix, nd)) || (st = dev_alloc(c, &c->d_ev_batch, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd)) ||
+        if ((st = dev_alloc(c, &c->d_ev_pix_own, nd)) || (st = dev_alloc(c, &c->d_ev_batch_own, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd)) ||
             (st = dev_alloc(c, &c->d_perm, ns)))
             return st;
+        c->d_ev_pix = c->d_ev_pix_own; c->d_ev_batch = c->d_ev_batch_own; c->have_ev_pm = true;
         HIP_TRY(c, hipMemsetAsync(c->d_perm, 0xFF, std::max<size_t>(ns, 1) * 4, s));
         HIP_TRY(c, hipMemsetAsync(d_bin_start, 0xFF, (nbins + 1) * 4, s));
         uint32_t* d_cf = d_emit;    // (emit is dead: its buffer now takes the candidate flags of the device order — nd <= 2 ns may exceed it)
@@ -413,7 +427,6 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, std::max<size_t>(nd, 1), s));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));
-    ws_release(c, 16, 31);   // hundreds of MB at 100 M events: not kept around
     c->keys_ready = true; c->key_t0 = t0; c->key_dt = dt; c->key_K = K;
     c->prepare_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return EMBA_OK;
@@ -428,7 +441,7 @@ emba_status ensure_pack(emba_ctx* c, int K)
         return EMBA_OK;
     }
     if (c->pack_own_cap < need) {
-        dev_free(c->d_pack_own);
+        dev_free(c, c->d_pack_own);
         emba_status st = dev_alloc(c, &c->d_pack_own, need);
         if (st) return st;
         c->pack_own_cap = need;
@@ -479,10 +492,11 @@ emba_status launch_ep_compaction(emba_ctx* c)
     c->ep_deferred = false;
     hipStream_t s = c->stream;
     if (c->n_pm) {
-        hipLaunchKernelGGL(emba_flag_count_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_flag, c->d_perm, (long)c->n_pm, c->d_fblk_cnt);
+        const uint32_t* perm = c->tile_order ? c->d_perm : nullptr;
+        hipLaunchKernelGGL(emba_flag_count_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_flag, perm, (long)c->n_pm, c->d_fblk_cnt);
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total,
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
-        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, c->d_perm, c->d_fblk_off,
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, perm, c->d_fblk_off,
                            (long)c->n_pm, c->d_ep, c->d_inl_idx);
         HIP_TRY(c, hipGetLastError());
     } else {
@@ -597,25 +611,25 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipSetDevice(c->device));
     if (cfg->stream) { c->stream = (hipStream_t)cfg->stream; c->own_stream = false; }
     else { CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-    CREATE_TRY(hipMalloc((void**)&c->d_lut, c->S * 3 * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&c->d_lut, c->S * 3 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_lut)] = c->S * 3 * sizeof(double);
     CREATE_TRY(hipMemcpy(c->d_lut, cfg->bearing_lut, c->S * 3 * sizeof(double), hipMemcpyHostToDevice));
     c->cfg.bearing_lut = nullptr;  // not retained
-    CREATE_TRY(hipMalloc((void**)&c->d_texel, c->npix * kTexelStride * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&c->d_count_own, c->npix * sizeof(int32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_texel, c->npix * kTexelStride * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_texel)] = c->npix * kTexelStride * sizeof(double);
+    CREATE_TRY(hipMalloc((void**)&c->d_count_own, c->npix * sizeof(int32_t))); c->caps[reinterpret_cast<void**>(&c->d_count_own)] = c->npix * sizeof(int32_t);
     c->d_count = c->d_count_own;
-    CREATE_TRY(hipMalloc((void**)&c->d_pixacc, c->npix * kPixAccStride * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t)));
-    CREATE_TRY(hipMalloc((void**)&c->d_active_bits, (c->npix + 31) / 32 * 4 + 8));
-    CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t)));
+    CREATE_TRY(hipMalloc((void**)&c->d_pixacc, c->npix * kPixAccStride * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_pixacc)] = c->npix * kPixAccStride * sizeof(double);
+    CREATE_TRY(hipMalloc((void**)&c->d_compact, c->npix * sizeof(int32_t))); c->caps[reinterpret_cast<void**>(&c->d_compact)] = c->npix * sizeof(int32_t);
+    CREATE_TRY(hipMalloc((void**)&c->d_active_bits, (c->npix + 31) / 32 * 4 + 8)); c->caps[reinterpret_cast<void**>(&c->d_active_bits)] = (c->npix + 31) / 32 * 4 + 8;
+    CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_active)] = c->npix * sizeof(uint32_t);
     c->n_ablk = (c->npix + kActivePix - 1) / kActivePix;
-    CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int)));
-    CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int)));
+    CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_cnt)] = c->n_ablk * sizeof(uint32_t);
+    CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_off)] = c->n_ablk * sizeof(uint32_t);
+    CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_err)] = sizeof(int);
+    CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_rect)] = 4 * sizeof(int);
     { const int init[4] = {0x7FFFFFFF, 0x7FFFFFFF, -1, -1}; CREATE_TRY(hipMemcpy(c->d_rect, init, sizeof init, hipMemcpyHostToDevice)); }
-    CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, ((c->npix + 1023) / 1024) * 4 * sizeof(int)));
-    CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t)));
-    CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, ((c->npix + 1023) / 1024) * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = ((c->npix + 1023) / 1024) * 4 * sizeof(int);
+    CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_total)] = 2 * sizeof(uint32_t);
+    CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_scalar)] = 2 * sizeof(double);
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
     memset(c->h_pinned, 0, 64);
     CREATE_TRY(hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0));
@@ -633,11 +647,7 @@ void emba_destroy(emba_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_window(c);
-    dev_free(c->d_lut); dev_free(c->d_texel); dev_free(c->d_Gx_own); dev_free(c->d_Gy_own); dev_free(c->d_Gx_trial); dev_free(c->d_Gy_trial); dev_free(c->d_x2);
-    dev_free(c->d_count_own); dev_free(c->d_pixacc); dev_free(c->d_SH); dev_free(c->d_SW); dev_free(c->d_lamH); dev_free(c->d_lamW); dev_free(c->d_pF); dev_free(c->d_pT); dev_free(c->d_pGx); dev_free(c->d_pGy);
-    dev_free(c->d_compact); dev_free(c->d_active_bits); dev_free(c->d_active); dev_free(c->d_ablk_cnt);
-    dev_free(c->d_ablk_off); dev_free(c->d_pack_own); dev_free(c->d_knots); dev_free(c->d_seg); dev_free(c->d_err); dev_free(c->d_rect); dev_free(c->d_blk_rect);
-    dev_free(c->d_total); dev_free(c->d_scalar);
+    free_all_buffers(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->h_knots) (void)hipHostFree(c->h_knots);
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
@@ -697,12 +707,14 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     const size_t n_cand = c->n_cand;
 
     if ((st = dev_alloc(c, &c->d_pose, c->n_batch * kPoseStride))) return st;
-    if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride))) return st;
+    bool rec_fresh = false;
+    if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride, &rec_fresh))) return st;
     if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
     c->n_fblk = (long)std::max<size_t>((ns + kFlagBlk - 1) / kFlagBlk, 1);
     if ((st = dev_alloc(c, &c->d_fblk_cnt, (size_t)c->n_fblk)) || (st = dev_alloc(c, &c->d_fblk_off, (size_t)c->n_fblk))) return st;
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
-    HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, std::max<size_t>(n_cand, 1) * kRecStride * sizeof(double), s));
+    // a record is valid iff it carries the current evaluation's stamp (record_valid): a reused buffer holds older stamps only, new memory is cleared
+    if (rec_fresh) HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, c->caps[reinterpret_cast<void**>(&c->d_rec)], s));
     HIP_TRY(c, hipStreamSynchronize(s));
     c->nblk = (long)((ns + kWarpNew - 1) / kWarpNew);
     c->have_events = true;
@@ -749,7 +761,6 @@ emba_status emba_set_events(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
         HIP_TRY(c, hipMemcpyAsync(dhy, hy, n_halo * 2, hipMemcpyHostToDevice, s));
     }
     st = set_events_core(c, dx, dy, dp, nullptr, bt.data(), n, dhx, dhy, dhb, n_halo);
-    ws_release(c, 16, 31);
     c->set_events_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return st;
 }
@@ -765,7 +776,6 @@ emba_status emba_set_events_dev(emba_ctx* c, const uint16_t* x_dev, const uint16
     const auto t_begin = std::chrono::steady_clock::now();
     free_window(c);
     emba_status st = set_events_core(c, x_dev, y_dev, pol_dev, t_ns_dev, nullptr, n, hx_dev, hy_dev, hbt_dev, n_halo);
-    ws_release(c, 16, 31);
     c->set_events_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return st;
 }
@@ -829,7 +839,7 @@ emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping)
         if ((st = dev_alloc(c, &c->d_Gy_trial, c->npix))) return st;
     }
     if (c->x2_cap < 2 * c->P) {
-        dev_free(c->d_x2);
+        dev_free(c, c->d_x2);
         if ((st = dev_alloc(c, &c->d_x2, 2 * c->P))) return st;
         c->x2_cap = 2 * c->P;
     }
@@ -917,12 +927,12 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st;
     if (c->knots_cap < K) {
-        dev_free(c->d_knots);
+        dev_free(c, c->d_knots);
         if ((st = dev_alloc(c, &c->d_knots, (size_t)4 * K))) return st;
         c->knots_cap = K;
     }
     if (c->seg_cap < K) {
-        dev_free(c->d_seg);
+        dev_free(c, c->d_seg);
         if ((st = dev_alloc(c, &c->d_seg, (size_t)4 * K))) return st;
         c->seg_cap = K;
     }
@@ -1042,7 +1052,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         PostWarpParams q{};
         q.count = c->d_count; q.npix = npix; q.thres = thres; q.ablk_cnt = c->d_ablk_cnt; q.ablk_off = c->d_ablk_off; q.n_ablk = (long)c->n_ablk;
         q.total_P = c->d_total + 1; q.total_P_host = c->h_pinned_dev + 2;
-        q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = c->d_perm; q.n_pm = (long)c->n_pm;
+        q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = c->tile_order ? c->d_perm : nullptr; q.n_pm = (long)c->n_pm;
         q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
@@ -1155,15 +1165,15 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     if (active_idx && P) HIP_TRY(c, hipMemcpyAsync(active_idx, c->d_active, P * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     double* d_A22 = nullptr; double* d_b2 = nullptr; double* d_A12 = nullptr;
     if ((A22 || b2) && P) {
-        if ((st = dev_alloc(c, &d_A22, 4 * P)) || (st = dev_alloc(c, &d_b2, 2 * P))) { dev_free(d_A22); return st; }
+        if ((st = dev_alloc(c, &d_A22, 4 * P)) || (st = dev_alloc(c, &d_b2, 2 * P))) { dev_free(c, d_A22); return st; }
         hipLaunchKernelGGL(emba_unpack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), (long)P, d_A22, d_b2);
         if (A22) (void)hipMemcpyAsync(A22, d_A22, 4 * P * sizeof(double), hipMemcpyDeviceToHost, s);
         if (b2) (void)hipMemcpyAsync(b2, d_b2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s);
     }
     if (A12_dense && P) {
-        if ((st = ensure_compact(c))) { dev_free(d_A22); dev_free(d_b2); return st; }
+        if ((st = ensure_compact(c))) { dev_free(c, d_A22); dev_free(c, d_b2); return st; }
         const size_t n12 = (size_t)dim * 2 * P;
-        if ((st = dev_alloc(c, &d_A12, n12))) { dev_free(d_A22); dev_free(d_b2); return st; }
+        if ((st = dev_alloc(c, &d_A12, n12))) { dev_free(c, d_A22); dev_free(c, d_b2); return st; }
         (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
         if (c->n_cand)
             hipLaunchKernelGGL(emba_dense_a12_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key,
@@ -1172,7 +1182,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     }
     hipError_t e = hipStreamSynchronize(s);
     c->knots_in_flight = false;
-    dev_free(d_A22); dev_free(d_b2); dev_free(d_A12);
+    dev_free(c, d_A22); dev_free(c, d_b2); dev_free(c, d_A12);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "form_finish: %s", hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
     c->finish_done = true;
@@ -1202,11 +1212,11 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     emba_status st;
     if ((st = dev_alloc(c, &d_c, M)) || (st = dev_alloc(c, &d_p, M)) || (st = dev_alloc(c, &d_x, M)) || (st = dev_alloc(c, &d_w, M)) ||
         (st = dev_alloc(c, &d_jc, 6 * M)) || (st = dev_alloc(c, &d_jp, 6 * M)) || (st = dev_alloc(c, &d_dp, 2 * M))) {
-        dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp);
+        dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp);
         return st;
     }
     hipStream_t s = c->stream;
-    if ((st = ensure_compact(c))) { dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp); return st; }
+    if ((st = ensure_compact(c))) { dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp); return st; }
     hipLaunchKernelGGL(emba_export_a12_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, (long)M,
                        c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp, c->rec_stamp);
     if (cp_c) (void)hipMemcpyAsync(cp_c, d_c, M * 4, hipMemcpyDeviceToHost, s);
@@ -1217,7 +1227,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     if (jp) (void)hipMemcpyAsync(jp, d_jp, 6 * M * 8, hipMemcpyDeviceToHost, s);
     if (dp) (void)hipMemcpyAsync(dp, d_dp, 2 * M * 8, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
-    dev_free(d_c); dev_free(d_p); dev_free(d_x); dev_free(d_w); dev_free(d_jc); dev_free(d_jp); dev_free(d_dp);
+    dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "get_A12_sparse: %s", hipGetErrorString(e));
     return EMBA_OK;
 }
@@ -1273,7 +1283,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     // device and host staging only for what was asked for (a 100 M-event pm dump is 1.6 GB, the full state 17 GB)
     const bool w_pm = pm, w_D = D, w_dp = dp, w_G = Gpm, w_t = temp, w_pi = pm_int, w_inl = inlier_idx, w_flag = inlier_idx || pm_int || Gpm || temp;
     double *d_pm = nullptr, *d_D = nullptr, *d_dp = nullptr, *d_G = nullptr, *d_t = nullptr; int32_t* d_pi = nullptr;
-    auto free_all = [&]() { dev_free(d_pm); dev_free(d_D); dev_free(d_dp); dev_free(d_G); dev_free(d_t); dev_free(d_pi); };
+    auto free_all = [&]() { dev_free(c, d_pm); dev_free(c, d_D); dev_free(c, d_dp); dev_free(c, d_G); dev_free(c, d_t); dev_free(c, d_pi); };
     emba_status st = EMBA_OK;
     if ((w_pm && (st = dev_alloc(c, &d_pm, 2 * ns))) || (w_D && (st = dev_alloc(c, &d_D, 12 * ns))) || (w_dp && (st = dev_alloc(c, &d_dp, 2 * ns))) ||
         (w_G && (st = dev_alloc(c, &d_G, 2 * ns))) || (w_t && (st = dev_alloc(c, &d_t, 2 * ns))) || (w_pi && (st = dev_alloc(c, &d_pi, 2 * ns)))) {
@@ -1318,14 +1328,14 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (Gpm) memset(Gpm, 0, 2 * n * 8);
     if (temp) memset(temp, 0, 2 * n * 8);
     // entry of the device order -> pm-order index -> original event (lead-in copies and halo entries map to nothing)
-    std::vector<uint32_t> h_evpix(ns), h_evbatch(cp_idx ? ns : 0), h_evpm(c->d_ev_pm ? ns : 0), h_pmorig(c->n_pm);
+    std::vector<uint32_t> h_evpix(ns), h_evbatch(cp_idx ? ns : 0), h_evpm(c->have_ev_pm ? ns : 0), h_pmorig(c->n_pm);
     HIP_TRY(c, hipMemcpy(h_evpix.data(), c->d_ev_pix, ns * 4, hipMemcpyDeviceToHost));
     if (cp_idx) HIP_TRY(c, hipMemcpy(h_evbatch.data(), c->d_ev_batch, ns * 4, hipMemcpyDeviceToHost));
-    if (c->d_ev_pm) HIP_TRY(c, hipMemcpy(h_evpm.data(), c->d_ev_pm, ns * 4, hipMemcpyDeviceToHost));
+    if (c->have_ev_pm) HIP_TRY(c, hipMemcpy(h_evpm.data(), c->d_ev_pm, ns * 4, hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(h_pmorig.data(), c->d_pm_orig, c->n_pm * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < ns; ++i) {
         if (h_evpix[i] & kEvLead) continue;                        // lead-in copy / halo
-        const uint32_t k = h_pmorig[c->d_ev_pm ? h_evpm[i] : i];
+        const uint32_t k = h_pmorig[c->have_ev_pm ? h_evpm[i] : i];
         if (k == 0xFFFFFFFFu) continue;
         const bool cand = (h_evpix[i] & kEvHasPred) != 0;
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
@@ -1792,7 +1802,7 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
     if (!c->d_SH) {   // first use: S_H, S_W, eigenvalues, two scratch planes
         if ((st = dev_alloc(c, &c->d_SH, (size_t)H * H)) || (st = dev_alloc(c, &c->d_SW, (size_t)W * W)) || (st = dev_alloc(c, &c->d_lamH, (size_t)H)) ||
             (st = dev_alloc(c, &c->d_lamW, (size_t)W)) || (st = dev_alloc(c, &c->d_pF, npix)) || (st = dev_alloc(c, &c->d_pT, npix))) {
-            dev_free(c->d_SH); dev_free(c->d_SW); dev_free(c->d_lamH); dev_free(c->d_lamW); dev_free(c->d_pF); dev_free(c->d_pT);
+            dev_free(c, c->d_SH); dev_free(c, c->d_SW); dev_free(c, c->d_lamH); dev_free(c, c->d_lamW); dev_free(c, c->d_pF); dev_free(c, c->d_pT);
             return st;
         }
         hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, s, H, c->d_SH);
@@ -1802,7 +1812,7 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
     }
     const double *gx = c->d_Gx, *gy = c->d_Gy;
     if (Gx_host) {
-        if (!c->d_pGx) { if ((st = dev_alloc(c, &c->d_pGx, npix)) || (st = dev_alloc(c, &c->d_pGy, npix))) { dev_free(c->d_pGx); return st; } }
+        if (!c->d_pGx) { if ((st = dev_alloc(c, &c->d_pGx, npix)) || (st = dev_alloc(c, &c->d_pGy, npix))) { dev_free(c, c->d_pGx); return st; } }
         HIP_TRY(c, hipMemcpyAsync(c->d_pGx, Gx_host, npix * sizeof(double), hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemcpyAsync(c->d_pGy, Gy_host, npix * sizeof(double), hipMemcpyHostToDevice, s));
         gx = c->d_pGx; gy = c->d_pGy;

@@ -95,6 +95,7 @@ struct emba_ctx {
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order) or 64 B per batch + d_seg (tile order)
     double* d_seg = nullptr; int seg_cap = 0;                 // per-segment rotation axis (compact pose form), 4 doubles per control pose
+    double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
@@ -595,6 +596,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
     if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
+    if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
@@ -710,6 +712,11 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     bool rec_fresh = false;
     if ((st = dev_alloc(c, &c->d_rec, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride, &rec_fresh))) return st;
     if ((st = dev_alloc(c, &c->d_slot_key, n_cand))) return st;
+    {
+        bool tag_fresh = false;
+        if ((st = dev_alloc(c, &c->d_tag, n_cand + kGramPad, &tag_fresh))) return st;
+        if (tag_fresh) HIP_TRY(c, hipMemsetAsync(c->d_tag, 0, c->caps[reinterpret_cast<void**>(&c->d_tag)], s));
+    }
     c->n_fblk = (long)std::max<size_t>((ns + kFlagBlk - 1) / kFlagBlk, 1);
     if ((st = dev_alloc(c, &c->d_fblk_cnt, (size_t)c->n_fblk)) || (st = dev_alloc(c, &c->d_fblk_off, (size_t)c->n_fblk))) return st;
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
@@ -984,7 +991,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
-        p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
+        p.count = c->d_count; p.rec = c->d_rec; p.tag = c->use_tags ? c->d_tag : nullptr; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp;
@@ -1116,6 +1123,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         GramParams p{};
         p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
         p.irls = irls; p.eta = eta; p.stamp = c->rec_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
+        p.tag = (c->use_tags && !ep_host) ? c->d_tag : nullptr;
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
         // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),

@@ -258,7 +258,7 @@ struct WarpParams {
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
-    int32_t* count; double* pixacc; double* rec; double* e_sorted; uint8_t* flag;
+    int32_t* count; double* pixacc; double* rec; double* tag; double* e_sorted; uint8_t* flag;   // tag: 8 B per record slot {pano pixel, stamp}, or nullptr
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count marker, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
@@ -468,6 +468,8 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
                                               double* s_tile /* STAGE * kRecLds doubles */, uint32_t* s_slot /* STAGE */)
 {
     const int c8 = t & 7;
+    // the Gram kernel's tag stream: {pano pixel, stamp} of every slot written now (one store instruction for the whole wave)
+    if (p.tag && o.inl) p.tag[slot] = __hiloint2double((int)p.stamp, (int)o.pi);
 #pragma unroll
     for (int st = 0; st < 64 / STAGE; ++st) {
         const unsigned long long smask = (STAGE == 64) ? inl_mask : ((inl_mask >> (STAGE * st)) & ((1ull << (STAGE & 63)) - 1ull));
@@ -1085,6 +1087,7 @@ struct GramParams {
     const double* rec; const uint32_t* slot_key; long n_slots; int chunk;   // chunk: record slots per wave (multiple of 8)
     const uint32_t* active_bits; int irls; double eta;                    // active_bits: count >= thres per pixel (model.cpp:333,409)
     uint32_t stamp;                                                       // records of the current evaluation (record_valid)
+    const double* tag;                                                    // per slot {pano pixel, stamp} (8 B), or nullptr: decide from the records themselves
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
 };
@@ -1282,6 +1285,47 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
             for (int v = 0; v + 1 < U; ++v) { y[v] = y[v + 1]; a_[v] = a_[v + 1]; }
         }
     };
+    if (p.tag) {
+        // Tag stream: one 8-B word {panorama pixel, evaluation stamp} per slot, written by the warp kernels next to the record.  A stage
+        // first reads its 32 tags (256 contiguous bytes), looks the activity bits up, and then fetches ONLY the records that take part
+        // (8 lanes = one 128-B line per record: a record that is stale, an outlier's, or on an inactive pixel is never read — about half
+        // of the slots of the BASELINE workload).  Loads return in order, so the three dependent steps of a stage are spread over three
+        // iterations: tags of stage i+2, activity bits of stage i+1 and records of stage i+1 are in flight while stage i is consumed.
+        const double* tag0 = p.tag + start;
+        auto tagload = [&](int off) -> double { const int sidx = off + lane; return (lane < 8 * U && off < len && sidx < len) ? tag0[sidx] : 0.0; };
+        auto bitgather = [&](int off, double tg) -> uint32_t {
+            const uint32_t pi = (uint32_t)__double2loint(tg);
+            const bool valid = lane < 8 * U && off + lane < len && (uint32_t)__double2hiint(tg) == p.stamp && pi != kInvalidPix;
+            return valid ? ((((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31)) & 1u) : 0u;
+        };
+        auto load_masked = [&](int off, uint32_t m, double2* x) {
+            const double2* q = rec0 + 8 * off;
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = ((m >> (8 * u + R)) & 1u) ? q[64 * u] : make_double2(0.0, 0.0);
+        };
+        auto keys = [&](int off) { k_first = key0[off]; k_last = key0[(off + 8 * U < len ? off + 8 * U : len) - 1]; };
+        double T = tagload(off0);
+        uint32_t B = bitgather(off0, T);
+        T = tagload(off0 + kStride);
+        uint32_t Mc = (uint32_t)__ballot(B != 0);
+        B = bitgather(off0 + kStride, T);
+        T = tagload(off0 + 2 * kStride);
+        load_masked(off0, Mc, xA);
+        for (int off = off0; off < len; off += kStride) {
+            const bool h1 = off + kStride < len;
+            const uint32_t Mn = h1 ? (uint32_t)__ballot(B != 0) : 0u;
+            B = bitgather(off + 2 * kStride, T);
+            T = tagload(off + 3 * kStride);
+            if (h1) load_masked(off + kStride, Mn, xB);
+            keys(off);
+#pragma unroll
+            for (int u = 0; u < U; ++u) act[u] = (Mc >> (8 * u + R)) & 1u;
+            if (Mc) consume(off, xA);
+#pragma unroll
+            for (int u = 0; u < U; ++u) xA[u] = xB[u];
+            Mc = Mn;
+        }
+    } else {
     load_records(off0, xA);
     for (int off = off0; off < len; off += 2 * kStride) {
         lookup(off, xA);                        // issued BEFORE B's record loads: memory operations return in order, so waiting
@@ -1292,6 +1336,7 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
         lookup(off + kStride, xB);
         if (off + 2 * kStride < len) load_records(off + 2 * kStride, xA);
         consume(off + kStride, xB);
+    }
     }
     if (dirty) flush();
     }  // have_work

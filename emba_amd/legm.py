@@ -216,6 +216,7 @@ class LEGM:
     def solveNormalEq(self, lam, fix_first_pose=False):
         """model.cpp:721-792 on the device-resident, L2-regularised normal equations (call after applyL2Reg, solver.cpp:130,190):
         returns (x1 [3K, zeros for a fixed first pose], x2 [2P])."""
+        self.last_counts()     # (P may have been left on the device by form_active(sync=False): the output buffer is sized from it)
         x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
         self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
         return x1, x2[:2 * self._P]
@@ -245,6 +246,7 @@ class LEGM:
 
     def solveNormalEqCG(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6):
         """model.cpp:794-840 (Eigen ConjugateGradient, 100 iterations, tolerance 1e-6) on the device: returns (x1, x2, iterations, error)."""
+        self.last_counts()
         x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
         it = C.c_int32(0); err = C.c_double(0)
         self._check(self._L.emba_solve_normal_eq_cg(self._ctx, float(lam), 1 if fix_first_pose else 0, int(max_iter), float(tol), _p(x1, _dp), _p(x2, _dp),

@@ -225,7 +225,7 @@ def main():
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
                        "setup": m.setup_info()},
-            "roofline": {"bound": "hbm", "kernel": "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "emba_warp_tiled_kernel" if m.setup_info()["tile_order"] else "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_launch"] if tr else None), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "counter_GBs": counter, "counter_frac": (counter / HBM_PEAK_GBS if counter else None),

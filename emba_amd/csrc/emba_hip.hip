@@ -991,7 +991,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
-        p.count = c->d_count; p.rec = c->d_rec; p.tag = c->use_tags ? c->d_tag : nullptr; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
+        p.count = c->d_count; p.rec = c->d_rec; p.tag = (c->use_tags && !c->tile_order) ? c->d_tag : nullptr; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp;
@@ -1123,7 +1123,9 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         GramParams p{};
         p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
         p.irls = irls; p.eta = eta; p.stamp = c->rec_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
-        p.tag = (c->use_tags && !ep_host) ? c->d_tag : nullptr;
+        // the tag stream pays where slots are dead (pixel order: about half of them at the BASELINE workload); in the tile order (dense regime:
+        // nearly every slot is live) the warp kernel's scattered 8-B tag stores cost more than the Gram kernel saves (40 M events: +370 vs -180 us)
+        p.tag = (c->use_tags && !c->tile_order && !ep_host) ? c->d_tag : nullptr;
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
         // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),

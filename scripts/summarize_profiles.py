@@ -26,9 +26,10 @@ with open(f"profiles/{tag}_pmc_summary.csv", "w") as fo:
     fo.write("kernel,launches,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean,hbm_bytes_per_launch_corrected(2*FETCH+WRITE)*1024,TCC_EA0_ATOMIC_requests_mean\n")
     for r in rows:
         fo.write('"%s",%d,%.1f,%.1f,%.0f,%.0f\n' % r)
-dom = [r for r in rows if "emba_warp_residual_kernel" in r[0] and "true" not in r[0]][0]
+cand = [r for r in rows if "emba_warp_tiled_kernel" in r[0]] or [r for r in rows if "emba_warp_residual_kernel" in r[0] and "true" not in r[0]]
+dom = cand[0]
 bench = json.loads([l for l in open(f"{src}/bench_trace.log") if l.startswith("{")][-1])
-json.dump({"kernel": "emba_warp_residual_kernel", "hbm_bytes_per_launch": dom[4], "FETCH_SIZE_KiB": dom[2], "WRITE_SIZE_KiB": dom[3],
+json.dump({"kernel": "emba_warp_tiled_kernel" if "tiled" in dom[0] else "emba_warp_residual_kernel", "hbm_bytes_per_launch": dom[4], "FETCH_SIZE_KiB": dom[2], "WRITE_SIZE_KiB": dom[3],
            "atomic_requests_per_launch": dom[5], "correction": "gfx950: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "workload": bench["config"]["workload"], "tag": tag},
           open(f"profiles/{tag}_traffic.json", "w"), indent=1)
 json.dump(bench, open(f"profiles/{tag}_bench_profiled.json", "w"))

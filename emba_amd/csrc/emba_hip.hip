@@ -86,7 +86,7 @@ struct emba_ctx {
     uint32_t* d_pm_pix = nullptr; uint32_t* d_pm_batch = nullptr; uint32_t* d_pm_orig = nullptr;   // pm-order = (sensor pixel, time): the reference's per-pixel vectors laid end to end
     uint32_t* d_ev_pix = nullptr; uint32_t* d_ev_batch = nullptr; uint32_t* d_ev_slot = nullptr;    // device order (== pm-order arrays in pixel order; own arrays in tile order)
     uint32_t* d_ev_pix_own = nullptr; uint32_t* d_ev_batch_own = nullptr;                          // tile order: the arrays d_ev_pix / d_ev_batch point to
-    uint32_t* d_ev_pm = nullptr; uint32_t* d_perm = nullptr;                                        // tile order only: entry -> pm index, pm index -> entry
+    uint32_t* d_ev_pm = nullptr;                                                                    // tile order only: entry -> pm index
     bool have_ev_pm = false;
     std::unordered_map<void**, size_t> caps;                                                        // capacities of the grow-only device buffers (dev_alloc)
     uint16_t* d_cp = nullptr;                                                                       // control-pose index per batch
@@ -355,16 +355,13 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
             return st;
         hipLaunchKernelGGL(emba_expand_write_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, d_emit, d_pos, (long)ns, k0, v0);
         if ((st = dev_sort(c, &k0, &v0, &k1, &v1, nd, bits_for(nbins)))) return st;
-        if ((st = dev_alloc(c, &c->d_ev_pix_own, nd)) || (st = dev_alloc(c, &c->d_ev_batch_own, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd)) ||
-            (st = dev_alloc(c, &c->d_perm, ns)))
-            return st;
+        if ((st = dev_alloc(c, &c->d_ev_pix_own, nd)) || (st = dev_alloc(c, &c->d_ev_batch_own, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd))) return st;
         c->d_ev_pix = c->d_ev_pix_own; c->d_ev_batch = c->d_ev_batch_own; c->have_ev_pm = true;
-        HIP_TRY(c, hipMemsetAsync(c->d_perm, 0xFF, std::max<size_t>(ns, 1) * 4, s));
         HIP_TRY(c, hipMemsetAsync(d_bin_start, 0xFF, (nbins + 1) * 4, s));
         uint32_t* d_cf = d_emit;    // (emit is dead: its buffer now takes the candidate flags of the device order — nd <= 2 ns may exceed it)
         if (nd > ns && (st = ws_get(c, 21, nd * 4, (void**)&d_cf))) return st;
         hipLaunchKernelGGL(emba_dev_gather_kernel, dim3(nblocks(nd)), dim3(256), 0, s, k0, v0, (long)nd, c->d_pm_pix, c->d_pm_batch, c->d_ev_pix, c->d_ev_batch,
-                           c->d_ev_pm, c->d_perm, d_cf, d_bin_start);
+                           c->d_ev_pm, d_cf, d_bin_start);
         // chunks: every occupied tile is cut into workgroup-sized pieces (host: <= 32 k tiles)
         std::vector<uint32_t> h_start(nbins + 1);
         HIP_TRY(c, hipMemcpyAsync(h_start.data(), d_bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -424,8 +421,9 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         if (M) hipLaunchKernelGGL(emba_slot_assign_kernel, dim3(nblocks(M)), dim3(256), 0, s, k0, v0, (long)M, c->d_ev_slot, c->d_slot_key);
     }
     // per-entry outputs of the evaluations
-    if ((st = dev_alloc(c, &c->d_e_sorted, nd)) || (st = dev_alloc(c, &c->d_flag, nd)) || (st = dev_alloc(c, &c->d_inl_idx, nd))) return st;
-    HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, std::max<size_t>(nd, 1), s));
+    // per-event outputs of the evaluations, indexed in pm-order in both orders
+    if ((st = dev_alloc(c, &c->d_e_sorted, ns)) || (st = dev_alloc(c, &c->d_flag, ns)) || (st = dev_alloc(c, &c->d_inl_idx, ns))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_flag, 0, std::max<size_t>(ns, 1), s));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));
     c->keys_ready = true; c->key_t0 = t0; c->key_dt = dt; c->key_K = K;
@@ -493,7 +491,7 @@ emba_status launch_ep_compaction(emba_ctx* c)
     c->ep_deferred = false;
     hipStream_t s = c->stream;
     if (c->n_pm) {
-        const uint32_t* perm = c->tile_order ? c->d_perm : nullptr;
+        const uint32_t* perm = nullptr;    // (flags and residuals are stored in pm-order by both warp kernels)
         hipLaunchKernelGGL(emba_flag_count_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_flag, perm, (long)c->n_pm, c->d_fblk_cnt);
         hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total,
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
@@ -986,7 +984,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
                            c->d_texel);
     if (c->n_sorted) {
         WarpParams p{};
-        p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)c->n_sorted;
+        p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)c->n_sorted;
         p.nblk = c->nblk; p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
@@ -1059,7 +1057,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         PostWarpParams q{};
         q.count = c->d_count; q.npix = npix; q.thres = thres; q.ablk_cnt = c->d_ablk_cnt; q.ablk_off = c->d_ablk_off; q.n_ablk = (long)c->n_ablk;
         q.total_P = c->d_total + 1; q.total_P_host = c->h_pinned_dev + 2;
-        q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = c->tile_order ? c->d_perm : nullptr; q.n_pm = (long)c->n_pm;
+        q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = nullptr; q.n_pm = (long)c->n_pm;
         q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
@@ -1105,7 +1103,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     if (ep_host && c->n_inliers) {
         HIP_TRY(c, hipMemcpyAsync(c->d_ep, ep_host, c->n_inliers * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(emba_override_ep_kernel, dim3((unsigned)((c->n_sorted + 255) / 256)), dim3(256), 0, s, c->d_ep, c->d_flag,
-                           c->d_inl_idx, c->d_ev_slot, (long)c->n_sorted, c->d_rec, c->d_e_sorted);
+                           c->d_inl_idx, c->d_ev_slot, c->d_ev_pix, c->tile_order ? c->d_ev_pm : nullptr, (long)c->n_sorted, c->d_rec, c->d_e_sorted);
     }
     // A11 = Zero, b1 = Zero (model.cpp:357-361).  A22/b2 of the active pixels were gathered from the per-pixel
     // accumulator by emba_form_active (quadratic cost, device-resident residuals); with IRLS weights or a
@@ -1251,8 +1249,8 @@ emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemsetAsync(c->d_scalar, 0, sizeof(double), s));
     if (c->n_sorted) {
-        const unsigned grid = (unsigned)std::min<size_t>((c->n_sorted + 255) / 256, 2048);
-        hipLaunchKernelGGL(emba_data_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (long)c->n_sorted, (int)irls, eta,
+        const unsigned grid = (unsigned)std::min<size_t>((c->n_pm + 255) / 256, 2048);
+        hipLaunchKernelGGL(emba_data_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (long)c->n_pm, (int)irls, eta,
                            c->d_scalar);
     }
     double v = 0;
@@ -1305,7 +1303,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (w_t) (void)hipMemsetAsync(d_t, 0, 2 * ns * 8, s);
     if (w_pi) (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
-    p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.n_sorted = (long)ns; p.nblk = c->nblk;
+    p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)ns; p.nblk = c->nblk;
     p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
@@ -1314,16 +1312,16 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
         h_pose(cp_idx ? c->n_batch * kPoseStride : 0);
-    std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? ns : 0);
-    std::vector<uint8_t> h_flag(w_flag ? ns : 0);
+    std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? c->n_pm : 0);     // (inlier numbers and flags are indexed in pm-order)
+    std::vector<uint8_t> h_flag(w_flag ? c->n_pm : 0);
     if (w_pm) (void)hipMemcpyAsync(h_pm.data(), d_pm, 2 * ns * 8, hipMemcpyDeviceToHost, s);
     if (w_D) (void)hipMemcpyAsync(h_D.data(), d_D, 12 * ns * 8, hipMemcpyDeviceToHost, s);
     if (w_dp) (void)hipMemcpyAsync(h_dp.data(), d_dp, 2 * ns * 8, hipMemcpyDeviceToHost, s);
     if (w_G) (void)hipMemcpyAsync(h_G.data(), d_G, 2 * ns * 8, hipMemcpyDeviceToHost, s);
     if (w_t) (void)hipMemcpyAsync(h_t.data(), d_t, 2 * ns * 8, hipMemcpyDeviceToHost, s);
     if (w_pi) (void)hipMemcpyAsync(h_pi.data(), d_pi, 2 * ns * 4, hipMemcpyDeviceToHost, s);
-    if (w_inl) (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, ns * 4, hipMemcpyDeviceToHost, s);
-    if (w_flag) (void)hipMemcpyAsync(h_flag.data(), c->d_flag, ns, hipMemcpyDeviceToHost, s);
+    if (w_inl) (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, c->n_pm * 4, hipMemcpyDeviceToHost, s);
+    if (w_flag) (void)hipMemcpyAsync(h_flag.data(), c->d_flag, c->n_pm, hipMemcpyDeviceToHost, s);
     if (cp_idx) (void)hipMemcpyAsync(h_pose.data(), c->d_pose, h_pose.size() * 8, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     free_all();
@@ -1345,17 +1343,18 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     HIP_TRY(c, hipMemcpy(h_pmorig.data(), c->d_pm_orig, c->n_pm * 4, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < ns; ++i) {
         if (h_evpix[i] & kEvLead) continue;                        // lead-in copy / halo
-        const uint32_t k = h_pmorig[c->have_ev_pm ? h_evpm[i] : i];
+        const size_t f = c->have_ev_pm ? h_evpm[i] : i;           // pm-order index: where flag / inlier number of this entry live
+        const uint32_t k = h_pmorig[f];
         if (k == 0xFFFFFFFFu) continue;
         const bool cand = (h_evpix[i] & kEvHasPred) != 0;
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
         if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
         if (cp_idx) cp_idx[k] = (int32_t)(c->tile_order ? h_pose[(size_t)h_evbatch[i] * kPoseStrideCompact + 7] : h_pose[(size_t)h_evbatch[i] * kPoseStride + 13]);
-        if (inlier_idx) inlier_idx[k] = cand ? (h_flag[i] ? h_inl[i] : -1) : -2;
-        if (pm_int && h_flag[i]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
+        if (inlier_idx) inlier_idx[k] = cand ? (h_flag[f] ? h_inl[f] : -1) : -2;
+        if (pm_int && h_flag[f]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
         if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }
-        if (Gpm && h_flag[i]) { Gpm[2 * k] = h_G[2 * i]; Gpm[2 * k + 1] = h_G[2 * i + 1]; }
-        if (temp && h_flag[i]) { temp[2 * k] = h_t[2 * i]; temp[2 * k + 1] = h_t[2 * i + 1]; }
+        if (Gpm && h_flag[f]) { Gpm[2 * k] = h_G[2 * i]; Gpm[2 * k + 1] = h_G[2 * i + 1]; }
+        if (temp && h_flag[f]) { temp[2 * k] = h_t[2 * i]; temp[2 * k + 1] = h_t[2 * i + 1]; }
     }
     return EMBA_OK;
 }

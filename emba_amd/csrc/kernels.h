@@ -253,7 +253,7 @@ constexpr int kTileWaves = TILE_WAVES;          // waves per workgroup of the ti
 constexpr int kTileRecStage = 16;               // records staged per wave at a time in the tiled kernel (a quarter of a wave)
 
 struct WarpParams {
-    const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; long n_sorted; long nblk;
+    const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; const uint32_t* ev_pm; long n_sorted; long nblk;   // ev_pm: entry -> pm-order index (nullptr: identity)
     const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; seg: compact pose only
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
@@ -290,14 +290,14 @@ struct LaneOut {
 // re-warps the entry in front of the wave's 63 new ones and takes no other part.
 // The event word and (compact form) the batch's pose record of one lane, loaded ahead of their use: the tiled kernel walks its
 // chunk group by group and fetches the NEXT group's words and pose lines while it works on the current one.
-struct LaneIn { uint32_t pw, bi, slot; bool valid; double2 P[4]; };
+struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double2 P[4]; };   // pm: the entry's index in pm-order (where its residual / flag go)
 
 // (the record slot is fetched here, with the event words, although only inliers use it: loaded where it is needed it would sit
 // behind the lane's own stores in the in-order memory counter and every staging round would wait for the previous round's stores)
 __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bool valid, LaneIn& in)
 {
-    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot;
-    if (valid) { in.pw = p.ev_pix[i]; in.bi = p.ev_batch[i]; in.slot = p.ev_slot[i]; }
+    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot; in.pm = (uint32_t)i;
+    if (valid) { in.pw = p.ev_pix[i]; in.bi = p.ev_batch[i]; in.slot = p.ev_slot[i]; if (p.ev_pm) in.pm = p.ev_pm[i]; }
 }
 __device__ __forceinline__ void load_pose_compact(const WarpParams& p, LaneIn& in)
 {
@@ -431,7 +431,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
 #pragma unroll
                 for (int j = 0; j < 6; ++j) o.jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
                 ngx = -gx; ngy = -gy;
-                p.e_sorted[i] = e;
+                p.e_sorted[in.pm] = e;
             }
         }
     }
@@ -444,7 +444,9 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
 #pragma unroll
         for (int j = 0; j < 6; ++j) o.jp[j] = dpp_shr1(gxn * D[j] + gyn * D[6 + j]);
     }
-    if (valid && t >= 1) p.flag[i] = inl ? 1 : 0;
+    // residual and inlier flag live at the entry's PM-ORDER index (= i in pixel order; a chain's entries are consecutive there too), so that the
+    // reference-order compaction reads them in order; a lead-in / halo copy owns no pm slot of its own and writes nothing
+    if (valid && t >= 1 && !(pw & 0x40000000u)) p.flag[in.pm] = inl ? 1 : 0;
 
     // the lane's terms of the per-pixel sums (model.cpp:227 count, :426-439 A22/b2), IRLS-weighted when the cost is declared
     double v0 = dpx * dpx, v1 = dpx * dpy, v2 = dpy * dpy, v3 = dpx * e, v4 = dpy * e;   // zero unless inlier (dpx,dpy,e are)
@@ -802,14 +804,16 @@ __global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __re
 
 // Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
 __global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const uint8_t* __restrict__ flag,
-                                        const int32_t* __restrict__ inl_idx, const uint32_t* __restrict__ ev_slot,
-                                        long n_sorted, double* __restrict__ rec, double* __restrict__ e_sorted)
+                                        const int32_t* __restrict__ inl_idx, const uint32_t* __restrict__ ev_slot, const uint32_t* __restrict__ ev_pix,
+                                        const uint32_t* __restrict__ ev_pm, long n_sorted, double* __restrict__ rec, double* __restrict__ e_sorted)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_sorted || !flag[i]) return;
-    const double e = ep_ext[inl_idx[i]];
+    if (i >= n_sorted || (ev_pix[i] & 0x40000000u)) return;      // (lead-in / halo copies are nobody's measurement)
+    const long f = ev_pm ? (long)ev_pm[i] : i;                   // residual, flag and inlier number live at the pm-order index
+    if (!flag[f]) return;
+    const double e = ep_ext[inl_idx[f]];
     rec[(size_t)kRecStride * ev_slot[i] + 14] = e;
-    e_sorted[i] = e;
+    e_sorted[f] = e;
 }
 
 // ------------------------------------------------------------------------------------------------

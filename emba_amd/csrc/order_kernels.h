@@ -283,7 +283,7 @@ __global__ void emba_expand_write_kernel(const uint32_t* __restrict__ pm_pix, co
 // device-order arrays of the tile order from the sorted (bin, value) pairs
 __global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long nd, const uint32_t* __restrict__ pm_pix,
                                        const uint32_t* __restrict__ pm_batch, uint32_t* __restrict__ ev_pix, uint32_t* __restrict__ ev_batch,
-                                       uint32_t* __restrict__ ev_pm /* pm index of the entry */, uint32_t* __restrict__ perm /* pm index -> entry */,
+                                       uint32_t* __restrict__ ev_pm /* pm index of the entry */,
                                        uint32_t* __restrict__ cand_flag, uint32_t* __restrict__ bin_start)
 {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -296,7 +296,6 @@ __global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const 
     ev_pix[j] = w;
     ev_batch[j] = pm_batch[i];
     ev_pm[j] = i;
-    if (!lead) perm[i] = (uint32_t)j;
     cand_flag[j] = (w & kEvHasPred) ? 1u : 0u;
     if (j == 0 || keys[j - 1] != keys[j]) bin_start[keys[j]] = (uint32_t)j;
 }

@@ -193,47 +193,41 @@ __device__ __forceinline__ void spline2_eval(const double* p0, const double* p1,
 
 __device__ __forceinline__ void project_jacobian(const double* rb, double fx, double fy, double* J23);
 
-// Compact form of d_val_d_knot[1] (tile order: the per-batch pose record shrinks from 112 B to one 64-B line).
-// J1 = u R0 Jl(u delta) Jl^-1(delta) R0^T (so3_spline.h:261-270).  Jl(u delta) and Jl^-1(delta) are polynomials in hat(delta)
-// (sophus_utils.hpp:332-414) and R0 hat(a) R0^T = hat(R0 a), so J1 = u I + a1 hat(k) + a2 hat(k)^2 with k = R0 delta/|delta| a
-// property of the spline SEGMENT and (u, a1, a2) of the batch.  a1, a2 are taken by projecting the reference-order J1 of the batch
-// onto hat(k) and hat(k)^2, so the per-event reconstruction returns that J1 to rounding (1e-16 relative: Jacobian tolerance only,
-// nothing index-level depends on J1).  k = 0 for coinciding knots (then J1 = u I).
-__device__ __forceinline__ void segment_axis(const double* p0, const double* p1, double* k)
+// Tile order: the pose of an event is evaluated PER EVENT from per-SEGMENT constants, so the warp kernel gathers nothing per batch.
+// (At 100 M events the batch table is 1 M records: every event pulled its own 128-B line from HBM — 13.6 GB per launch, 43 % of the
+// kernel's traffic by the counters — while the VALU was a third busy.)  The K-1 segment records (96 B each) stay in cache.
+//   seg[12] = { p0[4], delta[3], r1, k[3], r2 }   with delta = log(p0^-1 p1), theta = |delta|, k = R0 delta/theta (world-frame axis),
+//   r1 = -theta/2, r2 = theta^2 c(theta): the coefficients of Jl^-1(delta) = I + r1 A + r2 A^2 in A = hat(delta/theta)
+//   (sophus_utils.hpp:372-414, incl. its small-angle and near-pi branches).
+// Value: q = p0 * exp(u delta), the SAME calls in the same order as So3Spline<2>::evaluate (so3_spline.h:233-247) — bit-identical to the
+// per-batch evaluation, which is what round(pm) needs.  Jacobian: Jl(u delta) = I + p1 A + p2 A^2 (sophus_utils.hpp:332-362) commutes with
+// Jl^-1(delta) and R0 A R0^T = hat(k), hence J1 = u R0 Jl Jl^-1 R0^T = u (I + alpha hat(k) + gamma hat(k)^2) (so3_spline.h:261-270) with
+// alpha = p1 + r1 - p1 r2 - p2 r1, gamma = p2 + r2 + p1 r1 - p2 r2 (A^3 = -A): the reference's J1 to rounding (Jacobian tolerance only).
+__device__ __forceinline__ void segment_consts(const double* p0, const double* p1, double* seg)
 {
     double p0inv[4] = {-p0[0], -p0[1], -p0[2], p0[3]};
     quat_normalize(p0inv);
     double r01[4], delta[3], R0[9];
     so3_mul(p0inv, p1, r01);
     so3_log(r01, delta);
-    const double th = sqrt(sqn3(delta[0] * delta[0], delta[1] * delta[1], delta[2] * delta[2]));
-    if (!(th > 0.0)) { k[0] = 0; k[1] = 0; k[2] = 0; return; }
-    quat_to_matrix(p0, R0);
-    const double a0 = delta[0] / th, a1 = delta[1] / th, a2 = delta[2] / th;
+    const double n2 = sqn3(delta[0] * delta[0], delta[1] * delta[1], delta[2] * delta[2]);
+    const double th = sqrt(n2);
+    double k[3] = {0, 0, 0}, r2;
+    if (th > 0.0) {
+        quat_to_matrix(p0, R0);
+        const double a0 = delta[0] / th, a1 = delta[1] / th, a2 = delta[2] / th;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) k[r] = R0[3 * r] * a0 + R0[3 * r + 1] * a1 + R0[3 * r + 2] * a2;
-}
-
-// (u, a1, a2) of a batch from its exact J1 and the segment axis k
-__device__ __forceinline__ void project_j1(const double* J1, double u, const double* k, double& a1, double& a2)
-{
-    const double kk = k[0] * k[0] + k[1] * k[1] + k[2] * k[2];
-    a1 = 0; a2 = 0;
-    if (!(kk > 0.0)) return;
-    // antisymmetric part = hat(w), w = (J21 - J12, J02 - J20, J10 - J01) / 2  =>  a1 = w.k / k.k
-    const double w0 = 0.5 * (J1[7] - J1[5]), w1 = 0.5 * (J1[2] - J1[6]), w2 = 0.5 * (J1[3] - J1[1]);
-    a1 = (w0 * k[0] + w1 * k[1] + w2 * k[2]) / kk;
-    // symmetric part - u I = a2 N, N = k k^T - (k.k) I
-    double num = 0, den = 0;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const double n = k[r] * k[c] - ((r == c) ? kk : 0.0);
-            const double m = 0.5 * (J1[3 * r + c] + J1[3 * c + r]) - ((r == c) ? u : 0.0);
-            num += m * n; den += n * n;
-        }
-    a2 = (den > 0.0) ? num / den : 0.0;
+        for (int r = 0; r < 3; ++r) k[r] = R0[3 * r] * a0 + R0[3 * r + 1] * a1 + R0[3 * r + 2] * a2;
+    }
+    if (n2 > kSophusEps) {
+        if (th < kPi - sqrt(kSophusEps)) r2 = 1.0 - th * (1.0 + cos(th)) / (2.0 * sin(th));
+        else r2 = n2 / (kPi * kPi);
+    } else {
+        r2 = n2 / 12.0;
+    }
+    seg[0] = p0[0]; seg[1] = p0[1]; seg[2] = p0[2]; seg[3] = p0[3];
+    seg[4] = delta[0]; seg[5] = delta[1]; seg[6] = delta[2]; seg[7] = -0.5 * th;
+    seg[8] = k[0]; seg[9] = k[1]; seg[10] = k[2]; seg[11] = r2;
 }
 
 // J1 = u I + a1 hat(k) + a2 (k k^T - (k.k) I)
@@ -246,28 +240,65 @@ __device__ __forceinline__ void rebuild_j1(double u, double a1, double a2, const
     J1[6] = a2 * k[2] * k[0] - a1 * k[1]; J1[7] = a2 * k[2] * k[1] + a1 * k[0]; J1[8] = d + a2 * k[2] * k[2];
 }
 
+// sin and cos of the half angle behind a REAL call (see project_angles_call below: fp64 polynomial constants hoisted out of the tiled kernel's loop)
+__device__ __attribute__((noinline)) double2 sin_cos_call(double x) { return make_double2(sin(x), cos(x)); }
+
+template <bool CALL>
+__device__ __forceinline__ void spline2_event(const double* seg, double u, double* q_out, double* J1)
+{
+    // value: kdelta = delta * u; exp; p0 * exp  (the tail of spline2_eval, operation for operation)
+    const double kd[3] = {seg[4] * u, seg[5] * u, seg[6] * u};
+    const double theta_sq = sqn3(kd[0] * kd[0], kd[1] * kd[1], kd[2] * kd[2]);
+    double imag, real, p1c, p2c;            // p1c, p2c: coefficients of Jl(u delta) (only the Jacobian uses them)
+    if (theta_sq < kSophusEps * kSophusEps) {                          // so3.hpp:594
+        const double theta_po4 = theta_sq * theta_sq;
+        imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
+        real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
+        const double n = sqrt(theta_sq);
+        p1c = 0.5 * n; p2c = theta_sq / 6.0;
+    } else {
+        const double theta = sqrt(theta_sq);
+        const double half = 0.5 * theta;
+        double sh, ch;
+        if (CALL) { const double2 sc = sin_cos_call(half); sh = sc.x; ch = sc.y; }
+        else { sh = sin(half); ch = cos(half); }
+        imag = sh / theta;
+        real = ch;
+        if (theta_sq > kSophusEps) { p1c = 2.0 * sh * sh / theta; p2c = 1.0 - 2.0 * sh * ch / theta; }     // (1 - cos n)/n, (n - sin n)/n
+        else { p1c = 0.5 * theta; p2c = theta_sq / 6.0; }                                                    // sophus_utils.hpp:351 small branch
+    }
+    const double e[4] = {imag * kd[0], imag * kd[1], imag * kd[2], real};
+    so3_mul(seg, e, q_out);
+    const double r1 = seg[7], r2 = seg[11];
+    const double alpha = p1c + r1 - p1c * r2 - p2c * r1, gamma = p2c + r2 + p1c * r1 - p2c * r2;
+    rebuild_j1(u, u * alpha, u * gamma, seg + 8, J1);
+}
+
+__device__ __forceinline__ void project_jacobian(const double* rb, double fx, double fy, double* J23);
+
 // EquirectangularCamera::projectToImage (include/utils/equirectangular_camera.h:18-45) chained with
 // -[rb]x (event_pano_warper.cpp:62-65): pm (2) and J23 = dpm_drb * drb_ddrot (row-major 2x3).
 // The projection alone, as a REAL function (noinline): its atan2 / asin carry ~40 fp64 polynomial constants, which the compiler
 // hoists out of a loop and keeps in registers for the loop's whole life (fp64 literals cannot be encoded in VALU instructions
 // on gfx9: the tiled warp kernel, whose waves loop over event groups, went from 88 to 190 VGPRs that way).  Behind a call the
 // constants are materialised per call and die at the return.  Same expressions, same results as the inline form.
-__device__ __attribute__((noinline)) void project_angles_call(double x, double y, double z, double* phi, double* theta)
+// (results by value: out-pointers to the caller's locals would travel through scratch memory)
+__device__ __attribute__((noinline)) double2 project_angles_call(double x, double y, double z)
 {
-    *phi = atan2(x, z);
+    const double phi = atan2(x, z);
     const double r2 = x * x + y * y + z * z;
-    *theta = asin(y / sqrt(r2));
+    return make_double2(phi, asin(y / sqrt(r2)));
 }
+
 
 template <bool CALL = false>
 __device__ __forceinline__ void project_chain(const double* rb, double fx, double fy, double cx, double cy,
                                               double* pm, double* J23)
 {
     if (CALL) {
-        double phi, theta;
-        project_angles_call(rb[0], rb[1], rb[2], &phi, &theta);
-        pm[0] = cx + phi * fx;
-        pm[1] = cy + theta * fy;
+        const double2 a = project_angles_call(rb[0], rb[1], rb[2]);
+        pm[0] = cx + a.x * fx;
+        pm[1] = cy + a.y * fy;
         project_jacobian(rb, fx, fy, J23);
         return;
     }

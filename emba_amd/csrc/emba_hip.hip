@@ -89,12 +89,13 @@ struct emba_ctx {
     uint32_t* d_ev_pm = nullptr;                                                                    // tile order only: entry -> pm index
     bool have_ev_pm = false;
     std::unordered_map<void**, size_t> caps;                                                        // capacities of the grow-only device buffers (dev_alloc)
-    uint16_t* d_cp = nullptr;                                                                       // control-pose index per batch
+    uint16_t* d_cp = nullptr; double* d_batch_u = nullptr;                                          // control-pose index (= spline segment) and spline parameter per batch
+    double* d_ev_u = nullptr; uint16_t* d_ev_seg = nullptr;                                         // tile order: the same per entry of the device order
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
     bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
     size_t n_lead = 0;                             // lead-in copies the tile order added
-    int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order) or 64 B per batch + d_seg (tile order)
-    double* d_seg = nullptr; int seg_cap = 0;                 // per-segment rotation axis (compact pose form), 4 doubles per control pose
+    int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
+    double* d_seg = nullptr; int seg_cap = 0;                 // tile order: per-segment constants the tiled kernel evaluates each event's pose from (12 doubles per segment)
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
@@ -288,8 +289,8 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     uint32_t* d_err = nullptr;
     if ((st = ws_get(c, 19, 64, (void**)&d_err))) return st;
     HIP_TRY(c, hipMemsetAsync(d_err, 0xFF, 64, s));
-    if ((st = dev_alloc(c, &c->d_cp, nbatch))) return st;
-    if (nbatch) hipLaunchKernelGGL(emba_batch_cp_kernel, dim3(nblocks(nbatch)), dim3(256), 0, s, c->d_batch_t, (long)nbatch, t0, dt, K, c->d_cp, d_err);
+    if ((st = dev_alloc(c, &c->d_cp, nbatch)) || (st = dev_alloc(c, &c->d_batch_u, nbatch))) return st;
+    if (nbatch) hipLaunchKernelGGL(emba_batch_cp_kernel, dim3(nblocks(nbatch)), dim3(256), 0, s, c->d_batch_t, (long)nbatch, t0, dt, K, c->d_cp, c->d_batch_u, d_err);
     uint32_t h_err[16];
     HIP_TRY(c, hipMemcpyAsync(h_err, d_err, 64, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -355,13 +356,15 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
             return st;
         hipLaunchKernelGGL(emba_expand_write_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, d_emit, d_pos, (long)ns, k0, v0);
         if ((st = dev_sort(c, &k0, &v0, &k1, &v1, nd, bits_for(nbins)))) return st;
-        if ((st = dev_alloc(c, &c->d_ev_pix_own, nd)) || (st = dev_alloc(c, &c->d_ev_batch_own, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd))) return st;
+        if ((st = dev_alloc(c, &c->d_ev_pix_own, nd)) || (st = dev_alloc(c, &c->d_ev_batch_own, nd)) || (st = dev_alloc(c, &c->d_ev_pm, nd)) ||
+            (st = dev_alloc(c, &c->d_ev_u, nd)) || (st = dev_alloc(c, &c->d_ev_seg, nd)))
+            return st;
         c->d_ev_pix = c->d_ev_pix_own; c->d_ev_batch = c->d_ev_batch_own; c->have_ev_pm = true;
         HIP_TRY(c, hipMemsetAsync(d_bin_start, 0xFF, (nbins + 1) * 4, s));
         uint32_t* d_cf = d_emit;    // (emit is dead: its buffer now takes the candidate flags of the device order — nd <= 2 ns may exceed it)
         if (nd > ns && (st = ws_get(c, 21, nd * 4, (void**)&d_cf))) return st;
         hipLaunchKernelGGL(emba_dev_gather_kernel, dim3(nblocks(nd)), dim3(256), 0, s, k0, v0, (long)nd, c->d_pm_pix, c->d_pm_batch, c->d_ev_pix, c->d_ev_batch,
-                           c->d_ev_pm, d_cf, d_bin_start);
+                           c->d_ev_pm, c->d_cp, c->d_batch_u, c->d_ev_seg, c->d_ev_u, d_cf, d_bin_start);
         // chunks: every occupied tile is cut into workgroup-sized pieces (host: <= 32 k tiles)
         std::vector<uint32_t> h_start(nbins + 1);
         HIP_TRY(c, hipMemcpyAsync(h_start.data(), d_bin_start, (nbins + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -938,7 +941,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     }
     if (c->seg_cap < K) {
         dev_free(c, c->d_seg);
-        if ((st = dev_alloc(c, &c->d_seg, (size_t)4 * K))) return st;
+        if ((st = dev_alloc(c, &c->d_seg, (size_t)kSegStride * K))) return st;
         c->seg_cap = K;
     }
     if ((st = prepare_order(c, knots, t0_ns, dt_ns, K))) return st;
@@ -972,12 +975,12 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > 4 * c->npix ? 1 : 3);
     {   // pose table and (rectangle mode) texels in ONE launch: both depend only on the prep kernel
         const int nb = (int)c->n_batch;
-        const int n_pose_blk = (std::max(nb, c->tile_order ? (int)K - 1 : 0) + 63) / 64;   // (compact form: thread b also fills segment b of the axis table)
+        const int n_pose_blk = ((c->tile_order ? (int)K - 1 : nb) + 63) / 64;   // (tile order: K-1 segment records instead of nb batch poses)
         const int n_tex_blk = (c->use_texel == 3) ? 512 : 0;
         if (n_pose_blk + n_tex_blk)
             hipLaunchKernelGGL(emba_pose_texel_kernel, dim3(n_pose_blk + n_tex_blk), dim3(256), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
                                t0_ns, dt_ns, c->d_pose, c->d_err, n_pose_blk, n_tex_blk, c->d_Gx, c->d_Gy, c->H, c->W, c->d_blk_rect,
-                               n_prep_blk, rect_cur, c->d_texel, c->tile_order ? 1 : 0, c->d_seg);
+                               n_prep_blk, rect_cur, c->d_texel, c->tile_order ? c->d_seg : nullptr);
     }
     if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
@@ -985,6 +988,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)c->n_sorted;
+        p.ev_u = c->tile_order ? c->d_ev_u : nullptr; p.ev_seg = c->tile_order ? c->d_ev_seg : nullptr;
         p.nblk = c->nblk; p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
@@ -1304,6 +1308,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (w_pi) (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)ns; p.nblk = c->nblk;
+    p.ev_u = c->tile_order ? c->d_ev_u : nullptr; p.ev_seg = c->tile_order ? c->d_ev_seg : nullptr;
     p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
@@ -1311,7 +1316,8 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (c->tile_order) hipLaunchKernelGGL((emba_warp_residual_kernel<true, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
-        h_pose(cp_idx ? c->n_batch * kPoseStride : 0);
+        h_unused;
+    std::vector<uint16_t> h_cp(cp_idx ? c->n_batch : 0);
     std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? c->n_pm : 0);     // (inlier numbers and flags are indexed in pm-order)
     std::vector<uint8_t> h_flag(w_flag ? c->n_pm : 0);
     if (w_pm) (void)hipMemcpyAsync(h_pm.data(), d_pm, 2 * ns * 8, hipMemcpyDeviceToHost, s);
@@ -1322,7 +1328,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (w_pi) (void)hipMemcpyAsync(h_pi.data(), d_pi, 2 * ns * 4, hipMemcpyDeviceToHost, s);
     if (w_inl) (void)hipMemcpyAsync(h_inl.data(), c->d_inl_idx, c->n_pm * 4, hipMemcpyDeviceToHost, s);
     if (w_flag) (void)hipMemcpyAsync(h_flag.data(), c->d_flag, c->n_pm, hipMemcpyDeviceToHost, s);
-    if (cp_idx) (void)hipMemcpyAsync(h_pose.data(), c->d_pose, h_pose.size() * 8, hipMemcpyDeviceToHost, s);
+    if (cp_idx) (void)hipMemcpyAsync(h_cp.data(), c->d_cp, h_cp.size() * 2, hipMemcpyDeviceToHost, s);
     hipError_t e = hipStreamSynchronize(s);
     free_all();
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "dump_state: %s", hipGetErrorString(e));
@@ -1349,7 +1355,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
         const bool cand = (h_evpix[i] & kEvHasPred) != 0;
         if (pm) { pm[2 * k] = h_pm[2 * i]; pm[2 * k + 1] = h_pm[2 * i + 1]; }
         if (D) memcpy(D + 12 * (size_t)k, &h_D[12 * i], 12 * 8);
-        if (cp_idx) cp_idx[k] = (int32_t)(c->tile_order ? h_pose[(size_t)h_evbatch[i] * kPoseStrideCompact + 7] : h_pose[(size_t)h_evbatch[i] * kPoseStride + 13]);
+        if (cp_idx) cp_idx[k] = (int32_t)h_cp[h_evbatch[i]];
         if (inlier_idx) inlier_idx[k] = cand ? (h_flag[f] ? h_inl[f] : -1) : -2;
         if (pm_int && h_flag[f]) { pm_int[2 * k] = h_pi[2 * i]; pm_int[2 * k + 1] = h_pi[2 * i + 1]; }
         if (dp && cand) { dp[2 * k] = h_dp[2 * i]; dp[2 * k + 1] = h_dp[2 * i + 1]; }

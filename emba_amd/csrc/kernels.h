@@ -64,20 +64,9 @@ __device__ __forceinline__ long xcd_contiguous_block(long bid, long grid)
 // a2/a3: one thread per batch -> pose record.  LinearTrajectory::evaluate (trajectory.cpp:122-147) /
 // So3Spline<2>::evaluate (so3_spline.h:218-274).  s and u use the same int64 arithmetic as the reference.
 // ------------------------------------------------------------------------------------------------
-// compact != 0 (tile order): one 64-B record per batch {q[4], u, a1, a2, cp} instead, plus a per-SEGMENT axis table seg[4 s] =
-// {kx, ky, kz, 0} from which the warp kernel rebuilds J1 (device_math.h: segment_axis / project_j1 / rebuild_j1).
-constexpr int kPoseStrideCompact = 8;
 __device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
-                                            int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
-                                            int compact = 0, double* __restrict__ seg = nullptr)
+                                            int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err)
 {
-    if (compact && b < K - 1) {
-        double p0[4], p1[4], k[3];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * b + i]; p1[i] = knots[4 * (b + 1) + i]; }
-        segment_axis(p0, p1, k);
-        seg[4 * b] = k[0]; seg[4 * b + 1] = k[1]; seg[4 * b + 2] = k[2]; seg[4 * b + 3] = 0.0;
-    }
     if (b >= nb) return;
     const int64_t st = batch_t_ns[b] - t0_ns;
     const int64_t s = (st >= 0) ? st / dt_ns : -1;
@@ -91,20 +80,25 @@ __device__ __forceinline__ void pose_thread(int b, const int64_t* __restrict__ b
     for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * s + i]; p1[i] = knots[4 * (s + 1) + i]; }
     double q[4], J1[9];
     spline2_eval(p0, p1, u, q, J1);
-    if (compact) {
-        double k[3], a1, a2;
-        segment_axis(p0, p1, k);
-        project_j1(J1, u, k, a1, a2);
-        double2* o = reinterpret_cast<double2*>(pose + (size_t)kPoseStrideCompact * b);
-        o[0] = make_double2(q[0], q[1]); o[1] = make_double2(q[2], q[3]); o[2] = make_double2(u, a1); o[3] = make_double2(a2, (double)s);
-        return;
-    }
     double* o = pose + (size_t)kPoseStride * b;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = q[i];
 #pragma unroll
     for (int i = 0; i < 9; ++i) o[4 + i] = J1[i];
     o[13] = (double)s;
+}
+
+// Tile order: per-SEGMENT constants instead (device_math.h: segment_consts / spline2_event); thread s fills segment s of seg[12 s].
+constexpr int kSegStride = 12;
+__device__ __forceinline__ void seg_thread(int sidx, const double* __restrict__ knots, int K, double* __restrict__ seg)
+{
+    if (sidx >= K - 1) return;
+    double p0[4], p1[4], o[kSegStride];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { p0[i] = knots[4 * sidx + i]; p1[i] = knots[4 * (sidx + 1) + i]; }
+    segment_consts(p0, p1, o);
+#pragma unroll
+    for (int i = 0; i < kSegStride; ++i) seg[(size_t)kSegStride * sidx + i] = o[i];
 }
 
 __global__ __launch_bounds__(64) void emba_pose_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots, int K,
@@ -221,10 +215,16 @@ __global__ __launch_bounds__(256) void emba_pose_texel_kernel(const int64_t* __r
                                                               int n_pose_blk, int n_tex_blk, const double* __restrict__ Gx,
                                                               const double* __restrict__ Gy, int H, int W, const int* __restrict__ blk_rect,
                                                               int n_blk_rect, int* __restrict__ rect_out, double* __restrict__ texel,
-                                                              int compact, double* __restrict__ seg)
-{
-    if ((int)blockIdx.x < n_pose_blk) { if (threadIdx.x < 64) pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err, compact, seg); }
-    else texel_rect_blocks((long)blockIdx.x - n_pose_blk, n_tex_blk, Gx, Gy, H, W, blk_rect, n_blk_rect, rect_out, texel);
+                                                              double* __restrict__ seg)
+{   // seg != nullptr (tile order): the pose blocks fill the K-1 segment records; the per-batch table is not needed by the tiled kernel
+    if ((int)blockIdx.x < n_pose_blk) {
+        if (threadIdx.x < 64) {
+            if (seg) seg_thread(blockIdx.x * 64 + threadIdx.x, knots, K, seg);
+            else pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err);
+        }
+    }
+    else
+        texel_rect_blocks((long)blockIdx.x - n_pose_blk, n_tex_blk, Gx, Gy, H, W, blk_rect, n_blk_rect, rect_out, texel);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,6 +254,7 @@ constexpr int kTileRecStage = 16;               // records staged per wave at a 
 
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; const uint32_t* ev_pm; long n_sorted; long nblk;   // ev_pm: entry -> pm-order index (nullptr: identity)
+    const double* ev_u; const uint16_t* ev_seg;   // tile order: per entry the spline parameter u and the segment of its batch
     const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; seg: compact pose only
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
@@ -290,23 +291,20 @@ struct LaneOut {
 // re-warps the entry in front of the wave's 63 new ones and takes no other part.
 // The event word and (compact form) the batch's pose record of one lane, loaded ahead of their use: the tiled kernel walks its
 // chunk group by group and fetches the NEXT group's words and pose lines while it works on the current one.
-struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double2 P[4]; };   // pm: the entry's index in pm-order (where its residual / flag go)
+struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double u; };   // pm: the entry's index in pm-order (where its residual / flag go); u: tile order (bi is then the segment)
 
 // (the record slot is fetched here, with the event words, although only inliers use it: loaded where it is needed it would sit
 // behind the lane's own stores in the in-order memory counter and every staging round would wait for the previous round's stores)
 __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bool valid, LaneIn& in)
 {
-    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot; in.pm = (uint32_t)i;
-    if (valid) { in.pw = p.ev_pix[i]; in.bi = p.ev_batch[i]; in.slot = p.ev_slot[i]; if (p.ev_pm) in.pm = p.ev_pm[i]; }
-}
-__device__ __forceinline__ void load_pose_compact(const WarpParams& p, LaneIn& in)
-{
-    if (in.valid) {
-        const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStrideCompact * in.bi);
-        in.P[0] = P2[0]; in.P[1] = P2[1]; in.P[2] = P2[2]; in.P[3] = P2[3];
+    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot; in.pm = (uint32_t)i; in.u = 0.0;
+    if (valid) {
+        in.pw = p.ev_pix[i]; in.slot = p.ev_slot[i];
+        if (p.ev_pm) in.pm = p.ev_pm[i];
+        if (p.ev_u) { in.u = p.ev_u[i]; in.bi = p.ev_seg[i]; }       // tile order: spline parameter and segment of the event's batch
+        else in.bi = p.ev_batch[i];
     }
 }
-
 template <bool DUMP, bool COMPACT = false>
 __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o)
 {
@@ -323,14 +321,15 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
         pol = pw >> 31;
         const uint32_t bi = in.bi;
         double R[9], J1[9];
-        if (COMPACT) {   // one 64-B line per batch + the segment's axis (a K-entry table: cache-resident)
-            const double2 a0 = in.P[0], a1 = in.P[1], a2 = in.P[2], a3 = in.P[3];
-            const double q[4] = {a0.x, a0.y, a1.x, a1.y};
+        if (COMPACT) {   // tile order: pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
+            // (the K-1 segment records are cache-resident and fetched here, next to the bearing-vector gather whose latency is paid anyway:
+            // prefetched with the event words they cost 24 VGPRs per pipeline stage)
+            const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * ((p.ablate & 16) ? (bi & 1u) : bi));
+            const double2 s0 = S2[0], s1 = S2[1], s2 = S2[2], s3 = S2[3], s4 = S2[4], s5 = S2[5];
+            const double seg[kSegStride] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, s4.x, s4.y, s5.x, s5.y};
+            double q[4];
+            spline2_event<!DUMP>(seg, in.u, q, J1);
             quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
-            const double2* S2 = reinterpret_cast<const double2*>(p.seg + 4 * (size_t)(int)a3.y);
-            const double2 k01 = S2[0], k2_ = S2[1];
-            const double k[3] = {k01.x, k01.y, k2_.x};
-            rebuild_j1(a2.x, a2.y, a3.x, k, J1);
         } else {
             const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
             const double2 a0 = P2[0], a1 = P2[1], a2 = P2[2], a3 = P2[3], a4 = P2[4], a5 = P2[5], a6 = P2[6];
@@ -514,7 +513,6 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     LaneOut o;
     LaneIn in;
     load_event_words(p, i, valid, in);
-    if (COMPACT) load_pose_compact(p, in);
     warp_lane<DUMP, COMPACT>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;
@@ -591,26 +589,23 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
         const ChunkDesc ch = p.chunks[c];
         const long begin = ch.begin, end = ch.end;
         constexpr long kStep = (long)kWarpNew * kTileWaves;
-        // Two-deep software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter
-        // (vmcnt), so a load issued after a store cannot be waited for without waiting for the store's round trip as well.  Each
-        // iteration therefore: (1) issues the pose lines of group g+1 (their batch indices arrived during group g-1) and the event
-        // words + record slots of group g+2; (2) works on group g from registers — its only waits are for its own texel gather,
-        // behind which nothing slow is queued; (3) waits for everything once (the prefetches have had the whole group's arithmetic to
-        // arrive) and rotates the registers; (4) issues the record stores last, so nothing in the next iteration's steps (1)-(2)
-        // depends on them.  Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
-        LaneIn cur, nxt, nn;
+        // Software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter (vmcnt), so a
+        // load issued after a store cannot be waited for without waiting for the store's round trip as well.  Each iteration
+        // therefore: (1) issues the event words, spline parameters and record slots of group g+1; (2) works on group g from
+        // registers — its waits are for its own bearing-vector / segment / texel gathers, behind which nothing slow is queued;
+        // (3) waits for everything once (the prefetch has had the whole group's arithmetic to arrive) and rotates the registers;
+        // (4) issues the record stores last, so nothing in the next iteration's steps (1)-(2) depends on them.
+        // Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
+        LaneIn cur, nxt;
         {
             const long g0 = begin + (long)kWarpNew * wv;
-            const long i0 = g0 + t - 1, i1 = i0 + kStep;
+            const long i0 = g0 + t - 1;
             load_event_words(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
-            load_event_words(p, i1, g0 + kStep < end && i1 < end, nxt);
-            load_pose_compact(p, cur);
         }
 #pragma unroll 1
         for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += kStep) {   // wave-uniform
             const long i = g0 + t - 1;
-            load_pose_compact(p, nxt);
-            { const long i2 = i + 2 * kStep; load_event_words(p, i2, g0 + 2 * kStep < end && i2 < end, nn); }
+            { const long i1 = i + kStep; load_event_words(p, i1, g0 + kStep < end && i1 < end, nxt); }
             __builtin_amdgcn_sched_barrier(0);          // keep the prefetches where they are issued: ahead of this group's work
             LaneOut o;
             warp_lane<false, true>(p, i, cur, t, o);
@@ -630,8 +625,8 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
             const uint32_t slot = cur.slot;
-            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (3): prefetched words / pose lines are in; the compiler sees no pending load below
-            cur = nxt; nxt = nn;
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (3): the prefetched words are in; the compiler sees no pending load below
+            cur = nxt;
             __builtin_amdgcn_sched_barrier(0);
             store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)
         }

@@ -212,14 +212,15 @@ __global__ void emba_pm_gather_kernel(const uint32_t* __restrict__ keys, const u
 
 // control-pose index of every batch (basalt: s = (t - t0) / dt in int64, so3_spline.h:221-229); err = smallest batch outside the knots
 __global__ void emba_batch_cp_kernel(const int64_t* __restrict__ batch_t, long n_batch, int64_t t0, int64_t dt, int K, uint16_t* __restrict__ cp,
-                                     uint32_t* __restrict__ err)
+                                     double* __restrict__ u /* spline parameter of the batch, so3_spline.h:231 */, uint32_t* __restrict__ err)
 {
     const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n_batch) return;
     const int64_t st = batch_t[b] - t0;
     const int64_t s = (st >= 0) ? st / dt : -1;
-    if (st < 0 || s + 2 > (int64_t)K) { atomicMin(err, (uint32_t)b); cp[b] = 0; return; }
+    if (st < 0 || s + 2 > (int64_t)K) { atomicMin(err, (uint32_t)b); cp[b] = 0; u[b] = 0.0; return; }
     cp[b] = (uint16_t)s;
+    u[b] = (double)(st % dt) / (double)dt;
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -284,6 +285,7 @@ __global__ void emba_expand_write_kernel(const uint32_t* __restrict__ pm_pix, co
 __global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, long nd, const uint32_t* __restrict__ pm_pix,
                                        const uint32_t* __restrict__ pm_batch, uint32_t* __restrict__ ev_pix, uint32_t* __restrict__ ev_batch,
                                        uint32_t* __restrict__ ev_pm /* pm index of the entry */,
+                                       const uint16_t* __restrict__ cp, const double* __restrict__ batch_u, uint16_t* __restrict__ ev_seg, double* __restrict__ ev_u,
                                        uint32_t* __restrict__ cand_flag, uint32_t* __restrict__ bin_start)
 {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,8 +296,10 @@ __global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const 
     uint32_t w = pm_pix[i];
     if (lead) w = (w & ~kEvHasPred) | kEvLead;       // a copy that only serves as the next entry's predecessor
     ev_pix[j] = w;
-    ev_batch[j] = pm_batch[i];
+    const uint32_t b = pm_batch[i];
+    ev_batch[j] = b;
     ev_pm[j] = i;
+    ev_seg[j] = cp[b]; ev_u[j] = batch_u[b];     // what the tiled kernel evaluates the event's pose from (kernels.h: spline2_event)
     cand_flag[j] = (w & kEvHasPred) ? 1u : 0u;
     if (j == 0 || keys[j - 1] != keys[j]) bin_start[keys[j]] = (uint32_t)j;
 }

@@ -79,6 +79,38 @@ __device__ __forceinline__ void quat_to_matrix(const double* q, double* R)
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
+// sin and cos of the half rotation angle.  Between neighbouring control poses it is far below pi/4, where the two polynomial kernels
+// of fdlibm (k_sin.c / k_cos.c, |x| <= pi/4, < 1 ulp) need no argument reduction and no quadrant selection: a third of the instructions
+// of the general sin() + cos(), which stay as the fallback.  (The oracle calls the host libm; neither device form is bit-identical to it,
+// both are within an ulp — scripts/flip_rate.py measures what that does to round(pm).)
+__device__ __forceinline__ void sin_cos_half(double x, double& sn, double& cs)
+{
+    if (fabs(x) <= 0x1.921fb54442d18p-1) {
+        // (explicit fma: the same instructions wherever this is inlined, whatever the contraction mode)
+        const double z = x * x;
+        const double rs = fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                     -1.98412698298579493134e-04), 8.33333333332248946124e-03);
+        sn = fma(z * x, fma(z, rs, -1.66666666666666324348e-01), x);
+        const double rc = z * fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                              2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+        const double hz = 0.5 * z, w = 1.0 - hz;
+        cs = w + fma(z, rc, (1.0 - w) - hz);
+    } else {
+        sn = sin(x); cs = cos(x);
+    }
+}
+
+// Jacobian-only reciprocal: v_rcp_f64 and two Newton steps (about an ulp) instead of the IEEE division's ~14 instructions.  Never
+// used for anything an integer result depends on; its arguments here are O(1) (no scaling for denormal or huge values needed).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+
 // Sophus::SO3::expAndTheta (so3.hpp:583-619)
 __device__ __forceinline__ void so3_exp(const double* w, double* q)
 {
@@ -91,8 +123,10 @@ __device__ __forceinline__ void so3_exp(const double* w, double* q)
     } else {
         const double theta = sqrt(theta_sq);
         const double half = 0.5 * theta;
-        imag = sin(half) / theta;
-        real = cos(half);
+        double sn, cs;
+        sin_cos_half(half, sn, cs);
+        imag = sn / theta;
+        real = cs;
     }
     q[0] = imag * w[0]; q[1] = imag * w[1]; q[2] = imag * w[2]; q[3] = real;
 }
@@ -241,7 +275,12 @@ __device__ __forceinline__ void rebuild_j1(double u, double a1, double a2, const
 }
 
 // sin and cos of the half angle behind a REAL call (see project_angles_call below: fp64 polynomial constants hoisted out of the tiled kernel's loop)
-__device__ __attribute__((noinline)) double2 sin_cos_call(double x) { return make_double2(sin(x), cos(x)); }
+__device__ __attribute__((noinline)) double2 sin_cos_call(double x)
+{
+    double sn, cs;
+    sin_cos_half(x, sn, cs);
+    return make_double2(sn, cs);
+}
 
 template <bool CALL>
 __device__ __forceinline__ void spline2_event(const double* seg, double u, double* q_out, double* J1)
@@ -255,17 +294,17 @@ __device__ __forceinline__ void spline2_event(const double* seg, double u, doubl
         imag = 0.5 - (1.0 / 48.0) * theta_sq + (1.0 / 3840.0) * theta_po4;
         real = 1.0 - (1.0 / 8.0) * theta_sq + (1.0 / 384.0) * theta_po4;
         const double n = sqrt(theta_sq);
-        p1c = 0.5 * n; p2c = theta_sq / 6.0;
+        p1c = 0.5 * n; p2c = theta_sq * (1.0 / 6.0);
     } else {
         const double theta = sqrt(theta_sq);
         const double half = 0.5 * theta;
         double sh, ch;
         if (CALL) { const double2 sc = sin_cos_call(half); sh = sc.x; ch = sc.y; }
-        else { sh = sin(half); ch = cos(half); }
+        else sin_cos_half(half, sh, ch);
         imag = sh / theta;
         real = ch;
-        if (theta_sq > kSophusEps) { p1c = 2.0 * sh * sh / theta; p2c = 1.0 - 2.0 * sh * ch / theta; }     // (1 - cos n)/n, (n - sin n)/n
-        else { p1c = 0.5 * theta; p2c = theta_sq / 6.0; }                                                    // sophus_utils.hpp:351 small branch
+        if (theta_sq > kSophusEps) { const double it2 = 2.0 * rcp_nr(theta); p1c = sh * sh * it2; p2c = 1.0 - sh * ch * it2; }     // (1 - cos n)/n, (n - sin n)/n
+        else { p1c = 0.5 * theta; p2c = theta_sq * (1.0 / 6.0); }                                                    // sophus_utils.hpp:351 small branch
     }
     const double e[4] = {imag * kd[0], imag * kd[1], imag * kd[2], real};
     so3_mul(seg, e, q_out);
@@ -321,11 +360,14 @@ __device__ __forceinline__ void project_jacobian(const double* rb, double fx, do
     //   tmp1 = fx / ((1 + (x/z)^2) z) = fx z / (x^2 + z^2),   tmp1 * (x/z) = fx x / (x^2 + z^2),
     //   tmp2 = -fy / sqrt(1 - (y/rho)^2),  tmp3 = (y/rho) / rho^2  with 1/rho taken once.
     // Only the Jacobian is affected (last-bit differences); phi and theta — the rounded pixel — use the reference's expressions.
-    const double rho = sqrt(sum3(x * x, y * y, z * z));
-    const double inv_rho = 1.0 / rho;
+    // (round 2: the reciprocals are rcp_nr, and sqrt(1 - (y/rho)^2) = sqrt(x^2 + z^2) / rho shares 1/(x^2 + z^2) with the first row)
+    const double d2 = x * x + z * z;
+    const double rho = sqrt(d2 + y * y);
+    const double inv_rho = rcp_nr(rho);
     const double Ydivrho = y * inv_rho;
-    const double inv_d = fx / (x * x + z * z);
-    const double tmp2 = -fy / sqrt(1 - Ydivrho * Ydivrho);
+    const double inv_d2 = rcp_nr(d2);
+    const double inv_d = fx * inv_d2;
+    const double tmp2 = -fy * rho * (sqrt(d2) * inv_d2);
     const double tmp3 = Ydivrho * inv_rho * inv_rho;
     const double Jp[6] = {z * inv_d, 0.0, -x * inv_d, tmp2 * tmp3 * x, tmp2 * (tmp3 * y - inv_rho), tmp2 * tmp3 * z};
     const double M[9] = {0, rb[2], -rb[1], -rb[2], 0, rb[0], rb[1], -rb[0], 0};

@@ -1141,7 +1141,8 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         const long waves = ((long)c->n_cand + chunk - 1) / chunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
         constexpr long wpb = kGramBlock / 64;
-        hipLaunchKernelGGL(emba_gram_kernel, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
+        if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
+        else hipLaunchKernelGGL(emba_gram_kernel<false>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
     }
     HIP_TRY(c, hipGetLastError());

@@ -42,6 +42,9 @@ constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: n
 constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
 constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
+#ifndef GRAM_U_NT
+#define GRAM_U_NT 3
+#endif
 #ifndef GRAM_U
 #define GRAM_U 4
 #endif
@@ -488,7 +491,7 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
         for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
             const int rr = r0 + (t >> 3);
             if (rr < n_rec && !(p.ablate & 2))
-                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * s_slot[rr])[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
+                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * ((p.ablate & 32) ? (s_slot[rr] & 8191u) : s_slot[rr]))[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the next stage overwrites it
     }
@@ -1162,6 +1165,7 @@ __device__ __forceinline__ uint32_t rec_elem15_hi(double2 v)
     return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2hiint(v.y), (7 << 5) | 0x18);
 }
 
+template <bool TAGS>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
 {
     __shared__ uint32_t s_tag[kGramKeys];
@@ -1175,7 +1179,7 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
     // w, w+16, ...): at any moment the block reads a compact window of the stream, as a grid-stride loop would, instead of 16
     // separate streams 128 KB apart (4096 concurrent streams chip-wide cost DRAM page locality once the records exceed the
     // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
-    constexpr int U = GRAM_U;   // independent 1-KiB loads (8 records each) per wave and stage
+    constexpr int U = TAGS ? GRAM_U : GRAM_U_NT;   // independent 1-KiB loads (8 records each) per wave and stage
     constexpr int kStage = 8 * U, kStride = (kGramBlock / 64) * kStage;
     const long start = (long)blockIdx.x * (kGramBlock / 64) * p.chunk;
     const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
@@ -1227,7 +1231,7 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
         }
         return w;
     };
-    auto consume = [&](int off, const double2* x) {
+    auto consume = [&](int off, double2* x) {
         if ((k_first == cur_key) && (k_last == cur_key)) {             // fast path: the whole stage belongs to the current pair
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1248,10 +1252,9 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
         }
         // The stage straddles a pair boundary (a few dozen waves per launch): group the 8 records of each MFMA step by pair.
         // One copy of the code — the loop is kept rolled by rotating the stage's registers instead of indexing them.
-        double2 y[U];
-        uint32_t a_[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { y[u] = x[u]; a_[u] = act[u]; }
+        // (x and act are dead after this call: rotated in place)
+        double2* y = x;
+        uint32_t* a_ = act;
 #pragma unroll 1
         for (int u = 0; u < U; ++u) {
             const bool ok = a_[0] & 1u;
@@ -1284,57 +1287,120 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
             for (int v = 0; v + 1 < U; ++v) { y[v] = y[v + 1]; a_[v] = a_[v + 1]; }
         }
     };
-    if (p.tag) {
+    if (TAGS) {
         // Tag stream: one 8-B word {panorama pixel, evaluation stamp} per slot, written by the warp kernels next to the record.  A stage
         // first reads its 32 tags (256 contiguous bytes), looks the activity bits up, and then fetches ONLY the records that take part
         // (8 lanes = one 128-B line per record: a record that is stale, an outlier's, or on an inactive pixel is never read — about half
         // of the slots of the BASELINE workload).  Loads return in order, so the three dependent steps of a stage are spread over three
         // iterations: tags of stage i+2, activity bits of stage i+1 and records of stage i+1 are in flight while stage i is consumed.
+        // What keeps the three steps apart in the generated code: tags and activity words are loaded UNCONDITIONALLY (clamped / safe
+        // addresses, validity applied when the bit is extracted an iteration later), the pair keys come through the scalar cache, and
+        // the two record buffers and the two tag registers alternate by an iteration unrolled twice — a conditional load is waited for
+        // at the end of its branch, a vector key load or a copy of a register still being loaded waits for everything issued before it
+        // (all three were the case: one stage's full latency per iteration).
         const double* tag0 = p.tag + start;
-        auto tagload = [&](int off) -> double { const int sidx = off + lane; return (lane < 8 * U && off < len && sidx < len) ? tag0[sidx] : 0.0; };
-        auto bitgather = [&](int off, double tg) -> uint32_t {
-            const uint32_t pi = (uint32_t)__double2loint(tg);
-            const bool valid = lane < 8 * U && off + lane < len && (uint32_t)__double2hiint(tg) == p.stamp && pi != kInvalidPix;
-            return valid ? ((((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31)) & 1u) : 0u;
+        const int tag_lim = (int)((p.n_slots + kGramPad - 1 - start < (long)0x7FFFFFF0) ? (p.n_slots + kGramPad - 1 - start) : (long)0x7FFFFFF0);
+        auto tagload = [&](int off) -> double { const int sidx = off + lane; return tag0[sidx < tag_lim ? sidx : tag_lim]; };
+        auto tagvalid = [&](int off, double tg) -> bool {
+            return lane < 8 * U && off + lane < len && (uint32_t)__double2hiint(tg) == p.stamp && (uint32_t)__double2loint(tg) != kInvalidPix;
+        };
+        auto bitword = [&](int off, double tg) -> uint32_t { return p.active_bits[tagvalid(off, tg) ? ((uint32_t)__double2loint(tg) >> 5) : 0u]; };
+        auto bitmask = [&](int off, double tg, uint32_t w) -> uint32_t {
+            const uint32_t bit = (((p.ablate & 256) ? ~0u : w) >> ((uint32_t)__double2loint(tg) & 31u)) & (tagvalid(off, tg) ? 1u : 0u);
+            return (uint32_t)__ballot(bit != 0);
         };
         auto load_masked = [&](int off, uint32_t m, double2* x) {
             const double2* q = rec0 + 8 * off;
 #pragma unroll
             for (int u = 0; u < U; ++u) x[u] = ((m >> (8 * u + R)) & 1u) ? q[64 * u] : make_double2(0.0, 0.0);
         };
-        auto keys = [&](int off) { k_first = key0[off]; k_last = key0[(off + 8 * U < len ? off + 8 * U : len) - 1]; };
-        double T = tagload(off0);
-        uint32_t B = bitgather(off0, T);
-        T = tagload(off0 + kStride);
-        uint32_t Mc = (uint32_t)__ballot(B != 0);
-        B = bitgather(off0 + kStride, T);
-        T = tagload(off0 + 2 * kStride);
-        load_masked(off0, Mc, xA);
-        for (int off = off0; off < len; off += kStride) {
+        typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
+        const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)key0;
+        auto keys = [&](int off) { k_first = key_s[off]; k_last = key_s[(off + 8 * U < len ? off + 8 * U : len) - 1]; };
+        // iteration i: Tb = tags of stage i+1 (here), Tn = tags of stage i+2 (arriving), W = activity words of stage i+1 (arriving)
+        uint32_t Mc, W;
+        double Te, To;
+        auto iterate = [&](int off, double2* cur, double2* nxt, double& Tb, double& Tn) {
             const bool h1 = off + kStride < len;
-            const uint32_t Mn = h1 ? (uint32_t)__ballot(B != 0) : 0u;
-            B = bitgather(off + 2 * kStride, T);
-            T = tagload(off + 3 * kStride);
-            if (h1) load_masked(off + kStride, Mn, xB);
+            const uint32_t Mn = h1 ? bitmask(off + kStride, Tb, W) : 0u;
+            W = bitword(off + 2 * kStride, Tn);
+            Tb = tagload(off + 3 * kStride);                 // (Tb's stage is done with: its register takes stage i+3)
+            if (h1) load_masked(off + kStride, Mn, nxt);
             keys(off);
 #pragma unroll
             for (int u = 0; u < U; ++u) act[u] = (Mc >> (8 * u + R)) & 1u;
-            if (Mc) consume(off, xA);
-#pragma unroll
-            for (int u = 0; u < U; ++u) xA[u] = xB[u];
+            if (Mc) consume(off, cur);
             Mc = Mn;
+        };
+        Te = tagload(off0);
+        W = bitword(off0, Te);
+        To = tagload(off0 + kStride);
+        Mc = bitmask(off0, Te, W);
+        W = bitword(off0 + kStride, To);
+        Te = tagload(off0 + 2 * kStride);
+        load_masked(off0, Mc, xA);
+        for (int off = off0; off < len;) {
+            iterate(off, xA, xB, To, Te); off += kStride; if (off >= len) break;
+            iterate(off, xB, xA, Te, To); off += kStride;
         }
     } else {
-    load_records(off0, xA);
-    for (int off = off0; off < len; off += 2 * kStride) {
-        lookup(off, xA);                        // issued BEFORE B's record loads: memory operations return in order, so waiting
-        const bool haveB = off + kStride < len;  // for the lookups later leaves B's loads in flight
-        if (haveB) load_records(off + kStride, xB);
-        consume(off, xA);
-        if (!haveB) break;
-        lookup(off + kStride, xB);
-        if (off + 2 * kStride < len) load_records(off + 2 * kStride, xA);
-        consume(off + kStride, xB);
+    // No tag stream (tile order): the activity bits of a stage can only be looked up once its records are here, and loads return in
+    // order.  Four stages rotate through registers: per iteration the lookups of stage i+1 (whose records arrived an iteration ago)
+    // are issued, then the records of stage i+3, and stage i is consumed — its lookups were issued one iteration earlier, AHEAD of
+    // the record loads of stage i+2, so the wait for them leaves two stages of records in flight.  (Two stages, lookups in the
+    // critical path: 3.15 ms for 12.7 GB at 100 M events; without the lookups 2.24 ms.)
+    // The four stage buffers are used round-robin by an iteration unrolled four times — copying a register a load is still
+    // in flight to would wait for that load.
+    double2 xC[U], xD[U];
+    uint32_t actB[U], kfA = 0, klA = 0, kfB = 0, klB = 0;
+    // (pair keys through the scalar cache: as vector loads they would be waited for with every record load issued before them)
+    typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
+    const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)key0;
+    auto lookup_into = [&](int off, const double2* x, uint32_t* a, uint32_t& f, uint32_t& l) {
+        f = key_s[off < len ? off : len - 1];                    // (a stage past the end is never consumed)
+        l = key_s[(off + 8 * U < len ? off + 8 * U : len) - 1];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t pi = rec_elem15_lo(x[u]);
+            const bool in = off + 8 * u + R < len;
+            const bool valid = in && rec_elem15_hi(x[u]) == p.stamp && pi != kInvalidPix;
+            // An UNCONDITIONAL load from a safe address: a load the compiler can sink under a lane mask is waited for at the end of
+            // that branch, together with everything issued before it.  Only the raw word is kept: the bit is extracted when the
+            // stage is consumed (an iteration later), so nothing here waits for the gather.
+            a[u] = p.active_bits[valid ? (pi >> 5) : 0u];
+        }
+    };
+    auto resolve = [&](int off, const double2* x, const uint32_t* w) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t pi = rec_elem15_lo(x[u]);
+            const bool valid = (off + 8 * u + R < len) && rec_elem15_hi(x[u]) == p.stamp && pi != kInvalidPix;
+            act[u] = (((p.ablate & 256) ? ~0u : w[u]) >> (pi & 31)) & (valid ? 1u : 0u);
+        }
+    };
+    // one iteration: stage i in `cur` (its lookups in a_cur / f_cur, l_cur), stage i+1 in `nxt`, stage i+3 goes to `fre`
+    // (no load sits under a branch: stages past the block's end are fetched from a clamped, allocated offset and masked out — with
+    // conditional loads the compiler's wait-count bookkeeping degrades to "wait for everything" at the joins)
+    const int off_max = (int)((p.n_slots + kGramPad - 8 * U - start < (long)0x7FFFFFF0) ? (p.n_slots + kGramPad - 8 * U - start) : (long)0x7FFFFFF0);
+    auto load_clamped = [&](int off, double2* x) { load_records(off < off_max ? off : off_max, x); };
+    auto iterate = [&](int off, double2* cur, double2* nxt, double2* fre, uint32_t* a_cur, uint32_t f_cur, uint32_t l_cur, uint32_t* a_nxt,
+                       uint32_t& f_nxt, uint32_t& l_nxt) {
+        lookup_into(off + kStride, nxt, a_nxt, f_nxt, l_nxt);
+        load_clamped(off + 3 * kStride, fre);
+        k_first = f_cur; k_last = l_cur;
+        resolve(off, cur, a_cur);
+        consume(off, cur);
+    };
+    uint32_t actA[U];
+    load_clamped(off0, xA);
+    load_clamped(off0 + kStride, xB);
+    load_clamped(off0 + 2 * kStride, xC);
+    lookup_into(off0, xA, actA, kfA, klA);
+    for (int off = off0; off < len;) {
+        iterate(off, xA, xB, xD, actA, kfA, klA, actB, kfB, klB); off += kStride; if (off >= len) break;
+        iterate(off, xB, xC, xA, actB, kfB, klB, actA, kfA, klA); off += kStride; if (off >= len) break;
+        iterate(off, xC, xD, xB, actA, kfA, klA, actB, kfB, klB); off += kStride; if (off >= len) break;
+        iterate(off, xD, xA, xC, actB, kfB, klB, actA, kfA, klA); off += kStride;
     }
     }
     if (dirty) flush();

@@ -298,18 +298,25 @@ struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double u; };   // pm: the
 
 // (the record slot is fetched here, with the event words, although only inliers use it: loaded where it is needed it would sit
 // behind the lane's own stores in the in-order memory counter and every staging round would wait for the previous round's stores)
+// The loads are UNCONDITIONAL (index clamped into the arrays, `valid` applied by the consumer): a load under a lane mask is waited for
+// at the end of its branch, with everything issued before it — the tiled kernel's prefetch of the next group was waited for on the spot.
+template <bool COMPACT>
 __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bool valid, LaneIn& in)
 {
-    in.valid = valid; in.pw = 0; in.bi = 0; in.slot = kNoSlot; in.pm = (uint32_t)i; in.u = 0.0;
-    if (valid) {
-        in.pw = p.ev_pix[i]; in.slot = p.ev_slot[i];
-        if (p.ev_pm) in.pm = p.ev_pm[i];
-        if (p.ev_u) { in.u = p.ev_u[i]; in.bi = p.ev_seg[i]; }       // tile order: spline parameter and segment of the event's batch
-        else in.bi = p.ev_batch[i];
-    }
+    const long last = p.n_sorted - 1;               // (n_sorted >= 1 whenever a warp kernel is launched)
+    const long ic = i < 0 ? 0 : (i > last ? last : i);
+    in.valid = valid; in.u = 0.0;
+    in.pw = p.ev_pix[ic]; in.slot = p.ev_slot[ic];
+    if (COMPACT) { in.pm = p.ev_pm[ic]; in.u = p.ev_u[ic]; in.bi = p.ev_seg[ic]; }    // tile order: pm-order index, spline parameter and segment of the event's batch
+    else { in.pm = (uint32_t)ic; in.bi = p.ev_batch[ic]; }
 }
-template <bool DUMP, bool COMPACT = false>
-__device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o)
+
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// `prefetch` is called once, wave-uniformly, right after the texel gather has been waited for: the point of a group where nothing
+// the group still needs is loaded any more.  (Loads return in order: a prefetch issued earlier sits in front of the bearing-vector,
+// segment and texel gathers, and the waits for those L2 hits would pay the prefetch's HBM latency.)
+template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch>
+__device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o, PF prefetch = PF())
 {
     const bool valid = in.valid;
     double pm[2] = {0, 0};
@@ -323,6 +330,9 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
         const uint32_t pix = pw & 0x1FFFFFFFu;
         pol = pw >> 31;
         const uint32_t bi = in.bi;
+        const double* bv = p.lut + 3 * (size_t)pix;
+        double b0, b1, b2;
+        if (COMPACT) { b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; }   // tile order: the bearing-vector gather is in flight while the pose is evaluated
         double R[9], J1[9];
         if (COMPACT) {   // tile order: pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
             // (the K-1 segment records are cache-resident and fetched here, next to the bearing-vector gather whose latency is paid anyway:
@@ -340,8 +350,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
             quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
             J1[0] = a2.x; J1[1] = a2.y; J1[2] = a3.x; J1[3] = a3.y; J1[4] = a4.x; J1[5] = a4.y; J1[6] = a5.x; J1[7] = a5.y; J1[8] = a6.x;
         }
-        const double* bv = p.lut + 3 * (size_t)pix;
-        const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
+        if (!COMPACT) { b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; }  // (pixel order: after the pose record — measured: 52 vs 57 us at 1 M events the other way round)
         double rb[3];
         {   // feeds round(pm): no contraction (device_math.h), the oracle's three products and two sums
 #pragma clang fp contract(off)
@@ -437,6 +446,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
             }
         }
     }
+    prefetch();
     o.inl = inl; o.pi = pi; o.pmx = pmx; o.pmy = pmy; o.dpx = dpx; o.dpy = dpy; o.e = e;
     if (DUMP) return;
 
@@ -515,7 +525,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     const bool valid = (i >= 0) && (i < p.n_sorted);
     LaneOut o;
     LaneIn in;
-    load_event_words(p, i, valid, in);
+    load_event_words<COMPACT>(p, i, valid, in);
     warp_lane<DUMP, COMPACT>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;
@@ -592,26 +602,26 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
         const ChunkDesc ch = p.chunks[c];
         const long begin = ch.begin, end = ch.end;
         constexpr long kStep = (long)kWarpNew * kTileWaves;
-        // Software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter (vmcnt), so a
-        // load issued after a store cannot be waited for without waiting for the store's round trip as well.  Each iteration
-        // therefore: (1) issues the event words, spline parameters and record slots of group g+1; (2) works on group g from
-        // registers — its waits are for its own bearing-vector / segment / texel gathers, behind which nothing slow is queued;
-        // (3) waits for everything once (the prefetch has had the whole group's arithmetic to arrive) and rotates the registers;
-        // (4) issues the record stores last, so nothing in the next iteration's steps (1)-(2) depends on them.
+        // Software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter (vmcnt): waiting
+        // for a load means waiting for everything issued before it.  Each iteration therefore: (1) works on group g from registers
+        // — its waits are for its own bearing-vector / segment / texel gathers (cache hits), behind which nothing slow is queued;
+        // (2) once the texels are here issues the event words, spline parameters and record slots of group g+1 (HBM streams), which
+        // have the group's remaining arithmetic and LDS atomics to arrive; (3) waits for everything once and rotates the registers;
+        // (4) issues the record stores last.
         // Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
         LaneIn cur, nxt;
         {
             const long g0 = begin + (long)kWarpNew * wv;
             const long i0 = g0 + t - 1;
-            load_event_words(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
+            load_event_words<true>(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // (so that `cur` is known to be loaded on BOTH ways into the loop: see (3))
         }
 #pragma unroll 1
         for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += kStep) {   // wave-uniform
             const long i = g0 + t - 1;
-            { const long i1 = i + kStep; load_event_words(p, i1, g0 + kStep < end && i1 < end, nxt); }
-            __builtin_amdgcn_sched_barrier(0);          // keep the prefetches where they are issued: ahead of this group's work
+            auto prefetch = [&]() { const long i1 = i + kStep; load_event_words<true>(p, i1, g0 + kStep < end && i1 < end, nxt); };
             LaneOut o;
-            warp_lane<false, true>(p, i, cur, t, o);
+            warp_lane<false, true>(p, i, cur, t, o, prefetch);
             const unsigned long long inl_mask = __ballot(o.inl);
             if (o.inl) {
                 const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
@@ -628,7 +638,8 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 }
             }
             const uint32_t slot = cur.slot;
-            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (3): the prefetched words are in; the compiler sees no pending load below
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // (3) vmcnt(0): the prefetched words are in.  The builtin, not inline asm: the compiler's own wait-count bookkeeping must
+                                                  // know it, or it waits again at the next iteration's first use of `cur` — behind the record stores issued below
             cur = nxt;
             __builtin_amdgcn_sched_barrier(0);
             store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)

@@ -333,10 +333,10 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         for (size_t b = 0; b + 1 < nbins; ++b) n_used_bins += h_used[b];
         const double per_px = n_used_bins ? (double)c->n_used / ((double)n_used_bins * g.bw * g.bh) : 0.0;     // events per panorama pixel of the occupied tiles
         const double lead_frac = c->n_used ? (double)n_break / (double)c->n_used : 1.0;
-        // Measured (profiles/r02*_scaling_sweep.txt): the tile order wins once the working set has left the Infinity Cache (>= ~5 M events:
-        // 10 M / K=97 603 vs 743 us, 100 M 5.9 vs 8.7 ms) and loses below it (1 M events, 24 per pixel: 81 vs 58 us — every entry of the
-        // tile order is a warp, lead-ins included, and a workgroup's LDS tile is zeroed and flushed for a handful of groups).
-        tile = (c->order_mode == 2) || (c->n_used >= 5000000 && per_px >= 8.0 && lead_frac <= 0.35);
+        // Measured (profiles/r02c_order_sweep.txt): the tile order wins once the working set has left the Infinity Cache (3 M events, 1024x2048:
+        // 374 vs 394 us per step; 5 M / K=97: 558 vs 618; 100 M: 4.8 vs 8.7 ms warp) and loses below it (1 M events, 24 per pixel: 82 vs 52 us
+        // — every entry of the tile order is a warp, lead-ins included, and a workgroup's LDS tile is zeroed and flushed for a handful of groups).
+        tile = (c->order_mode == 2) || (c->n_used >= 3000000 && per_px >= 8.0 && lead_frac <= 0.35);
     }
 
     if (!tile) {

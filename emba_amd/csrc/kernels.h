@@ -42,6 +42,26 @@ constexpr int kWarpBlock = 64;     // the warp kernel's workgroup is ONE wave: n
 constexpr int kWarpNew = 63;       // new events per wave (lane 0 re-warps the predecessor of lane 1)
 constexpr int kRecLds = 18;        // doubles per record in the LDS staging tile (144 B: conflict-free 16-B accesses)
 constexpr int kPixAccStride = 8;  // doubles per pixacc line (64 B)
+// Streaming accesses marked non-temporal (they are written / read once per launch and should not displace the gather tables —
+// bearing vectors, texels, segment records, activity bits — from L2): REC_NT_STORE the 128-B record stores of the warp kernels
+// (measured: 10 M events 514 -> 467 us, 100 M 4.70 -> 4.46 ms, and the Gram kernel after it 309 -> 283 us), EP_NT_STORE the
+// residual / flag stores, GRAM_NT_LOAD the Gram kernel's record stream, EV_NT_LOAD the event-word stream.
+#ifndef REC_NT_STORE
+#define REC_NT_STORE 1
+#endif
+#ifndef EP_NT_STORE
+#define EP_NT_STORE 1     // 10 M: 496 -> 481 us, 100 M: 4.54 -> 4.40 ms, 1 M: equal
+#endif
+#ifndef GRAM_NT_LOAD
+#define GRAM_NT_LOAD 1    // Gram kernel, 10 M: 293 -> 269 us, 100 M: 2.65 -> 2.58 ms
+#endif
+#ifndef EV_NT_LOAD
+#define EV_NT_LOAD 1      // TILE ORDER ONLY (10 M: 496 -> 484 us); in pixel order at 1 M events the words are Infinity-Cache hits and NT loads cost 52 -> 72 us
+#endif
+#ifndef GRAM_TAG_NT
+#define GRAM_TAG_NT 0
+#endif
+template <class T> __device__ __forceinline__ T stream_load(const T* p, bool nt) { return nt ? __builtin_nontemporal_load(p) : *p; }
 #ifndef GRAM_DUMMY_LOADS
 #define GRAM_DUMMY_LOADS 0   // 1: dead records are loaded from one fixed line instead of skipped (exact wait counts; measured 4 % slower at 10 M events, equal at 1 M)
 #endif
@@ -309,9 +329,9 @@ __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bo
     const long last = p.n_sorted - 1;               // (n_sorted >= 1 whenever a warp kernel is launched)
     const long ic = i < 0 ? 0 : (i > last ? last : i);
     in.valid = valid; in.u = 0.0;
-    in.pw = p.ev_pix[ic]; in.slot = p.ev_slot[ic];
-    if (COMPACT) { in.pm = p.ev_pm[ic]; in.u = p.ev_u[ic]; in.bi = p.ev_seg[ic]; }    // tile order: pm-order index, spline parameter and segment of the event's batch
-    else { in.pm = (uint32_t)ic; in.bi = p.ev_batch[ic]; }
+    in.pw = stream_load(p.ev_pix + ic, COMPACT && EV_NT_LOAD); in.slot = stream_load(p.ev_slot + ic, COMPACT && EV_NT_LOAD);
+    if (COMPACT) { in.pm = stream_load(p.ev_pm + ic, EV_NT_LOAD); in.u = stream_load(p.ev_u + ic, EV_NT_LOAD); in.bi = stream_load(p.ev_seg + ic, EV_NT_LOAD); }    // tile order: pm-order index, spline parameter and segment of the event's batch
+    else { in.pm = (uint32_t)ic; in.bi = stream_load(p.ev_batch + ic, EV_NT_LOAD); }
 }
 
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
@@ -445,7 +465,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
 #pragma unroll
                 for (int j = 0; j < 6; ++j) o.jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
                 ngx = -gx; ngy = -gy;
-                p.e_sorted[in.pm] = e;
+                if (EP_NT_STORE) __builtin_nontemporal_store(e, &p.e_sorted[in.pm]); else p.e_sorted[in.pm] = e;
             }
         }
     }
@@ -461,7 +481,9 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
     }
     // residual and inlier flag live at the entry's PM-ORDER index (= i in pixel order; a chain's entries are consecutive there too), so that the
     // reference-order compaction reads them in order; a lead-in / halo copy owns no pm slot of its own and writes nothing
-    if (valid && t >= 1 && !(pw & 0x40000000u)) p.flag[in.pm] = inl ? 1 : 0;
+    if (valid && t >= 1 && !(pw & 0x40000000u)) {
+        if (EP_NT_STORE) __builtin_nontemporal_store((uint8_t)(inl ? 1 : 0), &p.flag[in.pm]); else p.flag[in.pm] = inl ? 1 : 0;
+    }
 
     // the lane's terms of the per-pixel sums (model.cpp:227 count, :426-439 A22/b2), IRLS-weighted when the cost is declared
     double v0 = dpx * dpx, v1 = dpx * dpy, v2 = dpy * dpy, v3 = dpx * e, v4 = dpy * e;   // zero unless inlier (dpx,dpy,e are)
@@ -504,7 +526,16 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
         for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
             const int rr = r0 + (t >> 3);
             if (rr < n_rec && !(p.ablate & 2))
-                reinterpret_cast<double2*>(p.rec + (size_t)kRecStride * ((p.ablate & 32) ? (s_slot[rr] & 8191u) : s_slot[rr]))[c8] = reinterpret_cast<const double2*>(s_tile + rr * kRecLds)[c8];
+            {
+                typedef double v2d __attribute__((ext_vector_type(2)));
+                v2d* dst = reinterpret_cast<v2d*>(p.rec + (size_t)kRecStride * ((p.ablate & 32) ? (s_slot[rr] & 8191u) : s_slot[rr])) + c8;
+                const v2d val = reinterpret_cast<const v2d*>(s_tile + rr * kRecLds)[c8];
+#if REC_NT_STORE
+                __builtin_nontemporal_store(val, dst);
+#else
+                *dst = val;
+#endif
+            }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the next stage overwrites it
     }
@@ -1223,7 +1254,11 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
     auto load_records = [&](int off, double2* x) {   // may run up to 8 U records past `end`: the record buffer is padded
         const double2* q = rec0 + 8 * off;           // (kGramPad) and those slots are masked
 #pragma unroll
-        for (int u = 0; u < U; ++u) x[u] = q[64 * u];
+        for (int u = 0; u < U; ++u) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            if (GRAM_NT_LOAD) { const v2d v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q + 64 * u)); x[u] = make_double2(v.x, v.y); }
+            else x[u] = q[64 * u];
+        }
     };
     auto lookup = [&](int off, const double2* x) {
         // first and last pair key of the stage (uniform addresses), issued ahead of the next stage's records
@@ -1334,6 +1369,12 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
 #if GRAM_DUMMY_LOADS
                 x[u] = *(((m >> (8 * u + R)) & 1u) ? q + 64 * u : dummy);
 #else
+                if (GRAM_TAG_NT) {
+                    typedef double v2d __attribute__((ext_vector_type(2)));
+                    v2d v = {0.0, 0.0};
+                    if ((m >> (8 * u + R)) & 1u) v = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(q + 64 * u));
+                    x[u] = make_double2(v.x, v.y);
+                } else
                 x[u] = ((m >> (8 * u + R)) & 1u) ? q[64 * u] : make_double2(0.0, 0.0);
 #endif
             }

@@ -99,6 +99,7 @@ struct emba_ctx {
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
+    bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
     double* d_ep = nullptr;
     // order / key cache
@@ -500,6 +501,7 @@ emba_status launch_ep_compaction(emba_ctx* c)
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
         hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, perm, c->d_fblk_off,
                            (long)c->n_pm, c->d_ep, c->d_inl_idx);
+        c->inl_idx_valid = true;
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
@@ -507,6 +509,18 @@ emba_status launch_ep_compaction(emba_ctx* c)
         HIP_TRY(c, hipMemcpyAsync(&c->h_pinned[1], c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));
     }
     c->inl_pending = true;
+    return EMBA_OK;
+}
+
+// Per-event inlier numbers (index into ep), for the consumers that need them: the fused post-warp launches skip them.
+emba_status ensure_inl_idx(emba_ctx* c)
+{
+    { emba_status st = launch_ep_compaction(c); if (st) return st; }
+    if (c->inl_idx_valid || !c->n_pm) return EMBA_OK;
+    hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, c->stream, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off,
+                       (long)c->n_pm, c->d_ep, c->d_inl_idx);   // (block offsets of this evaluation are still there; ep is rewritten with the same values)
+    HIP_TRY(c, hipGetLastError());
+    c->inl_idx_valid = true;
     return EMBA_OK;
 }
 
@@ -954,7 +968,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->h_knots_cap = K;
     }
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
-    c->inl_pending = c->P_pending = false; c->ep_deferred = false;
+    c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
     hipStream_t s = c->stream;
     if (c->knots_in_flight) HIP_TRY(c, hipStreamSynchronize(s));   // the previous prep kernel must have consumed the pinned staging buffer
     memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
@@ -1064,7 +1078,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.fblk_cnt = c->d_fblk_cnt; q.fblk_off = c->d_fblk_off; q.n_fblk = c->n_fblk; q.perm = nullptr; q.n_pm = (long)c->n_pm;
         q.total_inl = c->d_total; q.total_inl_host = c->h_pinned_dev;
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
-        q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = c->d_inl_idx;
+        q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = nullptr;   // (inlier numbers: on demand, ensure_inl_idx)
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
@@ -1105,6 +1119,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     const bool generic_a22 = !acc_matches || (ep_host != nullptr);
     if (generic_a22) { emba_status st = resolve_pending(c); if (st) return st; }   // needs n_inliers / P on the host (rare path)
     if (ep_host && c->n_inliers) {
+        { emba_status st = ensure_inl_idx(c); if (st) return st; }
         HIP_TRY(c, hipMemcpyAsync(c->d_ep, ep_host, c->n_inliers * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(emba_override_ep_kernel, dim3((unsigned)((c->n_sorted + 255) / 256)), dim3(256), 0, s, c->d_ep, c->d_flag,
                            c->d_inl_idx, c->d_ev_slot, c->d_ev_pix, c->tile_order ? c->d_ev_pm : nullptr, (long)c->n_sorted, c->d_rec, c->d_e_sorted);
@@ -1290,6 +1305,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state to dump");
     HIP_TRY(c, hipSetDevice(c->device));
     { emba_status st0 = resolve_pending(c); if (st0) return st0; }
+    if (inlier_idx) { emba_status st0 = ensure_inl_idx(c); if (st0) return st0; }
     const size_t ns = c->n_sorted, n = c->n_in;
     if (!ns) return EMBA_OK;
     hipStream_t s = c->stream;

@@ -828,8 +828,8 @@ __device__ __forceinline__ void compact_ep_block(long blk, const double* __restr
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (j[q] == 0xFFFFFFFFu) continue;
-        if (m & (1u << q)) { ep[k] = e_sorted[j[q]]; inl_idx[j[q]] = (int32_t)k; ++k; }
-        else inl_idx[j[q]] = -1;
+        if (m & (1u << q)) { ep[k] = e_sorted[j[q]]; if (inl_idx) inl_idx[j[q]] = (int32_t)k; ++k; }
+        else if (inl_idx) inl_idx[j[q]] = -1;
     }
 }
 

@@ -221,7 +221,8 @@ def main():
             "dtype": "f64", "data": "synthetic" if args.data == "uniform" else "synthetic (simulated scene)",
             "config": {"workload": w.describe(), "events_per_gpu": args.events_per_gpu, "total_events": n_total,
                        "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
-                       "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM",
+                       "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
+                               "(the host API's compacted ep vector is produced when it is asked for)",
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
                        "setup": m.setup_info()},

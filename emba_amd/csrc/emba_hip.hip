@@ -1083,7 +1083,10 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
         hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3(2), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(emba_post_warp_c_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, aw, q);
+        // (launch C is the active-set write alone: nothing on the device reads the compacted residual vector `ep` — costs, Gram and solvers
+        // work from the records and the per-event residuals — so it is produced when the host asks for it: resolve_pending /
+        // ensure_inl_idx run the standalone compaction, whose block offsets launch B has just left in place.  100 M events: 0.65 -> 0.2 ms)
+        hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
         c->inl_pending = true;
     } else {
         { emba_status st0 = launch_ep_compaction(c); if (st0) return st0; }

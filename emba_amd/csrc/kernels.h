@@ -939,7 +939,8 @@ __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* _
 
 // The two small post-warp chains (residual compaction: count -> scan -> compact; active set: count -> scan -> write) are
 // independent of each other, so their stages share launches ("heterogeneous" kernels):
-//   A = {active-count blocks | inlier-flag-count blocks}   B = {active-scan block | flag-scan block}   C = {active-write blocks | compaction blocks}
+//   A = {active-count blocks | inlier-flag-count blocks}   B = {active-scan block | flag-scan block}   C = active-write blocks (the residual
+//   compaction itself runs only when the host asks for `ep`: emba_compact_ep_kernel)
 struct PostWarpParams {
     const int32_t* count; long npix; int thres; uint32_t* ablk_cnt; uint32_t* ablk_off; long n_ablk; uint32_t* total_P; int* total_P_host;
     uint32_t* fblk_cnt; uint32_t* fblk_off; long n_fblk; const uint32_t* perm; long n_pm; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
@@ -1027,12 +1028,6 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
 }
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParams a) { active_write_block(blockIdx.x, a); }
-
-__global__ __launch_bounds__(256) void emba_post_warp_c_kernel(ActiveWriteParams a, PostWarpParams p)
-{
-    if ((long)blockIdx.x < a.n_ablk) active_write_block(blockIdx.x, a);
-    else compact_ep_block((long)blockIdx.x - a.n_ablk, p.e_sorted, p.flag, p.perm, p.fblk_off, p.n_pm, p.ep, p.inl_idx);
-}
 
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
 __global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)

@@ -83,6 +83,13 @@ def merge_ep(ep_parts, pix_parts):
     return ep[order]
 
 
+def _device_sync(dev):
+    """(the CPU stand-in engine of the gloo tests keeps its tensors on the host)"""
+    if dev.type == "cuda":
+        import torch
+        torch.cuda.synchronize(dev)
+
+
 class ShardedLEGM:
     """LEGM over `dist` (a torch.distributed-like module: all_reduce, get_rank, get_world_size)."""
 
@@ -156,7 +163,7 @@ class ShardedLEGM:
         if w > 1:
             dist.all_to_all_single(recv[: n_recv * 16], send[: n_send * 16], [int(v) * 16 for v in recv_counts], [int(v) * 16 for v in counts])
         else:
-            e.sync(); recv[: n_send * 16] = send[: n_send * 16]; torch.cuda.synchronize(dev)
+            e.sync(); recv[: n_send * 16] = send[: n_send * 16]; _device_sync(dev)
         S = torch.zeros(e.solve_shard_size(), dtype=torch.float64, device=dev)
         e.solve_shard_partial(r, w, recv, n_recv, lam, S)
         if w > 1:
@@ -165,7 +172,7 @@ class ShardedLEGM:
         x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
         if w > 1:
             dist.all_reduce(x2)
-        torch.cuda.synchronize(dev)
+        _device_sync(dev)
         return x1, x2[: 2 * self.P].cpu().numpy()
 
 

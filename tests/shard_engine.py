@@ -116,9 +116,91 @@ class OracleShardEngine:
             A22b2[:, 0] += alpha; A22b2[:, 2] += alpha
             A22b2[:, 3] -= alpha * self.Gx.ravel()[self.active]
             A22b2[:, 4] -= alpha * self.Gy.ravel()[self.active]
+        self.pack[: self.pack_len].copy_(torch.from_numpy(pk))    # in place, like the device engine: the solve phases read the regularised pack
         A22 = np.stack([A22b2[:, 0], A22b2[:, 1], A22b2[:, 1], A22b2[:, 2]], axis=1).reshape(P, 2, 2)
         return dict(A11=pk[:9 * K * K].reshape(3 * K, 3 * K, order="F"), b1=pk[9 * K * K:9 * K * K + 3 * K], active=self.active,
                     A22=A22, b2=A22b2[:, 3:5].ravel(), P=P)
 
     def last_counts(self):
         return len(self.meas), self.P
+
+    def sync(self):
+        pass
+
+    # ---- sharded Schur solve (ShardedLEGM.solveNormalEq): the phase interface of emba_solve_shard_* on numpy --------------------
+    # A packed record is 16 doubles like the device's: jc[6] jp[6] e {compact pixel, pair} dp[2]; here {compact pixel, pair} travel as ONE
+    # exactly representable double (pixel + 2^24 (4096 c + p)) — the layout is private to an engine, only its size is shared.
+    @staticmethod
+    def _owner(k, P, n):
+        r = min((k * n) // max(P, 1), n - 1)
+        while r + 1 < n and (P * (r + 1)) // n <= k:
+            r += 1
+        while r > 0 and (P * r) // n > k:
+            r -= 1
+        return r
+
+    def _active_records(self):
+        return [(m, int(self.compact[m["pi"]])) for m in self.meas if self.compact[m["pi"]] >= 0]
+
+    def solve_shard_size(self):
+        return (3 * self.K + 1) ** 2
+
+    def solve_shard_count(self, n_ranks):
+        cnt = np.zeros(n_ranks, dtype=np.int64)
+        for _, ci in self._active_records():
+            cnt[self._owner(ci, self.P, n_ranks)] += 1
+        return cnt
+
+    def solve_shard_pack(self, n_ranks, send):
+        recs = sorted(self._active_records(), key=lambda mc: self._owner(mc[1], self.P, n_ranks))     # stable: grouped by owner
+        out = np.zeros((max(len(recs), 1), 16))
+        for i, (m, ci) in enumerate(recs):
+            out[i, :6] = m["jc"]; out[i, 6:12] = m["jp"]; out[i, 12] = m["e"]
+            out[i, 13] = float(ci) + float(1 << 24) * (m["c"] * 4096 + m["p"])
+            out[i, 14] = m["dp"][0]; out[i, 15] = m["dp"][1]
+        send[: out.size].copy_(torch.from_numpy(out.ravel()))
+
+    def _pixel_terms(self, recv, n_recv, lam):
+        """per OWNED pixel: A12 columns (3K x 2) from the received records, C = A22m, b2 (global, from the reduced pack)."""
+        K = self.K
+        pk = self.pack[: self.pack_len].numpy()
+        A22b2 = pk[9 * K * K + 3 * K:].reshape(self.P, 5)
+        R = recv[: n_recv * 16].numpy().reshape(n_recv, 16)
+        cols = {}
+        for r in R:
+            code = int(r[13]); ci = code % (1 << 24); pair = code >> 24; c, p = pair // 4096, pair % 4096
+            v = np.concatenate([r[:6], r[6:12]]); dp = r[14:16]
+            idx = np.r_[3 * c:3 * c + 6, 3 * p:3 * p + 6]
+            A = cols.setdefault(ci, np.zeros((3 * K, 2)))
+            np.add.at(A, (idx[:, None], np.arange(2)[None, :]), np.outer(v, dp))          # quadratic cost (w = 1): model.cpp:483-487
+        out = {}
+        for ci, A in cols.items():
+            a = A22b2[ci]
+            C = np.array([[a[0] * (1 + lam), a[1]], [a[1], a[2] * (1 + lam)]])            # A22m = A22 + lambda diag(A22), :743-759
+            out[ci] = (A, C, a[3:5])
+        return out
+
+    def solve_shard_partial(self, rank, n_ranks, recv, n_recv, lam, S):
+        n = 3 * self.K
+        Sa = np.zeros((n + 1, n + 1))
+        for ci, (A, C, b2) in self._pixel_terms(recv, n_recv, lam).items():
+            W = A @ np.linalg.inv(C)
+            Sa[:n, :n] -= W @ A.T
+            Sa[:n, n] -= W @ b2
+        S.copy_(torch.from_numpy(Sa.ravel()))
+
+    def solve_shard_finish(self, rank, n_ranks, recv, n_recv, lam, fix_first_pose, S, x2):
+        K = self.K; n = 3 * K
+        pk = self.pack[: self.pack_len].numpy()
+        A11 = pk[:9 * K * K].reshape(n, n, order="F"); b1 = pk[9 * K * K:9 * K * K + n]
+        Sa = S.numpy().reshape(n + 1, n + 1)
+        Sm = Sa[:n, :n] + A11 + lam * np.diag(np.diag(A11))                               # A11m, :728-730
+        rhs = Sa[:n, n] + b1
+        sk = 3 if fix_first_pose else 0
+        x1 = np.zeros(n)
+        x1[sk:] = np.linalg.solve(Sm[sk:, sk:], rhs[sk:])
+        xx = np.zeros(2 * max(self.P, 1))
+        for ci, (A, C, b2) in self._pixel_terms(recv, n_recv, lam).items():
+            xx[2 * ci:2 * ci + 2] = np.linalg.solve(C, b2 - A.T @ x1)                    # :790-791
+        x2.copy_(torch.from_numpy(xx))
+        return x1

@@ -72,6 +72,45 @@ def test_two_rank_gloo_matches_single_process_oracle(oracle_mod, tmp_path, cfg, 
     assert int(r[0]["n_local"]) + int(r[1]["n_local"]) == (w.events.size() // 100) * 100
 
 
+def _solve_worker(rank, world, port, cfg, out_dir, lam, fix):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from shard_engine import OracleShardEngine
+        from emba_amd.sharded import ShardedLEGM
+        w = small_workload(**cfg)
+        npix = w.pano_h * w.pano_w
+        count = torch.zeros(npix, dtype=torch.int32)
+        pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64)
+        eng = OracleShardEngine(w)
+        sh = ShardedLEGM(eng, dist, count, pack, w.sensor_w, None)
+        sh.set_events(w.events)
+        eng.upload_map(w.Gx, w.Gy)
+        sh.iteration(w.traj, w.thres_valid_pixel, w.alpha, download=True)
+        x1, x2 = sh.solveNormalEq(lam, fix)
+        np.savez(os.path.join(out_dir, f"sol{rank}.npz"), x1=x1, x2=x2)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lam,fix", [(2, 1e-3, True), (3, 1e-2, False)])
+def test_sharded_solve_protocol_over_gloo(oracle_mod, tmp_path, world, lam, fix):
+    """ShardedLEGM.solveNormalEq (f1 on N ranks: counts all-reduce, record all-to-all by pixel owner, Schur all-reduce, x2 all-reduce)
+    with real collectives over gloo; every rank must end with the x1 / x2 of the single-process oracle solve (model.cpp:721-792)."""
+    cfg = dict(n_events=2400, pano_h=64, K=5, sensor=(12, 8), focal=10.0)
+    mp.spawn(_solve_worker, args=(world, _free_port(), cfg, str(tmp_path), lam, fix), nprocs=world, join=True)
+    w = small_workload(**cfg)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+    for r in range(world):
+        s = np.load(tmp_path / f"sol{r}.npz")
+        assert s["x1"].shape == ox1.shape and s["x2"].shape == ox2.shape
+        assert np.allclose(s["x1"], ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()), f"rank {r} x1"
+        assert np.allclose(s["x2"], ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max()), f"rank {r} x2"
+
+
 def test_partition_and_halo_properties():
     from emba_amd.sharded import batch_ranges, shard_events, batch_mid_ns
     w = small_workload(n_events=10050, pano_h=64, K=5, sensor=(12, 8), focal=10.0)

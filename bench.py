@@ -158,7 +158,7 @@ def main():
         @staticmethod
         def get_world_size(): return world
         @staticmethod
-        def all_reduce(t): dist.all_reduce(t)
+        def all_reduce(t, async_op=False): return dist.all_reduce(t, async_op=async_op)
         @staticmethod
         def all_to_all_single(out, inp, out_splits, in_splits): dist.all_to_all_single(out, inp, out_splits, in_splits)
 

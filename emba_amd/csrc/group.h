@@ -76,6 +76,8 @@ struct emba_group {
     std::vector<Rccl::comm_t> comm;
     std::vector<hipEvent_t> ev;          // one per rank (local exchange ordering)
     hipEvent_t ev0 = nullptr;
+    std::vector<hipStream_t> side;       // one per rank: exchange 2b (the A22 | b2 rows) runs here while the rank's own stream forms A11 | b1
+    std::vector<hipEvent_t> ev_side, ev_side0;   // ordering between a rank's stream and its side stream / among the side streams
     std::string err;
     size_t npix = 0; int sw = 0;
     // exchange buffers, per rank, on the rank's device
@@ -105,23 +107,26 @@ enum class XType { U8, I32, F64 };
 inline size_t xsize(XType t) { return t == XType::U8 ? 1 : t == XType::I32 ? 4 : 8; }
 
 // all-reduce(SUM) of bufs[r] (count elements each) over the ranks, in place, on the ranks' streams
-emba_status group_allreduce(emba_group* g, void* const* bufs, size_t count, XType t)
+emba_status group_allreduce(emba_group* g, void* const* bufs, size_t count, XType t, bool on_side = false)
 {
     if ((g->n == 1 && !g->use_rccl) || count == 0) return EMBA_OK;
+    auto S = [&](int r) { return on_side ? g->side[r] : g->ctx[r]->stream; };
+    std::vector<hipEvent_t>& ev = on_side ? g->ev_side0 : g->ev;     // (the two exchanges may be in flight at once: separate events)
+    hipEvent_t ev0 = on_side ? g->ev_side0[g->n] : g->ev0;
     if (g->use_rccl) {
         const int dt = t == XType::U8 ? Rccl::kUint8 : t == XType::I32 ? Rccl::kInt32 : Rccl::kFloat64;
         G_NCCL(g, g_rccl.GroupStart());
         for (int r = 0; r < g->n; ++r) {
             G_HIP(g, hipSetDevice(g->dev[r]));
-            G_NCCL(g, g_rccl.AllReduce(bufs[r], bufs[r], count, dt, Rccl::kSum, g->comm[r], g->ctx[r]->stream));
+            G_NCCL(g, g_rccl.AllReduce(bufs[r], bufs[r], count, dt, Rccl::kSum, g->comm[r], S(r)));
         }
         G_NCCL(g, g_rccl.GroupEnd());
         return EMBA_OK;
     }
     // ranks on one device: rank 0's stream sums everybody's buffer into its own once the producers are done, the others copy it back
     G_HIP(g, hipSetDevice(g->dev[0]));
-    hipStream_t s0 = g->ctx[0]->stream;
-    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(g->ev[r], g->ctx[r]->stream)); G_HIP(g, hipStreamWaitEvent(s0, g->ev[r], 0)); }
+    hipStream_t s0 = S(0);
+    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(ev[r], S(r))); G_HIP(g, hipStreamWaitEvent(s0, ev[r], 0)); }
     const unsigned grid = (unsigned)((count + 255) / 256);
     for (int r = 1; r < g->n; ++r) {
         if (t == XType::F64) hipLaunchKernelGGL(emba::emba_add_f64_kernel, dim3(grid), dim3(256), 0, s0, (double*)bufs[0], (const double*)bufs[r], (long)count);
@@ -129,13 +134,13 @@ emba_status group_allreduce(emba_group* g, void* const* bufs, size_t count, XTyp
         else hipLaunchKernelGGL(emba::emba_add_u8_kernel, dim3(grid), dim3(256), 0, s0, (uint8_t*)bufs[0], (const uint8_t*)bufs[r], (long)count);
     }
     G_HIP(g, hipGetLastError());
-    G_HIP(g, hipEventRecord(g->ev0, s0));
+    G_HIP(g, hipEventRecord(ev0, s0));
     for (int r = 1; r < g->n; ++r) {
-        G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev0, 0));
-        G_HIP(g, hipMemcpyAsync(bufs[r], bufs[0], count * xsize(t), hipMemcpyDeviceToDevice, g->ctx[r]->stream));
+        G_HIP(g, hipStreamWaitEvent(S(r), ev0, 0));
+        G_HIP(g, hipMemcpyAsync(bufs[r], bufs[0], count * xsize(t), hipMemcpyDeviceToDevice, S(r)));
     }
     // rank 0 must not overwrite its buffer before the copies have read it
-    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(g->ev[r], g->ctx[r]->stream)); G_HIP(g, hipStreamWaitEvent(s0, g->ev[r], 0)); }
+    for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(ev[r], S(r))); G_HIP(g, hipStreamWaitEvent(s0, ev[r], 0)); }
     return EMBA_OK;
 }
 
@@ -207,6 +212,7 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
     g->npix = (size_t)cfg->pano_w * cfg->pano_h; g->sw = cfg->sensor_w;
     g->ctx.assign(n_ranks, nullptr); g->dev.assign(devices, devices + n_ranks); g->comm.assign(n_ranks, nullptr); g->ev.assign(n_ranks, nullptr);
     g->count.assign(n_ranks, nullptr); g->count_u8.assign(n_ranks, nullptr); g->pack.assign(n_ranks, nullptr); g->n_local.assign(n_ranks, 0);
+    g->side.assign(n_ranks, nullptr); g->ev_side.assign(n_ranks, nullptr); g->ev_side0.assign(n_ranks + 1, nullptr);
     auto bail = [&](emba_status st, const std::string& msg) { fail(nullptr, st, "%s", msg.c_str()); emba_group_destroy(g); return st; };
     for (int r = 0; r < n_ranks; ++r) {
         emba_cfg c2 = *cfg;
@@ -214,8 +220,13 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
         const emba_status st = emba_create(&c2, &g->ctx[r]);
         if (st) return bail(st, std::string("rank ") + std::to_string(r) + ": " + emba_last_error(nullptr));
         if (hipSetDevice(devices[r]) != hipSuccess || hipEventCreateWithFlags(&g->ev[r], hipEventDisableTiming) != hipSuccess) return bail(EMBA_ERR_HIP, "hipEventCreate failed");
+        if (hipStreamCreateWithFlags(&g->side[r], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_side[r], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&g->ev_side0[r], hipEventDisableTiming) != hipSuccess)
+            return bail(EMBA_ERR_HIP, "side stream / event creation failed");
     }
-    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->ev0, hipEventDisableTiming) != hipSuccess) return bail(EMBA_ERR_HIP, "hipEventCreate failed");
+    if (hipSetDevice(devices[0]) != hipSuccess || hipEventCreateWithFlags(&g->ev0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&g->ev_side0[n_ranks], hipEventDisableTiming) != hipSuccess)
+        return bail(EMBA_ERR_HIP, "hipEventCreate failed");
     const std::set<int> distinct(g->dev.begin(), g->dev.end());
     // EMBA_GROUP_FORCE_RCCL=1: a one-rank group goes through RCCL as well (what a one-GPU box can rehearse of the RCCL path: the run-time
     // binding, communicator set-up and every collective call, with world size 1)
@@ -243,9 +254,13 @@ void emba_group_destroy(emba_group* g)
         if (g->count_u8[r]) (void)hipFree(g->count_u8[r]);
         if (g->pack[r]) (void)hipFree(g->pack[r]);
         if (g->ev[r]) (void)hipEventDestroy(g->ev[r]);
+        if (g->side[r]) { (void)hipStreamSynchronize(g->side[r]); (void)hipStreamDestroy(g->side[r]); }
+        if (g->ev_side[r]) (void)hipEventDestroy(g->ev_side[r]);
+        if (g->ev_side0[r]) (void)hipEventDestroy(g->ev_side0[r]);
         emba_destroy(g->ctx[r]);
     }
     if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (!g->ev_side0.empty() && g->ev_side0[g->n]) (void)hipEventDestroy(g->ev_side0[g->n]);
     delete g;
 }
 
@@ -327,9 +342,26 @@ emba_status emba_group_step(emba_group* g, const double* knots, int32_t K, int64
         G_TRY(g, r, emba_form_active(g->ctx[r], thres, &Pr, &pl));                                              // F1 (global counts: identical everywhere)
         if (r && Pr != g->P) return gfail(g, EMBA_ERR_STATE, "ranks disagree on the active set (%zu vs %zu pixels)", Pr, g->P);
         g->P = Pr;
-        G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                                       // F2
     }
-    { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }   // X2
+    // X2 in two parts.  The A22 | b2 rows (5 doubles per active pixel: the bulk of the exchange) are final once the active set has been
+    // written — the cost was declared before the evaluation, so form_accumulate only adds the A11 | b1 head — and their all-reduce runs
+    // on the ranks' SIDE streams while the Gram kernels form the head on the ranks' own streams; the small head follows.
+    const size_t head = pl - 5 * g->P;
+    std::vector<void*> rows(g->n, nullptr);
+    for (int r = 0; r < g->n; ++r) {
+        rows[r] = g->pack[r] + head;
+        G_HIP(g, hipSetDevice(g->dev[r]));
+        G_HIP(g, hipEventRecord(g->ev_side[r], g->ctx[r]->stream));          // the active-set write of this rank
+        G_HIP(g, hipStreamWaitEvent(g->side[r], g->ev_side[r], 0));
+    }
+    { emba_status st = group_allreduce(g, rows.data(), 5 * g->P, XType::F64, /*on_side=*/true); if (st) return st; }   // X2b
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                  // F2
+    { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), head, XType::F64); if (st) return st; }        // X2a
+    for (int r = 0; r < g->n; ++r) {
+        G_HIP(g, hipSetDevice(g->dev[r]));
+        G_HIP(g, hipEventRecord(g->ev_side[r], g->side[r]));
+        G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev_side[r], 0));  // F3 reads the reduced rows
+    }
     g->n_inliers = 0;
     for (int r = 0; r < g->n; ++r) {
         G_TRY(g, r, emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));   // F3: applyL2Reg once, after the reduce

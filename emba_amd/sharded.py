@@ -118,6 +118,8 @@ class ShardedLEGM:
         if not multi and not download and hasattr(e, "step"):     # single GPU, nothing to exchange: one library call per step
             n_inl, self.P = e.step(traj, thres_valid_pixel, alpha, cost_type, a)
             return n_inl, None
+        # declare the cost before the evaluation: the per-pixel sums then already carry its weights and A22 | b2 are final after F1
+        split_x2 = bool(multi and hasattr(e, "declare_cost") and e.declare_cost(cost_type, a))
         e.eval_launch(traj)                                   # E1
         if multi:
             cap = 255 // max(self.world, 1)
@@ -132,9 +134,19 @@ class ShardedLEGM:
         e.eval_finish()                                       # E2 (enqueue only)
         # F1: a single GPU never needs P on the host mid-step; with several ranks the host needs the pack length for X2
         self.P, self.pack_len = e.form_active(thres_valid_pixel, sync=multi)
+        # X2 in two parts: the per-pixel A22 | b2 rows are final once the active set has been written (F1), so their all-reduce — the
+        # bulk of the exchange: 5 doubles per active pixel — runs on the collective's own stream WHILE the Gram kernel (F2) forms
+        # A11 | b1; only the 9K^2 + 3K head waits for it.  (async_op: the collective waits for the work enqueued so far on the
+        # current stream, and wait() makes the current stream wait for the collective.)
+        head = self.pack_len - 5 * self.P if split_x2 else self.pack_len
+        part = None
+        if split_x2 and self.P:
+            part = dist.all_reduce(self.pack[head: self.pack_len], async_op=True)   # X2b (SUM)
         e.form_accumulate(cost_type, a)                       # F2
         if multi:
-            dist.all_reduce(self.pack[: self.pack_len])       # X2 (SUM)
+            dist.all_reduce(self.pack[: head])                # X2a (SUM)
+            if part is not None:
+                part.wait()
         out = e.form_finish(alpha, download)                  # F3 — the step's host synchronization
         n_inl, self.P = e.last_counts()
         return n_inl, out
@@ -201,6 +213,12 @@ class HipEngine:
 
     def upload_map(self, Gx, Gy):
         self.m.upload_map(Gx, Gy)
+
+    def declare_cost(self, cost_type, a):
+        """emba_set_cost: evaluations accumulate the per-pixel sums with this cost's weights, so the A22 | b2 rows written by
+        form_active are final (form_accumulate only adds A11 | b1) and their all-reduce may start before the Gram kernel."""
+        self.m.set_cost(cost_type, a)
+        return True
 
     def eval_launch(self, traj):
         self.m.eval_launch(traj)

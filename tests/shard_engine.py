@@ -17,6 +17,20 @@ class OracleShardEngine:
     def bind_exchange(self, count_tensor, pack_tensor):
         self.count, self.pack = count_tensor, pack_tensor
 
+    def declare_cost(self, cost_type, a):
+        """like the device engine after emba_set_cost: form_active leaves the final A22 | b2 rows in the pack, form_accumulate only
+        writes the A11 | b1 head — ShardedLEGM may then reduce the rows while the head is still being formed"""
+        self.cost = (cost_type, a)
+        return True
+
+    def _weight(self, e):
+        cost_type, a = getattr(self, "cost", ("quadratic", 0.0))
+        if cost_type == "cauchy":
+            return 1.0 / (1.0 + a * e * e)
+        if cost_type == "huber":
+            return 1.0 if abs(e) < a else a / abs(e)
+        return 1.0
+
     def set_events(self, events, halo):
         self.ev, self.halo = events, halo
 
@@ -84,29 +98,35 @@ class OracleShardEngine:
         self.compact = -np.ones(cnt.size, dtype=np.int64)
         self.compact[self.active] = np.arange(self.active.size)
         self.P = self.active.size
-        self.pack_len = 9 * self.K * self.K + 3 * self.K + 5 * self.P
-        return self.P, self.pack_len
-
-    def form_accumulate(self, cost_type, a):
         K, P = self.K, self.P
-        A11 = np.zeros((3 * K, 3 * K)); b1 = np.zeros(3 * K); A22b2 = np.zeros((max(P, 1), 5))
+        self.pack_len = 9 * K * K + 3 * K + 5 * P
+        A22b2 = np.zeros((max(P, 1), 5))
         for m in self.meas:
             ci = self.compact[m["pi"]]
             if ci < 0:
                 continue
             e, dp = m["e"], m["dp"]
-            wgt = 1.0
-            if cost_type == "cauchy":
-                wgt = 1.0 / (1.0 + a * e * e)
-            elif cost_type == "huber":
-                wgt = 1.0 if abs(e) < a else a / abs(e)
+            wgt = self._weight(e)
             A22b2[ci] += [wgt * dp[0] * dp[0], wgt * dp[0] * dp[1], wgt * dp[1] * dp[1], dp[0] * wgt * e, dp[1] * wgt * e]
+        self.pack[9 * K * K + 3 * K: self.pack_len].copy_(torch.from_numpy(A22b2[:P].ravel()))
+        return self.P, self.pack_len
+
+    def form_accumulate(self, cost_type, a):
+        assert (cost_type, a) == getattr(self, "cost", (cost_type, a)), "the stand-in forms A22 | b2 with the DECLARED cost"
+        self.cost = (cost_type, a)
+        K = self.K
+        A11 = np.zeros((3 * K, 3 * K)); b1 = np.zeros(3 * K)
+        for m in self.meas:
+            if self.compact[m["pi"]] < 0:
+                continue
+            e = m["e"]
+            wgt = self._weight(e)
             v = np.concatenate([m["jc"], m["jp"]])
             idx = np.r_[3 * m["c"]:3 * m["c"] + 6, 3 * m["p"]:3 * m["p"] + 6]
             np.add.at(A11, (idx[:, None], idx[None, :]), wgt * np.outer(v, v))
             np.add.at(b1, idx, v * wgt * e)
-        flat = np.concatenate([A11.ravel(order="F"), b1, A22b2[:P].ravel()])
-        self.pack[: self.pack_len].copy_(torch.from_numpy(flat))
+        # ONLY the head: the A22 | b2 rows may be in an all-reduce right now
+        self.pack[: 9 * K * K + 3 * K].copy_(torch.from_numpy(np.concatenate([A11.ravel(order="F"), b1])))
 
     def form_finish(self, alpha, download):
         K, P = self.K, self.P

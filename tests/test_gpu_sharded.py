@@ -32,7 +32,12 @@ class _ThreadDist:
     def get_world_size(self):
         return self.s.world
 
-    def all_reduce(self, t):
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_reduce(self, t, async_op=False):
+        """(async_op: performed on the spot; the handle's wait() has nothing left to do — rank threads cannot overlap it)"""
         import torch
         self.sync_fn()                       # producer kernels of this rank are done
         self.s.slots[self.rank] = t
@@ -45,7 +50,7 @@ class _ThreadDist:
                 sl.copy_(total)
             torch.cuda.synchronize()
         self.s.barrier.wait()
-
+        return self._Done() if async_op else None
 
     def all_to_all_single(self, out, inp, out_splits, in_splits):
         """Rank r's j-th input piece goes to rank j, where it becomes the r-th output piece."""

@@ -99,6 +99,7 @@ struct emba_ctx {
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
+    size_t n_outside_tile = 0; int n_rebin = 0; uint32_t last_rebin_stamp = 0;   // tile order: inliers found outside their tile in the last evaluation; how often the window was re-binned
     bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
     double* d_ep = nullptr;
@@ -553,8 +554,16 @@ emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
     c->knots_in_flight = false;   // (the prep kernel that reads the pinned knot buffer precedes the post-warp kernels)
     if (c->inl_pending) {
         c->inl_pending = false;
-        if (c->h_pinned[1]) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
+        if (c->h_pinned[1] & 1) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots");
         c->n_inliers = (size_t)(uint32_t)c->h_pinned[0];
+        c->n_outside_tile = (size_t)((uint32_t)c->h_pinned[1] >> 1);
+        // Tile order: the bins were predicted with the trajectory of the window's first evaluation.  Events that have since left their
+        // tile (+ margin) are still handled correctly, but one by one through HBM atomics; once that is a fifth of the inliers the order
+        // is rebuilt from the CURRENT trajectory at the next evaluation (an LM loop that starts far from its solution).
+        // (not again within three evaluations: a loop whose every trial moves the events further than the margin would re-bin each time)
+        if (c->tile_order && c->n_inliers && c->n_outside_tile * 5 > c->n_inliers && c->rec_stamp - c->last_rebin_stamp >= 3) {
+            c->keys_ready = false; ++c->n_rebin; c->last_rebin_stamp = c->rec_stamp;
+        }
         c->eval_done = true;
     }
     if (c->P_pending) {
@@ -685,6 +694,7 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
                             size_t n, const uint16_t* hx, const uint16_t* hy, const int64_t* hbt, size_t n_halo)
 {
     hipStream_t s = c->stream;
+    c->last_rebin_stamp = c->rec_stamp - 3; c->n_outside_tile = 0;   // a new window may be re-binned at its first drifted evaluation
     const size_t n_used = (n / 100) * 100;   // quirk Q1: std::ceil of an integer division (model.cpp:79)
     const size_t nb = n_used / 100;
     if (n_used + n_halo >= 0x3FFFFFFFull) return fail(c, EMBA_ERR_INVALID_ARG, "too many events for 32-bit indices");
@@ -800,6 +810,14 @@ emba_status emba_set_events_dev(emba_ctx* c, const uint16_t* x_dev, const uint16
     emba_status st = set_events_core(c, x_dev, y_dev, pol_dev, t_ns_dev, nullptr, n, hx_dev, hy_dev, hbt_dev, n_halo);
     c->set_events_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     return st;
+}
+
+emba_status emba_last_tile_drift(const emba_ctx* c, size_t* n_outside, int32_t* n_rebin)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (n_outside) *n_outside = c->n_outside_tile;
+    if (n_rebin) *n_rebin = c->n_rebin;
+    return EMBA_OK;
 }
 
 emba_status emba_last_setup_ms(const emba_ctx* c, double* set_events_ms, double* prepare_ms, int32_t* tile_order, size_t* n_entries, size_t* n_chunks)
@@ -1008,6 +1026,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
         p.fx = c->fx; p.fy = c->fy; p.cx = c->cx; p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px;
         p.count = c->d_count; p.rec = c->d_rec; p.tag = (c->use_tags && !c->tile_order) ? c->d_tag : nullptr; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
+        p.err = c->d_err;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp;

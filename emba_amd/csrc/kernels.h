@@ -286,6 +286,7 @@ struct WarpParams {
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
     int32_t* count; double* pixacc; double* rec; double* tag; double* e_sorted; uint8_t* flag;   // tag: 8 B per record slot {pano pixel, stamp}, or nullptr
+    int* err;   // the step's status word: bit 0 = a batch outside the knots; bits 1.. = inliers the tiled kernel found OUTSIDE their tile (drift of the trajectory since the order was built)
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count marker, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
@@ -658,9 +659,11 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
             LaneOut o;
             warp_lane<false, true>(p, i, cur, t, o, prefetch);
             const unsigned long long inl_mask = __ballot(o.inl);
+            bool outside = false;
             if (o.inl) {
                 const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
-                if (lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH) {
+                outside = !(lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH);
+                if (!outside) {
                     const int q = ly * kTileW + lx;
                     if (!(p.ablate & 8)) {
                         atomicAdd(&s_sum[0][q], o.v0); atomicAdd(&s_sum[1][q], o.v1); atomicAdd(&s_sum[2][q], o.v2);
@@ -671,6 +674,10 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                     p.count[o.pi] = 1;
                     atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
                 }
+            }
+            {   // how many: the host re-bins the window for the next evaluation when the trajectory has drifted away from the one the order was built for
+                const unsigned long long om = __ballot(outside);
+                if (om && t == 0 && p.err) atomicAdd(p.err, 2 * (int)__popcll(om));
             }
             const uint32_t slot = cur.slot;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // (3) vmcnt(0): the prefetched words are in.  The builtin, not inline asm: the compiler's own wait-count bookkeeping must

@@ -134,6 +134,12 @@ class LEGM:
         self._check(self._L.emba_last_setup_ms(self._ctx, C.byref(a), C.byref(b), C.byref(t), C.byref(ne), C.byref(nc)))
         return dict(set_events_ms=a.value, prepare_ms=b.value, tile_order=bool(t.value), entries=ne.value, chunks=nc.value)
 
+    def tile_drift(self):
+        """(inliers of the last resolved evaluation outside their tile, times the window was re-binned): emba_last_tile_drift."""
+        n, r = C.c_size_t(0), C.c_int32(0)
+        self._check(self._L.emba_last_tile_drift(self._ctx, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def event_counts(self):
         a, b = C.c_size_t(0), C.c_size_t(0)
         self._check(self._L.emba_event_counts(self._ctx, C.byref(a), C.byref(b)))

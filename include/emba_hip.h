@@ -107,6 +107,12 @@ emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint
 emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
                                size_t* n_entries, size_t* n_chunks);
 
+/* Tile order only: inliers of the last resolved evaluation that the tiled kernel found outside their tile (+ margin) — the
+ * trajectory has moved them since the order was built; they are handled correctly, one HBM atomic each — and how many times this
+ * context has rebuilt the order of a window for that reason (done at the next evaluation once a fifth of the inliers are outside).
+ * No reference counterpart (the reference has no device order).  Either pointer may be NULL. */
+emba_status emba_last_tile_drift(const emba_ctx* ctx, size_t* n_outside, int32_t* n_rebin);
+
 /* Number of events actually used (floor(n/100)*100) and of measurement candidates
  * (events that have a predecessor at their sensor pixel). */
 emba_status emba_event_counts(const emba_ctx* ctx, size_t* n_used, size_t* n_candidates);

@@ -173,6 +173,46 @@ def test_repeated_calls_and_new_trajectory(gpu, oracle_mod):
         w.Gy = w.Gy + rng.normal(size=w.Gy.shape) * 1e-3
 
 
+def test_tile_order_rebins_after_trajectory_drift(gpu, oracle_mod, monkeypatch):
+    """Tile order: the bins come from the first trajectory of a window.  A trajectory that has since moved most events out of their
+    tile (+ 8-px margin) must still give the oracle's results (those events go to HBM one by one), is reported by
+    emba_last_tile_drift, and makes the NEXT evaluation rebuild the order — after which (same poses) nothing is outside any more."""
+    from emba_amd.synth import so3_exp_xyzw
+    monkeypatch.setenv("EMBA_ORDER", "tile")
+    w = small_workload(n_events=60000, pano_h=256, K=11, sensor=(48, 36), focal=40.0)
+    m = make_legm(w)
+    m.set_events(w.events)
+
+    def evaluate():
+        nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+        ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, None, True, nem)
+        m.formNormalEq(ep, w.K, nem, w.thres_valid_pixel)
+        ne = m.applyL2Reg(w.alpha)
+        o = oracle_run(oracle_mod, w)
+        assert np.array_equal(nem, o["num_ev_map"])
+        assert_close(ep, o["ep"], "ep")
+        compare_normal_eq(ne, o["ne"])
+
+    evaluate()
+    assert m.setup_info()["tile_order"]
+    out0, rebins0 = m.tile_drift()
+    assert out0 == 0 and rebins0 == 0
+    # rotate every control pose by ~0.3 rad about the vertical axis: tens of panorama pixels at this focal length
+    e = so3_exp_xyzw(np.array([0.0, 0.3, 0.0]))
+    ex, ey, ez, ew = e
+    for i in range(w.K):
+        bx, by, bz, bw = w.traj.knots_xyzw[i]
+        q = np.array([ew * bx + ex * bw + ey * bz - ez * by, ew * by + ey * bw + ez * bx - ex * bz,
+                      ew * bz + ez * bw + ex * by - ey * bx, ew * bw - ex * bx - ey * by - ez * bz])
+        w.traj.knots_xyzw[i] = q / np.linalg.norm(q)
+    evaluate()                   # old bins, new poses: correct, but most inliers are found outside their tile
+    out1, rebins1 = m.tile_drift()
+    assert out1 > 0 and rebins1 == 1, (out1, rebins1)
+    evaluate()                   # the order was rebuilt from these poses at the start of this evaluation
+    out2, rebins2 = m.tile_drift()
+    assert out2 == 0 and rebins2 == 1, (out2, rebins2)
+
+
 def test_edge_cases(gpu, oracle_mod):
     from emba_amd import EmbaError
     # fewer events than one batch, and none at all

@@ -518,8 +518,11 @@ emba_status ensure_inl_idx(emba_ctx* c)
 {
     { emba_status st = launch_ep_compaction(c); if (st) return st; }
     if (c->inl_idx_valid || !c->n_pm) return EMBA_OK;
+    // (the fused step leaves the per-block inlier counts of this evaluation in d_fblk_cnt, not their prefix)
+    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, c->stream, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total, (int*)nullptr, (const int*)nullptr,
+                       (int*)nullptr);
     hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, c->stream, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off,
-                       (long)c->n_pm, c->d_ep, c->d_inl_idx);   // (block offsets of this evaluation are still there; ep is rewritten with the same values)
+                       (long)c->n_pm, c->d_ep, c->d_inl_idx);   // (ep is rewritten with the same values)
     HIP_TRY(c, hipGetLastError());
     c->inl_idx_valid = true;
     return EMBA_OK;
@@ -1101,7 +1104,10 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
-        hipLaunchKernelGGL(emba_post_warp_b_kernel, dim3(2), dim3(256), 0, s, q);
+        // (no scan launch: the write kernel's blocks take their own prefix over launch A's per-block counts, its last block publishes
+        // P, the inlier total, the status word and the sequence words the host polls)
+        aw.blk_cnt = c->d_ablk_cnt; aw.fblk_cnt = c->d_fblk_cnt; aw.n_fblk = c->n_fblk; aw.total_P = q.total_P; aw.total_P_host = q.total_P_host;
+        aw.total_inl = q.total_inl; aw.total_inl_host = q.total_inl_host; aw.err_dev = q.err_dev; aw.err_host = q.err_host; aw.seq = q.seq; aw.seq_host = q.seq_host;
         // (launch C is the active-set write alone: nothing on the device reads the compacted residual vector `ep` — costs, Gram and solvers
         // work from the records and the per-event residuals — so it is produced when the host asks for it: resolve_pending /
         // ensure_inl_idx run the standalone compaction, whose block offsets launch B has just left in place.  100 M events: 0.65 -> 0.2 ms)

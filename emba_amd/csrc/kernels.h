@@ -946,8 +946,8 @@ __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* _
 
 // The two small post-warp chains (residual compaction: count -> scan -> compact; active set: count -> scan -> write) are
 // independent of each other, so their stages share launches ("heterogeneous" kernels):
-//   A = {active-count blocks | inlier-flag-count blocks}   B = {active-scan block | flag-scan block}   C = active-write blocks (the residual
-//   compaction itself runs only when the host asks for `ep`: emba_compact_ep_kernel)
+//   A = {active-count blocks | inlier-flag-count blocks}, then the active-write blocks, which take their own prefix over A's per-block counts
+//   and publish the totals (no scan launch in between; the residual compaction itself runs only when the host asks for `ep`)
 struct PostWarpParams {
     const int32_t* count; long npix; int thres; uint32_t* ablk_cnt; uint32_t* ablk_off; long n_ablk; uint32_t* total_P; int* total_P_host;
     uint32_t* fblk_cnt; uint32_t* fblk_off; long n_fblk; const uint32_t* perm; long n_pm; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
@@ -959,22 +959,17 @@ struct PostWarpParams {
 struct ActiveWriteParams {
     const int32_t* count; long npix; int thres; const uint32_t* blk_off; int32_t* compact; uint32_t* active_idx; const double* pixacc;
     double* A22b2; double* pack_head; long head_len; double alpha; const double* Gx; const double* Gy; uint8_t* active_bits; long max_P; long n_ablk;
+    // Fused step (blk_cnt != nullptr): no scan launch in between.  Every block sums the counts of the blocks in front of it itself (at most a
+    // few thousand L2-resident words), and the LAST block publishes what the host polls for: P, the inlier total (sum of the flag-count
+    // blocks of launch A), the status word, then the two sequence words.
+    const uint32_t* blk_cnt; const uint32_t* fblk_cnt; long n_fblk; uint32_t* total_P; int* total_P_host; uint32_t* total_inl; int* total_inl_host;
+    const int* err_dev; int* err_host; int seq; int* seq_host;
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
     if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
-}
-
-__global__ __launch_bounds__(256) void emba_post_warp_b_kernel(PostWarpParams p)
-{
-    if (blockIdx.x == 0) block_scan_256(p.ablk_cnt, p.ablk_off, p.n_ablk, p.total_P, p.total_P_host, nullptr, nullptr);
-    else block_scan_256(p.fblk_cnt, p.fblk_off, p.n_fblk, p.total_inl, p.total_inl_host, p.err_dev, p.err_host);
-    if (threadIdx.x == 0 && p.seq_host) {   // same thread as the count stores of block_scan_256: fence, then publish
-        __threadfence_system();
-        __hip_atomic_store(p.seq_host + blockIdx.x, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
 }
 
 __device__ __forceinline__ void active_write_block(long blk, const ActiveWriteParams& a)
@@ -1000,9 +995,44 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
         if (lane >= o) x += y;
     }
     if (lane == 63) s_w[wv] = x;
-    __syncthreads();
-    uint32_t k = a.blk_off[blk] + x - mine;
+    uint32_t front = 0;
+    if (a.blk_cnt) {   // exclusive prefix of this block over the per-block counts of launch A
+        __shared__ uint32_t s_f[4];
+        uint32_t part = 0;
+        for (long j = threadIdx.x; j < blk; j += 256) part += a.blk_cnt[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) s_f[wv] = part;
+        __syncthreads();
+        front = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+    } else {
+        __syncthreads();
+        front = a.blk_off[blk];
+    }
+    uint32_t k = front + x - mine;
     for (int w = 0; w < wv; ++w) k += s_w[w];
+    if (a.blk_cnt && blk == a.n_ablk - 1) {   // the last block publishes the step's counts (what launch B did)
+        __shared__ uint32_t s_i[4];
+        uint32_t part = 0;
+        for (long j = threadIdx.x; j < a.n_fblk; j += 256) part += a.fblk_cnt[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) s_i[wv] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t P = front + (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+            const uint32_t n_inl = (s_i[0] + s_i[1]) + (s_i[2] + s_i[3]);
+            a.total_P[0] = P; a.total_inl[0] = n_inl;
+            if (a.total_P_host) a.total_P_host[0] = (int)P;
+            if (a.total_inl_host) a.total_inl_host[0] = (int)n_inl;
+            if (a.err_host) a.err_host[0] = a.err_dev[0];
+            if (a.seq_host) {
+                __threadfence_system();
+                __hip_atomic_store(a.seq_host + 0, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.seq_host + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     if (compact && p0 + 8 <= npix) {   // compact index of 8 consecutive pixels: two 16-B stores
         int cv[8];
         uint32_t kk = k;

@@ -1,3 +1,4 @@
+# pixel order vs tile order at the sizes around the cross-over (profiles/r02c_order_sweep.txt)
 mkdir -p gpurun_out; rm -f gpurun_out/scaling.log
 run() { for o in ${ORDERS:-auto}; do EMBA_ORDER=$o timeout -k 10 400 python bench.py --steps ${4:-10} --warmup 2 --no-cpu-baseline --events-per-gpu $1 --pano-h $2 --knots $3 ${5:-} 2>/dev/null | python -c "
 import sys,json

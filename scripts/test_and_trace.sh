@@ -1,3 +1,4 @@
+# -m gpu tests, then rocprofv3 kernel-trace stats of the bench at 1 M and 100 M events (quick look at per-kernel times)
 set -e
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r20_tests.log 2>&1 || { tail -30 gpurun_out/r20_tests.log; exit 1; }
 tail -2 gpurun_out/r20_tests.log

@@ -346,6 +346,16 @@ emba_status emba_group_step(emba_group* g, const double* knots, int32_t K, int64
     // X2 in two parts.  The A22 | b2 rows (5 doubles per active pixel: the bulk of the exchange) are final once the active set has been
     // written — the cost was declared before the evaluation, so form_accumulate only adds the A11 | b1 head — and their all-reduce runs
     // on the ranks' SIDE streams while the Gram kernels form the head on the ranks' own streams; the small head follows.
+    // (worth it once the Gram kernel is long enough to hide a collective behind — the head then costs one more collective's latency: from a
+    // few million events per rank; EMBA_X2_SPLIT=0/1 overrides)
+    size_t n_max = 0;
+    for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
+    bool split = n_max >= 3000000;
+    if (const char* v = getenv("EMBA_X2_SPLIT")) split = atoi(v) != 0;
+    if (!split) {
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                  // F2
+        { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }         // X2
+    } else {
     const size_t head = pl - 5 * g->P;
     std::vector<void*> rows(g->n, nullptr);
     for (int r = 0; r < g->n; ++r) {
@@ -361,6 +371,7 @@ emba_status emba_group_step(emba_group* g, const double* knots, int32_t K, int64
         G_HIP(g, hipSetDevice(g->dev[r]));
         G_HIP(g, hipEventRecord(g->ev_side[r], g->side[r]));
         G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev_side[r], 0));  // F3 reads the reduced rows
+    }
     }
     g->n_inliers = 0;
     for (int r = 0; r < g->n; ++r) {

@@ -119,7 +119,8 @@ class ShardedLEGM:
             n_inl, self.P = e.step(traj, thres_valid_pixel, alpha, cost_type, a)
             return n_inl, None
         # declare the cost before the evaluation: the per-pixel sums then already carry its weights and A22 | b2 are final after F1
-        split_x2 = bool(multi and hasattr(e, "declare_cost") and e.declare_cost(cost_type, a))
+        # ... which pays once the Gram kernel is long enough to hide a collective behind (the head then costs a third collective's latency)
+        split_x2 = bool(multi and hasattr(e, "declare_cost") and e.declare_cost(cost_type, a)) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays())
         e.eval_launch(traj)                                   # E1
         if multi:
             cap = 255 // max(self.world, 1)
@@ -219,6 +220,15 @@ class HipEngine:
         form_active are final (form_accumulate only adds A11 | b1) and their all-reduce may start before the Gram kernel."""
         self.m.set_cost(cost_type, a)
         return True
+
+    def x2_split_pays(self):
+        """Splitting exchange 2 hides the bulk of it behind the Gram kernel but adds one small collective: worth it from a few million
+        events per rank (Gram kernel >= ~100 us against a collective's tens of microseconds of latency); EMBA_X2_SPLIT=0/1 overrides."""
+        import os
+        v = os.environ.get("EMBA_X2_SPLIT")
+        if v is not None:
+            return v != "0"
+        return getattr(self.m, "n_events", 0) >= 3_000_000
 
     def eval_launch(self, traj):
         self.m.eval_launch(traj)

@@ -74,6 +74,7 @@ def test_cpp_sharded_host_matches_oracle(tmp_path, hip_lib, oracle_mod, devices,
     p = tmp_path / "in.bin"
     _write_case(p, w, o, (lam, fix, x1, x2))
     env = dict(os.environ)
+    env["EMBA_X2_SPLIT"] = "0" if devices == "0,0,0" else "1"     # exchange 2 split (rows on the side streams, under the Gram kernel) or in one piece
     if force_rccl:      # one rank through RCCL itself: run-time binding of librccl, ncclCommInitAll, grouped all-reduce / send / recv calls
         env["EMBA_GROUP_FORCE_RCCL"] = "1"
     r = subprocess.run([exe, str(p), devices], capture_output=True, text=True, timeout=180, env=env)

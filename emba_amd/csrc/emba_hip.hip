@@ -1360,8 +1360,7 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     p.flag = c->d_flag; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
     if (c->tile_order) hipLaunchKernelGGL((emba_warp_residual_kernel<true, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
-    std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0),
-        h_unused;
+    std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0);
     std::vector<uint16_t> h_cp(cp_idx ? c->n_batch : 0);
     std::vector<int32_t> h_pi(w_pi ? 2 * ns : 0), h_inl(w_inl ? c->n_pm : 0);     // (inlier numbers and flags are indexed in pm-order)
     std::vector<uint8_t> h_flag(w_flag ? c->n_pm : 0);

@@ -281,7 +281,7 @@ constexpr int kTileRecStage = 16;               // records staged per wave at a 
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; const uint32_t* ev_pm; long n_sorted; long nblk;   // ev_pm: entry -> pm-order index (nullptr: identity)
     const double* ev_u; const uint16_t* ev_seg;   // tile order: per entry the spline parameter u and the segment of its batch
-    const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; seg: compact pose only
+    const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; pose: per-batch table (pixel order); seg: per-segment records (tile order)
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
     int W, H; double fx, fy, cx, cy, C_th, outlier_px;
@@ -316,8 +316,8 @@ struct LaneOut {
 
 // The per-event part shared by both kernels.  Every lane of the wave must call it (cross-lane moves inside); lane 0 of a wave
 // re-warps the entry in front of the wave's 63 new ones and takes no other part.
-// The event word and (compact form) the batch's pose record of one lane, loaded ahead of their use: the tiled kernel walks its
-// chunk group by group and fetches the NEXT group's words and pose lines while it works on the current one.
+// The event words of one lane, loaded ahead of their use: the tiled kernel walks its chunk group by group and fetches the NEXT group's
+// words while it works on the current one.
 struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double u; };   // pm: the entry's index in pm-order (where its residual / flag go); u: tile order (bi is then the segment)
 
 // (the record slot is fetched here, with the event words, although only inliers use it: loaded where it is needed it would sit

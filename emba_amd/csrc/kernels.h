@@ -223,15 +223,28 @@ __device__ __forceinline__ void texel_rect_blocks(long blk, long nblocks, const 
 __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy,
                                                          int H, int W, double* __restrict__ texel)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    // One texel per thread; the 48-B texels of a wave go through LDS so that the wave writes its 3 KB as three fully coalesced 1-KB
+    // stores (16 B per lane, consecutive lanes) instead of three stores that each touch every line of the span partially.
+    static_assert(kTexelStride == 6, "three 16-B pieces per texel");
+    __shared__ __attribute__((aligned(16))) double s_t[4][64 * kTexelStride];
+    const int x0 = blockIdx.x * blockDim.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = x0 + threadIdx.x;
     const int y = blockIdx.y;
-    if (x >= W) return;
-    double gx, gy, gxx, gxy, gyy;
-    hessian_at(Gx, Gy, H, W, x, y, gx, gy, gxx, gxy, gyy);
-    double2* t = reinterpret_cast<double2*>(texel + (size_t)kTexelStride * ((size_t)y * W + x));
-    t[0] = make_double2(gx, gy);
-    t[1] = make_double2(gxx, gxy);
-    t[2] = make_double2(gyy, 0.0);
+    double gx = 0, gy = 0, gxx = 0, gxy = 0, gyy = 0;
+    if (x < W) hessian_at(Gx, Gy, H, W, x, y, gx, gy, gxx, gxy, gyy);
+    double2* l = reinterpret_cast<double2*>(s_t[wv] + kTexelStride * lane);
+    l[0] = make_double2(gx, gy); l[1] = make_double2(gxx, gxy); l[2] = make_double2(gyy, 0.0);
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (one wave reads what it wrote itself: LDS operations complete in order)
+    const int xw = x0 + 64 * wv;                                // first texel of this wave
+    const int n_tex = (W - xw < 64) ? (W - xw) : 64;           // texels of this wave inside the row
+    if (n_tex <= 0) return;
+    double2* out = reinterpret_cast<double2*>(texel + (size_t)kTexelStride * ((size_t)y * W + xw));
+    const double2* in = reinterpret_cast<const double2*>(s_t[wv]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = 64 * k + lane;                            // 16-B piece i of the wave's 3 * 64 pieces
+        if (i < 3 * n_tex) out[i] = in[i];
+    }
 }
 
 // Pose table and texel rectangle in one launch (both only need the prep kernel): blocks [0, n_pose_blk) evaluate the spline for

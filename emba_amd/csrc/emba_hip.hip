@@ -1580,24 +1580,26 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
 // Eigen's ldlt (model.cpp:789).
 emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int skip, double* d_rhs, int* d_info)
 {
+    // The right-hand side sits in S as row n (schur kernels: the augmented block).  The panel loop carries it along as one more row below
+    // the matrix — its triangular solve and trailing updates ARE the forward substitution — so only L^T x = z is left for the solve kernel.
     hipStream_t s = c->stream;
     const int m = n - skip;
-    hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);
     double* Sm = d_S + (size_t)lds_ * skip + skip;
     for (int jb = 0; jb < m; jb += 64) {
         const int nb = std::min(64, m - jb);
         hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
-        const int below = m - jb - nb;
+        const int below = m - jb - nb;                      // matrix rows under the panel; the rhs row (index m) comes on top of them
+        hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 255) / 256), dim3(256), 0, s, Sm, lds_, m + 1, jb, nb);
         if (below > 0) {
-            hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 255) / 256), dim3(256), 0, s, Sm, lds_, m, jb, nb);
-            const int tb = (below + 63) / 64;
+            const int tb = (below + 1 + 63) / 64;
             SyrkParams tp{};
-            tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below; tp.k = nb;
+            tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below + 1; tp.k = nb;
             tp.C = Sm + (size_t)lds_ * (jb + nb) + (jb + nb); tp.ldc = lds_; tp.slab = nullptr; tp.nbp = tb * (tb + 1) / 2; tp.direct = 1;
             hipLaunchKernelGGL(emba_syrk_kernel, dim3(tp.nbp, 1), dim3(256), 0, s, tp);
         }
     }
-    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
+    hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);   // z = row n of the factor
+    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip, 1);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }

@@ -298,13 +298,14 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
 
 // Solve L L^T x = b in place (one workgroup; 64-wide blocks: substitution inside a block by one wave in LDS, then the rest of the
 // right-hand side is updated by all threads).
-__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b)
+// backward_only: b already holds z = L^-1 rhs (the factorisation carried the right-hand side along as an extra row: schur_factor_solve)
+__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b, int backward_only)
 {
     __shared__ double s_l[64 * 65];
     __shared__ double s_x[64];
     const int t = threadIdx.x;
     // forward: L z = b
-    for (int jb = 0; jb < n; jb += 64) {
+    for (int jb = 0; jb < n && !backward_only; jb += 64) {
         const int nb = (n - jb < 64) ? n - jb : 64;
         for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
         if (t < 64) s_x[t] = (t < nb) ? b[jb + t] : 0.0;

@@ -118,10 +118,24 @@ class ShardedLEGM:
         if not multi and not download and hasattr(e, "step"):     # single GPU, nothing to exchange: one library call per step
             n_inl, self.P = e.step(traj, thres_valid_pixel, alpha, cost_type, a)
             return n_inl, None
+        self.evaluate(traj, cost_type, a)
+        return self.form(thres_valid_pixel, alpha, cost_type, a, download)
+
+    def evaluate(self, traj, cost_type="quadratic", a=0.0):
+        """E1: evaluateDataError of this rank's shard (enqueue only).  Nothing is exchanged: the data cost is a sum over ranks
+        (ShardedModel.dataCost), the count map is reduced when formNormalEq asks for it (form)."""
+        e = self.engine
+        multi = self.world > 1 or self.force_collectives
         # declare the cost before the evaluation: the per-pixel sums then already carry its weights and A22 | b2 are final after F1
-        # ... which pays once the Gram kernel is long enough to hide a collective behind (the head then costs a third collective's latency)
-        split_x2 = bool(multi and hasattr(e, "declare_cost") and e.declare_cost(cost_type, a)) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays())
+        self._declared = bool(multi and hasattr(e, "declare_cost") and e.declare_cost(cost_type, a))
         e.eval_launch(traj)                                   # E1
+
+    def form(self, thres_valid_pixel, alpha, cost_type="quadratic", a=0.0, download=False):
+        """X1, E2, F1, F2, X2, F3 on the state of the last evaluate(): formNormalEq[IRLS] + applyL2Reg over all ranks."""
+        e, dist = self.engine, self.dist
+        multi = self.world > 1 or self.force_collectives
+        # ... the split of exchange 2 pays once the Gram kernel is long enough to hide a collective behind (the head then costs a third collective's latency)
+        split_x2 = getattr(self, "_declared", False) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays())
         if multi:
             cap = 255 // max(self.world, 1)
             if self.count_u8 is not None and thres_valid_pixel <= cap and hasattr(e, "count_compress"):
@@ -151,7 +165,6 @@ class ShardedLEGM:
         out = e.form_finish(alpha, download)                  # F3 — the step's host synchronization
         n_inl, self.P = e.last_counts()
         return n_inl, out
-
 
     def solveNormalEq(self, lam, fix_first_pose=False):
         """LEGM::solveNormalEq (model.cpp:721-792) over all ranks, after iteration(): the sparse A12 factors are time-sharded, a pixel's
@@ -187,6 +200,73 @@ class ShardedLEGM:
             dist.all_reduce(x2)
         _device_sync(dev)
         return x1, x2[: 2 * self.P].cpu().numpy()
+
+
+class ShardedModel:
+    """The model interface emba_amd.solver.solve_time_window drives (EMBA::solveTimeWindow, solver.cpp:63-353), over all ranks: every rank
+    runs the same loop on its time shard and takes the same decisions, because everything a decision depends on is reduced — the data cost
+    is summed over the ranks, the normal equations and the Schur solve are the sharded ones, the map is replicated and updated with the
+    same x2 everywhere.  Use with resident=True.  `legm` is this rank's emba_amd.LEGM (already wrapped by `sharded`'s engine)."""
+
+    def __init__(self, sharded, legm):
+        self.sh, self.m = sharded, legm
+        self.cost = ("quadratic", 0.0)
+        self._thres = None
+        self.H, self.W = legm.H, legm.W
+
+    def set_events(self, events):
+        self.sh.set_events(events)
+
+    def set_cost(self, cost_type="quadratic", a=0.0):
+        self.cost = (cost_type, a)
+
+    def upload_map(self, Gx, Gy):
+        self.m.upload_map(Gx, Gy)
+
+    def eval_launch(self, traj):
+        self.sh.evaluate(traj, *self.cost)
+
+    def eval_finish(self):
+        self.sh.engine.eval_finish()
+
+    def dataCost(self, cost_type="quadratic", a=0.0):
+        import torch
+        local = self.m.dataCost(cost_type, a)                 # this rank's measurements only (halo entries are not counted)
+        if self.sh.world == 1:
+            return local
+        t = torch.tensor([local], dtype=torch.float64, device=self.sh.pack.device)
+        self.sh.dist.all_reduce(t)
+        return float(t.item())
+
+    def regCost(self, alpha):
+        return self.m.regCost(alpha)                          # replicated map: identical on every rank
+
+    def form_active(self, thres):
+        self._thres = thres
+
+    def form_accumulate(self, cost_type="quadratic", a=0.0):
+        self.cost = (cost_type, a)
+
+    def form_finish(self, alpha):
+        self.sh.form(self._thres, alpha, *self.cost)
+
+    def solveNormalEq(self, lam, fix_first_pose=False):
+        return self.sh.solveNormalEq(lam, fix_first_pose)
+
+    def solveNormalEqCG(self, lam, fix_first_pose=False):
+        raise NotImplementedError("solveNormalEqCG is single-GPU (emba_solve_normal_eq_cg); the sharded loop uses the Schur solve")
+
+    def updateMap(self, x2, damping):
+        self.m.updateMap(x2, damping)
+
+    def acceptMap(self):
+        self.m.acceptMap()
+
+    def rejectMap(self):
+        self.m.rejectMap()
+
+    def downloadMap(self):
+        return self.m.downloadMap()
 
 
 class HipEngine:

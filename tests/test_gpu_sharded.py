@@ -159,3 +159,57 @@ def test_sharded_schur_solve(oracle_mod, cfg, world, lam, fix):
         assert x1.shape == ox1.shape and x2.shape == ox2.shape
         assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()), f"rank {r} x1"
         assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max()), f"rank {r} x2"
+
+
+def _lm_rank_main(shared, rank, w, init, ba, lm, results):
+    try:
+        import torch
+        from emba_amd import LEGM
+        from emba_amd.sharded import HipEngine, ShardedLEGM, ShardedModel
+        from emba_amd.solver import solve_time_window
+        dev = torch.device("cuda", 0)
+        npix = w.pano_h * w.pano_w
+        m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+        count = torch.zeros(npix, dtype=torch.int32, device=dev)
+        pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        sh = ShardedLEGM(HipEngine(m, check_stream=False), _ThreadDist(shared, rank, m.sync), count, pack, w.sensor_w, None)
+        model = ShardedModel(sh, m)
+        r = solve_time_window(model, init, w.events, w.Gx, w.Gy, ba, lm, resident=True)
+        results[rank] = dict(res=r, maps=model.downloadMap())
+    except Exception as e:  # noqa: BLE001
+        shared.errors.append((rank, repr(e)))
+        shared.barrier.abort()
+        raise
+
+
+@pytest.mark.parametrize("world,ba_kw", [(2, dict(alpha=5.0)), (3, dict(use_IRLS=True, cost_type="huber", eta=0.1, alpha=1.0))])
+def test_sharded_lm_loop_matches_oracle_loop(oracle_mod, world, ba_kw):
+    """EMBA::solveTimeWindow (solver.cpp:63-353) over time shards: every rank-thread runs emba_amd.solver.solve_time_window on a
+    ShardedModel (summed data cost, sharded normal equations and Schur solve, replicated map) and must take the accept / reject
+    decisions of the single-process oracle loop, with the same costs, trajectory and map (VERDICT r1 #6)."""
+    import torch
+    assert torch.cuda.is_available()
+    from emba_amd import synth
+    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+    from helpers import OracleModel
+    from test_lm_solver_cpu import perturbed
+    w = synth.make_scene_workload(n_steps=1000)
+    init = perturbed(w)
+    ba, lm = BASettings(**ba_kw), LMSettings(max_num_iter=10)
+    om = OracleModel(oracle_mod, w)
+    ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, lm)
+    shared, results = _Shared(world), [None] * world
+    th = [threading.Thread(target=_lm_rank_main, args=(shared, r, w, init, ba, lm, results)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not shared.errors, shared.errors
+    for r in range(world):
+        rg = results[r]["res"]
+        assert [e[4] for e in rg.log] == [e[4] for e in ro.log], f"rank {r}: accept/reject sequence differs"
+        assert rg.iterations == ro.iterations and rg.converged == ro.converged
+        for g, o in zip(rg.log, ro.log):
+            assert g[3] == pytest.approx(o[3], rel=1e-7) and g[2] == pytest.approx(o[2], rel=1e-7)
+        assert np.abs(rg.traj.knots_xyzw - ro.traj.knots_xyzw).max() < 1e-7
+        for d, o in zip(results[r]["maps"], om.downloadMap()):
+            assert np.abs(d - o).max() < 1e-7 * np.abs(o).max()

@@ -4,6 +4,8 @@
 
   python examples/run_ba.py --demo out/                       # simulate a scene, perturb the trajectory, refine, write results
   python examples/run_ba.py --events ev.npz --poses init_traj.txt --map-dir init_map/ --calib calib.npz --out out/
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/run_ba.py ... # the window's events time-sharded
+                                                  # over the GPUs of one node (RCCL); every rank runs the same LM loop, rank 0 writes
 
 Inputs: events (.npz: x, y u16; polarity u8; t_ns i64), initial poses ("t tx ty tz qx qy qz qw" per line), initial map
 (Gx.bin / Gy.bin raw float64, H x 2H), calibration (.npz: K [3,3], D [<=5] plumb_bob, width, height).
@@ -37,6 +39,7 @@ def main():
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--sharded", action="store_true", help="go through the multi-GPU host (ShardedLEGM / ShardedModel) even with one rank")
     a = ap.parse_args()
     if a.alpha is None:
         a.alpha = 0.0 if a.demo else 5.0
@@ -65,13 +68,38 @@ def main():
         truth, C_th = None, a.C_th
 
     H, W = Gx.shape
-    model = LEGM(sw, sh, lut, C_th, W, H)
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    legm = None
+    if world > 1 or a.sharded:
+        # one process per GPU (torchrun): kernels and RCCL collectives share one explicit torch stream
+        import torch
+        import torch.distributed as dist
+        from emba_amd.sharded import HipEngine, ShardedLEGM, ShardedModel
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29519")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        tstream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        legm = LEGM(sw, sh, lut, C_th, W, H, device=local_rank, stream=tstream.cuda_stream)
+        count_t = torch.zeros(H * W, dtype=torch.int32, device=dev)
+        pack_t = torch.zeros(9 * traj.size() ** 2 + 3 * traj.size() + 5 * H * W, dtype=torch.float64, device=dev)
+        sh_ = ShardedLEGM(HipEngine(legm), dist, count_t, pack_t, sw, torch.zeros(H * W, dtype=torch.uint8, device=dev))
+        sh_.force_collectives = world == 1
+        model = ShardedModel(sh_, legm)
+    else:
+        model = legm = LEGM(sw, sh, lut, C_th, W, H)
     ba = BASettings(use_IRLS=a.cost != "quadratic", cost_type=a.cost, eta=a.eta, thres_valid_pixel=a.thres_valid_pixel, alpha=a.alpha,
                     damping_factor=a.damping_factor)
-    print(f"{events.size()} events, {traj.size()} control poses, panorama {H}x{W}")
+    if rank == 0:
+        print(f"{events.size()} events, {traj.size()} control poses, panorama {H}x{W}" + (f", {world} rank(s) through the sharded host" if legm is not model else ""))
     t0 = time.time()
     res = solve_time_window(model, traj, events, Gx, Gy, ba, LMSettings(max_num_iter=a.max_iter), verbose=a.verbose, resident=True)
     dt = time.time() - t0
+    if rank != 0:                                           # every rank holds the same result; rank 0 writes it
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
+        return
     print(f"{res.iterations} LM iterations in {dt * 1e3:.1f} ms ({'converged' if res.converged else 'stopped'}), cost {res.cost_min:.6e}")
     if truth is not None:
         err = lambda tr: np.degrees(np.mean([np.linalg.norm(so3.log(so3.mul(so3.inverse(p), q))) for p, q in zip(tr.knots_xyzw, truth.knots_xyzw)]))
@@ -79,7 +107,10 @@ def main():
     eio.write_trajectory(os.path.join(a.out, "refined_traj.txt"), res.traj)
     eio.save_map(a.out, *model.downloadMap())
     # intensity panorama from the refined gradient map (solver.cpp:417-425 / 471-479), reconstructed on the device
-    eio.save_pgm(os.path.join(a.out, "map_poisson_opt.pgm"), eio.normalize_robust(model.reconstructIntensity(), 0.1))
+    eio.save_pgm(os.path.join(a.out, "map_poisson_opt.pgm"), eio.normalize_robust(legm.reconstructIntensity(), 0.1))
+    if legm is not model:
+        import torch.distributed as dist
+        dist.barrier(); dist.destroy_process_group()
 
 
 if __name__ == "__main__":

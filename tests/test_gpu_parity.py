@@ -620,7 +620,8 @@ def test_declared_cost_is_a_pure_speed_hint(gpu, oracle_mod, declared, used):
     compare_normal_eq(ne, o["ne"])
 
 
-def test_run_ba_command_line_on_files(gpu, tmp_path):
+@pytest.mark.parametrize("sharded", [False, True])
+def test_run_ba_command_line_on_files(gpu, tmp_path, sharded):
     """examples/run_ba.py on data from disk: event file, pose file, Gx.bin/Gy.bin, calibration -> refined trajectory,
     refined map and the Poisson-reconstructed panorama, in the reference's formats."""
     import subprocess, sys, os
@@ -641,7 +642,8 @@ def test_run_ba_command_line_on_files(gpu, tmp_path):
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(root, "examples", "run_ba.py"), str(out), "--events", str(tmp_path / "ev.npz"),
                         "--poses", str(tmp_path / "poses.txt"), "--map-dir", str(tmp_path / "map"), "--calib", str(tmp_path / "calib.npz"),
-                        "--dt-knots", "0.05", "--t-beg", "0.1", "--t-end", "0.35", "--alpha", "0.0", "--max-iter", "10"],
+                        "--dt-knots", "0.05", "--t-beg", "0.1", "--t-end", "0.35", "--alpha", "0.0", "--max-iter", "10"]
+                       + (["--sharded"] if sharded else []),      # the torchrun host with one rank: ShardedModel, RCCL collectives at world size 1
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     t, qs = eio.load_poses(out / "refined_traj.txt")

@@ -94,6 +94,19 @@ def cpu_baseline(w, budget_s=10.0):
                           "sample": f"full workload ({ev.size()} events), {nn} passes, median pass {medn * 1e3:.1f} ms"}}
 
 
+def launch_ranks(n):
+    """One rank per GPU as a child `python -m torch.distributed.run` (rendezvous on 127.0.0.1, a free port), same arguments."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,16 +124,19 @@ def main():
                     help="rehearsal on ONE GPU: initialise RCCL with world_size 1 and run both all-reduces of the sharded protocol")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` typed as is: start one rank per GPU ourselves.  This process has not touched the GPU (torch is not
+        # even imported yet) and never will: it starts torch.distributed.run as a CHILD process and passes its exit code on.
+        sys.exit(launch_ranks(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+
+    import torch
+    import torch.distributed as dist
+
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -182,9 +198,21 @@ def main():
     for _ in range(args.warmup):
         step()
     # beyond the caller's W steps: keep stepping (untimed) until >= 50 ms of GPU work has run, so that a short timed region
-    # (20 steps = 2.6 ms at 1 M events) does not sit on the clock ramp of a cold chip
+    # (20 steps = 2.6 ms at 1 M events) does not sit on the clock ramp of a cold chip.  The NUMBER of extra steps is one decision
+    # for all ranks (every step issues collectives: a rank-local wall-clock loop would leave the ranks a step apart): three steps
+    # are timed between barriers, the slowest rank's time is all-reduced, and everybody runs the same count.
+    barrier()
     t_w = time.perf_counter()
-    while time.perf_counter() - t_w < 0.05:
+    for _ in range(3):
+        step()
+    barrier()
+    t_w = (time.perf_counter() - t_w) / 3
+    if use_dist:
+        tt = torch.tensor([t_w], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_w = float(tt.item())
+    n_extra = int(min(max(np.ceil(0.05 / max(t_w, 1e-6)), 1), 2000))
+    for _ in range(n_extra):
         step()
     barrier()
     # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region: each event record

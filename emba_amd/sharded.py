@@ -24,6 +24,7 @@ import math
 
 import numpy as np
 
+from ._lib import ERR_NUMERIC as _ERR_NUMERIC, EmbaError
 from .legm import EventPacket
 
 BATCH = 100  # model.cpp:78
@@ -109,6 +110,10 @@ class ShardedLEGM:
         local, halo = shard_events(events, self.sensor_w, self.rank, self.world)
         self.engine.set_events(local, halo)
         self.n_local = local.size()
+        # rank-invariant size of the largest shard: decisions that change the SEQUENCE of collectives (the split of exchange 2) must not
+        # depend on this rank's own event count — shards differ by one batch, and ranks on different sides of a threshold would issue
+        # different collectives
+        self.n_max = max(hi - lo for lo, hi in batch_ranges(events.size(), self.world))
         return local
 
     def iteration(self, traj, thres_valid_pixel, alpha, cost_type="quadratic", a=0.0, download=False):
@@ -135,7 +140,7 @@ class ShardedLEGM:
         e, dist = self.engine, self.dist
         multi = self.world > 1 or self.force_collectives
         # ... the split of exchange 2 pays once the Gram kernel is long enough to hide a collective behind (the head then costs a third collective's latency)
-        split_x2 = getattr(self, "_declared", False) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays())
+        split_x2 = getattr(self, "_declared", False) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays(getattr(self, "n_max", 0)))
         if multi:
             cap = 255 // max(self.world, 1)
             if self.count_u8 is not None and thres_valid_pixel <= cap and hasattr(e, "count_compress"):
@@ -194,11 +199,23 @@ class ShardedLEGM:
         e.solve_shard_partial(r, w, recv, n_recv, lam, S)
         if w > 1:
             dist.all_reduce(S)
-        x2 = torch.zeros(2 * max(self.P, 1), dtype=torch.float64, device=dev)
-        x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
+        # A numeric failure is rank-LOCAL (a 2x2 block of A22m that is not positive definite shows up on its pixel's owner only): the
+        # decision to raise must be global, or one rank leaves the protocol while the others wait in the next collective.  The status rides
+        # as one more element of the x2 all-reduce, which every rank always executes; then all ranks raise together.
+        x2 = torch.zeros(2 * max(self.P, 1) + 1, dtype=torch.float64, device=dev)
+        x1, failure = None, None
+        try:
+            x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
+        except Exception as exc:   # noqa: BLE001
+            if getattr(exc, "status", None) != _ERR_NUMERIC:
+                raise
+            failure = exc
+            x2[-1] = 1.0
         if w > 1:
             dist.all_reduce(x2)
         _device_sync(dev)
+        if float(x2[-1].item()) != 0.0:
+            raise failure if failure is not None else EmbaError(_ERR_NUMERIC, "the damped normal equations are not positive definite on another rank")
         return x1, x2[: 2 * self.P].cpu().numpy()
 
 
@@ -301,14 +318,15 @@ class HipEngine:
         self.m.set_cost(cost_type, a)
         return True
 
-    def x2_split_pays(self):
+    def x2_split_pays(self, n_max):
         """Splitting exchange 2 hides the bulk of it behind the Gram kernel but adds one small collective: worth it from a few million
-        events per rank (Gram kernel >= ~100 us against a collective's tens of microseconds of latency); EMBA_X2_SPLIT=0/1 overrides."""
+        events per rank (Gram kernel >= ~100 us against a collective's tens of microseconds of latency); EMBA_X2_SPLIT=0/1 overrides.
+        n_max: events of the LARGEST shard — the same number on every rank (ShardedLEGM.set_events)."""
         import os
         v = os.environ.get("EMBA_X2_SPLIT")
         if v is not None:
             return v != "0"
-        return getattr(self.m, "n_events", 0) >= 3_000_000
+        return n_max >= 3_000_000
 
     def eval_launch(self, traj):
         self.m.eval_launch(traj)

@@ -112,7 +112,8 @@ class OracleShardEngine:
         return self.P, self.pack_len
 
     def form_accumulate(self, cost_type, a):
-        assert (cost_type, a) == getattr(self, "cost", (cost_type, a)), "the stand-in forms A22 | b2 with the DECLARED cost"
+        norm = lambda c: (c[0], c[1] if c[0] != "quadratic" else 0.0)     # (the parameter means nothing for the quadratic cost)
+        assert norm((cost_type, a)) == norm(getattr(self, "cost", (cost_type, a))), "the stand-in forms A22 | b2 with the DECLARED cost"
         self.cost = (cost_type, a)
         K = self.K
         A11 = np.zeros((3 * K, 3 * K)); b1 = np.zeros(3 * K)
@@ -192,7 +193,7 @@ class OracleShardEngine:
             v = np.concatenate([r[:6], r[6:12]]); dp = r[14:16]
             idx = np.r_[3 * c:3 * c + 6, 3 * p:3 * p + 6]
             A = cols.setdefault(ci, np.zeros((3 * K, 2)))
-            np.add.at(A, (idx[:, None], np.arange(2)[None, :]), np.outer(v, dp))          # quadratic cost (w = 1): model.cpp:483-487
+            np.add.at(A, (idx[:, None], np.arange(2)[None, :]), self._weight(r[12]) * np.outer(v, dp))   # model.cpp:483-487 / 679-683 (IRLS weight)
         out = {}
         for ci, A in cols.items():
             a = A22b2[ci]
@@ -222,5 +223,39 @@ class OracleShardEngine:
         xx = np.zeros(2 * max(self.P, 1))
         for ci, (A, C, b2) in self._pixel_terms(recv, n_recv, lam).items():
             xx[2 * ci:2 * ci + 2] = np.linalg.solve(C, b2 - A.T @ x1)                    # :790-791
-        x2.copy_(torch.from_numpy(xx))
+        x2[: xx.size].copy_(torch.from_numpy(xx))            # (the caller's buffer carries a status word behind the 2P entries)
         return x1
+
+    # ---- what ShardedModel asks of "this rank's LEGM" in the LM loop (emba_amd.solver.solve_time_window over ranks) -------------
+    @property
+    def H(self):
+        return self.w.pano_h
+
+    @property
+    def W(self):
+        return self.w.pano_w
+
+    def set_cost(self, cost_type="quadratic", a=0.0):
+        self.cost = (cost_type, a)
+
+    def dataCost(self, cost_type="quadratic", a=0.0):
+        """this rank's measurements only (solver.cpp:88 / model.cpp:279-314)"""
+        e = np.array([m["e"] for m in self.meas])
+        return O.data_cost(e, {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a)
+
+    def regCost(self, alpha):
+        return O.reg_cost(self.Gx, self.Gy, alpha)
+
+    def updateMap(self, x2, damping):
+        self._cur = (self.Gx, self.Gy)
+        self.Gx, self.Gy = O.update_map(self.active.astype(np.uint32), np.asarray(x2), damping, self.Gx, self.Gy)
+
+    def acceptMap(self):
+        self._cur = None
+
+    def rejectMap(self):
+        self.Gx, self.Gy = self._cur
+        self._cur = None
+
+    def downloadMap(self):
+        return self.Gx, self.Gy

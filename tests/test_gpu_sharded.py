@@ -213,3 +213,94 @@ def test_sharded_lm_loop_matches_oracle_loop(oracle_mod, world, ba_kw):
         assert np.abs(rg.traj.knots_xyzw - ro.traj.knots_xyzw).max() < 1e-7
         for d, o in zip(results[r]["maps"], om.downloadMap()):
             assert np.abs(d - o).max() < 1e-7 * np.abs(o).max()
+
+
+# ---- the node: 8 ranks, at the shard sizes of the SCALE run (8 x 1 M events) and of config 4 (town.launch: 8 x 5 M, K = 97, 640x480) --------
+def _rank8_main(shared, rank, w, init, lam, damping, results):
+    """One rank of eight on device 0: iteration (X1 as saturated bytes with cap = 255 // 8 = 31, X2), the sharded Schur solve (8-owner
+    all-to-all), then ONE Levenberg-Marquardt trial through ShardedModel (updateTraj on the host, updateMap on every replica, evaluation
+    of the trial point, summed cost)."""
+    try:
+        import torch
+        from emba_amd import LEGM, io as emba_io
+        from emba_amd.sharded import HipEngine, ShardedLEGM, ShardedModel
+        dev = torch.device("cuda", 0)
+        npix = w.pano_h * w.pano_w
+        m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+        count = torch.zeros(npix, dtype=torch.int32, device=dev)
+        pack = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
+        cu8 = torch.zeros(npix, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        sh = ShardedLEGM(HipEngine(m, check_stream=False), _ThreadDist(shared, rank, m.sync), count, pack, w.sensor_w, cu8)
+        model = ShardedModel(sh, m)
+        model.set_events(w.events)
+        model.upload_map(w.Gx, w.Gy)
+        n_inl, ne = sh.iteration(init, w.thres_valid_pixel, w.alpha, download=True)
+        cost0 = model.dataCost() + model.regCost(w.alpha)
+        x1, x2 = sh.solveNormalEq(lam, True)
+        traj_new = emba_io.incremental_update(init, x1, True)
+        model.updateMap(x2, damping)
+        model.eval_launch(traj_new)
+        model.eval_finish()
+        cost1 = model.dataCost() + model.regCost(w.alpha)
+        results[rank] = dict(ne=ne, count=count.cpu().numpy(), n_inl=n_inl, x1=x1, x2=x2, cost0=cost0, cost1=cost1, setup=m.setup_info())
+        m.close()
+    except Exception as e:  # noqa: BLE001
+        shared.errors.append((rank, repr(e)))
+        shared.barrier.abort()
+        raise
+
+
+@pytest.mark.parametrize("name,n_total,sensor,pano_h,K,yaw", [
+    ("SCALE workload: 8 x 1 M events", 8_000_000, (240, 180), 1024, 21, 0.5),
+    ("town.launch shape: 8 x 5 M events", 40_000_000, (640, 480), 1024, 97, 0.1),
+])
+def test_eight_ranks_at_full_shard_size(oracle_mod, name, n_total, sensor, pano_h, K, yaw):
+    """world = 8 through emba_amd.sharded with the real engine (eight contexts on one MI355X, the collectives through the thread stand-in):
+    count map activity, active set, normal-equation blocks, the sharded solve and one LM decision against the single-process oracle."""
+    import torch
+    assert torch.cuda.is_available()
+    from emba_amd import io as emba_io
+    from emba_amd.synth import make_workload
+    from helpers import OracleModel
+    from test_lm_solver_cpu import perturbed
+    O = oracle_mod
+    world, lam, damping = 8, 1e-3, 1.0
+    w = make_workload(n_events=n_total, pano_h=pano_h, K=K, sensor=sensor, focal=200.0 * sensor[0] / 240, yaw_rate=yaw)
+    init = perturbed(w, 0.002)
+    shared, results = _Shared(world), [None] * world
+    th = [threading.Thread(target=_rank8_main, args=(shared, r, w, init, lam, damping, results)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=900) for t in th]
+    assert not shared.errors, shared.errors
+    O.set_threads(min(O.max_threads(), 16))     # (omp mode == ref mode: tests/test_oracle_pinned.py)
+    try:
+        om = OracleModel(O, w, sparse=True)
+        om.set_events(w.events)
+        ep_o = om.evaluateDataError(init, w.Gx, w.Gy)
+        cost0 = om.dataCost() + om.regCost(w.alpha)
+        nem0 = om.nem.copy()
+        om.formNormalEq(ep_o, w.K, None, w.thres_valid_pixel)
+        om.applyL2Reg(w.alpha)
+        ne_o = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in om.ne.items()}
+        ox1, ox2 = om.solveNormalEq(lam, True)
+        om.updateMap(ox2, damping)
+        om.evaluateDataError(emba_io.incremental_update(init, ox1, True), None, None)
+        cost1 = om.dataCost() + om.regCost(w.alpha)
+    finally:
+        O.set_threads(1)
+    cap = 255 // world
+    assert sum(results[r]["n_inl"] for r in range(world)) == ep_o.size
+    for r in range(world):
+        got = results[r]["count"].reshape(w.pano_h, w.pano_w)
+        assert np.array_equal(got >= w.thres_valid_pixel, nem0 >= w.thres_valid_pixel), f"{name}: rank {r} activity"      # X1: saturated bytes
+        assert np.array_equal(got[nem0 < cap], nem0[nem0 < cap])                                                            # exact below the per-rank cap
+        ne = results[r]["ne"]
+        assert ne["P"] == ne_o["P"] and np.array_equal(ne["active"], ne_o["active"]), f"{name}: rank {r} active set"
+        for k in ("A11", "b1", "A22", "b2"):
+            assert_close(ne[k], ne_o[k], f"rank{r} {k}")
+        assert np.allclose(results[r]["x1"], ox1, rtol=1e-6, atol=1e-8 * np.abs(ox1).max()), f"rank {r} x1"
+        assert np.allclose(results[r]["x2"], ox2, rtol=1e-6, atol=1e-8 * np.abs(ox2).max()), f"rank {r} x2"
+        assert results[r]["cost0"] == pytest.approx(cost0, rel=1e-9) and results[r]["cost1"] == pytest.approx(cost1, rel=1e-7)
+        assert (results[r]["cost1"] < results[r]["cost0"]) == (cost1 < cost0), "LM decision differs"
+    assert all(np.array_equal(results[0]["x1"], results[r]["x1"]) for r in range(1, world)), "the replicated solve must be identical on every rank"

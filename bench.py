@@ -120,6 +120,9 @@ def main():
                     help="uniform: SURVEY §8d's i.i.d. events (the BASELINE workload).  scene: events an ideal event camera fires while "
                          "rotating in front of an analytic scene (edge-clustered, polarity-consistent; emba_amd.synth.simulate_events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of the N-rank launch on a ONE-GPU box: every rank uses device 0 and the collectives go through gloo "
+                         "(RCCL refuses two ranks on one device); exercises the launcher, the sharding and the protocol, not xGMI")
     ap.add_argument("--force-collectives", action="store_true",
                     help="rehearsal on ONE GPU: initialise RCCL with world_size 1 and run both all-reduces of the sharded protocol")
     args = ap.parse_args()
@@ -138,13 +141,18 @@ def main():
     import torch.distributed as dist
 
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_collectives
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if args.one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from emba_amd import LEGM
     from emba_amd.sharded import HipEngine, ShardedLEGM
@@ -234,6 +242,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # the exchanges alone (same buffers, same sizes, same stream), untimed w.r.t. `value`: what a step spends in collectives
+    coll_ms = None
+    if use_dist:
+        plen = int(sh.pack_len) if sh.pack_len else pack_t.numel()
+        barrier()
+        t_c = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(count_u8)
+            dist.all_reduce(pack_t[:plen])
+        barrier()
+        coll_ms = (time.perf_counter() - t_c) / 10 * 1e3
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total / (elapsed / args.steps)
@@ -252,6 +272,8 @@ def main():
                        "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
                                "(the host API's compacted ep vector is produced when it is asked for)",
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
+                       "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms,
+                       "backend": ("gloo, all ranks on device 0 (rehearsal)" if args.one_device else "rccl") if use_dist else None,
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
                        "setup": m.setup_info()},
             "roofline": {"bound": "hbm", "kernel": "emba_warp_tiled_kernel" if m.setup_info()["tile_order"] else "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,

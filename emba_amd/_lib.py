@@ -52,6 +52,7 @@ SIGNATURES = {
     "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "emba_solve_normal_eq": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, _dp, _dp]),
+    "emba_last_solve_info": (C.c_int, [C.c_void_p, _i32p]),
     "emba_solve_shard_size": (C.c_int, [C.c_void_p, _szp]),
     "emba_solve_shard_count": (C.c_int, [C.c_void_p, C.c_int32, _szp]),
     "emba_solve_shard_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),

@@ -128,6 +128,7 @@ struct emba_ctx {
     int n_cu = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
+    int solve_info = 0;         // last Schur solve: bit 0 a 2x2 block not positive definite (error), bit 1 a pivot of S vanished (zero update, like Eigen's ldlt)
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
     struct { void* p = nullptr; size_t bytes = 0; } ws[32];   // 0-15 Schur solve, 16-31 sort / order preparation
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
@@ -1651,7 +1652,18 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (x2_host && P) HIP_TRY(c, hipMemcpyAsync(x2_host, d_x2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    c->solve_info = info;
+    // bit 0: a 2x2 block A22m_i is not positive definite — the reference's A22m_i.inverse() (model.cpp:750) returns inf / nan there and the
+    // step is lost (NaN cost: rejected); reported as EMBA_ERR_NUMERIC.  bit 1: a pivot of S vanished — handled like Eigen's ldlt (zero
+    // update in that component), not an error.
+    if (info & 1) return fail(c, EMBA_ERR_NUMERIC, "a 2x2 block of A22 + lambda*diag(A22) is not positive definite (the reference's inverse() gives inf/nan)");
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_last_solve_info(const emba_ctx* c, int32_t* info)
+{
+    if (!c || !info) return EMBA_ERR_INVALID_ARG;
+    *info = c->solve_info;
     return EMBA_OK;
 }
 
@@ -1763,7 +1775,8 @@ extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_
     HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
     if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
-    if (info) return fail(c, EMBA_ERR_NUMERIC, "damped normal equations are not positive definite (info=%d)", info);
+    c->solve_info = info;
+    if (info & 1) return fail(c, EMBA_ERR_NUMERIC, "a 2x2 block of A22 + lambda*diag(A22) is not positive definite (the reference's inverse() gives inf/nan)");
     return EMBA_OK;
 }
 

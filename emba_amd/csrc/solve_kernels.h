@@ -263,11 +263,16 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
 #pragma unroll
         for (int k = 0; k < j; ++k) v -= row[k] * readlane_f64(row[k], j);
         const double d = readlane_f64(v, j);
-        bad |= (j < nb) && !(d > 0.0);
-        const double piv = sqrt(d);
-        row[j] = (r == j) ? piv : v / piv;     // rows above the diagonal hold garbage that is never read (k < j <= r below)
+        // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
+        // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
+        // The case that occurs in practice is a control pose no event constrains: its rows and columns of S are exactly zero, so d == 0
+        // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
+        const bool ok = d > 0.0;
+        bad |= (j < nb) && !ok;
+        const double piv = ok ? sqrt(d) : 0.0;
+        row[j] = (r == j) ? piv : (ok ? v / piv : 0.0);     // rows above the diagonal hold garbage that is never read (k < j <= r below)
     }
-    if (bad && r == 0) atomicOr(info, 2);
+    if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
 #pragma unroll
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
@@ -289,7 +294,8 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
             double v = x[c];
 #pragma unroll
             for (int k = 0; k < c; ++k) v -= x[k] * s[k * 65 + c];     // L_diag[c][k]
-            x[c] = v / s[c * 65 + c];
+            const double dg = s[c * 65 + c];
+            x[c] = (dg != 0.0) ? v / dg : 0.0;                        // zeroed column of a vanishing pivot (emba_chol_diag_kernel)
         }
     }
 #pragma unroll
@@ -313,7 +319,8 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
         if (t < 64) {
             double v = s_x[t];
             for (int j = 0; j < nb; ++j) {
-                const double xj = __shfl(v, j) / s_l[j * 65 + j];
+                const double dg = s_l[j * 65 + j];
+                const double xj = (dg != 0.0) ? __shfl(v, j) / dg : 0.0;
                 if (t == j) v = xj; else if (t > j && t < nb) v -= s_l[j * 65 + t] * xj;
             }
             s_x[t] = v;
@@ -336,7 +343,8 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
         if (t < 64) {
             double v = s_x[t];
             for (int j = nb - 1; j >= 0; --j) {
-                const double xj = __shfl(v, j) / s_l[j * 65 + j];
+                const double dg = s_l[j * 65 + j];
+                const double xj = (dg != 0.0) ? __shfl(v, j) / dg : 0.0;            // pseudo-inverse: zero update where the pivot vanished
                 if (t == j) v = xj; else if (t < j) v -= s_l[t * 65 + j] * xj;      // L^T[t][j] = L[j][t]
             }
             s_x[t] = v;

@@ -227,6 +227,12 @@ class LEGM:
         self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
         return x1, x2[:2 * self._P]
 
+    def last_solve_info(self):
+        """bit 0: a 2x2 block was not positive definite (the solve raised EMBA_ERR_NUMERIC); bit 1: a pivot of S vanished (zero update)."""
+        v = C.c_int32(0)
+        self._check(self._L.emba_last_solve_info(self._ctx, C.byref(v)))
+        return v.value
+
     # -- sharded Schur solve: primitives around the caller's two collectives (emba_amd.sharded.ShardedLEGM.solveNormalEq) --------
     def solve_shard_size(self):
         n = C.c_size_t(0)

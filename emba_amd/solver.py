@@ -95,9 +95,10 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             else:
                 x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)         # :190-194
         except Exception as e:   # noqa: BLE001
-            # The reference factors S with Eigen's pivoted ldlt (model.cpp:789), which also returns for a semi-definite S (e.g. a control
-            # pose no event constrains: its rows of A11 + lambda*diag(A11) stay zero), and then accepts or rejects the step on its cost.
-            # The device factorisation is a Cholesky and reports a vanishing pivot (EMBA_ERR_NUMERIC): treat the step as rejected.
+            # EMBA_ERR_NUMERIC: a 2x2 block A22_i + lambda*diag(A22_i) is not positive definite.  The reference's A22m_i.inverse()
+            # (model.cpp:750) returns inf / nan there, x1 / x2 and the trial cost become NaN, `cost_new < cost_min` is false and the step is
+            # rejected (solver.cpp:340-352): the same decision, without evaluating the NaN trial point.  (A vanishing pivot of S is not an
+            # error any more: like Eigen's ldlt, model.cpp:789, the device solve returns a zero update for that component.)
             if getattr(e, "status", None) != _ERR_NUMERIC and "singular" not in str(e):
                 raise
             it += 1

@@ -49,7 +49,9 @@ typedef enum {
                                    (BASALT_ASSERT at so3_spline.h:221-229 in the reference) */
     EMBA_ERR_STATE = 5,         /* call order violated (e.g. form before eval) */
     EMBA_ERR_CAPACITY = 6,      /* a caller-provided buffer is too small */
-    EMBA_ERR_NUMERIC = 7        /* the damped system is not positive definite (Cholesky pivot <= 0) */
+    EMBA_ERR_NUMERIC = 7        /* a 2x2 block A22_i + lambda*diag(A22_i) is not positive definite: the reference's A22m_i.inverse()
+                                   (model.cpp:750) yields inf/nan there and the LM step is lost.  (A vanishing pivot of the Schur
+                                   complement is NOT an error: like Eigen's ldlt, model.cpp:789, it gives a zero update.) */
 } emba_status;
 
 typedef struct emba_ctx emba_ctx;
@@ -195,12 +197,17 @@ emba_status emba_reconstruct_intensity(emba_ctx* ctx, const double* Gx_host, con
 /* Schur-complement solve: LEGM::solveNormalEq(A11, A12, A22_blocks, b1, b2, lambda, x1, x2), model.cpp:721-792,
  * on the device-resident normal equations of the last emba_form_finish (so after applyL2Reg, as in solver.cpp:130,190-202),
  * consuming the SPARSE A12 factors: S = A11m - A12 A22m^-1 A12^T is formed chunk-wise from per-pixel column pairs built from the
- * records, x1 = S \ (b1 - A12 A22m^-1 b2) by Cholesky, x2 = A22m^-1 (b2 - A12^T x1).  LM damping as the reference:
+ * records, x1 = S \ (b1 - A12 A22m^-1 b2) by a blocked Cholesky that treats a vanishing pivot the way Eigen's ldlt does (model.cpp:789:
+ * the pseudo-inverse of D — a control pose no event constrains gets a ZERO update; emba_last_solve_info bit 1 reports it),
+ * x2 = A22m^-1 (b2 - A12^T x1).  LM damping as the reference:
  * A11m = A11 + lambda*diag(A11), A22m = A22 + lambda*diag(A22).  fix_first_pose != 0 reproduces the first-window trim of
  * solver.cpp:156-165 (rows/cols 0..2 dropped; x1[0..2] = 0 on return).  x1_host: 3K doubles, x2_host: 2P doubles (either may
  * be NULL).  Works on this context's own records: with a sharded window use emba_solve_shard_* (a pixel's A12 columns are sums over all
  * ranks' records, so the records are first re-distributed by pixel owner). */
 emba_status emba_solve_normal_eq(emba_ctx* ctx, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
+/* Diagnostics of the last Schur solve of this context: bit 0 = a 2x2 block was not positive definite (EMBA_ERR_NUMERIC was returned),
+ * bit 1 = a pivot of S vanished and its component got a zero update (what ldlt.info() == NumericalIssue is in the reference: never read). */
+emba_status emba_last_solve_info(const emba_ctx* ctx, int32_t* info);
 
 /* The same Schur solve for a window sharded over n_ranks GPUs (events sharded by time, A12 factors stay sharded).
  * A pixel's A12 columns are sums over ALL ranks' records of that pixel, and S needs the outer products of the summed columns, so the

@@ -5,6 +5,7 @@
 #define _GNU_SOURCE
 #include "emba_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -873,6 +874,89 @@ void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, c
     free(act);
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The two Eigen calls of LEGM::solveNormalEq, restated from the reference's vendored Eigen 3.3.9 and PINNED against it
+ * (oracle/ref_eigen.cpp, tests/golden/eigen_solvers.npz, tests/test_oracle_pinned.py).
+ * ---------------------------------------------------------------------------------------------------------------- */
+/* Eigen::Matrix2d::inverse(), model.cpp:750 — Eigen/src/LU/InverseImpl.h (compute_inverse<.., 2>): invdet = 1 / determinant,
+ * every entry a product with invdet; determinant = m00*m11 - m10*m01 (Eigen/src/LU/Determinant.h).  A singular block gives
+ * inf / nan exactly as in the reference (no check there).  Row-major in and out. */
+void emba_oracle_inverse2(const double* A, double* out)
+{
+    const double det = A[0] * A[3] - A[2] * A[1];
+    const double invdet = 1.0 / det;
+    out[0] = A[3] * invdet;
+    out[2] = -A[2] * invdet;
+    out[1] = -A[1] * invdet;
+    out[3] = A[0] * invdet;
+}
+
+/* x = S.ldlt().solve(rhs), model.cpp:789 — Eigen::LDLT<MatrixXd, Lower>: Eigen/src/Cholesky/LDLT.h:294-395 (ldlt_inplace<Lower>::
+ * unblocked, the only variant: symmetric pivoting on the largest |diagonal| entry, a zero pivot leaves its column as it is) and
+ * :561-596 (_solve_impl: P, L^-1, PSEUDO-inverse of D with tolerance numeric_limits<double>::min(), L^-T, P^T).  S is n x n
+ * column-major, its lower triangle is read and overwritten.  Returns what ldlt.info() would say (0 Success, 1 NumericalIssue);
+ * the reference never looks at it, x is produced either way.  vecD / transp (may be NULL): D and the transpositions. */
+int emba_oracle_ldlt_solve(double* A, int n, const double* rhs, double* x, double* vecD, int* transp)
+{
+#define M_(r, c) A[(size_t)(r) + (size_t)n * (size_t)(c)]
+    int* tr = (int*)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    double* temp = (double*)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    int found_zero_pivot = 0, ret = 1;
+    if (n <= 1) {                                                                   /* :305-313 */
+        for (int k = 0; k < n; ++k) tr[k] = k;
+    } else {
+        for (int k = 0; k < n; ++k) {
+            int big = k;                                                            /* :318-320: first maximum of |diag| over the tail */
+            double bv = fabs(M_(k, k));
+            for (int i = k + 1; i < n; ++i) if (fabs(M_(i, i)) > bv) { bv = fabs(M_(i, i)); big = i; }
+            tr[k] = big;
+            if (k != big) {                                                         /* :323-339: symmetric swap inside the lower triangle */
+                for (int j = 0; j < k; ++j) { const double t = M_(k, j); M_(k, j) = M_(big, j); M_(big, j) = t; }
+                for (int i = big + 1; i < n; ++i) { const double t = M_(i, k); M_(i, k) = M_(i, big); M_(i, big) = t; }
+                { const double t = M_(k, k); M_(k, k) = M_(big, big); M_(big, big) = t; }
+                for (int i = k + 1; i < big; ++i) { const double t = M_(i, k); M_(i, k) = M_(big, i); M_(big, i) = t; }
+            }
+            const int rs = n - k - 1;
+            if (k > 0) {                                                            /* :350-356 */
+                for (int j = 0; j < k; ++j) temp[j] = M_(j, j) * M_(k, j);
+                double dot = 0.0;
+                for (int j = 0; j < k; ++j) dot += M_(k, j) * temp[j];
+                M_(k, k) -= dot;
+                for (int i = k + 1; i < n; ++i) {
+                    double acc = 0.0;
+                    for (int j = 0; j < k; ++j) acc += M_(i, j) * temp[j];
+                    M_(i, k) -= acc;
+                }
+            }
+            const double akk = M_(k, k);
+            const int pivot_is_valid = fabs(akk) > 0.0;                             /* :362-363 */
+            if (k == 0 && !pivot_is_valid) {                                        /* :365-376: the whole diagonal is zero */
+                for (int j = 0; j < n; ++j) {
+                    tr[j] = j;
+                    for (int i = j + 1; i < n; ++i) if (M_(i, j) != 0.0) ret = 0;
+                }
+                break;
+            }
+            if (rs > 0 && pivot_is_valid) { for (int i = k + 1; i < n; ++i) M_(i, k) /= akk; }   /* :378-379 */
+            else if (rs > 0) { for (int i = k + 1; i < n; ++i) if (M_(i, k) != 0.0) ret = 0; }    /* :380-381 */
+            if (found_zero_pivot && pivot_is_valid) ret = 0;                        /* :383-384 */
+            else if (!pivot_is_valid) found_zero_pivot = 1;
+        }
+    }
+    /* _solve_impl, :561-596 */
+    for (int i = 0; i < n; ++i) x[i] = rhs[i];
+    for (int k = 0; k < n; ++k) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }        /* dst = P b */
+    for (int r = 0; r < n; ++r) { double v = x[r]; for (int k = 0; k < r; ++k) v -= M_(r, k) * x[k]; x[r] = v; }  /* unit lower */
+    for (int i = 0; i < n; ++i) { const double d = M_(i, i); if (fabs(d) > DBL_MIN) x[i] /= d; else x[i] = 0.0; } /* pseudo-inverse of D */
+    for (int r = n - 1; r >= 0; --r) { double v = x[r]; for (int k = r + 1; k < n; ++k) v -= M_(k, r) * x[k]; x[r] = v; }
+    for (int k = n - 1; k >= 0; --k) if (tr[k] != k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }   /* dst = P^T dst */
+    if (vecD) for (int i = 0; i < n; ++i) vecD[i] = M_(i, i);
+    if (transp) for (int i = 0; i < n; ++i) transp[i] = tr[i];
+    free(tr); free(temp);
+    return ret ? 0 : 1;
+#undef M_
+}
+
 /* f1 — LEGM::solveNormalEq, model.cpp:721-792 */
 int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double* A12, const double* A22, const double* b1,
                                 const double* b2, double lambda, double* x1, double* x2)
@@ -887,9 +971,8 @@ int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double
         for (int r = 0; r < n; ++r) S[r + (size_t)n * c] = A11[r + (size_t)n * c] + ((r == c) ? lambda * A11[r + (size_t)n * c] : 0.0);
     /* A22m_i = A22_i + lambda*diag(A22_i), inverse of each 2x2, :743-759 */
     for (size_t i = 0; i < P; ++i) {
-        const double a = A22[4 * i] + lambda * A22[4 * i], b = A22[4 * i + 1], c = A22[4 * i + 2], d = A22[4 * i + 3] + lambda * A22[4 * i + 3];
-        const double det = a * d - b * c;
-        Binv[4 * i] = d / det; Binv[4 * i + 1] = -b / det; Binv[4 * i + 2] = -c / det; Binv[4 * i + 3] = a / det;
+        const double Am[4] = {A22[4 * i] + lambda * A22[4 * i], A22[4 * i + 1], A22[4 * i + 2], A22[4 * i + 3] + lambda * A22[4 * i + 3]};
+        emba_oracle_inverse2(Am, Binv + 4 * i);                                              /* A22m_i.inverse(), :750 */
     }
     /* W = A12 * A22m_inv, :784 */
     for (size_t i = 0; i < P; ++i)
@@ -910,30 +993,14 @@ int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double
             if (a == 0.0) continue;
             for (int r = 0; r < n; ++r) S[r + (size_t)n * c] -= W[r + (size_t)n * k] * a;
         }
-    /* x1 = S.ldlt().solve(rhs), :789 — unpivoted LDL^T in place (lower) */
-    int bad = 0;
-    for (int j = 0; j < n; ++j) {
-        double d = S[j + (size_t)n * j];
-        for (int k = 0; k < j; ++k) d -= S[j + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
-        if (d == 0.0) { bad = 1; break; }
-        S[j + (size_t)n * j] = d;
-        for (int r = j + 1; r < n; ++r) {
-            double v = S[r + (size_t)n * j];
-            for (int k = 0; k < j; ++k) v -= S[r + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
-            S[r + (size_t)n * j] = v / d;
-        }
-    }
-    if (!bad) {
-        for (int r = 0; r < n; ++r) { double v = rhs[r]; for (int k = 0; k < r; ++k) v -= S[r + (size_t)n * k] * x1[k]; x1[r] = v; }
-        for (int r = 0; r < n; ++r) x1[r] /= S[r + (size_t)n * r];
-        for (int r = n - 1; r >= 0; --r) { double v = x1[r]; for (int k = r + 1; k < n; ++k) v -= S[k + (size_t)n * r] * x1[k]; x1[r] = v; }
-        /* x2 = A22m_inv * (b2 - A12^T x1), :791 */
-        for (size_t i = 0; i < P; ++i) {
-            double t0 = b2[2 * i], t1 = b2[2 * i + 1];
-            for (int r = 0; r < n; ++r) { t0 -= A12[r + (size_t)n * (2 * i)] * x1[r]; t1 -= A12[r + (size_t)n * (2 * i + 1)] * x1[r]; }
-            x2[2 * i] = Binv[4 * i] * t0 + Binv[4 * i + 1] * t1;
-            x2[2 * i + 1] = Binv[4 * i + 2] * t0 + Binv[4 * i + 3] * t1;
-        }
+    /* x1 = S.ldlt().solve(rhs), :789 */
+    const int bad = emba_oracle_ldlt_solve(S, n, rhs, x1, NULL, NULL);
+    /* x2 = A22m_inv * (b2 - A12^T x1), :791 */
+    for (size_t i = 0; i < P; ++i) {
+        double t0 = b2[2 * i], t1 = b2[2 * i + 1];
+        for (int r = 0; r < n; ++r) { t0 -= A12[r + (size_t)n * (2 * i)] * x1[r]; t1 -= A12[r + (size_t)n * (2 * i + 1)] * x1[r]; }
+        x2[2 * i] = Binv[4 * i] * t0 + Binv[4 * i + 1] * t1;
+        x2[2 * i + 1] = Binv[4 * i + 2] * t0 + Binv[4 * i + 3] * t1;
     }
     free(Binv); free(W); free(S); free(rhs);
     return bad;
@@ -994,26 +1061,6 @@ static factor_t* build_factors(const emba_oracle* o, const double* ep, const int
     return NULL;
 }
 
-/* unpivoted LDL^T solve of the m x m column-major system in place (the dense route's code) */
-static int ldlt_solve(double* S, int n, const double* rhs, double* x1)
-{
-    for (int j = 0; j < n; ++j) {
-        double d = S[j + (size_t)n * j];
-        for (int k = 0; k < j; ++k) d -= S[j + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
-        if (d == 0.0) return 1;
-        S[j + (size_t)n * j] = d;
-        for (int r = j + 1; r < n; ++r) {
-            double v = S[r + (size_t)n * j];
-            for (int k = 0; k < j; ++k) v -= S[r + (size_t)n * k] * S[j + (size_t)n * k] * S[k + (size_t)n * k];
-            S[r + (size_t)n * j] = v / d;
-        }
-    }
-    for (int r = 0; r < n; ++r) { double v = rhs[r]; for (int k = 0; k < r; ++k) v -= S[r + (size_t)n * k] * x1[k]; x1[r] = v; }
-    for (int r = 0; r < n; ++r) x1[r] /= S[r + (size_t)n * r];
-    for (int r = n - 1; r >= 0; --r) { double v = x1[r]; for (int k = r + 1; k < n; ++k) v -= S[k + (size_t)n * r] * x1[k]; x1[r] = v; }
-    return 0;
-}
-
 /* column pair (c0, c1) of A12 for one active pixel from its factors, as sparse 6-row bands written into dense scratch of length n */
 static void pixel_columns(const factor_t* F, uint32_t f0, uint32_t f1, double* c0, double* c1, int* bands, int* nb_out, uint8_t* mark)
 {
@@ -1057,9 +1104,8 @@ int emba_oracle_solve_sparse(emba_oracle* o, const double* ep, int K, const int3
         }
     for (int r = 0; r < n; ++r) rhs[r] = b1[r];
     for (size_t i = 0; i < P; ++i) {
-        const double aa = A22[4 * i] + lambda * A22[4 * i], bb = A22[4 * i + 1], cc = A22[4 * i + 2], dd = A22[4 * i + 3] + lambda * A22[4 * i + 3];
-        const double det = aa * dd - bb * cc;
-        Binv[4 * i] = dd / det; Binv[4 * i + 1] = -bb / det; Binv[4 * i + 2] = -cc / det; Binv[4 * i + 3] = aa / det;   /* :743-759 */
+        const double Am[4] = {A22[4 * i] + lambda * A22[4 * i], A22[4 * i + 1], A22[4 * i + 2], A22[4 * i + 3] + lambda * A22[4 * i + 3]};
+        emba_oracle_inverse2(Am, Binv + 4 * i);                                              /* :743-759 */
         int nb;
         pixel_columns(F, off[i], off[i + 1], c0, c1, bands, &nb, mark);
         for (int k = 0; k < nb; ++k) {                                                       /* W = A12 * A22m_inv, :784 */
@@ -1079,8 +1125,8 @@ int emba_oracle_solve_sparse(emba_oracle* o, const double* ep, int K, const int3
         }
     }
     for (int r = 0; r < n; ++r) x1[r] = 0.0;
-    const int bad = ldlt_solve(S, m, rhs + skip, x1 + skip);                                 /* :789 */
-    if (!bad)
+    const int bad = emba_oracle_ldlt_solve(S, m, rhs + skip, x1 + skip, NULL, NULL);         /* :789 */
+    {
         for (size_t i = 0; i < P; ++i) {                                                     /* x2 = A22m_inv (b2 - A12^T x1), :791 */
             int nb;
             pixel_columns(F, off[i], off[i + 1], c0, c1, bands, &nb, mark);
@@ -1089,6 +1135,7 @@ int emba_oracle_solve_sparse(emba_oracle* o, const double* ep, int K, const int3
             x2[2 * i] = Binv[4 * i] * t0 + Binv[4 * i + 1] * t1;
             x2[2 * i + 1] = Binv[4 * i + 2] * t0 + Binv[4 * i + 3] * t1;
         }
+    }
     free(F); free(off); free(S); free(rhs); free(c0); free(c1); free(w0); free(w1); free(bands); free(mark); free(Binv);
     return bad;
 }

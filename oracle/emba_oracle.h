@@ -118,11 +118,18 @@ void emba_oracle_update_map(size_t P, const uint32_t* active_idx, size_t npix, c
                             double* Gx, double* Gy);
 
 /* f1: LEGM::solveNormalEq (model.cpp:721-792), dense like the reference (small sizes only): A11 n x n and A12 n x 2P
- * column-major, A22 P x [xx xy; xy yy], LM damping A?m = A + lambda*diag(A).  x1[n], x2[2P].  The n x n solve is an unpivoted
- * LDL^T (the reference uses Eigen's pivoted ldlt; for the positive definite S of a damped system both give the solution to
- * rounding).  Returns 0, or 1 if a pivot vanishes. */
+ * column-major, A22 P x [xx xy; xy yy], LM damping A?m = A + lambda*diag(A).  x1[n], x2[2P].  The n x n solve is Eigen's pivoted
+ * LDL^T restated (emba_oracle_ldlt_solve), the 2x2 inverses Eigen's Matrix2d::inverse (emba_oracle_inverse2).  Always produces x1 / x2
+ * like the reference (a zero pivot gives a zero component, a singular 2x2 block inf / nan); returns what ldlt.info() would say
+ * (0 Success, 1 NumericalIssue), which the reference never reads. */
 int emba_oracle_solve_normal_eq(int n, size_t P, const double* A11, const double* A12, const double* A22, const double* b1,
                                 const double* b2, double lambda, double* x1, double* x2);
+
+/* The two Eigen calls of solveNormalEq, restated from the reference's vendored Eigen 3.3.9 and pinned against it (oracle/ref_eigen.cpp):
+ * Matrix2d::inverse() (model.cpp:750; row-major 2x2 in and out) and S.ldlt().solve(rhs) (model.cpp:789; S n x n column-major, lower
+ * triangle read and overwritten; vecD / transp may be NULL). */
+void emba_oracle_inverse2(const double* A, double* out);
+int emba_oracle_ldlt_solve(double* S, int n, const double* rhs, double* x, double* vecD, int* transp);
 
 /* f1 on the sparse form of A12 (one rank-1 factor per measurement, taken from the state of the last evaluateDataError): the same
  * LEGM::solveNormalEq / solveNormalEqCG (model.cpp:721-792 / 794-840) for sizes where the dense 3K x 2P matrix does not fit.

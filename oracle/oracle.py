@@ -87,6 +87,9 @@ def lib():
         L.emba_oracle_count_map.restype = C.c_long
         L.emba_oracle_count_map.argtypes = [C.c_void_p, _dp, C.c_int, C.c_int64, C.c_int64, C.POINTER(C.c_uint16),
                                             C.POINTER(C.c_uint16), C.POINTER(C.c_int64), C.c_size_t, _dp, _i32p, _i32p]
+        L.emba_oracle_inverse2.argtypes = [_dp, _dp]
+        L.emba_oracle_ldlt_solve.restype = C.c_int
+        L.emba_oracle_ldlt_solve.argtypes = [_dp, C.c_int, _dp, _dp, _dp, _i32p]
         L.emba_oracle_set_threads.argtypes = [C.c_int]
         L.emba_oracle_get_threads.restype = C.c_int
         L.emba_oracle_max_threads.restype = C.c_int
@@ -114,6 +117,48 @@ def ref():
         R.ref_left_jacobian.argtypes = [_dp, _dp, _dp]
         _ref = R
     return _ref
+
+
+_ref_eigen = None
+_REF_EIGEN = os.path.join(_HERE, "_ref", "libref_eigen.so")
+
+
+def ref_eigen():
+    """The reference's own vendored Eigen behind oracle/ref_eigen.cpp (LDLT, Matrix2d::inverse, ConjugateGradient), or None when
+    oracle/_ref was not built / shipped."""
+    global _ref_eigen
+    if _ref_eigen is None and os.path.exists(_REF_EIGEN):
+        R = C.CDLL(_REF_EIGEN)
+        R.ref_ldlt_solve.restype = C.c_int
+        R.ref_ldlt_solve.argtypes = [C.c_int, _dp, _dp, _dp, _dp, _i32p]
+        R.ref_inverse2.argtypes = [_dp, _dp]
+        R.ref_cg_solve.argtypes = [C.c_int, C.c_long, _i32p, _i32p, _dp, _dp, C.c_int, C.c_double, _dp, C.POINTER(C.c_int), _dp]
+        _ref_eigen = R
+    return _ref_eigen
+
+
+def ref_ldlt_solve(S, rhs):
+    """Eigen: S.ldlt().solve(rhs) -> (x, vecD, transpositions, info)."""
+    S = np.array(S, dtype=np.float64, order="F"); rhs = _f64(rhs)
+    n = S.shape[0]
+    x = np.zeros(n); d = np.zeros(n); tr = np.zeros(n, dtype=np.int32)
+    info = ref_eigen().ref_ldlt_solve(n, _ptr(S, _dp), _ptr(rhs, _dp), _ptr(x, _dp), _ptr(d, _dp), _ptr(tr, _i32p))
+    return x, d, tr, info
+
+
+def ref_inverse2(A):
+    A = _f64(np.asarray(A, dtype=np.float64).reshape(4)); out = np.zeros(4)
+    ref_eigen().ref_inverse2(_ptr(A, _dp), _ptr(out, _dp))
+    return out.reshape(2, 2)
+
+
+def ref_cg_solve(n, rows, cols, vals, b, max_iter=100, tol=1e-6):
+    """Eigen::ConjugateGradient<SpMat, Lower|Upper> on the matrix given by triplets -> (x, iterations, error)."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32); cols = np.ascontiguousarray(cols, dtype=np.int32); vals = _f64(vals); b = _f64(b)
+    x = np.zeros(n); it = C.c_int(0); err = np.zeros(1)
+    ref_eigen().ref_cg_solve(int(n), int(vals.size), _ptr(rows, _i32p), _ptr(cols, _i32p), _ptr(vals, _dp), _ptr(b, _dp), int(max_iter), float(tol),
+                             _ptr(x, _dp), C.byref(it), _ptr(err, _dp))
+    return x, it.value, float(err[0])
 
 
 def _f64(a):
@@ -197,9 +242,24 @@ def solve_normal_eq(ne, lam, fix_first_pose=False):
     x1 = np.zeros(n); x2 = np.zeros(2 * max(P, 1))
     rc = lib().emba_oracle_solve_normal_eq(n, P, _ptr(A11s, _dp), _ptr(A12s, _dp), _ptr(A22, _dp), _ptr(b1s, _dp), _ptr(b2, _dp), float(lam),
                                            _ptr(x1, _dp), _ptr(x2, _dp))
-    if rc:
-        raise ValueError("singular system")
+    # (rc = what Eigen's ldlt.info() would report; the reference never reads it and uses x1 / x2 as they come)
     return np.concatenate([np.zeros(sk), x1]), x2[:2 * P]
+
+
+def ldlt_solve(S, rhs):
+    """x = S.ldlt().solve(rhs) (model.cpp:789; Eigen's pivoted LDLT restated): returns (x, vecD, transpositions, info)."""
+    S = np.array(S, dtype=np.float64, order="F"); rhs = _f64(rhs)
+    n = S.shape[0]
+    x = np.zeros(n); d = np.zeros(n); tr = np.zeros(n, dtype=np.int32)
+    info = lib().emba_oracle_ldlt_solve(_ptr(S, _dp), n, _ptr(rhs, _dp), _ptr(x, _dp), _ptr(d, _dp), _ptr(tr, _i32p))
+    return x, d, tr, info
+
+
+def inverse2(A):
+    """Eigen::Matrix2d::inverse() (model.cpp:750) restated."""
+    A = _f64(np.asarray(A, dtype=np.float64).reshape(4)); out = np.zeros(4)
+    lib().emba_oracle_inverse2(_ptr(A, _dp), _ptr(out, _dp))
+    return out.reshape(2, 2)
 
 
 def data_cost(ep, irls=0, a=0.0):
@@ -310,8 +370,7 @@ class OracleLEGM:
         """LEGM::solveNormalEq (model.cpp:721-792) from the sparse A12 factors of the last evaluate_data_error (after apply_l2)."""
         keep, args = self._sparse_args(ne, ep, K, num_ev_map, thres, irls, a, lam, fix_first_pose)
         x1 = np.zeros(3 * K); x2 = np.zeros(2 * max(ne["P"], 1))
-        if lib().emba_oracle_solve_sparse(*args, _ptr(x1, _dp), _ptr(x2, _dp)):
-            raise ValueError("singular system")
+        lib().emba_oracle_solve_sparse(*args, _ptr(x1, _dp), _ptr(x2, _dp))     # (returns ldlt.info(); the reference never reads it)
         return x1, x2[:2 * ne["P"]]
 
     def solve_cg_sparse(self, ne, ep, K, num_ev_map, thres, irls=0, a=0.0, lam=1e-3, fix_first_pose=False, max_iter=100, tol=1e-6):

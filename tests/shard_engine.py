@@ -219,7 +219,7 @@ class OracleShardEngine:
         rhs = Sa[:n, n] + b1
         sk = 3 if fix_first_pose else 0
         x1 = np.zeros(n)
-        x1[sk:] = np.linalg.solve(Sm[sk:, sk:], rhs[sk:])
+        x1[sk:] = O.ldlt_solve(Sm[sk:, sk:], rhs[sk:])[0]                                  # S.ldlt().solve(...), :789 (Eigen's pivoted LDLT restated)
         xx = np.zeros(2 * max(self.P, 1))
         for ci, (A, C, b2) in self._pixel_terms(recv, n_recv, lam).items():
             xx[2 * ci:2 * ci + 2] = np.linalg.solve(C, b2 - A.T @ x1)                    # :790-791

@@ -457,6 +457,55 @@ def test_schur_solve_parity(gpu, oracle_mod, cfg, lam, fix, cost):
     assert np.allclose(x1b, ob1, rtol=1e-7, atol=1e-9 * np.abs(ob1).max()) and np.allclose(x2b, ob2, rtol=1e-7, atol=1e-9 * np.abs(ob2).max())
 
 
+def _unobserved_pose_workload(K=8, frac=0.55, **kw):
+    """K control poses, events only in the first part of the window: the last control poses are constrained by no event (their rows and
+    columns of A11, A12 — hence of the Schur complement — are exactly zero)."""
+    from emba_amd.legm import EventPacket
+    cfg = dict(n_events=20000, pano_h=128, K=K, sensor=(32, 24), focal=30.0)
+    cfg.update(kw)
+    w = small_workload(**cfg)
+    ev = w.events
+    n = (int(ev.size() * frac) // 100) * 100
+    w.events = EventPacket(ev.x[:n], ev.y[:n], ev.polarity[:n], ev.t_ns[:n])
+    return w
+
+
+@pytest.mark.parametrize("K,kw", [(8, {}), (90, dict(n_events=60000, pano_h=256, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3))])
+def test_schur_solve_with_an_unobserved_control_pose(gpu, oracle_mod, K, kw):
+    """model.cpp:789 is Eigen's PIVOTED ldlt: for a semi-definite S (a control pose no event constrains) it returns, with a ZERO update in
+    the unconstrained components (pinned against the reference's Eigen: tests/golden/eigen_solvers.npz).  The device factorisation must do
+    the same — not raise, not produce NaN — and agree with the oracle everywhere else (one 64-wide tile and several)."""
+    w = _unobserved_pose_workload(K, **kw)
+    g = gpu_run(w)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    dead = np.diag(o["ne"]["A11"]) == 0
+    assert dead.sum() >= 3 and not dead[:3 * (K // 2)].any()
+    for lam, fix in ((1e-3, True), (1e-1, False)):
+        x1, x2 = g["legm"].solveNormalEq(lam, fix_first_pose=fix)
+        ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+        assert np.isfinite(x1).all() and np.isfinite(x2).all()
+        assert (x1[dead] == 0).all() and (ox1[dead] == 0).all(), "unconstrained control poses must get a zero update"
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()) and np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+        assert g["legm"].last_solve_info() == 2          # a pivot vanished (diagnostic), no 2x2 block failed
+    # and the LM loop walks through it like the reference would: same decisions as the oracle loop, no "reject forever"
+    from emba_amd import LEGM
+    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+    from helpers import OracleModel
+    from test_lm_solver_cpu import perturbed
+    if K > 8:
+        return
+    init = perturbed(w, 0.003)
+    ba, lm = BASettings(alpha=5.0), LMSettings(max_num_iter=4)
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    rg = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, lm, resident=True)
+    ro = solve_time_window(OracleModel(oracle_mod, w), init, w.events, w.Gx, w.Gy, ba, lm)
+    assert [e[4] for e in rg.log] == [e[4] for e in ro.log] and any(e[4] for e in rg.log)
+    for a, b in zip(rg.log, ro.log):
+        assert a[3] == pytest.approx(b[3], rel=1e-7)
+    assert np.abs(rg.traj.knots_xyzw - ro.traj.knots_xyzw).max() < 1e-8
+    assert np.array_equal(rg.traj.knots_xyzw[-1], init.knots_xyzw[-1])      # the unconstrained last pose never moved
+
+
 @pytest.mark.parametrize("cfg,lam,fix,cost", [
     (dict(n_events=20000), 1e-3, True, ("quadratic", 0.0)),
     (dict(n_events=30000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01), 1e-2, False, ("huber", 0.1)),

@@ -236,6 +236,7 @@ def _rank8_main(shared, rank, w, init, lam, damping, results):
         model.set_events(w.events)
         model.upload_map(w.Gx, w.Gy)
         n_inl, ne = sh.iteration(init, w.thres_valid_pixel, w.alpha, download=True)
+        count_h = count.cpu().numpy()          # (the trial evaluation below starts a new count map)
         cost0 = model.dataCost() + model.regCost(w.alpha)
         x1, x2 = sh.solveNormalEq(lam, True)
         traj_new = emba_io.incremental_update(init, x1, True)
@@ -243,7 +244,7 @@ def _rank8_main(shared, rank, w, init, lam, damping, results):
         model.eval_launch(traj_new)
         model.eval_finish()
         cost1 = model.dataCost() + model.regCost(w.alpha)
-        results[rank] = dict(ne=ne, count=count.cpu().numpy(), n_inl=n_inl, x1=x1, x2=x2, cost0=cost0, cost1=cost1, setup=m.setup_info())
+        results[rank] = dict(ne=ne, count=count_h, n_inl=n_inl, x1=x1, x2=x2, cost0=cost0, cost1=cost1, setup=m.setup_info())
         m.close()
     except Exception as e:  # noqa: BLE001
         shared.errors.append((rank, repr(e)))

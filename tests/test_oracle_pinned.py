@@ -375,3 +375,88 @@ def test_omp_mode_and_lean_count_map_agree_with_the_reference_order_pass(oracle_
         n_used = (ev.size() // 100) * 100
         assert n_inl == ep1.size and np.array_equal(nem_l, nem1)
         assert np.array_equal(pm_l[:n_used], d1["pm"][:n_used]) and np.array_equal(pmi_l[:n_used], d1["pm_int"][:n_used])
+
+
+# ---- f1: the solvers' Eigen calls, PINNED to the reference's own vendored Eigen (tests/golden/eigen_solvers.npz) ---------------------------
+EIGEN_GOLD = os.path.join(os.path.dirname(__file__), "golden", "eigen_solvers.npz")
+
+
+def test_ldlt_and_inverse2_match_the_reference_eigen_golden(oracle_mod):
+    """S.ldlt().solve(rhs) (model.cpp:789) and Matrix2d::inverse() (model.cpp:750) as Eigen 3.3.9 executes them: the oracle's restatement
+    takes the same pivots (transpositions identical), leaves the same D, gives the same solution — including a Schur complement with a
+    control pose no event constrains (zero rows: Eigen pivots them last and its pseudo-inverse of D returns a ZERO update there), an
+    indefinite matrix, the all-zero matrix and n = 1 — and the same inverse entries, inf / nan of a singular block included."""
+    O = oracle_mod
+    g = np.load(EIGEN_GOLD)
+    for name in g["ldlt_names"]:
+        S, rhs = g[f"ldlt_{name}_S"], g[f"ldlt_{name}_rhs"]
+        x, d, tr, info = O.ldlt_solve(S, rhs)
+        assert np.array_equal(tr, g[f"ldlt_{name}_tr"]), f"{name}: pivot order differs from Eigen's"
+        assert info == int(g[f"ldlt_{name}_info"])
+        ex, eD = g[f"ldlt_{name}_x"], g[f"ldlt_{name}_D"]
+        assert np.array_equal(d == 0, eD == 0) and np.allclose(d, eD, rtol=1e-10, atol=1e-13 * np.abs(eD).max())
+        assert np.array_equal(x == 0, ex == 0), f"{name}: zero components differ"
+        assert np.allclose(x, ex, rtol=1e-9, atol=1e-11 * max(np.abs(ex).max(), 1e-300)), name
+    x = O.ldlt_solve(g["ldlt_unobserved_pose_S"], g["ldlt_unobserved_pose_rhs"])[0]
+    dead = np.diag(g["ldlt_unobserved_pose_S"]) == 0
+    assert dead.sum() >= 3 and (x[dead] == 0).all() and (x[~dead] != 0).all()
+    got = np.array([O.inverse2(a).ravel() for a in g["inv2_A"]])
+    exp = g["inv2_out"]
+    assert np.array_equal(np.isfinite(got), np.isfinite(exp)) and np.array_equal(np.isnan(got), np.isnan(exp))
+    fin = np.isfinite(exp)
+    assert np.array_equal(got[fin], exp[fin]), "2x2 inverse is expected to match Eigen bit for bit (same five operations)"
+    assert np.array_equal(np.sign(got[np.isinf(exp)]), np.sign(exp[np.isinf(exp)]))
+
+
+def test_cg_matches_the_reference_eigen_golden(oracle_mod):
+    """solveNormalEqCG (model.cpp:794-840): the oracle's matrix-free restatement of Eigen's ConjugateGradient loop against Eigen's own run
+    on the assembled sparse matrix — same number of iterations, same error estimate, same iterate."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_eigen_golden import full_system_triplets
+    O = oracle_mod
+    g = np.load(EIGEN_GOLD)
+    w = small_workload(n_events=2400, pano_h=64, K=5, sensor=(12, 8), focal=10.0)
+    r = oracle_run(O, w, dense_A12=True)
+    ne, o = r["ne"], r["oracle"]
+    for name in ("trimmed", "full"):
+        lam, skip = float(g[f"cg_{name}_lam"]), int(g[f"cg_{name}_skip"])
+        n, rows, cols, vals, b = full_system_triplets(ne, lam, skip)
+        # the fixture's input IS this system (the workload generator and the oracle are deterministic)
+        assert np.array_equal(rows, g[f"cg_{name}_rows"]) and np.array_equal(cols, g[f"cg_{name}_cols"])
+        assert np.allclose(vals, g[f"cg_{name}_vals"], rtol=1e-13, atol=0) and np.allclose(b, g[f"cg_{name}_b"], rtol=1e-13, atol=0)
+        x1, x2, it, err = o.solve_cg_sparse(ne, r["ep"], w.K, r["num_ev_map"], w.thres_valid_pixel, 0, 0.0, lam, bool(skip))
+        ex = g[f"cg_{name}_x"]
+        assert it == int(g[f"cg_{name}_iters"]), (it, int(g[f"cg_{name}_iters"]))
+        assert err == pytest.approx(float(g[f"cg_{name}_err"]), rel=1e-6)
+        got = np.concatenate([x1[skip:], x2])
+        assert np.allclose(got, ex, rtol=1e-7, atol=1e-9 * np.abs(ex).max())
+
+
+def test_solver_restatements_live_against_the_reference_eigen_build(oracle_mod):
+    """Where oracle/_ref/libref_eigen.so is present (authoring container, and the GPU box: it travels prebuilt): random systems beyond the
+    golden file — SPD, semi-definite with zero rows, indefinite — same pivots, same zero pattern, same solution."""
+    O = oracle_mod
+    if O.ref_eigen() is None:
+        pytest.skip("oracle/_ref/libref_eigen.so not present")
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        n = int(rng.integers(2, 60))
+        B = rng.normal(size=(n, n))
+        S = B @ B.T + 1e-2 * np.eye(n)
+        rhs = rng.normal(size=n)
+        kind = trial % 4
+        if kind == 1:      # unobserved poses: whole rows / columns vanish
+            dead = rng.choice(n, size=max(1, n // 5), replace=False)
+            S[dead, :] = 0; S[:, dead] = 0; rhs[dead] = 0
+        elif kind == 2:    # indefinite
+            S[rng.integers(0, n), rng.integers(0, n)] *= -3; S = 0.5 * (S + S.T)
+        elif kind == 3:    # equal diagonal entries: the pivot search must take the FIRST maximum
+            S = np.eye(n) * 2.0 + 0.1 * (B + B.T) / n; np.fill_diagonal(S, 2.0)
+        a, b = O.ldlt_solve(S, rhs), O.ref_ldlt_solve(S, rhs)
+        assert np.array_equal(a[2], b[2]) and a[3] == b[3], f"trial {trial}: pivots / info"
+        assert np.array_equal(a[0] == 0, b[0] == 0)
+        assert np.allclose(a[0], b[0], rtol=1e-8, atol=1e-10 * np.abs(b[0]).max()), f"trial {trial}"
+    for _ in range(100):
+        A = rng.normal(size=4)
+        assert np.array_equal(O.inverse2(A), O.ref_inverse2(A))

@@ -46,6 +46,7 @@ SIGNATURES = {
     "emba_form_normal_eq": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp, _dp, _szp, _u32p,
                                       C.c_size_t, _dp, _dp, _dp]),
     "emba_get_A12_sparse": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _dp, _dp, _dp, _dp]),
+    "emba_get_inlier_pixels": (C.c_int, [C.c_void_p, _u32p]),
     "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
     "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),
     "emba_dump_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, _dp, _dp, _dp]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "emba_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "emba_map_accept": (C.c_int, [C.c_void_p]),
     "emba_map_reject": (C.c_int, [C.c_void_p]),
+    "emba_trial_reject": (C.c_int, [C.c_void_p]),
     "emba_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_reconstruct_intensity": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
@@ -92,6 +94,12 @@ SIGNATURES = {
     "emba_group_set_events": (C.c_int, [C.c_void_p, _u16p, _u16p, _u8p, _i64p, C.c_size_t]),
     "emba_group_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_group_step": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
+    "emba_group_eval": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, _dp, _dp, _szp, _i32p]),
+    "emba_group_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
+    "emba_group_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "emba_group_apply_l2": (C.c_int, [C.c_void_p, C.c_double]),
+    "emba_group_solve_cg": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _i32p, _dp]),
+    "emba_group_trial_reject": (C.c_int, [C.c_void_p]),
     "emba_group_download": (C.c_int, [C.c_void_p, _dp, _dp, _u32p, C.c_size_t, _dp, _dp]),
     "emba_group_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dp, _dp]),
     "emba_group_solve": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, _dp, _dp]),

@@ -98,6 +98,15 @@ struct emba_ctx {
     double* d_seg = nullptr; int seg_cap = 0;                 // tile order: per-segment constants the tiled kernel evaluates each event's pose from (12 doubles per segment)
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
+    // Two record sets (a rejected LM trial must not cost a re-evaluation).  d_rec / d_tag / set_stamp are the WORKING set: what
+    // the last evaluation wrote and what formNormalEq and the solvers read.  An evaluation that would overwrite records the current normal
+    // equations were formed from (accum_done) first swaps in the other set; emba_map_reject / emba_trial_reject swaps back, so the solver can be
+    // called again with a larger lambda on untouched equations (solver.cpp:340-352 reuses A, b).  Nothing else needs a second copy: the
+    // pack, the active set and the compact index are written by formNormalEq only, which never runs on a rejected trial.
+    double* d_rec2 = nullptr; double* d_tag2 = nullptr;
+    uint32_t set_stamp = 0, set_stamp2 = 0;      // stamp of the evaluation that wrote each set
+    bool eq_in_alt = false;                      // the equations in the pack belong to the OTHER set (a trial evaluation has been written since)
+    struct EqState { bool active_done = false, accum_done = false, finish_done = false, compact_valid = false, l2_fused = false; size_t P = 0, pack_len = 0; int K = 0, thres = 0, irls = 0; double eta = 0; } eq_saved;
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
     size_t n_outside_tile = 0; int n_rebin = 0; uint32_t last_rebin_stamp = 0;   // tile order: inliers found outside their tile in the last evaluation; how often the window was re-binned
     bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
@@ -751,6 +760,13 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
     // a record is valid iff it carries the current evaluation's stamp (record_valid): a reused buffer holds older stamps only, new memory is cleared
     if (rec_fresh) HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, c->caps[reinterpret_cast<void**>(&c->d_rec)], s));
+    c->eq_in_alt = false;
+    if (c->d_rec2) {   // the second record set (if an LM loop has made one) follows the window's size
+        bool f2 = false, t2 = false;
+        if ((st = dev_alloc(c, &c->d_rec2, (std::max<size_t>(n_cand, 1) + kGramPad) * kRecStride, &f2)) || (st = dev_alloc(c, &c->d_tag2, n_cand + kGramPad, &t2))) return st;
+        if (f2) HIP_TRY(c, hipMemsetAsync(c->d_rec2, 0, c->caps[reinterpret_cast<void**>(&c->d_rec2)], s));
+        if (t2) HIP_TRY(c, hipMemsetAsync(c->d_tag2, 0, c->caps[reinterpret_cast<void**>(&c->d_tag2)], s));
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
     c->nblk = (long)((ns + kWarpNew - 1) / kWarpNew);
     c->have_events = true;
@@ -913,13 +929,31 @@ emba_status emba_map_accept(emba_ctx* c)
     return EMBA_OK;
 }
 
+emba_status emba_trial_reject(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eq_in_alt) return EMBA_OK;     // nothing was evaluated since the equations were formed (or they have been re-formed)
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->P_pending || c->inl_pending || c->ep_deferred) { emba_status st = resolve_pending(c); if (st) return st; }
+    std::swap(c->d_rec, c->d_rec2); std::swap(c->d_tag, c->d_tag2); std::swap(c->set_stamp, c->set_stamp2);
+    std::swap(c->caps[reinterpret_cast<void**>(&c->d_rec)], c->caps[reinterpret_cast<void**>(&c->d_rec2)]);
+    std::swap(c->caps[reinterpret_cast<void**>(&c->d_tag)], c->caps[reinterpret_cast<void**>(&c->d_tag2)]);
+    c->eq_in_alt = false;
+    c->active_done = c->eq_saved.active_done; c->accum_done = c->eq_saved.accum_done; c->finish_done = c->eq_saved.finish_done;
+    c->compact_valid = c->eq_saved.compact_valid; c->l2_fused = c->eq_saved.l2_fused; c->P = c->eq_saved.P; c->pack_len = c->eq_saved.pack_len;
+    c->K = c->eq_saved.K; c->thres = c->eq_saved.thres; c->irls = c->eq_saved.irls; c->eta = c->eq_saved.eta;
+    // the per-event residuals, the count map and the per-pixel sums are the rejected trial's: formNormalEq needs a new evaluation
+    c->eval_launched = c->eval_done = false; c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
+    return EMBA_OK;
+}
+
 emba_status emba_map_reject(emba_ctx* c)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->map_is_trial) return fail(c, EMBA_ERR_STATE, "no trial map (call emba_update_map first)");
     c->d_Gx = c->d_Gx_cur; c->d_Gy = c->d_Gy_cur;
     c->map_is_trial = false;
-    return EMBA_OK;
+    return emba_trial_reject(c);           // and the normal equations the trial evaluation set aside are current again
 }
 
 emba_status emba_download_map(emba_ctx* c, double* Gx_host, double* Gy_host)
@@ -981,7 +1015,6 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->seg_cap = K;
     }
     if ((st = prepare_order(c, knots, t0_ns, dt_ns, K))) return st;
-    c->K = K;
     if ((st = ensure_pack(c, K))) return st;
     if (c->h_knots_cap < K) {
         if (c->h_knots) (void)hipHostFree(c->h_knots);
@@ -989,9 +1022,28 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         HIP_TRY(c, hipHostGetDevicePointer((void**)&c->h_knots_dev, c->h_knots, 0));
         c->h_knots_cap = K;
     }
+    hipStream_t s = c->stream;
+    if (c->accum_done) {
+        // The working record set is what the current normal equations were formed from: this evaluation (an LM trial, or simply the next
+        // step) writes the OTHER set, so that a rejection can go back to untouched equations (emba_trial_reject).
+        if (c->P_pending || c->inl_pending) { if ((st = resolve_pending(c, true))) return st; }
+        if (!c->d_rec2) {
+            const size_t nrec = (std::max<size_t>(c->n_cand, 1) + kGramPad) * kRecStride, ntag = c->n_cand + kGramPad;
+            if ((st = dev_alloc(c, &c->d_rec2, nrec)) || (st = dev_alloc(c, &c->d_tag2, ntag))) return st;
+            HIP_TRY(c, hipMemsetAsync(c->d_rec2, 0, nrec * sizeof(double), s));     // (new memory: no record may look valid)
+            HIP_TRY(c, hipMemsetAsync(c->d_tag2, 0, ntag * sizeof(double), s));
+        }
+        c->eq_saved.active_done = c->active_done; c->eq_saved.accum_done = c->accum_done; c->eq_saved.finish_done = c->finish_done;
+        c->eq_saved.compact_valid = c->compact_valid; c->eq_saved.l2_fused = c->l2_fused; c->eq_saved.P = c->P; c->eq_saved.pack_len = c->pack_len;
+        c->eq_saved.K = c->K; c->eq_saved.thres = c->thres; c->eq_saved.irls = c->irls; c->eq_saved.eta = c->eta;
+        std::swap(c->d_rec, c->d_rec2); std::swap(c->d_tag, c->d_tag2); std::swap(c->set_stamp, c->set_stamp2);
+        std::swap(c->caps[reinterpret_cast<void**>(&c->d_rec)], c->caps[reinterpret_cast<void**>(&c->d_rec2)]);
+        std::swap(c->caps[reinterpret_cast<void**>(&c->d_tag)], c->caps[reinterpret_cast<void**>(&c->d_tag2)]);
+        c->eq_in_alt = true;
+    }
+    c->K = K;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
-    hipStream_t s = c->stream;
     if (c->knots_in_flight) HIP_TRY(c, hipStreamSynchronize(s));   // the previous prep kernel must have consumed the pinned staging buffer
     memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
@@ -1033,7 +1085,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.err = c->d_err;
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
-        p.stamp = ++c->rec_stamp;
+        p.stamp = ++c->rec_stamp; c->set_stamp = p.stamp;
         p.chunks = c->d_chunks; p.n_chunks = c->n_chunks;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
@@ -1127,6 +1179,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->l2_fused = (c->fused_alpha != 0.0);
     c->fused_alpha = 0.0;
     c->thres = thres;
+    c->eq_in_alt = false;   // new equations are being formed from the working set: the other set's are obsolete
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
     emba_status st = resolve_pending(c, true);   // counts only: a sharded host sizes exchange 2 from P while the gather still runs
@@ -1163,12 +1216,12 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         HIP_TRY(c, hipMemsetAsync(pack_A22b2(c), 0, 5 * c->P * sizeof(double), s));
         if (c->n_cand)
             hipLaunchKernelGGL(emba_a22_from_records_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec,
-                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c), c->rec_stamp);
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c), c->set_stamp);
     }
     if (c->n_cand) {
         GramParams p{};
         p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
-        p.irls = irls; p.eta = eta; p.stamp = c->rec_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
+        p.irls = irls; p.eta = eta; p.stamp = c->set_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         // the tag stream pays where slots are dead (pixel order: about half of them at the BASELINE workload); in the tile order (dense regime:
         // nearly every slot is live) the warp kernel's scattered 8-B tag stores cost more than the Gram kernel saves (40 M events: +370 vs -180 us)
         p.tag = (c->use_tags && !c->tile_order && !ep_host) ? c->d_tag : nullptr;
@@ -1234,7 +1287,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
         (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
         if (c->n_cand)
             hipLaunchKernelGGL(emba_dense_a12_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key,
-                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, c->irls, c->eta, dim, d_A12, c->rec_stamp);
+                               (long)c->n_cand, c->d_count, c->d_compact, c->thres, c->irls, c->eta, dim, d_A12, c->set_stamp);
         (void)hipMemcpyAsync(A12_dense, d_A12, n12 * sizeof(double), hipMemcpyDeviceToHost, s);
     }
     hipError_t e = hipStreamSynchronize(s);
@@ -1275,7 +1328,7 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     hipStream_t s = c->stream;
     if ((st = ensure_compact(c))) { dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp); return st; }
     hipLaunchKernelGGL(emba_export_a12_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key, (long)M,
-                       c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp, c->rec_stamp);
+                       c->d_count, c->d_compact, c->thres, c->irls, c->eta, d_c, d_p, d_x, d_w, d_jc, d_jp, d_dp, c->set_stamp);
     if (cp_c) (void)hipMemcpyAsync(cp_c, d_c, M * 4, hipMemcpyDeviceToHost, s);
     if (cp_p) (void)hipMemcpyAsync(cp_p, d_p, M * 4, hipMemcpyDeviceToHost, s);
     if (pix) (void)hipMemcpyAsync(pix, d_x, M * 4, hipMemcpyDeviceToHost, s);
@@ -1286,6 +1339,23 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     hipError_t e = hipStreamSynchronize(s);
     dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "get_A12_sparse: %s", hipGetErrorString(e));
+    return EMBA_OK;
+}
+
+emba_status emba_get_inlier_pixels(emba_ctx* c, uint32_t* pix_host)
+{
+    if (!c || !pix_host) return c ? fail(c, EMBA_ERR_INVALID_ARG, "pix_host NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st;
+    if ((st = resolve_pending(c)) || (st = ensure_inl_idx(c))) return st;
+    if (!c->n_inliers) return EMBA_OK;
+    uint32_t* d_out = nullptr;
+    if ((st = ws_get(c, 15, c->n_inliers * 4, (void**)&d_out))) return st;
+    hipLaunchKernelGGL(emba_inlier_pix_kernel, dim3(nblocks(c->n_pm)), dim3(256), 0, c->stream, c->d_pm_pix, c->d_flag, c->d_inl_idx, (long)c->n_pm, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(pix_host, d_out, c->n_inliers * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EMBA_OK;
 }
 
@@ -1608,7 +1678,7 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
 RecView local_view(emba_ctx* c)
 {
     RecView v{};
-    v.rec = c->d_rec; v.slot_key = c->d_slot_key; v.compact = c->d_compact; v.stamp = c->rec_stamp; v.packed = 0; v.pix_base = 0;
+    v.rec = c->d_rec; v.slot_key = c->d_slot_key; v.compact = c->d_compact; v.stamp = c->set_stamp; v.packed = 0; v.pix_base = 0;
     return v;
 }
 

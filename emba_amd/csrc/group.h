@@ -14,7 +14,11 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <set>
+#include <thread>
 
 namespace emba {
 
@@ -68,6 +72,51 @@ Rccl g_rccl;
 
 }  // namespace
 
+// One host thread per rank, so that a step's launches on N devices are issued side by side instead of one rank after the other
+// (8 ranks x ~6 launches x ~6 us of launch time is more than the 0.12 ms step they start at 1 M events per GPU).  Fork-join: run(fn) calls
+// fn(rank) on every rank's thread and returns the first non-OK status.  The collectives themselves are issued by the caller's thread
+// (ncclGroupStart / End around all ranks' calls).
+struct RankPool {
+    int n = 0;
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<emba_status(int)> job;
+    std::vector<emba_status> st;
+    long gen = 0; int remaining = 0; bool stop = false;
+    void start(int n_, const std::vector<int>& dev)
+    {
+        n = n_; st.assign(n, EMBA_OK);
+        for (int r = 0; r < n; ++r)
+            th.emplace_back([this, r, d = dev[r]]() {
+                (void)hipSetDevice(d);
+                long seen = 0;
+                for (;;) {
+                    std::function<emba_status(int)> f;
+                    { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
+                    const emba_status s = f(r);
+                    { std::lock_guard<std::mutex> lk(mu); st[r] = s; if (--remaining == 0) cv_done.notify_all(); }
+                }
+            });
+    }
+    emba_status run(const std::function<emba_status(int)>& f)
+    {
+        if (th.empty()) { for (int r = 0; r < n; ++r) { const emba_status s = f(r); if (s) return s; } return EMBA_OK; }
+        { std::lock_guard<std::mutex> lk(mu); job = f; remaining = n; ++gen; }
+        cv_go.notify_all();
+        { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return remaining == 0; }); }
+        for (int r = 0; r < n; ++r) if (st[r]) return st[r];
+        return EMBA_OK;
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : th) if (t.joinable()) t.join();
+        th.clear();
+    }
+};
+
 struct emba_group {
     int n = 0;
     std::vector<emba_ctx*> ctx;
@@ -85,6 +134,14 @@ struct emba_group {
     // per-iteration results
     size_t P = 0, n_inliers = 0; int K = 0;
     std::vector<size_t> n_local;
+    std::vector<size_t> lo;              // first global event of every rank's range
+    bool x1_done = false;                // the count maps of the last evaluation have been all-reduced already (emba_group_eval returned num_ev_map)
+    int decl_irls = 0; double decl_eta = 0.0;   // robust cost declared for the evaluations (emba_group_set_cost)
+    // grow-only scratch of the sharded solve, per rank (an LM loop calls it every iteration)
+    std::vector<double*> sv_send, sv_recv, sv_S, sv_x2; std::vector<size_t> cap_send, cap_recv, cap_S, cap_x2;
+    RankPool pool;
+    int sw_ = 0;
+    std::vector<uint16_t> ev_x, ev_y;    // sensor coordinates of the window's events (host copy): the merged residual vector of emba_group_eval is ordered by sensor pixel
 };
 
 namespace {
@@ -102,6 +159,29 @@ emba_status gfail(emba_group* g, emba_status st, const char* fmt, ...)
 #define G_TRY(g, r, call) do { emba_status st_ = (call); if (st_) return gfail((g), st_, "rank %d: %s", (r), emba_last_error((g)->ctx[(r)])); } while (0)
 #define G_HIP(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return gfail((g), EMBA_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); } while (0)
 #define G_NCCL(g, call) do { int e_ = (call); if (e_ != 0) return gfail((g), EMBA_ERR_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(e_)); } while (0)
+
+// fork-join over the ranks' threads; a failure is reported with the first failing rank's message
+emba_status gpool(emba_group* g, const std::function<emba_status(int)>& f)
+{
+    const emba_status st = g->pool.run(f);
+    if (!st) return EMBA_OK;
+    int bad = 0;
+    if (!g->pool.th.empty()) { for (int r = 0; r < g->n; ++r) if (g->pool.st[r]) { bad = r; break; } }
+    else { for (int r = 0; r < g->n; ++r) if (emba_last_error(g->ctx[r])[0]) { bad = r; break; } }
+    return gfail(g, st, "rank %d: %s", bad, emba_last_error(g->ctx[bad]));
+}
+
+template <typename T>
+emba_status grow(emba_group* g, int r, T** p, size_t* cap, size_t count)
+{
+    if (*p && *cap >= count) return EMBA_OK;
+    G_HIP(g, hipSetDevice(g->dev[r]));
+    if (*p) { G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream)); (void)hipFree(*p); *p = nullptr; }
+    const size_t want = std::max<size_t>(count + count / 8, 16);
+    G_HIP(g, hipMalloc((void**)p, want * sizeof(T)));
+    *cap = want;
+    return EMBA_OK;
+}
 
 enum class XType { U8, I32, F64 };
 inline size_t xsize(XType t) { return t == XType::U8 ? 1 : t == XType::I32 ? 4 : 8; }
@@ -213,6 +293,9 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
     g->ctx.assign(n_ranks, nullptr); g->dev.assign(devices, devices + n_ranks); g->comm.assign(n_ranks, nullptr); g->ev.assign(n_ranks, nullptr);
     g->count.assign(n_ranks, nullptr); g->count_u8.assign(n_ranks, nullptr); g->pack.assign(n_ranks, nullptr); g->n_local.assign(n_ranks, 0);
     g->side.assign(n_ranks, nullptr); g->ev_side.assign(n_ranks, nullptr); g->ev_side0.assign(n_ranks + 1, nullptr);
+    g->lo.assign(n_ranks, 0); g->sw_ = cfg->sensor_w;
+    g->sv_send.assign(n_ranks, nullptr); g->sv_recv.assign(n_ranks, nullptr); g->sv_S.assign(n_ranks, nullptr); g->sv_x2.assign(n_ranks, nullptr);
+    g->cap_send.assign(n_ranks, 0); g->cap_recv.assign(n_ranks, 0); g->cap_S.assign(n_ranks, 0); g->cap_x2.assign(n_ranks, 0);
     auto bail = [&](emba_status st, const std::string& msg) { fail(nullptr, st, "%s", msg.c_str()); emba_group_destroy(g); return st; };
     for (int r = 0; r < n_ranks; ++r) {
         emba_cfg c2 = *cfg;
@@ -240,6 +323,9 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
     } else if (n_ranks > 1 && distinct.size() != 1) {
         return bail(EMBA_ERR_INVALID_ARG, "a group's ranks must sit on distinct devices (RCCL) or all on one device (in-library exchange)");
     }
+    g->pool.n = n_ranks;
+    // EMBA_GROUP_THREADS=0: the caller's thread drives every rank itself (debugging)
+    if (n_ranks > 1 && !(getenv("EMBA_GROUP_THREADS") && !atoi(getenv("EMBA_GROUP_THREADS")))) g->pool.start(n_ranks, g->dev);
     *out = g;
     return EMBA_OK;
 }
@@ -247,6 +333,11 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
 void emba_group_destroy(emba_group* g)
 {
     if (!g) return;
+    g->pool.shutdown();
+    for (int r = 0; r < g->n; ++r) {
+        if (g->ctx[r]) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream); }
+        for (double* p : {g->sv_send[r], g->sv_recv[r], g->sv_S[r], g->sv_x2[r]}) if (p) (void)hipFree(p);
+    }
     for (int r = 0; r < g->n; ++r) {
         if (g->ctx[r]) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream); }
         if (g->use_rccl && g->comm[r]) (void)g_rccl.CommDestroy(g->comm[r]);
@@ -297,9 +388,10 @@ emba_status emba_group_set_events(emba_group* g, const uint16_t* x, const uint16
         // the last rank also receives the n % 100 tail the reference drops (quirk Q1): emba_set_events ignores it the same way
         const size_t n_r = (r == g->n - 1) ? n - lo : hi - lo;
         G_TRY(g, r, emba_set_events(g->ctx[r], x + lo, y + lo, pol + lo, t_ns + lo, n_r, hx.data(), hy.data(), hbt.data(), hx.size()));
-        g->n_local[r] = hi - lo;
+        g->n_local[r] = hi - lo; g->lo[r] = lo;
         b += cnt;
     }
+    g->x1_done = false;
     return EMBA_OK;
 }
 
@@ -307,6 +399,161 @@ emba_status emba_group_upload_map(emba_group* g, const double* Gx, const double*
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_upload_map(g->ctx[r], Gx, Gy));
+    return EMBA_OK;
+}
+
+// Declare the robust cost of the formNormalEq[IRLS] calls that follow the next evaluations (emba_set_cost on every rank): the per-pixel
+// sums then carry its weights and the A22 | b2 rows of exchange 2 are final as soon as the active set has been written.  Speed only.
+emba_status emba_group_set_cost(emba_group* g, int32_t irls, double eta)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_set_cost(g->ctx[r], irls, eta));
+    g->decl_irls = irls; g->decl_eta = irls ? eta : 0.0;
+    return EMBA_OK;
+}
+
+// exchange 1 on the count maps of the last evaluation: exact int32 sums, or saturated bytes when the activity threshold allows
+emba_status group_exchange_counts(emba_group* g, int thres, bool exact)
+{
+    if (g->x1_done) return EMBA_OK;
+    const int cap = 255 / g->n;
+    if (!exact && thres >= 1 && thres <= cap) {   // sum_i min(c_i, cap) >= thres <=> sum_i c_i >= thres, and world * cap <= 255 cannot wrap
+        { emba_status st = gpool(g, [&](int r) { return emba_count_compress(g->ctx[r], g->count_u8[r], cap); }); if (st) return st; }
+        { emba_status st = group_allreduce(g, (void* const*)g->count_u8.data(), g->npix, XType::U8); if (st) return st; }
+        { emba_status st = gpool(g, [&](int r) { return emba_count_expand(g->ctx[r], g->count_u8[r]); }); if (st) return st; }
+    } else {
+        { emba_status st = gpool(g, [&](int r) { return emba_count_map_ready(g->ctx[r]); }); if (st) return st; }
+        { emba_status st = group_allreduce(g, (void* const*)g->count.data(), g->npix, XType::I32); if (st) return st; }
+    }
+    g->x1_done = true;
+    return EMBA_OK;
+}
+
+// LEGM::evaluateDataError (model.cpp:72-258) over all ranks: E1 on every rank's shard (+ X1 when the caller wants num_ev_map).
+// Gx / Gy: host planes to upload first, or both NULL for the resident (current or trial) map.  Outputs (any may be NULL):
+// ep_out (capacity >= events used) = the residuals of ALL ranks merged into the reference's order (sensor pixel major, then time:
+// ranks are time-ordered, so inside a pixel rank r's measurements precede rank r+1's); *n_inliers their number; num_ev_map_out the
+// GLOBAL count map (exact int32 exchange).
+emba_status emba_group_eval(emba_group* g, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, const double* Gx, const double* Gy,
+                            double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    if ((Gx == nullptr) != (Gy == nullptr)) return gfail(g, EMBA_ERR_INVALID_ARG, "pass both Gx and Gy, or neither");
+    g->K = K;
+    const bool single = (g->n == 1 && !g->use_rccl);
+    if (Gx) { emba_status st = emba_group_upload_map(g, Gx, Gy); if (st) return st; }
+    if (single) {
+        G_TRY(g, 0, emba_eval_launch(g->ctx[0], knots, K, t0_ns, dt_ns));
+        G_TRY(g, 0, emba_eval_finish(g->ctx[0], ep_out, (ep_out || n_inliers || num_ev_map_out) ? &g->n_inliers : nullptr, num_ev_map_out));
+        if (n_inliers) *n_inliers = g->n_inliers;
+        return EMBA_OK;
+    }
+    { emba_status st = group_ensure_buffers(g, K); if (st) return st; }
+    { emba_status st = gpool(g, [&](int r) { return emba_eval_launch(g->ctx[r], knots, K, t0_ns, dt_ns); }); if (st) return st; }    // E1
+    g->x1_done = false;
+    if (num_ev_map_out) {
+        { emba_status st = group_exchange_counts(g, 0, /*exact=*/true); if (st) return st; }                                              // X1
+        G_HIP(g, hipSetDevice(g->dev[0]));
+        G_HIP(g, hipStreamSynchronize(g->ctx[0]->stream));
+        G_HIP(g, hipMemcpy(num_ev_map_out, g->count[0], g->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    if (ep_out || n_inliers) {
+        // per rank: residuals in the rank's own reference order + the sensor pixel of each; merged by (pixel, rank)
+        std::vector<std::vector<double>> ep(g->n); std::vector<std::vector<uint32_t>> px(g->n);
+        size_t total = 0;
+        for (int r = 0; r < g->n; ++r) {
+            ep[r].resize(std::max<size_t>(g->n_local[r], 1));
+            size_t m = 0;
+            G_TRY(g, r, emba_eval_finish(g->ctx[r], ep_out ? ep[r].data() : nullptr, &m, nullptr));
+            ep[r].resize(m); total += m;
+            if (ep_out) { px[r].resize(std::max<size_t>(m, 1)); G_TRY(g, r, emba_get_inlier_pixels(g->ctx[r], px[r].data())); px[r].resize(m); }
+        }
+        g->n_inliers = total;
+        if (n_inliers) *n_inliers = total;
+        if (ep_out) {
+            const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
+            std::vector<size_t> start(S + 1, 0);                              // global offset of every sensor pixel's block
+            for (int r = 0; r < g->n; ++r) for (uint32_t p : px[r]) ++start[p + 1];
+            for (size_t p = 0; p < S; ++p) start[p + 1] += start[p];
+            std::vector<size_t> cur(start.begin(), start.end() - 1);
+            for (int r = 0; r < g->n; ++r)                                    // rank-major inside a pixel: earlier ranks first
+                for (size_t i = 0; i < ep[r].size(); ++i) ep_out[cur[px[r][i]]++] = ep[r][i];
+        }
+    }
+    return EMBA_OK;
+}
+
+// LEGM::formNormalEq[IRLS] + applyL2Reg (model.cpp:316-719) over all ranks on the state of the last emba_group_eval:
+// X1 (unless the evaluation already exchanged the counts) | E2, F1 | F2 | X2 | F3.
+emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    if (g->n == 1 && !g->use_rccl) {
+        emba_ctx* c = g->ctx[0];
+        G_TRY(g, 0, emba_eval_finish(c, nullptr, nullptr, nullptr));
+        const bool fuse = (irls == c->acc_irls) && (irls == 0 || eta == c->acc_eta);
+        if (fuse) c->fused_alpha = alpha;   // A22 / b2 come from the accumulator lines: applyL2Reg rides along with the gather (as in emba_step)
+        G_TRY(g, 0, emba_form_active(c, thres, nullptr, nullptr));
+        G_TRY(g, 0, emba_form_accumulate(c, nullptr, irls, eta));
+        G_TRY(g, 0, emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));
+        G_TRY(g, 0, emba_last_counts(c, &g->n_inliers, &g->P));
+        if (n_inliers) *n_inliers = g->n_inliers;
+        if (P) *P = g->P;
+        return EMBA_OK;
+    }
+    { emba_status st = group_exchange_counts(g, thres, /*exact=*/false); if (st) return st; }                                               // X1
+    g->x1_done = false;   // (consumed: the next evaluation starts a new count map)
+    { emba_status st = gpool(g, [&](int r) {                                                                                              // E2, F1 (enqueue only)
+          emba_status s1 = emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr);
+          return s1 ? s1 : emba_form_active(g->ctx[r], thres, nullptr, nullptr); });
+      if (st) return st; }
+    // the active set comes from the GLOBAL counts: identical on every rank, so rank 0's P sizes exchange 2 (one host wait instead of N)
+    size_t pl = 0;
+    { size_t ni = 0; G_TRY(g, 0, emba_last_counts(g->ctx[0], &ni, &g->P)); pl = g->ctx[0]->pack_len; }
+    // X2 in two parts.  The A22 | b2 rows (5 doubles per active pixel: the bulk of the exchange) are final once the active set has been
+    // written — when the cost was declared before the evaluation, form_accumulate only adds the A11 | b1 head — and their all-reduce runs
+    // on the ranks' SIDE streams while the Gram kernels form the head on the ranks' own streams; the small head follows.
+    // (worth it once the Gram kernel is long enough to hide a collective behind — the head then costs one more collective's latency: from a
+    // few million events per rank; EMBA_X2_SPLIT=0/1 overrides)
+    size_t n_max = 0;
+    for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
+    const bool rows_final = (irls == g->decl_irls) && (irls == 0 || eta == g->decl_eta);
+    bool split = n_max >= 3000000;
+    if (const char* v = getenv("EMBA_X2_SPLIT")) split = atoi(v) != 0;
+    split = split && rows_final;
+    if (!split) {
+        { emba_status st = gpool(g, [&](int r) { return emba_form_accumulate(g->ctx[r], nullptr, irls, eta); }); if (st) return st; }      // F2
+        { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }                          // X2
+    } else {
+        const size_t head = pl - 5 * g->P;
+        std::vector<void*> rows(g->n, nullptr);
+        for (int r = 0; r < g->n; ++r) {
+            rows[r] = g->pack[r] + head;
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            G_HIP(g, hipEventRecord(g->ev_side[r], g->ctx[r]->stream));          // the active-set write of this rank
+            G_HIP(g, hipStreamWaitEvent(g->side[r], g->ev_side[r], 0));
+        }
+        { emba_status st = group_allreduce(g, rows.data(), 5 * g->P, XType::F64, /*on_side=*/true); if (st) return st; }                    // X2b
+        { emba_status st = gpool(g, [&](int r) { return emba_form_accumulate(g->ctx[r], nullptr, irls, eta); }); if (st) return st; }      // F2
+        { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), head, XType::F64); if (st) return st; }                        // X2a
+        for (int r = 0; r < g->n; ++r) {
+            G_HIP(g, hipSetDevice(g->dev[r]));
+            G_HIP(g, hipEventRecord(g->ev_side[r], g->side[r]));
+            G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev_side[r], 0));  // F3 reads the reduced rows
+        }
+    }
+    std::vector<size_t> ni(g->n, 0), pp(g->n, 0);
+    { emba_status st = gpool(g, [&](int r) {                                                                                              // F3: applyL2Reg once, after the reduce
+          emba_status s1 = emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+          return s1 ? s1 : emba_last_counts(g->ctx[r], &ni[r], &pp[r]); });
+      if (st) return st; }
+    g->n_inliers = 0;
+    for (int r = 0; r < g->n; ++r) {
+        g->n_inliers += ni[r];
+        if (pp[r] != g->P) return gfail(g, EMBA_ERR_STATE, "ranks disagree on the active set (%zu vs %zu pixels)", pp[r], g->P);
+    }
+    if (n_inliers) *n_inliers = g->n_inliers;
+    if (P) *P = g->P;
     return EMBA_OK;
 }
 
@@ -322,67 +569,17 @@ emba_status emba_group_step(emba_group* g, const double* knots, int32_t K, int64
         if (P) *P = g->P;
         return EMBA_OK;
     }
-    { emba_status st = group_ensure_buffers(g, K); if (st) return st; }
-    for (int r = 0; r < g->n; ++r) {
-        G_TRY(g, r, emba_set_cost(g->ctx[r], irls, eta));
-        G_TRY(g, r, emba_eval_launch(g->ctx[r], knots, K, t0_ns, dt_ns));                                   // E1
-    }
-    const int cap = 255 / g->n;
-    if (thres <= cap) {   // X1 as saturated bytes: sum_i min(c_i, cap) >= thres <=> sum_i c_i >= thres, and world * cap <= 255 cannot wrap
-        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_compress(g->ctx[r], g->count_u8[r], cap));
-        { emba_status st = group_allreduce(g, (void* const*)g->count_u8.data(), g->npix, XType::U8); if (st) return st; }
-        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_expand(g->ctx[r], g->count_u8[r]));
-    } else {
-        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_count_map_ready(g->ctx[r]));
-        { emba_status st = group_allreduce(g, (void* const*)g->count.data(), g->npix, XType::I32); if (st) return st; }
-    }
-    size_t Pr = 0, pl = 0;
-    for (int r = 0; r < g->n; ++r) {
-        G_TRY(g, r, emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr));                                   // E2 (enqueue only)
-        G_TRY(g, r, emba_form_active(g->ctx[r], thres, &Pr, &pl));                                              // F1 (global counts: identical everywhere)
-        if (r && Pr != g->P) return gfail(g, EMBA_ERR_STATE, "ranks disagree on the active set (%zu vs %zu pixels)", Pr, g->P);
-        g->P = Pr;
-    }
-    // X2 in two parts.  The A22 | b2 rows (5 doubles per active pixel: the bulk of the exchange) are final once the active set has been
-    // written — the cost was declared before the evaluation, so form_accumulate only adds the A11 | b1 head — and their all-reduce runs
-    // on the ranks' SIDE streams while the Gram kernels form the head on the ranks' own streams; the small head follows.
-    // (worth it once the Gram kernel is long enough to hide a collective behind — the head then costs one more collective's latency: from a
-    // few million events per rank; EMBA_X2_SPLIT=0/1 overrides)
-    size_t n_max = 0;
-    for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
-    bool split = n_max >= 3000000;
-    if (const char* v = getenv("EMBA_X2_SPLIT")) split = atoi(v) != 0;
-    if (!split) {
-        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                  // F2
-        { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }         // X2
-    } else {
-    const size_t head = pl - 5 * g->P;
-    std::vector<void*> rows(g->n, nullptr);
-    for (int r = 0; r < g->n; ++r) {
-        rows[r] = g->pack[r] + head;
-        G_HIP(g, hipSetDevice(g->dev[r]));
-        G_HIP(g, hipEventRecord(g->ev_side[r], g->ctx[r]->stream));          // the active-set write of this rank
-        G_HIP(g, hipStreamWaitEvent(g->side[r], g->ev_side[r], 0));
-    }
-    { emba_status st = group_allreduce(g, rows.data(), 5 * g->P, XType::F64, /*on_side=*/true); if (st) return st; }   // X2b
-    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_form_accumulate(g->ctx[r], nullptr, irls, eta));                  // F2
-    { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), head, XType::F64); if (st) return st; }        // X2a
-    for (int r = 0; r < g->n; ++r) {
-        G_HIP(g, hipSetDevice(g->dev[r]));
-        G_HIP(g, hipEventRecord(g->ev_side[r], g->side[r]));
-        G_HIP(g, hipStreamWaitEvent(g->ctx[r]->stream, g->ev_side[r], 0));  // F3 reads the reduced rows
-    }
-    }
-    g->n_inliers = 0;
-    for (int r = 0; r < g->n; ++r) {
-        G_TRY(g, r, emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr));   // F3: applyL2Reg once, after the reduce
-        size_t ni = 0, pp = 0;
-        G_TRY(g, r, emba_last_counts(g->ctx[r], &ni, &pp));
-        g->n_inliers += ni;
-    }
-    if (n_inliers) *n_inliers = g->n_inliers;
-    if (P) *P = g->P;
-    return EMBA_OK;
+    { emba_status st = emba_group_set_cost(g, irls, eta); if (st) return st; }      // the step's own cost: A22 | b2 final after F1
+    { emba_status st = emba_group_eval(g, knots, K, t0_ns, dt_ns, nullptr, nullptr, nullptr, nullptr, nullptr); if (st) return st; }
+    return emba_group_form(g, thres, irls, eta, alpha, n_inliers, P);
+}
+
+// LEGM::applyL2Reg (model.cpp:689-719) as a call of its own, for hosts that keep the reference's formNormalEq / applyL2Reg split
+// (emba_group_form with alpha = 0 first): applied once per set of equations on every rank's replica of the reduced pack.
+emba_status emba_group_apply_l2(emba_group* g, double alpha)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    return gpool(g, [&](int r) { return emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr); });
 }
 
 // The reduced blocks (identical on every rank; read from rank 0): the out-arguments of formNormalEq + applyL2Reg.
@@ -413,43 +610,46 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
     if (g->n == 1 && !g->use_rccl) { G_TRY(g, 0, emba_solve_normal_eq(g->ctx[0], lambda, fix_first_pose, x1_host, x2_host)); return EMBA_OK; }
     const int n = g->n;
     std::vector<std::vector<size_t>> cnt(n, std::vector<size_t>(n, 0));
-    for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_count(g->ctx[r], n, cnt[r].data()));
-    std::vector<double*> send(n, nullptr), recv(n, nullptr), S(n, nullptr), x2(n, nullptr);
-    std::vector<size_t> n_recv(n, 0);
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_count(g->ctx[r], n, cnt[r].data()); }); if (st) return st; }
+    std::vector<size_t> n_recv(n, 0), n_send(n, 0);
+    std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
+    for (int r = 0; r < n; ++r) for (int d = 0; d < n; ++d) { n_send[r] += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
     size_t s_doubles = 0;
     G_TRY(g, 0, emba_solve_shard_size(g->ctx[0], &s_doubles));
-    auto cleanup = [&]() { for (int r = 0; r < n; ++r) { (void)hipSetDevice(g->dev[r]); (void)hipStreamSynchronize(g->ctx[r]->stream);
-                                                         for (double* p : {send[r], recv[r], S[r], x2[r]}) if (p) (void)hipFree(p); } };
-    emba_status st = EMBA_OK;
-    auto run = [&]() -> emba_status {
-        std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
-        for (int r = 0; r < n; ++r) {
-            size_t ns = 0;
-            for (int d = 0; d < n; ++d) { ns += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
-            G_HIP(g, hipSetDevice(g->dev[r]));
-            G_HIP(g, hipMalloc((void**)&send[r], std::max<size_t>(ns, 1) * 16 * 8));
-            G_TRY(g, r, emba_solve_shard_pack(g->ctx[r], n, send[r]));
-        }
-        for (int r = 0; r < n; ++r) {
-            G_HIP(g, hipSetDevice(g->dev[r]));
-            G_HIP(g, hipMalloc((void**)&recv[r], std::max<size_t>(n_recv[r], 1) * 16 * 8));
-            G_HIP(g, hipMalloc((void**)&S[r], s_doubles * 8));
-            G_HIP(g, hipMalloc((void**)&x2[r], std::max<size_t>(2 * g->P, 2) * 8));
-        }
-        { emba_status s2 = group_alltoall(g, send.data(), recv.data(), cnt16); if (s2) return s2; }
-        for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_partial(g->ctx[r], r, n, recv[r], n_recv[r], lambda, S[r]));
-        { emba_status s2 = group_allreduce(g, (void* const*)S.data(), s_doubles, XType::F64); if (s2) return s2; }
-        for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_finish(g->ctx[r], r, n, recv[r], n_recv[r], lambda, fix_first_pose, S[r], r == 0 ? x1_host : nullptr, x2[r]));
-        { emba_status s2 = group_allreduce(g, (void* const*)x2.data(), 2 * g->P, XType::F64); if (s2) return s2; }
-        if (x2_host && g->P) {
-            G_HIP(g, hipSetDevice(g->dev[0]));
-            G_HIP(g, hipMemcpyAsync(x2_host, x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-        }
-        return EMBA_OK;
-    };
-    st = run();
-    cleanup();
-    return st;
+    // grow-only scratch (an LM loop solves every iteration: no hipMalloc / hipFree per call)
+    for (int r = 0; r < n; ++r) {
+        emba_status st;
+        if ((st = grow(g, r, &g->sv_send[r], &g->cap_send[r], std::max<size_t>(n_send[r], 1) * 16)) || (st = grow(g, r, &g->sv_recv[r], &g->cap_recv[r], std::max<size_t>(n_recv[r], 1) * 16)) ||
+            (st = grow(g, r, &g->sv_S[r], &g->cap_S[r], s_doubles)) || (st = grow(g, r, &g->sv_x2[r], &g->cap_x2[r], std::max<size_t>(2 * g->P, 2))))
+            return st;
+    }
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_pack(g->ctx[r], n, g->sv_send[r]); }); if (st) return st; }
+    { emba_status st = group_alltoall(g, g->sv_send.data(), g->sv_recv.data(), cnt16); if (st) return st; }
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_partial(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, g->sv_S[r]); }); if (st) return st; }
+    { emba_status st = group_allreduce(g, (void* const*)g->sv_S.data(), s_doubles, XType::F64); if (st) return st; }
+    // a 2x2 block that is not positive definite shows up on its pixel's owner only: every rank finishes (x2 exchange included) and the
+    // failure is reported once, for the group
+    std::vector<emba_status> fin(n, EMBA_OK);
+    (void)g->pool.run([&](int r) {
+        fin[r] = emba_solve_shard_finish(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, fix_first_pose, g->sv_S[r], r == 0 ? x1_host : nullptr, g->sv_x2[r]);
+        return EMBA_OK; });
+    for (int r = 0; r < n; ++r) if (fin[r] && fin[r] != EMBA_ERR_NUMERIC) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
+    { emba_status st = group_allreduce(g, (void* const*)g->sv_x2.data(), 2 * g->P, XType::F64); if (st) return st; }
+    G_HIP(g, hipSetDevice(g->dev[0]));
+    if (x2_host && g->P) G_HIP(g, hipMemcpyAsync(x2_host, g->sv_x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    for (int r = 0; r < n; ++r) { G_HIP(g, hipSetDevice(g->dev[r])); G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream)); }
+    for (int r = 0; r < n; ++r) if (fin[r]) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
+    return EMBA_OK;
+}
+
+// LEGM::solveNormalEqCG (model.cpp:794-840): provided for a one-rank group (the sharded loop uses the Schur solve)
+emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host, double* x2_host,
+                                int32_t* iterations, double* error)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    if (g->n != 1 || g->use_rccl) return gfail(g, EMBA_ERR_STATE, "solveNormalEqCG is provided for one rank; a sharded window uses the Schur solve");
+    G_TRY(g, 0, emba_solve_normal_eq_cg(g->ctx[0], lambda, fix_first_pose, max_iter, tol, x1_host, x2_host, iterations, error));
+    return EMBA_OK;
 }
 
 // LEGM::updateMap (model.cpp:863-903) and the LM decision on every rank's replica of the map
@@ -475,6 +675,13 @@ emba_status emba_group_download_map(emba_group* g, double* Gx, double* Gy)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
     G_TRY(g, 0, emba_download_map(g->ctx[0], Gx, Gy));
+    return EMBA_OK;
+}
+// the last evaluation was a rejected trial that involved no map update: the equations formed before it are current again on every rank
+emba_status emba_group_trial_reject(emba_group* g)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_trial_reject(g->ctx[r]));
     return EMBA_OK;
 }
 

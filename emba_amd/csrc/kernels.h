@@ -866,6 +866,16 @@ __global__ __launch_bounds__(256) void emba_compact_ep_kernel(const double* __re
     compact_ep_block(blockIdx.x, e_sorted, flag, perm, fblk_off, n_pm, ep, inl_idx);
 }
 
+// Sensor pixel of every inlier measurement, in ep order (the pm-order IS sensor pixel major, then time): what a multi-GPU host needs to
+// merge the ranks' residual vectors into the reference's order.
+__global__ void emba_inlier_pix_kernel(const uint32_t* __restrict__ pm_pix, const uint8_t* __restrict__ flag, const int32_t* __restrict__ inl_idx, long n_pm,
+                                       uint32_t* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pm || !flag[i]) return;
+    out[inl_idx[i]] = pm_pix[i] & 0x1FFFFFFFu;
+}
+
 // Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
 __global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const uint8_t* __restrict__ flag,
                                         const int32_t* __restrict__ inl_idx, const uint32_t* __restrict__ ev_slot, const uint32_t* __restrict__ ev_pix,
@@ -1591,7 +1601,9 @@ __device__ __forceinline__ bool record_active(const double* rec, const int32_t* 
 {
     const double2 tail = reinterpret_cast<const double2*>(rec)[7];
     uint32_t pi;
-    if (!record_valid(tail.y, stamp, pi) || count[pi] < thres) return false;
+    // (activity from the compact index of the active set, not from the count map: after a rejected LM trial the count map is the trial's)
+    if (!record_valid(tail.y, stamp, pi) || compact[pi] < 0) return false;
+    (void)count; (void)thres;
     const double e = tail.x;
     double ww = 1.0;
     if (irls == 2) ww = 1.0 / (1.0 + eta * e * e);

@@ -1,36 +1,120 @@
 // emba_amd/host/legm_adapter.hpp — the drop-in `EMBA::LEGM` for the reference tree (tub-rip/emba).
 //
-// NOT compiled in this repository: it needs the reference's own dependencies (ROS messages, OpenCV, Eigen, glog,
-// the reference's utils/trajectory.h and emba/model.h typedefs).  A maintainer adds it to the reference as
-// `src/emba/model_hip.cpp` in place of the LEGM part of `src/emba/model.cpp` (INTEGRATION.md has the CMake lines).
-// It keeps the public signatures of reference include/emba/model.h:76-108 verbatim, so src/emba/solver.cpp and
-// src/emba/emba.cpp compile unchanged, and forwards to emba_host::LEGM (legm_host.hpp) -> C ABI -> HIP kernels.
+// A maintainer adds it to the reference as `src/emba/model_hip.cpp` in place of the LEGM methods of `src/emba/model.cpp`
+// (INTEGRATION.md has the CMake lines).  It keeps the public signatures of reference include/emba/model.h:76-128 verbatim — the eight
+// methods solveTimeWindow calls (src/emba/solver.cpp:63-353): the constructor, evaluateDataError, formNormalEq, formNormalEqIRLS,
+// applyL2Reg, solveNormalEq, solveNormalEqCG, updateMap — so src/emba/solver.cpp and src/emba/emba.cpp compile UNCHANGED, and forwards to
+// emba_host::ShardedLEGM (legm_sharded.hpp) -> emba_group_* of the C ABI -> HIP kernels, on ONE GPU or on several
+// (environment EMBA_HIP_DEVICES="0,1,...,7": events time-sharded, two RCCL exchanges per iteration; default "0").
 //
-// What stays on the CPU in the reference: Model::updateTraj, LEGM::solveNormalEq[CG], updateMap, recoverA22FromBlocks
-// (model.cpp:22-53, 721-903) — unchanged reference code ("next" rows of SURVEY §8f).
+// What stays reference code: Model::updateTraj, evaluateRegError, evaluateRobustDataCost, recoverA22FromBlocks (model.cpp:22-53, 260-314,
+// 842-861) — O(K) / O(HW) host work on objects the caller owns.
+//
+// It needs the reference's own dependencies (ROS messages, OpenCV, Eigen, glog) to be built there.  In THIS repository it is compiled
+// and run against tests/cpp/mock_ref (the few declarations it touches, with the LEGM signatures string-compared with the reference's
+// header) and the reference's vendored Eigen: tests/cpp/adapter_test.cpp drives it through solveTimeWindow's call order on the GPU.
+//
+// The LM loop's hidden protocol, inferred from the calls (solver.cpp never tells the model whether a step was accepted):
+//   updateMap(Gx_new, ..)            builds the TRIAL map on the device and fills the caller's clones
+//   evaluateDataError(.., Gx_new, ..) evaluates it without an upload (the Mats are the ones updateMap just filled)
+//   formNormalEq* next                => the trial was ACCEPTED  (solver.cpp:93-131 runs only when the cost has decreased)
+//   solveNormalEq* next               => the trial was REJECTED  (solver.cpp:340-352: lambda *= 10, A and b reused): the device goes back to
+//                                        the equations it formed before the trial (second record set, emba_map_reject) — no re-evaluation
 #pragma once
 #ifndef EMBA_LEGM_ADAPTER_SKETCH
-#error "This header documents the reference-side binding; build it inside the reference tree with -DEMBA_LEGM_ADAPTER_SKETCH"
+#error "This header is the reference-side binding; build it inside the reference tree (or against tests/cpp/mock_ref) with -DEMBA_LEGM_ADAPTER_SKETCH"
 #endif
 
 #include <glog/logging.h>
 #include <opencv2/core.hpp>
 
-#include "emba/model.h"                 // reference header: class EMBA::LEGM, typedefs VecXd/MatXd/Mat2d/EventPacket
-#include "emba_amd/host/legm_host.hpp"  // this repository
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "emba/model.h"                    // reference header: class EMBA::LEGM, typedefs VecXd/MatXd/Mat2d/EventPacket
+#include "emba_amd/host/legm_sharded.hpp"  // this repository
 
 namespace EMBA {
 
-// One emba_host::LEGM per EMBA::LEGM object, created in the constructor from the bearing LUT that the reference's own
+// One emba_host::ShardedLEGM per EMBA::LEGM object, created in the constructor from the bearing LUT that the reference's own
 // EventWarper::precomputeBearingVectors builds (event_pano_warper.cpp:27-41) — expose it with a one-line getter
 // `const std::vector<cv::Point3d>& EventWarper::bearingVectors() const { return precomputed_bearing_vectors_; }`.
 struct LegmHipState {
-    std::unique_ptr<emba_host::LEGM> impl;
-    emba_host::EventPacket packet;       // dvs_msgs::Event -> {x, y, t_ns, polarity}; rebuilt only when `events` changes
-    const dvs_msgs::Event* src = nullptr; size_t n = 0;
+    std::unique_ptr<emba_host::ShardedLEGM> impl;
+    emba_host::EventPacket packet;       // dvs_msgs::Event -> {x, y, t_ns, polarity}; rebuilt only when the CONTENT of `events` changes
+    const dvs_msgs::Event* src = nullptr; size_t n = 0; uint64_t t_first = 0, t_mid = 0, t_last = 0;
     emba_host::NormalEquations ne;
+    int K = 0;                           // control poses of the last evaluation
+    size_t n_ep = 0;                     // size of the ep vector the last evaluateDataError returned
+    // the trial map: the Mats updateMap filled last (data pointers + a strided sample of their content)
+    const unsigned char* trial_gx = nullptr; const unsigned char* trial_gy = nullptr;
+    std::vector<double> trial_sample;
+    bool trial_pending = false;          // the last evaluation was on the trial map and its fate is not known yet
+    bool map_is_trial = false;           // the device holds a trial map nobody has decided about
 };
 static std::map<const LEGM*, LegmHipState> g_state;   // or a member `LegmHipState hip_;` added to class LEGM
+
+namespace legm_hip_detail {
+
+inline std::vector<int> devices_from_env()
+{
+    std::vector<int> dev;
+    if (const char* e = std::getenv("EMBA_HIP_DEVICES")) {
+        std::string s(e), tok;
+        for (size_t i = 0; i <= s.size(); ++i) {
+            if (i == s.size() || s[i] == ',') { if (!tok.empty()) dev.push_back(std::atoi(tok.c_str())); tok.clear(); }
+            else tok.push_back(s[i]);
+        }
+    }
+    if (dev.empty()) dev.push_back(0);
+    return dev;
+}
+
+constexpr size_t kSample = 97;           // values compared to recognise the trial Mats (a stride over the plane)
+inline void sample_plane(const double* p, size_t n, std::vector<double>& out)
+{
+    const size_t step = n / kSample ? n / kSample : 1;
+    for (size_t i = 0; i < n; i += step) out.push_back(p[i]);
+}
+
+// the LM decision the reference never announces: see the header comment
+inline void settle_trial(LegmHipState& st, bool accepted)
+{
+    if (!st.map_is_trial) return;
+    try { if (accepted) st.impl->acceptMap(); else st.impl->rejectMap(); }
+    catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    st.map_is_trial = false; st.trial_pending = false;
+    if (!accepted) { st.trial_gx = st.trial_gy = nullptr; }
+}
+
+inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2,
+                          size_t num_pix, std::set<size_t>& active, std::set<size_t>& inactive)
+{
+    const int dim = ne.dim_ctrl_poses; const size_t P = ne.num_active_pixels;
+    A11 = Eigen::Map<const MatXd>(ne.A11.data(), dim, dim);
+    b1 = Eigen::Map<const VecXd>(ne.b1.data(), dim);
+    b2 = Eigen::Map<const VecXd>(ne.b2.data(), 2 * P);
+    A22_blocks.resize(P);
+    for (size_t i = 0; i < P; ++i) A22_blocks[i] << ne.A22_blocks[4 * i], ne.A22_blocks[4 * i + 1], ne.A22_blocks[4 * i + 2], ne.A22_blocks[4 * i + 3];
+    // The dense 3K x 2P matrix of model.cpp:358 (0.7 GB at K = 201, P = 68 k) is NOT produced: its only consumers, solveNormalEq[CG], are
+    // bound to the device solvers below, which work from the sparse factors.  An empty matrix with the right row count keeps the
+    // first-window trim of solver.cpp:156-165 (A12.block(3, 0, dim - 3, A12.cols())) well-formed.
+    A12 = MatXd(dim, 0);
+    active.clear(); inactive.clear();
+    auto hint = active.end();
+    for (uint32_t p : ne.active_pix_idxes) hint = active.insert(hint, p);          // already ascending: O(P)
+#ifdef EMBA_HIP_FILL_INACTIVE
+    // (the reference's updateMap walks this set, model.cpp:889-901; the device updateMap below does not — 2 M tree nodes per call saved)
+    size_t a = 0; auto ih = inactive.end();
+    for (size_t p = 0; p < num_pix; ++p) { if (a < P && ne.active_pix_idxes[a] == p) { ++a; continue; } ih = inactive.insert(ih, p); }
+#else
+    (void)num_pix;
+#endif
+}
+
+}  // namespace legm_hip_detail
 
 LEGM::LEGM(const sensor_msgs::CameraInfo& camera_info_msg, double C_th, int pano_width, int pano_height)
 {
@@ -41,8 +125,8 @@ LEGM::LEGM(const sensor_msgs::CameraInfo& camera_info_msg, double C_th, int pano
     std::vector<double> lut(3 * bv.size());
     for (size_t i = 0; i < bv.size(); ++i) { lut[3 * i] = bv[i].x; lut[3 * i + 1] = bv[i].y; lut[3 * i + 2] = bv[i].z; }
     try {
-        g_state[this].impl.reset(new emba_host::LEGM(camera_info_msg.width, camera_info_msg.height, lut.data(), C_th,
-                                                     pano_width, pano_height));
+        g_state[this].impl.reset(new emba_host::ShardedLEGM(camera_info_msg.width, camera_info_msg.height, lut.data(), C_th, pano_width, pano_height,
+                                                            legm_hip_detail::devices_from_env()));
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
 }
 
@@ -51,43 +135,39 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
 {
     auto& st = g_state[this];
     CHECK(Gx.isContinuous() && Gy.isContinuous() && Gx.type() == CV_64FC1 && num_ev_map.type() == CV_32SC1);
-    if (st.src != events.data() || st.n != events.size()) {        // the sliding window hands the same packet to every LM trial
+    // the sliding window hands the same packet to every LM trial; a new window may reuse the allocation: keyed on content
+    const uint64_t tf = events.empty() ? 0 : events.front().ts.toNSec(), tl = events.empty() ? 0 : events.back().ts.toNSec(),
+                   tm = events.empty() ? 0 : events[events.size() / 2].ts.toNSec();
+    if (st.src != events.data() || st.n != events.size() || st.t_first != tf || st.t_last != tl || st.t_mid != tm) {
         st.packet.resize(events.size());
         for (size_t k = 0; k < events.size(); ++k)
             st.packet[k] = {events[k].x, events[k].y, (int64_t)events[k].ts.toNSec(), (bool)events[k].polarity};
-        st.src = events.data(); st.n = events.size();
+        st.src = events.data(); st.n = events.size(); st.t_first = tf; st.t_last = tl; st.t_mid = tm;
     }
     // control poses as quaternions (x,y,z,w) + spline timing exactly as LinearTrajectory stores them (trajectory.cpp:59-64)
     const int K = (int)traj_ptr->size();
     std::vector<double> knots(4 * K);
     for (int i = 0; i < K; ++i) {
-        const Eigen::Quaterniond& q = traj_ptr->getControlPose(i).unit_quaternion();
+        const Eigen::Quaterniond q = traj_ptr->getControlPose(i).unit_quaternion();   // a COPY: getControlPose returns an SO3d by value (trajectory.h:47,135)
         knots[4 * i] = q.x(); knots[4 * i + 1] = q.y(); knots[4 * i + 2] = q.z(); knots[4 * i + 3] = q.w();
     }
     emba_host::TrajectoryView tv{knots.data(), K, traj_ptr->startTimeNs(), traj_ptr->knotIntervalNs()};  // t_beg_ns_, dt_knots_ns_
+    // Are these the Mats updateMap has just filled?  Then the device already holds this map (the trial): no upload.
+    const size_t npix = (size_t)Gx.rows * Gx.cols;
+    bool resident = false;
+    if (st.map_is_trial && Gx.ptr<unsigned char>() == st.trial_gx && Gy.ptr<unsigned char>() == st.trial_gy) {
+        std::vector<double> s;
+        legm_hip_detail::sample_plane(Gx.ptr<double>(), npix, s); legm_hip_detail::sample_plane(Gy.ptr<double>(), npix, s);
+        resident = (s.size() == st.trial_sample.size()) && std::memcmp(s.data(), st.trial_sample.data(), s.size() * sizeof(double)) == 0;
+    }
+    if (!resident && st.map_is_trial) legm_hip_detail::settle_trial(st, false);   // some other map: the pending trial is void
     try {
-        std::vector<double> ep = st.impl->evaluateDataError(tv, Gx.ptr<double>(), Gy.ptr<double>(), st.packet, eval_deriv,
-                                                            num_ev_map.ptr<int32_t>());
+        std::vector<double> ep = st.impl->evaluateDataError(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
+                                                            eval_deriv, num_ev_map.ptr<int32_t>());
+        st.K = K; st.n_ep = ep.size(); st.trial_pending = resident;
         return Eigen::Map<VecXd>(ep.data(), (Eigen::Index)ep.size());
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     return VecXd();
-}
-
-static void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1,
-                          VecXd& b2, size_t num_pix, std::set<size_t>& active, std::set<size_t>& inactive, bool with_A12)
-{
-    const int dim = ne.dim_ctrl_poses; const size_t P = ne.num_active_pixels;
-    A11 = Eigen::Map<const MatXd>(ne.A11.data(), dim, dim);
-    b1 = Eigen::Map<const VecXd>(ne.b1.data(), dim);
-    b2 = Eigen::Map<const VecXd>(ne.b2.data(), 2 * P);
-    A22_blocks.resize(P);
-    for (size_t i = 0; i < P; ++i) A22_blocks[i] << ne.A22_blocks[4 * i], ne.A22_blocks[4 * i + 1], ne.A22_blocks[4 * i + 2], ne.A22_blocks[4 * i + 3];
-    if (with_A12) A12 = Eigen::Map<const MatXd>(ne.A12.data(), dim, 2 * P);
-    active.clear(); inactive.clear();
-    auto hint = active.end();
-    for (uint32_t p : ne.active_pix_idxes) hint = active.insert(hint, p);          // already ascending: O(P)
-    size_t a = 0; auto ih = inactive.end();
-    for (size_t p = 0; p < num_pix; ++p) { if (a < P && ne.active_pix_idxes[a] == p) { ++a; continue; } ih = inactive.insert(ih, p); }
 }
 
 void LEGM::formNormalEq(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2, const VecXd& ep,
@@ -95,13 +175,11 @@ void LEGM::formNormalEq(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, 
                         std::set<size_t>& active_pix_idxes, std::set<size_t>& inactive_pix_idxes)
 {
     auto& st = g_state[this];
-    std::vector<double> epv(ep.data(), ep.data() + ep.size());
-    try {
-        // dense A12 (3K x 2P doubles, model.cpp:358) is what the reference's solveNormalEq consumes; ask for it only while that
-        // solver is still the CPU one — the sparse factors (emba_get_A12_sparse) are the scalable form.
-        st.impl->formNormalEq(st.ne, epv, num_ctrl_poses, thres_valid_pixel, /*want_dense_A12=*/true);
-    } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
-    export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes, true);
+    CHECK((size_t)ep.size() == st.n_ep) << "formNormalEq expects the residual vector evaluateDataError returned (solver.cpp:99-102: the model state is that call's)";
+    legm_hip_detail::settle_trial(st, true);        // formNormalEq after a trial evaluation: the step was accepted (solver.cpp:93-131)
+    try { st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel); }
+    catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
 }
 
 void LEGM::formNormalEqIRLS(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2, const VecXd& ep,
@@ -110,10 +188,13 @@ void LEGM::formNormalEqIRLS(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_bloc
                             const double a)
 {
     auto& st = g_state[this];
-    std::vector<double> epv(ep.data(), ep.data() + ep.size());
-    try { st.impl->formNormalEqIRLS(st.ne, epv, num_ctrl_poses, thres_valid_pixel, cost_type, a, true); }
-    catch (const std::exception& e) { LOG(FATAL) << e.what(); }
-    export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes, true);
+    CHECK((size_t)ep.size() == st.n_ep) << "formNormalEqIRLS expects the residual vector evaluateDataError returned";
+    legm_hip_detail::settle_trial(st, true);
+    try {
+        st.impl->setCost(cost_type, a);             // later evaluations accumulate the weighted per-pixel sums directly (speed only)
+        st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel, cost_type, a);
+    } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
 }
 
 void LEGM::applyL2Reg(std::vector<Mat2d>& A22_blocks, VecXd& b2, const std::set<size_t>& active_pix_idxes, const double alpha,
@@ -125,6 +206,64 @@ void LEGM::applyL2Reg(std::vector<Mat2d>& A22_blocks, VecXd& b2, const std::set<
     const size_t P = st.ne.num_active_pixels;
     for (size_t i = 0; i < P; ++i) A22_blocks[i] << st.ne.A22_blocks[4 * i], st.ne.A22_blocks[4 * i + 1], st.ne.A22_blocks[4 * i + 2], st.ne.A22_blocks[4 * i + 3];
     b2 = Eigen::Map<const VecXd>(st.ne.b2.data(), 2 * P);
+}
+
+// The blocks the caller passes are the ones formNormalEq + applyL2Reg exported (minus the first-window trim, detected from A11.rows()):
+// the device solves on its resident copy and the sparse A12 factors.
+void LEGM::solveNormalEq(const MatXd& A11, const MatXd& A12, const std::vector<Mat2d>& A22_blocks, const VecXd& b1, const VecXd& b2,
+                         const double lambda, VecXd& x1, VecXd& x2)
+{
+    auto& st = g_state[this];
+    (void)A12; (void)b1;
+    CHECK(A11.rows() == 3 * st.K || A11.rows() == 3 * st.K - 3) << "A11 is neither the full nor the first-window-trimmed system";
+    CHECK((size_t)b2.size() == 2 * A22_blocks.size() && A22_blocks.size() == st.ne.num_active_pixels);
+    const bool fix_first_pose = A11.rows() == 3 * st.K - 3;          // solver.cpp:156-165 dropped the first control pose
+    legm_hip_detail::settle_trial(st, false);       // solveNormalEq again without a formNormalEq in between: the trial was rejected
+    std::vector<double> v1, v2;
+    try { st.impl->solveNormalEq(lambda, fix_first_pose, v1, v2); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    const int skip = fix_first_pose ? 3 : 0;
+    x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
+    x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());
+}
+
+std::pair<int, double> LEGM::solveNormalEqCG(const MatXd& A11, const MatXd& A12, const std::vector<Mat2d>& A22_blocks, const VecXd& b1,
+                                             const VecXd& b2, const double lambda, VecXd& x1, VecXd& x2)
+{
+    auto& st = g_state[this];
+    (void)A12; (void)b1; (void)b2; (void)A22_blocks;
+    CHECK(A11.rows() == 3 * st.K || A11.rows() == 3 * st.K - 3);
+    const bool fix_first_pose = A11.rows() == 3 * st.K - 3;
+    legm_hip_detail::settle_trial(st, false);
+    std::vector<double> v1, v2;
+    std::pair<int, double> res(0, 0.0);
+    try { res = st.impl->solveNormalEqCG(lambda, fix_first_pose, v1, v2); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    const int skip = fix_first_pose ? 3 : 0;
+    x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
+    x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());
+    return res;
+}
+
+// Gx_new / Gy_new are clones of the current map (solver.cpp:237-238); the device builds the same trial map from ITS current map and the
+// caller's clones are overwritten with it, so that everything solver.cpp later does with them (Gx = Gx_new on acceptance, saveEvoData)
+// sees the reference's values.
+void LEGM::updateMap(cv::Mat& Gx_new, cv::Mat& Gy_new, const VecXd& x2, const double damping_factor,
+                     const std::set<size_t>& active_pix_idxes, const std::set<size_t>& inactive_pix_idxes)
+{
+    auto& st = g_state[this];
+    (void)inactive_pix_idxes;
+    CHECK(active_pix_idxes.size() == st.ne.num_active_pixels && (size_t)x2.size() == 2 * st.ne.num_active_pixels);
+    CHECK(Gx_new.isContinuous() && Gy_new.isContinuous() && Gx_new.type() == CV_64FC1);
+    legm_hip_detail::settle_trial(st, false);       // (a trial nobody evaluated or decided about is dropped)
+    std::vector<double> v2(x2.data(), x2.data() + x2.size());
+    try {
+        st.impl->updateMap(v2, damping_factor);
+        st.impl->downloadMap(Gx_new.ptr<double>(), Gy_new.ptr<double>());
+    } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    st.map_is_trial = true; st.trial_pending = false;
+    st.trial_gx = Gx_new.ptr<unsigned char>(); st.trial_gy = Gy_new.ptr<unsigned char>();
+    st.trial_sample.clear();
+    const size_t npix = (size_t)Gx_new.rows * Gx_new.cols;
+    legm_hip_detail::sample_plane(Gx_new.ptr<double>(), npix, st.trial_sample); legm_hip_detail::sample_plane(Gy_new.ptr<double>(), npix, st.trial_sample);
 }
 
 }  // namespace EMBA

@@ -8,6 +8,7 @@
 // re-distributed by pixel owner.  No Python, no extra processes or threads.  Free of ROS / OpenCV / Eigen types like legm_host.hpp.
 #pragma once
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "legm_host.hpp"
@@ -44,6 +45,45 @@ public:
         check(emba_group_set_events(g_, x.data(), y.data(), pol.data(), t.data(), ev.size()));
     }
     void uploadMap(const double* Gx, const double* Gy) { check(emba_group_upload_map(g_, Gx, Gy)); }
+
+    // ---- the reference's call shape (what emba_amd/host/legm_adapter.hpp forwards to; solver.cpp:63-353 calls these in this order) ----
+    // VecXd evaluateDataError(traj, Gx, Gy, events, eval_deriv, num_ev_map)   model.cpp:72-258.  Gx == Gy == nullptr: evaluate on the map
+    // resident on the device (the trial map updateMap built).  Returns ep of ALL ranks merged into the reference's order; num_ev_map (may
+    // be nullptr) receives the global count map.
+    std::vector<double> evaluateDataError(const TrajectoryView& traj, const double* Gx, const double* Gy, const EventPacket& events, bool eval_deriv,
+                                          int32_t* num_ev_map)
+    {
+        if (!eval_deriv) throw std::runtime_error("eval_deriv=false is never used by the reference (solver.cpp:75,251) and is not provided");
+        ensureEvents(events);
+        K_ = traj.num_ctrl_poses;
+        std::vector<double> ep(events.size() ? events.size() : 1);
+        size_t n_inl = 0;
+        check(emba_group_eval(g_, traj.knots_xyzw, traj.num_ctrl_poses, traj.t0_ns, traj.dt_ns, Gx, Gy, ep.data(), &n_inl, num_ev_map));
+        ep.resize(n_inl);
+        n_inliers_ = n_inl;
+        return ep;
+    }
+    // formNormalEq / formNormalEqIRLS (model.cpp:316-687) on the device-resident residuals of the last evaluateDataError; applyL2Reg apart
+    void formNormalEq(NormalEquations& ne, int num_ctrl_poses, int thres_valid_pixel, const std::string& cost_type = "quadratic", double a = 0.0)
+    {
+        if (num_ctrl_poses != K_) throw std::runtime_error("num_ctrl_poses differs from the trajectory used in evaluateDataError");
+        size_t n_inl = 0;
+        check(emba_group_form(g_, thres_valid_pixel, irls_code(cost_type), a, 0.0, &n_inl, &P_));
+        download(ne);
+    }
+    void applyL2Reg(NormalEquations& ne, double alpha) { check(emba_group_apply_l2(g_, alpha)); download(ne); }
+    // declare the robust cost of the formNormalEq calls to come (speed only: emba_group_set_cost)
+    void setCost(const std::string& cost_type, double a) { check(emba_group_set_cost(g_, irls_code(cost_type), a)); }
+    // solveNormalEqCG (model.cpp:794-840): returns (cg.iterations(), cg.error())
+    std::pair<int, double> solveNormalEqCG(double lambda, bool fix_first_pose, std::vector<double>& x1, std::vector<double>& x2)
+    {
+        x1.assign(3 * (size_t)K_, 0.0); x2.assign(2 * P_, 0.0);
+        int32_t it = 0; double err = 0;
+        check(emba_group_solve_cg(g_, lambda, fix_first_pose ? 1 : 0, 100, 1e-6, x1.data(), P_ ? x2.data() : nullptr, &it, &err));
+        return {it, err};
+    }
+    void rejectTrial() { check(emba_group_trial_reject(g_)); }
+    size_t numInliers() const { return n_inliers_; }
 
     // evaluateDataError (model.cpp:72-258) + formNormalEq[IRLS] (:316-687) + applyL2Reg (:689-719) on the resident map, over all ranks.
     // Returns the number of inlier measurements; numActivePixels() afterwards.
@@ -95,9 +135,20 @@ private:
     {   // the reference aborts through glog CHECK / LOG(FATAL); callers that link glog can catch and LOG(FATAL)
         if (st != EMBA_OK) throw std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + emba_group_last_error(g_));
     }
+    // the sliding window hands the same packet to every LM trial: registered once per CONTENT (allocation, size, first / last timestamp —
+    // a window that reuses the allocation with new events of equal count differs in its timestamps)
+    void ensureEvents(const EventPacket& ev)
+    {
+        const Event* d = ev.data();
+        const int64_t tf = ev.empty() ? 0 : ev.front().t_ns, tl = ev.empty() ? 0 : ev.back().t_ns, tm = ev.empty() ? 0 : ev[ev.size() / 2].t_ns;
+        if (have_ev_ && d == ev_ptr_ && ev.size() == ev_n_ && tf == ev_t0_ && tl == ev_t1_ && tm == ev_tm_) return;
+        setEvents(ev);
+        have_ev_ = true; ev_ptr_ = d; ev_n_ = ev.size(); ev_t0_ = tf; ev_t1_ = tl; ev_tm_ = tm;
+    }
     emba_group* g_ = nullptr;
     int W_, H_, K_ = 0;
-    size_t P_ = 0;
+    size_t P_ = 0, n_inliers_ = 0;
+    bool have_ev_ = false; const Event* ev_ptr_ = nullptr; size_t ev_n_ = 0; int64_t ev_t0_ = 0, ev_t1_ = 0, ev_tm_ = 0;
 };
 
 }  // namespace emba_host

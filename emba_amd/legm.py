@@ -277,6 +277,10 @@ class LEGM:
     def rejectMap(self):
         self._check(self._L.emba_map_reject(self._ctx))
 
+    def rejectTrial(self):
+        """emba_trial_reject: the last evaluation was a rejected trial; the equations formed before it are current again."""
+        self._check(self._L.emba_trial_reject(self._ctx))
+
     def downloadMap(self):
         Gx = np.empty((self.H, self.W)); Gy = np.empty((self.H, self.W))
         self._check(self._L.emba_download_map(self._ctx, _p(Gx, _dp), _p(Gy, _dp)))

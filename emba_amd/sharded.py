@@ -202,7 +202,10 @@ class ShardedLEGM:
         # A numeric failure is rank-LOCAL (a 2x2 block of A22m that is not positive definite shows up on its pixel's owner only): the
         # decision to raise must be global, or one rank leaves the protocol while the others wait in the next collective.  The status rides
         # as one more element of the x2 all-reduce, which every rank always executes; then all ranks raise together.
-        x2 = torch.zeros(2 * max(self.P, 1) + 1, dtype=torch.float64, device=dev)
+        # x1 rides along too (rank 0's copy, zeros from the others): the replicated factorisation combines partial tiles with LDS atomics,
+        # so its result is equal across ranks only to rounding — every rank must apply the SAME pose update or the replicas drift apart.
+        n2, n1 = 2 * max(self.P, 1), 3 * int(e.K)
+        x2 = torch.zeros(n2 + 1 + n1, dtype=torch.float64, device=dev)      # [x2 (2P) | status | x1 (3K)]
         x1, failure = None, None
         try:
             x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
@@ -210,12 +213,15 @@ class ShardedLEGM:
             if getattr(exc, "status", None) != _ERR_NUMERIC:
                 raise
             failure = exc
-            x2[-1] = 1.0
+            x2[n2] = 1.0
+        if r == 0 and x1 is not None:
+            x2[n2 + 1:] = torch.from_numpy(np.ascontiguousarray(x1)).to(dev)
         if w > 1:
             dist.all_reduce(x2)
         _device_sync(dev)
-        if float(x2[-1].item()) != 0.0:
+        if float(x2[n2].item()) != 0.0:
             raise failure if failure is not None else EmbaError(_ERR_NUMERIC, "the damped normal equations are not positive definite on another rank")
+        x1 = x2[n2 + 1:].cpu().numpy().copy()
         return x1, x2[: 2 * self.P].cpu().numpy()
 
 
@@ -295,6 +301,10 @@ class HipEngine:
         that synchronises by itself (the thread stand-in of tests/test_gpu_sharded.py drains the engine's stream first)."""
         self.m = legm
         self.check_stream = check_stream
+
+    @property
+    def K(self):
+        return self.m.K
 
     def bind_exchange(self, count_tensor, pack_tensor):
         assert count_tensor.is_cuda and pack_tensor.is_cuda and count_tensor.is_contiguous() and pack_tensor.is_contiguous()

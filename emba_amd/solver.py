@@ -127,11 +127,10 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
                     return LMResult(traj, cost_min, it, True, log)
         else:                                                                        # :340-352
             decreased = False
+            # the reference reuses its host copies of A, b after a rejection (formNormalEq is skipped, solver.cpp:66-131).  On the device the
+            # trial evaluation wrote a SECOND record set; rejectMap (emba_map_reject) makes the set the equations were formed from current
+            # again — pack, active set and records untouched — so a rejection costs one evaluation, like in the reference.
             model.rejectMap()
-            # the reference reuses its host copies of A, b after a rejection (formNormalEq is skipped, solver.cpp:66-131); here that
-            # state lives on the device and the trial evaluation overwrote it: restore it at the accepted point
-            ph.evaluate(traj)
-            ph.form(traj.size())
             lam *= 10
             count_tol = 0
     return LMResult(traj, cost_min, it, False, log)

@@ -155,6 +155,10 @@ emba_status emba_form_normal_eq(emba_ctx* ctx, const double* ep, int32_t thres_v
 emba_status emba_get_A12_sparse(emba_ctx* ctx, int32_t* cp_c, int32_t* cp_p, int32_t* pix, double* w,
                                 double* jc /*n*6*/, double* jp /*n*6*/, double* dp /*n*2*/);
 
+/* Sensor pixel (y * sensor_w + x) of every inlier measurement of the last evaluation, in the order of ep (sensor pixel major, then time;
+ * model.cpp:179-186): pix_host has capacity n_inliers.  What a multi-GPU host merges the ranks' residual vectors by (emba_group_eval). */
+emba_status emba_get_inlier_pixels(emba_ctx* ctx, uint32_t* pix_host);
+
 /* Cost terms of the caller (solver.cpp:88-91,257-268), reduced on the device from the resident
  * residuals / map: data = 0.5*ep.ep (irls 0) or evaluateRobustDataCost (model.cpp:279-314);
  * reg = 0.5*alpha*sum(Gx^2+Gy^2) over all pixels (model.cpp:260-277). */
@@ -183,6 +187,13 @@ emba_status emba_bind_map_dev(emba_ctx* ctx, const double* Gx_dev, const double*
 emba_status emba_update_map(emba_ctx* ctx, const double* x2_host, double damping);
 emba_status emba_map_accept(emba_ctx* ctx);
 emba_status emba_map_reject(emba_ctx* ctx);
+/* A rejected LM trial without a re-evaluation (solver.cpp:340-352 simply reuses A and b).  An evaluation that follows emba_form_* writes its
+ * factor records into a SECOND record set, so the records, pack and active set the current normal equations consist of stay intact while
+ * the trial point is evaluated.  emba_trial_reject (called by emba_map_reject; callable on its own when no map update was involved) makes
+ * them current again: emba_solve_normal_eq[_cg], emba_update_map, emba_form_finish downloads work as if the trial evaluation had not
+ * happened.  An ACCEPTED trial needs no call: the following emba_form_* forms new equations from the trial's records.  After a rejection
+ * formNormalEq needs a new evaluation first (count map and per-pixel sums are the trial's). */
+emba_status emba_trial_reject(emba_ctx* ctx);
 emba_status emba_download_map(emba_ctx* ctx, double* Gx_host, double* Gy_host);
 
 /* Intensity panorama from the gradient map: poisson_reconstruction::reconstructFromGradient,
@@ -316,7 +327,10 @@ emba_status emba_last_kernel_ms(emba_ctx* ctx, float* warp_ms, float* accum_ms);
  * through in-library copies and add kernels instead — same protocol, no RCCL.  Same call order as the single-GPU entry points:
  *   emba_group_set_events -> emba_group_upload_map -> { emba_group_step -> [emba_group_download] -> emba_group_solve ->
  *   emba_group_update_map -> emba_group_step ... -> emba_group_map_accept / _reject }.  emba_group_ctx gives a rank's context for
- * anything else (diagnostics, dumps). */
+ * anything else (diagnostics, dumps).  emba_group_eval + emba_group_form are the two halves of emba_group_step with the reference's
+ * call shape (solver.cpp:75,251 evaluateDataError; :114-130 formNormalEq[IRLS] + applyL2Reg), so the EMBA::LEGM adapter
+ * (emba_amd/host/legm_adapter.hpp) sits on a group of any size — one rank included — without a change to solver.cpp.
+ * With more than one rank every rank's launches are issued from a host thread of its own (EMBA_GROUP_THREADS=0: from the caller's). */
 typedef struct emba_group emba_group;
 emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, emba_group** out);   /* cfg->device, cfg->stream are ignored */
 void        emba_group_destroy(emba_group* g);
@@ -329,13 +343,29 @@ emba_status emba_group_upload_map(emba_group* g, const double* Gx, const double*
 /* evaluateDataError + formNormalEq[IRLS] + applyL2Reg over all ranks; n_inliers = total over the ranks, P = active pixels */
 emba_status emba_group_step(emba_group* g, const double* knots_xyzw, int32_t K, int64_t t0_ns, int64_t dt_ns, int32_t thres_valid_pixel,
                             int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
+/* LEGM::evaluateDataError over all ranks.  Gx / Gy: host planes to upload first, or both NULL for the resident (current or trial) map.
+ * Outputs (any may be NULL): ep_out (capacity >= events used) = the residuals of all ranks merged into the reference's order, *n_inliers
+ * their number, num_ev_map_out the GLOBAL count map (exact int32 exchange; without it exchange 1 is left to emba_group_form, which may
+ * send saturated bytes). */
+emba_status emba_group_eval(emba_group* g, const double* knots_xyzw, int32_t K, int64_t t0_ns, int64_t dt_ns, const double* Gx, const double* Gy,
+                            double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out);
+/* LEGM::formNormalEq[IRLS] + applyL2Reg over all ranks on the state of the last emba_group_eval (device-resident residuals). */
+emba_status emba_group_form(emba_group* g, int32_t thres_valid_pixel, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
+/* LEGM::applyL2Reg as a call of its own (after emba_group_form with alpha = 0): once per set of equations, on every rank's replica. */
+emba_status emba_group_apply_l2(emba_group* g, double alpha);
+/* emba_set_cost on every rank: the robust cost of the emba_group_form calls to come (speed only; emba_group_step declares its own). */
+emba_status emba_group_set_cost(emba_group* g, int32_t irls, double eta);
 emba_status emba_group_download(emba_group* g, double* A11, double* b1, uint32_t* active_idx, size_t cap_P, double* A22, double* b2);
 emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost);
 emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
+/* LEGM::solveNormalEqCG: one-rank groups only (EMBA_ERR_STATE otherwise: a sharded window uses the Schur solve) */
+emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host, double* x2_host,
+                                int32_t* iterations, double* error);
 emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping);
 emba_status emba_group_map_accept(emba_group* g);
 emba_status emba_group_map_reject(emba_group* g);
 emba_status emba_group_download_map(emba_group* g, double* Gx_host, double* Gy_host);
+emba_status emba_group_trial_reject(emba_group* g);   /* emba_trial_reject on every rank (emba_group_map_reject includes it) */
 
 #ifdef __cplusplus
 }

@@ -7,4 +7,4 @@
 struct MockLogFatal { ~MockLogFatal() { std::abort(); } template <class T> MockLogFatal& operator<<(const T& v) { std::cerr << v; return *this; } };
 #define FATAL 3
 #define LOG(severity) MockLogFatal()
-#define CHECK(cond) if (!(cond)) MockLogFatal() << "CHECK failed: " #cond
+#define CHECK(cond) if (!(cond)) MockLogFatal() << "CHECK failed: " #cond " "

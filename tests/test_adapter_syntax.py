@@ -1,7 +1,7 @@
 """emba_amd/host/legm_adapter.hpp — the `EMBA::LEGM` member definitions a maintainer adds to the reference tree — cannot be BUILT here
 (ROS, OpenCV, glog are absent), but a compiler can still check it: g++ -fsyntax-only against tests/cpp/mock_ref (the few glog / cv::Mat /
 message / class declarations it touches) and the reference's own vendored Eigen.  The mock's LEGM declarations are compared with the text
-of the reference header, so "keeps the public signatures of include/emba/model.h:76-108 verbatim" is checked, not claimed."""
+of the reference header, so "keeps the public signatures of include/emba/model.h:76-128 verbatim" is checked, not claimed."""
 import os
 import re
 import subprocess
@@ -25,7 +25,7 @@ def _decls(text, names):
     """name -> whitespace-free declaration text (from the name to the closing ';')"""
     out = {}
     for n in names:
-        m = re.search(r"\b(?:VecXd|void)\s+" + n + r"\s*\(.*?\)\s*;", text, flags=re.S)
+        m = re.search(r"\b(?:VecXd|void|std::pair<int,\s*double>)\s+" + n + r"\s*\(.*?\)\s*;", text, flags=re.S)
         assert m, n
         out[n] = _norm(m.group(0))
     return out
@@ -41,7 +41,7 @@ def test_adapter_compiles_against_the_reference_signatures():
 
 @needs_ref
 def test_mock_declarations_are_the_reference_headers():
-    names = ["evaluateDataError", "formNormalEq", "formNormalEqIRLS", "applyL2Reg"]
+    names = ["evaluateDataError", "formNormalEq", "formNormalEqIRLS", "applyL2Reg", "solveNormalEq", "solveNormalEqCG", "updateMap"]
     ref = _decls(open(os.path.join(REF, "include", "emba", "model.h")).read(), names)
     mock = _decls(open(os.path.join(MOCK, "emba", "model.h")).read(), names)
     for n in names:

@@ -82,3 +82,62 @@ def test_cpp_sharded_host_matches_oracle(tmp_path, hip_lib, oracle_mod, devices,
     last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""      # (RCCL prints a version banner first)
     assert r.returncode == 0 and last.startswith("OK"), r.stdout + r.stderr
     assert f"world={len(devices.split(','))} rccl={int(force_rccl)}" in last
+
+
+ADAPTER_EXE = os.path.join(ROOT, "tests", "cpp", "_build", "adapter_test")
+
+
+def test_adapter_binary_builds_where_the_reference_is_present(hip_lib):
+    """The drop-in EMBA::LEGM (legm_adapter.hpp: all eight methods of model.h:76-128) compiles and LINKS against the mock of the reference's
+    declarations + the reference's own Eigen (built here; the binary travels to the GPU box)."""
+    if not os.path.isdir("/root/reference/thirdparty/basalt-headers/thirdparty/eigen"):
+        pytest.skip("the reference's vendored Eigen is not present on this machine")
+    import __graft_entry__ as ge
+    exe = ge.build_adapter_test()
+    assert exe and os.path.exists(exe)
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0,0", False, False), ("0,0", True, False)])
+def test_adapter_runs_the_reference_call_order(tmp_path, hip_lib, oracle_mod, devices, use_irls, use_cg):
+    """solveTimeWindow's call order (solver.cpp:63-353) through the EMBA::LEGM adapter — evaluateDataError, formNormalEq[IRLS], applyL2Reg,
+    the first-window trim, solveNormalEq[CG], updateMap, evaluateDataError on the trial Mats, accept / reject inferred from the calls — on one
+    rank and on 2 / 3 ranks of one GPU, against the same loop on the CPU oracle: decisions, costs, trajectory, map."""
+    if not os.path.exists(ADAPTER_EXE):
+        pytest.skip("tests/cpp/_build/adapter_test was not built (needs the reference's Eigen at build time)")
+    from emba_amd import synth
+    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+    from helpers import OracleModel
+    from test_lm_solver_cpu import perturbed
+    w = synth.make_scene_workload(n_steps=1000)
+    init = perturbed(w)
+    wi = synth.Workload(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th, w.Gx, w.Gy, init, w.events, w.thres_valid_pixel, 5.0)
+    p = tmp_path / "in.bin"
+    o = dict(ep=np.zeros(0), num_ev_map=np.zeros((w.pano_h, w.pano_w), np.int32),
+             ne=dict(P=0, A11=np.zeros((3 * w.K, 3 * w.K)), b1=np.zeros(3 * w.K), A22=np.zeros((0, 2, 2)), b2=np.zeros(0), active=np.zeros(0, np.uint32)))
+    _write_case(p, wi, o)           # (only the inputs are read by adapter_test)
+    max_iter = 8
+    env = dict(os.environ); env["EMBA_HIP_DEVICES"] = devices
+    r = subprocess.run([ADAPTER_EXE, str(p), str(max_iter), "1" if use_irls else "0", "1" if use_cg else "0"], capture_output=True, text=True, timeout=300, env=env)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    lm = [l.split() for l in lines if l.startswith("LM ")]
+    end = [l.split() for l in lines if l.startswith("END ")][0]
+    knots = np.array([[float(v) for v in l.split()[1:]] for l in lines if l.startswith("KNOT ")])
+    ba = BASettings(use_IRLS=use_irls, cost_type="huber", eta=0.1, alpha=5.0, use_CG=use_cg)
+    om = OracleModel(oracle_mod, w, use_cg=use_cg)
+    ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, LMSettings(max_num_iter=max_iter))
+    assert len(lm) == len(ro.log) and int(end[1]) == ro.iterations and bool(int(end[2])) == ro.converged
+    assert [int(l[5]) for l in lm] == [int(e[4]) for e in ro.log], "accept / reject sequence differs from the oracle loop"
+    assert any(int(l[5]) for l in lm) and not all(int(l[5]) for l in lm), "the case is meant to contain accepted AND rejected steps"
+    tol = 1e-5 if use_cg else 1e-7
+    for l, e in zip(lm, ro.log):
+        assert float(l[3]) == pytest.approx(e[2], rel=tol) and float(l[4]) == pytest.approx(e[3], rel=tol)
+    assert np.abs(knots - ro.traj.knots_xyzw).max() < (1e-5 if use_cg else 1e-7)
+    Gx_o, Gy_o = om.downloadMap()
+    n = Gx_o.size
+    sx = float((Gx_o.ravel() * ((np.arange(n) % 7) + 1)).sum()); sy = float((Gy_o.ravel() * ((np.arange(n) % 5) + 1)).sum())
+    mp_ = [l.split() for l in lines if l.startswith("MAP ")][0]
+    assert float(mp_[1]) == pytest.approx(sx, rel=1e-5 if use_cg else 1e-7, abs=1e-9) and float(mp_[2]) == pytest.approx(sy, rel=1e-5 if use_cg else 1e-7, abs=1e-9)

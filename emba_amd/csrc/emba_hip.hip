@@ -69,7 +69,10 @@ struct emba_ctx {
     double* d_pack_own = nullptr; size_t pack_own_cap = 0;
     double* d_pack = nullptr; size_t pack_cap = 0; bool pack_bound = false;
     double* d_knots = nullptr; int knots_cap = 0;
-    int* d_err = nullptr;
+    int* d_err = nullptr;           // status word of the CURRENT evaluation: one of the two words of d_err2 (they alternate: an evaluation's first launch
+    int* d_err2 = nullptr;          // clears the NEXT evaluation's word while its own pose threads may already be setting bits of the current one)
+    uint32_t eval_seq = 0;
+    int rect_sel = 0;               // which half of d_blk_rect the next evaluation's prep blocks write (the texel blocks read the other: the previous launch's)
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
     int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P [3] step sequence number
@@ -663,10 +666,18 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->n_ablk = (c->npix + kActivePix - 1) / kActivePix;
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_cnt)] = c->n_ablk * sizeof(uint32_t);
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_off)] = c->n_ablk * sizeof(uint32_t);
-    CREATE_TRY(hipMalloc((void**)&c->d_err, sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_err)] = sizeof(int);
+    CREATE_TRY(hipMalloc((void**)&c->d_err2, 2 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_err2)] = 2 * sizeof(int);
+    CREATE_TRY(hipMemset(c->d_err2, 0, 2 * sizeof(int)));
+    c->d_err = c->d_err2;
     CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_rect)] = 4 * sizeof(int);
     { const int init[4] = {0x7FFFFFFF, 0x7FFFFFFF, -1, -1}; CREATE_TRY(hipMemcpy(c->d_rect, init, sizeof init, hipMemcpyHostToDevice)); }
-    CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, ((c->npix + 1023) / 1024) * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = ((c->npix + 1023) / 1024) * 4 * sizeof(int);
+    {   // two sets of per-prep-block boxes (written by one evaluation's launch, read by the next one's texel blocks), both empty to begin with
+        const size_t nbx = (c->npix + 1023) / 1024;
+        CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, 2 * nbx * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = 2 * nbx * 4 * sizeof(int);
+        std::vector<int> init(2 * nbx * 4);
+        for (size_t i = 0; i < 2 * nbx; ++i) { init[4 * i] = 0x7FFFFFFF; init[4 * i + 1] = 0x7FFFFFFF; init[4 * i + 2] = -1; init[4 * i + 3] = -1; }
+        CREATE_TRY(hipMemcpy(c->d_blk_rect, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_total)] = 2 * sizeof(uint32_t);
     CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_scalar)] = 2 * sizeof(double);
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
@@ -1044,8 +1055,6 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->K = K;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
-    if (c->knots_in_flight) HIP_TRY(c, hipStreamSynchronize(s));   // the previous prep kernel must have consumed the pinned staging buffer
-    memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
@@ -1053,22 +1062,35 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     }
     int* rect_cur = c->d_rect;
     const int n_prep_blk = (int)((c->npix + 1023) / 1024);
-    hipLaunchKernelGGL(emba_prep_kernel, dim3((unsigned)n_prep_blk), dim3(256), 0, s, c->d_count, (long)c->npix,
-                       c->d_pixacc, c->d_err, c->h_knots_dev, c->d_knots, 4 * (int)K, c->W, c->d_blk_rect);
-    c->knots_in_flight = true;   // cleared by the next host synchronisation (an event here would cost a ~6 us bubble per step)
-
     // Hessian source: with several events per panorama pixel (measured break-even: ~4) the full texel pack (one 48-B gather per
-    // measurement instead of an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels the previous
-    // evaluation touched, and the warp kernel falls back to the stencil outside it.
+    // measurement instead of an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels an
+    // earlier evaluation touched, and the warp kernel falls back to the stencil outside it.
     c->use_texel = c->texel_mode == 1 ? 1 : c->texel_mode == 2 ? 0 : c->texel_mode == 3 ? 3 : (c->n_sorted > 4 * c->npix ? 1 : 3);
-    {   // pose table and (rectangle mode) texels in ONE launch: both depend only on the prep kernel
+    {   // ONE launch in front of the warp kernel: prep || pose table (or segment records) || texel rectangle — independent of each other
+        PrepPoseTexelParams q{};
+        InlineKnots kn;
         const int nb = (int)c->n_batch;
-        const int n_pose_blk = ((c->tile_order ? (int)K - 1 : nb) + 63) / 64;   // (tile order: K-1 segment records instead of nb batch poses)
-        const int n_tex_blk = (c->use_texel == 3) ? 512 : 0;
-        if (n_pose_blk + n_tex_blk)
-            hipLaunchKernelGGL(emba_pose_texel_kernel, dim3(n_pose_blk + n_tex_blk), dim3(256), 0, s, c->d_batch_t, nb, c->d_knots, (int)K,
-                               t0_ns, dt_ns, c->d_pose, c->d_err, n_pose_blk, n_tex_blk, c->d_Gx, c->d_Gy, c->H, c->W, c->d_blk_rect,
-                               n_prep_blk, rect_cur, c->d_texel, c->tile_order ? c->d_seg : nullptr);
+        ++c->eval_seq;
+        c->d_err = c->d_err2 + (c->eval_seq & 1u);
+        q.count = c->d_count; q.npix = (long)c->npix; q.pixacc = c->d_pixacc; q.W = c->W; q.H = c->H; q.n_prep = n_prep_blk;
+        q.blk_rect_w = c->d_blk_rect + (size_t)c->rect_sel * n_prep_blk * 4; q.blk_rect_r = c->d_blk_rect + (size_t)(1 - c->rect_sel) * n_prep_blk * 4;
+        c->rect_sel = 1 - c->rect_sel;
+        q.batch_t_ns = c->d_batch_t; q.nb = nb; q.K = (int)K; q.t0_ns = t0_ns; q.dt_ns = dt_ns; q.pose = c->d_pose; q.err = c->d_err;
+        q.err_next = c->d_err2 + ((c->eval_seq + 1u) & 1u);
+        q.n_pose = ((c->tile_order ? (int)K - 1 : nb) + 63) / 64;   // (tile order: K-1 segment records instead of nb batch poses)
+        q.seg = c->tile_order ? c->d_seg : nullptr;
+        q.knots_dev = c->d_knots; q.knots_out = c->d_knots;
+        q.inline_knots = (K <= kInlineKnots) ? 1 : 0;
+        if (q.inline_knots) memcpy(kn.q, knots, (size_t)4 * K * sizeof(double));       // by value in the kernel arguments: no staging copy at all
+        else {
+            if (c->knots_in_flight) HIP_TRY(c, hipStreamSynchronize(s));               // the previous copy must have consumed the pinned staging buffer
+            memcpy(c->h_knots, knots, (size_t)4 * K * sizeof(double));
+            HIP_TRY(c, hipMemcpyAsync(c->d_knots, c->h_knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
+            c->knots_in_flight = true;   // cleared by the next host synchronisation
+        }
+        q.n_tex = (c->use_texel == 3) ? 512 : 0;
+        q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect_out = rect_cur; q.texel = c->d_texel;
+        hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_prep + q.n_pose + q.n_tex)), dim3(256), 0, s, q, kn);
     }
     if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,

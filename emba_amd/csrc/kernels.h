@@ -247,25 +247,6 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
     }
 }
 
-// Pose table and texel rectangle in one launch (both only need the prep kernel): blocks [0, n_pose_blk) evaluate the spline for
-// 256 batches each, the remaining n_tex_blk blocks pack the texels of the rectangle.
-__global__ __launch_bounds__(256) void emba_pose_texel_kernel(const int64_t* __restrict__ batch_t_ns, int nb, const double* __restrict__ knots,
-                                                              int K, int64_t t0_ns, int64_t dt_ns, double* __restrict__ pose, int* __restrict__ err,
-                                                              int n_pose_blk, int n_tex_blk, const double* __restrict__ Gx,
-                                                              const double* __restrict__ Gy, int H, int W, const int* __restrict__ blk_rect,
-                                                              int n_blk_rect, int* __restrict__ rect_out, double* __restrict__ texel,
-                                                              double* __restrict__ seg)
-{   // seg != nullptr (tile order): the pose blocks fill the K-1 segment records; the per-batch table is not needed by the tiled kernel
-    if ((int)blockIdx.x < n_pose_blk) {
-        if (threadIdx.x < 64) {
-            if (seg) seg_thread(blockIdx.x * 64 + threadIdx.x, knots, K, seg);
-            else pose_thread(blockIdx.x * 64 + threadIdx.x, batch_t_ns, nb, knots, K, t0_ns, dt_ns, pose, err);
-        }
-    }
-    else
-        texel_rect_blocks((long)blockIdx.x - n_pose_blk, n_tex_blk, Gx, Gy, H, W, blk_rect, n_blk_rect, rect_out, texel);
-}
-
 // ------------------------------------------------------------------------------------------------
 // a4-a7 (+ the per-measurement half of a9): the dominant kernel, in two forms that share every per-event expression.
 // One lane per entry of the device-order event array: gather the batch pose, warp (event_pano_warper.cpp:43-74 +
@@ -949,11 +930,14 @@ __global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __
 }
 
 __device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
-                                                   uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr)
+                                                   uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr,
+                                                   uint8_t* __restrict__ active_bits = nullptr)
 {
     __shared__ uint32_t s_w[4];
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
-    uint32_t c = __popc(raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres) : active_mask8(count, p0, npix, thres));
+    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres) : active_mask8(count, p0, npix, thres);
+    if (active_bits && p0 < npix) active_bits[p0 >> 3] = (uint8_t)m8;
+    uint32_t c = __popc(m8);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -977,6 +961,8 @@ struct PostWarpParams {
     const double* e_sorted; const uint8_t* flag; double* ep; int32_t* inl_idx;
     int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts (two words: [0] behind P, [1] behind the inlier count): the host may poll them instead of waiting for the stream
     int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
+    uint8_t* active_bits; double* pack_head; long head_len;   // non-null: launch A also writes the 1-bit activity map and clears A11 | b1, so that the Gram
+                                                              // kernel depends on launch A only and can run BESIDE the active-set write (emba_aw_gram_kernel)
 };
 
 struct ActiveWriteParams {
@@ -987,11 +973,14 @@ struct ActiveWriteParams {
     // blocks of launch A), the status word, then the two sequence words.
     const uint32_t* blk_cnt; const uint32_t* fblk_cnt; long n_fblk; uint32_t* total_P; int* total_P_host; uint32_t* total_inl; int* total_inl_host;
     const int* err_dev; int* err_host; int seq; int* seq_host;
+    int bits_head_done;   // launch A has already written the activity bits and cleared the head of the pack
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
-    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc);
+    // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack
+    if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
 }
 
@@ -1005,11 +994,11 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
     const int32_t* __restrict__ count = a.count; const double* __restrict__ pixacc = a.pixacc; int32_t* __restrict__ compact = a.compact;
     const long npix = a.npix;
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
-    for (long i = blk * 256 + threadIdx.x; i < a.head_len; i += a.n_ablk * 256) a.pack_head[i] = 0.0;
+    if (!a.bits_head_done) for (long i = blk * 256 + threadIdx.x; i < a.head_len; i += a.n_ablk * 256) a.pack_head[i] = 0.0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
     const uint32_t m = active_mask8(count, p0, npix, a.thres);
-    if (p0 < npix) a.active_bits[p0 >> 3] = (uint8_t)m;
+    if (!a.bits_head_done && p0 < npix) a.active_bits[p0 >> 3] = (uint8_t)m;
     const uint32_t mine = __popc(m);
     uint32_t x = mine;
 #pragma unroll
@@ -1089,6 +1078,77 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParams a) { active_write_block(blockIdx.x, a); }
 
+// The same active-set write for a workgroup of NSUB x 256 threads (the fused emba_aw_gram_kernel): every 256-thread group is one block of
+// the kernel above (blk = NSUB * blk0 + group), all barriers are taken by all threads.  Only the fused-step form: per-block counts of
+// launch A in a.blk_cnt, bits and head already written there, no compact index.
+template <int NSUB>
+__device__ __forceinline__ void active_write_multi(long blk0, const ActiveWriteParams& a)
+{
+    __shared__ uint32_t s_w[NSUB][4], s_f[NSUB][4], s_i[NSUB * 4];
+    const int t = threadIdx.x & 255, sub = threadIdx.x >> 8, lane = t & 63, wv = t >> 6;
+    const long blk = blk0 * NSUB + sub;
+    const bool live = blk < a.n_ablk;
+    const long npix = a.npix;
+    const long p0 = blk * kActivePix + 8 * t;
+    const uint32_t m = live ? active_mask8(a.count, p0, npix, a.thres) : 0u;
+    const uint32_t mine = __popc(m);
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[sub][wv] = x;
+    uint32_t part = 0;
+    if (live) for (long j = t; j < blk; j += 256) part += a.blk_cnt[j];          // exclusive prefix over the per-block counts of launch A
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 0) s_f[sub][wv] = part;
+    // the workgroup that holds the LAST block also sums launch A's inlier-flag counts and publishes what the host polls for
+    const bool has_last = (blk0 * NSUB <= a.n_ablk - 1) && (blk0 * NSUB + NSUB - 1 >= a.n_ablk - 1);   // workgroup-uniform
+    uint32_t ipart = 0;
+    if (has_last) {
+        for (long j = threadIdx.x; j < a.n_fblk; j += NSUB * 256) ipart += a.fblk_cnt[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) ipart += __shfl_xor(ipart, o);
+        if (lane == 0) s_i[threadIdx.x >> 6] = ipart;
+    }
+    __syncthreads();
+    const uint32_t front = (s_f[sub][0] + s_f[sub][1]) + (s_f[sub][2] + s_f[sub][3]);
+    uint32_t k = front + x - mine;
+    for (int w = 0; w < wv; ++w) k += s_w[sub][w];
+    if (has_last && blk == a.n_ablk - 1 && t == 0) {
+        const uint32_t P = front + (s_w[sub][0] + s_w[sub][1]) + (s_w[sub][2] + s_w[sub][3]);
+        uint32_t n_inl = 0;
+        for (int w = 0; w < NSUB * 4; ++w) n_inl += s_i[w];
+        a.total_P[0] = P; a.total_inl[0] = n_inl;
+        if (a.total_P_host) a.total_P_host[0] = (int)P;
+        if (a.total_inl_host) a.total_inl_host[0] = (int)n_inl;
+        if (a.err_host) a.err_host[0] = a.err_dev[0];
+        if (a.seq_host) {
+            __threadfence_system();
+            __hip_atomic_store(a.seq_host + 0, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.seq_host + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long i = p0 + j;
+        if (i >= npix) break;
+        if (m & (1u << j)) {
+            a.active_idx[k] = (uint32_t)i;
+            if (a.A22b2 && (long)k < a.max_P) {
+                const double2* q2 = reinterpret_cast<const double2*>(a.pixacc + (size_t)kPixAccStride * i);
+                const double2 a0 = q2[0], a1 = q2[1];
+                const double a4 = a.pixacc[(size_t)kPixAccStride * i + 4];
+                double* q = a.A22b2 + 5 * (size_t)k;
+                const double alpha = a.alpha;
+                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * a.Gx[i]; q[4] = a4 - alpha * a.Gy[i]; }
+                else { q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4; }
+            }
+            ++k;
+        }
+    }
+}
+
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
 __global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)
 {
@@ -1122,18 +1182,10 @@ __global__ void emba_compact_map_kernel(const uint32_t* __restrict__ active_idx,
 }
 
 // Start of an evaluation ("prep"): zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched
-// (`count` still holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels); block 0 also
-// resets the device error word and pulls the control poses from the pinned host staging buffer (no copy / memset nodes).
-__global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ count, long npix, double* __restrict__ pixacc,
-                                                        int* __restrict__ err, const double* __restrict__ knots_host,
-                                                        double* __restrict__ knots_dev, int n_knot_doubles, int W,
-                                                        int* __restrict__ blk_rect)
+// (`count` still holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels).
+__device__ __forceinline__ void prep_block(long blk, int32_t* __restrict__ count, long npix, double* __restrict__ pixacc, int W, int* __restrict__ blk_rect)
 {
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) err[0] = 0;
-        for (int i = threadIdx.x; i < n_knot_doubles; i += 256) knots_dev[i] = knots_host[i];
-    }
-    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long p0 = (blk * 256 + threadIdx.x) * 4;
     int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
     if (p0 < npix) {
         int cc[4] = {0, 0, 0, 0};
@@ -1153,8 +1205,8 @@ __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ co
                 xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
             }
     }
-    // bounding box of the touched pixels of this block -> blk_rect[block]; the pose kernel's extra block reduces them into the
-    // texel rectangle of THIS evaluation (no global atomics: they would all land on the same four words and serialise).
+    // bounding box of the touched pixels of this block -> blk_rect[block]; the texel blocks of the NEXT evaluation's launch reduce them into
+    // their texel rectangle (no global atomics: they would all land on the same four words and serialise).
     __shared__ int s_box[4][4];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -1169,7 +1221,46 @@ __global__ __launch_bounds__(256) void emba_prep_kernel(int32_t* __restrict__ co
         r.y = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
         r.z = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
         r.w = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
-        reinterpret_cast<int4*>(blk_rect)[blockIdx.x] = r;
+        reinterpret_cast<int4*>(blk_rect)[blk] = r;
+    }
+}
+
+// ONE launch in front of the warp kernel (was two: prep, then pose || texel): the three jobs are independent of each other —
+//   blocks [0, n_prep)                  "prep": zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched (`count` still
+//                                       holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels), per-block boxes
+//   blocks [n_prep, n_prep + n_pose)    a2/a3 pose table (pixel order) or the K-1 segment records (tile order)
+//   the remaining n_tex blocks          texel pack inside the rectangle the boxes of the PREVIOUS launch's prep blocks span (one evaluation
+//                                       older than before; a hint only: outside it the warp kernel falls back to the stencil)
+// The control poses travel BY VALUE in the kernel arguments (K <= kInlineKnots: no staging copy, no dependency on another block);
+// larger K reads them from `knots_dev`, which the host has copied there before the launch.
+// err_next: the status word of the NEXT evaluation, cleared here (this launch's pose threads may already be setting bits of err).
+constexpr int kInlineKnots = 104;
+struct InlineKnots { double q[4 * kInlineKnots]; };
+struct PrepPoseTexelParams {
+    int32_t* count; long npix; double* pixacc; int W, H; int* blk_rect_w; const int* blk_rect_r; int n_prep;
+    const int64_t* batch_t_ns; int nb; int K; int64_t t0_ns, dt_ns; double* pose; int* err; int* err_next; int n_pose; double* seg;
+    const double* knots_dev; double* knots_out; int inline_knots;
+    int n_tex; const double* Gx; const double* Gy; int* rect_out; double* texel;
+};
+
+__global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexelParams p, InlineKnots kn)
+{
+    const int b = (int)blockIdx.x;
+    if (b < p.n_prep) {
+        if (b == 0) {
+            if (threadIdx.x == 0) p.err_next[0] = 0;
+            if (p.inline_knots && p.knots_out) for (int i = threadIdx.x; i < 4 * p.K; i += 256) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
+        }
+        prep_block(b, p.count, p.npix, p.pixacc, p.W, p.blk_rect_w);
+    } else if (b < p.n_prep + p.n_pose) {
+        if (threadIdx.x < 64) {
+            const double* knots = p.inline_knots ? kn.q : p.knots_dev;
+            const int i = (b - p.n_prep) * 64 + threadIdx.x;
+            if (p.seg) seg_thread(i, knots, p.K, p.seg);
+            else pose_thread(i, p.batch_t_ns, p.nb, knots, p.K, p.t0_ns, p.dt_ns, p.pose, p.err);
+        }
+    } else {
+        texel_rect_blocks((long)b - p.n_prep - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.blk_rect_r, p.n_prep, p.rect_out, p.texel);
     }
 }
 
@@ -1266,8 +1357,8 @@ __device__ __forceinline__ uint32_t rec_elem15_hi(double2 v)
     return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2hiint(v.y), (7 << 5) | 0x18);
 }
 
-template <bool TAGS>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
-__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
+template <bool TAGS, int kGramBlock>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
+__device__ __forceinline__ void gram_body(const GramParams& p, const long gram_blk)
 {
     __shared__ uint32_t s_tag[kGramKeys];
     __shared__ double s_tile[kGramKeys * 256];
@@ -1282,7 +1373,7 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
     // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
     constexpr int U = TAGS ? GRAM_U : GRAM_U_NT;   // independent 1-KiB loads (8 records each) per wave and stage
     constexpr int kStage = 8 * U, kStride = (kGramBlock / 64) * kStage;
-    const long start = (long)blockIdx.x * (kGramBlock / 64) * p.chunk;
+    const long start = gram_blk * (kGramBlock / 64) * p.chunk;
     const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
     const int len = (int)(end - start);                              // <= 16 * kGramChunk: stage offsets are 32-bit
     const int off0 = wv * kStage;
@@ -1531,6 +1622,25 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p)
         const uint32_t key = s_tag[i >> 8];
         if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
     }
+}
+
+template <bool TAGS>
+__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p) { gram_body<TAGS, kGramBlock>(p, blockIdx.x); }
+
+// The fused single-GPU step's last launch: active-set write || Gram.  Both depend only on launch A (per-block counts, activity bits, cleared
+// head), so the 10-us active-set write hides behind the 30-us Gram kernel instead of standing in front of it.  Workgroups of 512 threads
+// (two fit a CU at the Gram body's register count): in the first 2 * min(n_aw, n_gram) workgroups the roles alternate, so that every CU
+// starts with one of each; the rest of the longer role follows.
+constexpr int kFusedBlock = 512;
+template <bool TAGS>
+__global__ __launch_bounds__(kFusedBlock) void emba_aw_gram_kernel(ActiveWriteParams a, GramParams g, int n_aw, int n_gram)
+{
+    const int b = (int)blockIdx.x, both = 2 * (n_aw < n_gram ? n_aw : n_gram);
+    bool is_aw; int idx;
+    if (b < both) { is_aw = (b & 1) != 0; idx = b >> 1; }
+    else { is_aw = n_aw > n_gram; idx = b - both + (both >> 1); }
+    if (is_aw) active_write_multi<kFusedBlock / 256>(idx, a);
+    else gram_body<TAGS, kFusedBlock>(g, idx);
 }
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic

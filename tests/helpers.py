@@ -67,6 +67,7 @@ class OracleModel:
         self.ep, self.nem = self.o.evaluate_data_error(traj.knots_xyzw, traj.t0_ns, traj.dt_ns, self.used[0], self.used[1],
                                                        ev.x, ev.y, ev.polarity, ev.t_ns)
         self.K = traj.size()
+        self._traj_eval = traj
         if num_ev_map is not None:
             num_ev_map[...] = self.nem
         return self.ep
@@ -78,10 +79,12 @@ class OracleModel:
         return self.O.reg_cost(self.used[0], self.used[1], alpha)
 
     def formNormalEq(self, ep, K, nem, thres):
+        self._traj_form = self._traj_eval
         self.irls, self.a, self.thres = 0, 0.0, thres
         self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, 0, 0.0, not self.sparse)
 
     def formNormalEqIRLS(self, ep, K, nem, thres, cost_type, a):
+        self._traj_form = self._traj_eval
         self.irls, self.a, self.thres = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost_type], a, thres
         self.ne = self.o.form_normal_eq(self.ep, self.K, self.nem, thres, self.irls, a, not self.sparse)
 
@@ -106,6 +109,11 @@ class OracleModel:
 
     def rejectMap(self):
         self.trial = None
+        if self.sparse:
+            # The reference keeps A, b (dense A12 included) on the host across a rejected trial (solver.cpp:340-352).  The sparse solvers of
+            # the oracle rebuild the A12 factors from the state of its LAST evaluateDataError — the rejected trial's — so that state is
+            # brought back to the point the equations were formed at (test infrastructure: costs one CPU evaluation).
+            self.evaluateDataError(self._traj_form, None, None)
 
     def downloadMap(self):
         return self.trial if self.trial is not None else self.cur

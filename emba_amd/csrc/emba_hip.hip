@@ -1090,7 +1090,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         }
         q.n_tex = (c->use_texel == 3) ? 512 : 0;
         q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect_out = rect_cur; q.texel = c->d_texel;
-        hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_prep + q.n_pose + q.n_tex)), dim3(256), 0, s, q, kn);
+        hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_pose + q.n_tex + q.n_prep)), dim3(256), 0, s, q, kn);
     }
     if (c->use_texel == 1)
         hipLaunchKernelGGL(emba_texel_kernel, dim3((c->W + 255) / 256, c->H), dim3(256), 0, s, c->d_Gx, c->d_Gy, c->H, c->W,
@@ -1167,7 +1167,6 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     aw.A22b2 = pack_A22b2(c); aw.pack_head = c->d_pack; aw.head_len = head; aw.alpha = c->fused_alpha; aw.Gx = c->d_Gx; aw.Gy = c->d_Gy;
     aw.active_bits = c->d_active_bits; aw.max_P = (long)((c->pack_cap - (size_t)head) / 5); aw.n_ablk = (long)c->n_ablk;
     if (c->ep_deferred && c->n_sorted) {
-        // residual compaction (count -> scan -> compact) and active set (count -> scan -> write) share three launches
         c->ep_deferred = false;
         PostWarpParams q{};
         q.count = c->d_count; q.npix = npix; q.thres = thres; q.ablk_cnt = c->d_ablk_cnt; q.ablk_off = c->d_ablk_off; q.n_ablk = (long)c->n_ablk;
@@ -1178,14 +1177,18 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = nullptr;   // (inlier numbers: on demand, ensure_inl_idx)
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
+        // launch A: {active counts (+ markers -> counts, activity bits, cleared A11 | b1) || inlier-flag counts}; launch B: the active-set write,
+        // whose blocks take their own prefix over launch A's per-block counts and whose last block publishes P, the inlier total, the status
+        // word and the sequence words the host polls.  (Nothing on the device reads the compacted residual vector `ep` — costs, Gram and solvers
+        // work from the records and the per-event residuals — so it is produced when the host asks for it: resolve_pending / ensure_inl_idx
+        // run the standalone compaction from the per-block flag counts left here.  100 M events: 0.65 -> 0.2 ms.)
+        // Tried and dropped (round 3, 1 M events): both launches as ONE kernel with the per-block counts published through flags (look-back,
+        // and "sum every predecessor"): 38-270 us against 6.3 + 11.2 — the eight XCDs' L2s are not coherent with each other, so every flag is a
+        // round trip to the memory side (and a release / acquire pair writes back / invalidates a whole L2); a kernel boundary is cheaper.
+        q.active_bits = c->d_active_bits; q.pack_head = c->d_pack; q.head_len = head; aw.bits_head_done = 1;
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
-        // (no scan launch: the write kernel's blocks take their own prefix over launch A's per-block counts, its last block publishes
-        // P, the inlier total, the status word and the sequence words the host polls)
         aw.blk_cnt = c->d_ablk_cnt; aw.fblk_cnt = c->d_fblk_cnt; aw.n_fblk = c->n_fblk; aw.total_P = q.total_P; aw.total_P_host = q.total_P_host;
         aw.total_inl = q.total_inl; aw.total_inl_host = q.total_inl_host; aw.err_dev = q.err_dev; aw.err_host = q.err_host; aw.seq = q.seq; aw.seq_host = q.seq_host;
-        // (launch C is the active-set write alone: nothing on the device reads the compacted residual vector `ep` — costs, Gram and solvers
-        // work from the records and the per-event residuals — so it is produced when the host asks for it: resolve_pending /
-        // ensure_inl_idx run the standalone compaction, whose block offsets launch B has just left in place.  100 M events: 0.65 -> 0.2 ms)
         hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
         c->inl_pending = true;
     } else {

@@ -302,8 +302,11 @@ __device__ __forceinline__ double dpp_shl1(double v)
 }
 
 // What one lane knows about its measurement after the shared part.
+#ifndef WARP_LATE_EP
+#define WARP_LATE_EP 0     // pixel-order kernel: residual / flag stores issued after the record stores and atomics instead of in the middle
+#endif
 struct LaneOut {
-    bool inl; uint32_t pi; int pmx, pmy;
+    bool inl; uint32_t pi; int pmx, pmy; bool wr_flag;
     double jc[6], jp[6], dpx, dpy, e;
     double v0, v1, v2, v3, v4;   // the lane's terms of the per-pixel sums {w dx dx, w dx dy, w dy dy, dx we, dy we} (0 unless inlier)
 };
@@ -333,7 +336,7 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // `prefetch` is called once, wave-uniformly, right after the texel gather has been waited for: the point of a group where nothing
 // the group still needs is loaded any more.  (Loads return in order: a prefetch issued earlier sits in front of the bearing-vector,
 // segment and texel gathers, and the waits for those L2 hits would pay the prefetch's HBM latency.)
-template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch>
+template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch, bool LATE_EP = false>
 __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o, PF prefetch = PF())
 {
     const bool valid = in.valid;
@@ -367,6 +370,9 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
             const double q[4] = {a0.x, a0.y, a1.x, a1.y};
             quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
             J1[0] = a2.x; J1[1] = a2.y; J1[2] = a3.x; J1[3] = a3.y; J1[4] = a4.x; J1[5] = a4.y; J1[6] = a5.x; J1[7] = a5.y; J1[8] = a6.x;
+            // (tried, round 3: J1 gathered after the projection — 18 registers fewer across it, 80 VGPRs and 6 waves / SIMD with the LDS
+            // regions below aliased — 55.6 us against 50.7 at 1 M events: more resident waves do not help a kernel that runs at the memory
+            // side's request rate, and the second gather is one more dependent trip)
         }
         if (!COMPACT) { b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; }  // (pixel order: after the pose record — measured: 52 vs 57 us at 1 M events the other way round)
         double rb[3];
@@ -460,7 +466,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
 #pragma unroll
                 for (int j = 0; j < 6; ++j) o.jc[j] = t0 * D[j] + t1 * D[6 + j];          // model.cpp:449
                 ngx = -gx; ngy = -gy;
-                if (EP_NT_STORE) __builtin_nontemporal_store(e, &p.e_sorted[in.pm]); else p.e_sorted[in.pm] = e;
+                if (!LATE_EP) { if (EP_NT_STORE) __builtin_nontemporal_store(e, &p.e_sorted[in.pm]); else p.e_sorted[in.pm] = e; }
             }
         }
     }
@@ -476,7 +482,8 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
     }
     // residual and inlier flag live at the entry's PM-ORDER index (= i in pixel order; a chain's entries are consecutive there too), so that the
     // reference-order compaction reads them in order; a lead-in / halo copy owns no pm slot of its own and writes nothing
-    if (valid && t >= 1 && !(pw & 0x40000000u)) {
+    o.wr_flag = valid && t >= 1 && !(pw & 0x40000000u);
+    if (!LATE_EP && o.wr_flag) {
         if (EP_NT_STORE) __builtin_nontemporal_store((uint8_t)(inl ? 1 : 0), &p.flag[in.pm]); else p.flag[in.pm] = inl ? 1 : 0;
     }
 
@@ -542,9 +549,12 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
 template <bool DUMP, bool COMPACT = false>
 __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
 {
-    __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time
-    __shared__ double s_acc[64 * 6];                                        // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted
-    __shared__ uint32_t s_q[64];                                            // ... and their panorama pixels
+    // One wave per workgroup, LDS operations complete in order: the record staging tile (first) and the run sums (afterwards) share
+    // the same bytes, so that LDS (160 KB per CU) does not cap the resident waves below what the registers allow.
+    __shared__ __attribute__((aligned(16))) double s_tile[32 * kRecLds];   // 32 staged records (half a wave) at a time: 4608 B
+    static_assert(32 * kRecLds >= 64 * 6 + 32, "the run sums and their pixels must fit the staging tile");
+    double* const s_acc = s_tile;                                           // per-run sums {xx xy yy bx by n} of the wave's emitting lanes, compacted (3072 B)
+    uint32_t* const s_q = reinterpret_cast<uint32_t*>(s_tile + 64 * 6);     // ... and their panorama pixels (256 B)
     __shared__ uint32_t s_slot[32];                                         // record slots of the staged half's inliers
 
     const long b = xcd_contiguous_block(blockIdx.x, gridDim.x);
@@ -555,7 +565,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     LaneOut o;
     LaneIn in;
     load_event_words<COMPACT>(p, i, valid, in);
-    warp_lane<DUMP, COMPACT>(p, i, in, t, o);
+    warp_lane<DUMP, COMPACT, NoPrefetch, (WARP_LATE_EP != 0) && !DUMP>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;
     const uint32_t pi = o.pi;
@@ -609,6 +619,10 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
             if (t < 60 && k < n_emit && !(p.ablate & 8))
                 atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[6 * k + comp]);
         }
+    }
+    if (WARP_LATE_EP) {   // residual and inlier flag at the entry's pm-order index, last: nothing in this wave waits for them
+        if (inl) { if (EP_NT_STORE) __builtin_nontemporal_store(o.e, &p.e_sorted[in.pm]); else p.e_sorted[in.pm] = o.e; }
+        if (o.wr_flag) { if (EP_NT_STORE) __builtin_nontemporal_store((uint8_t)(inl ? 1 : 0), &p.flag[in.pm]); else p.flag[in.pm] = inl ? 1 : 0; }
     }
 }
 
@@ -961,8 +975,8 @@ struct PostWarpParams {
     const double* e_sorted; const uint8_t* flag; double* ep; int32_t* inl_idx;
     int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts (two words: [0] behind P, [1] behind the inlier count): the host may poll them instead of waiting for the stream
     int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
-    uint8_t* active_bits; double* pack_head; long head_len;   // non-null: launch A also writes the 1-bit activity map and clears A11 | b1, so that the Gram
-                                                              // kernel depends on launch A only and can run BESIDE the active-set write (emba_aw_gram_kernel)
+    uint8_t* active_bits; double* pack_head; long head_len;   // non-null: launch A also writes the 1-bit activity map and clears A11 | b1 (the Gram kernel then
+                                                              // depends on launch A only)
 };
 
 struct ActiveWriteParams {
@@ -1078,77 +1092,6 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParams a) { active_write_block(blockIdx.x, a); }
 
-// The same active-set write for a workgroup of NSUB x 256 threads (the fused emba_aw_gram_kernel): every 256-thread group is one block of
-// the kernel above (blk = NSUB * blk0 + group), all barriers are taken by all threads.  Only the fused-step form: per-block counts of
-// launch A in a.blk_cnt, bits and head already written there, no compact index.
-template <int NSUB>
-__device__ __forceinline__ void active_write_multi(long blk0, const ActiveWriteParams& a)
-{
-    __shared__ uint32_t s_w[NSUB][4], s_f[NSUB][4], s_i[NSUB * 4];
-    const int t = threadIdx.x & 255, sub = threadIdx.x >> 8, lane = t & 63, wv = t >> 6;
-    const long blk = blk0 * NSUB + sub;
-    const bool live = blk < a.n_ablk;
-    const long npix = a.npix;
-    const long p0 = blk * kActivePix + 8 * t;
-    const uint32_t m = live ? active_mask8(a.count, p0, npix, a.thres) : 0u;
-    const uint32_t mine = __popc(m);
-    uint32_t x = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
-    if (lane == 63) s_w[sub][wv] = x;
-    uint32_t part = 0;
-    if (live) for (long j = t; j < blk; j += 256) part += a.blk_cnt[j];          // exclusive prefix over the per-block counts of launch A
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-    if (lane == 0) s_f[sub][wv] = part;
-    // the workgroup that holds the LAST block also sums launch A's inlier-flag counts and publishes what the host polls for
-    const bool has_last = (blk0 * NSUB <= a.n_ablk - 1) && (blk0 * NSUB + NSUB - 1 >= a.n_ablk - 1);   // workgroup-uniform
-    uint32_t ipart = 0;
-    if (has_last) {
-        for (long j = threadIdx.x; j < a.n_fblk; j += NSUB * 256) ipart += a.fblk_cnt[j];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) ipart += __shfl_xor(ipart, o);
-        if (lane == 0) s_i[threadIdx.x >> 6] = ipart;
-    }
-    __syncthreads();
-    const uint32_t front = (s_f[sub][0] + s_f[sub][1]) + (s_f[sub][2] + s_f[sub][3]);
-    uint32_t k = front + x - mine;
-    for (int w = 0; w < wv; ++w) k += s_w[sub][w];
-    if (has_last && blk == a.n_ablk - 1 && t == 0) {
-        const uint32_t P = front + (s_w[sub][0] + s_w[sub][1]) + (s_w[sub][2] + s_w[sub][3]);
-        uint32_t n_inl = 0;
-        for (int w = 0; w < NSUB * 4; ++w) n_inl += s_i[w];
-        a.total_P[0] = P; a.total_inl[0] = n_inl;
-        if (a.total_P_host) a.total_P_host[0] = (int)P;
-        if (a.total_inl_host) a.total_inl_host[0] = (int)n_inl;
-        if (a.err_host) a.err_host[0] = a.err_dev[0];
-        if (a.seq_host) {
-            __threadfence_system();
-            __hip_atomic_store(a.seq_host + 0, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(a.seq_host + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
-    if (!live) return;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const long i = p0 + j;
-        if (i >= npix) break;
-        if (m & (1u << j)) {
-            a.active_idx[k] = (uint32_t)i;
-            if (a.A22b2 && (long)k < a.max_P) {
-                const double2* q2 = reinterpret_cast<const double2*>(a.pixacc + (size_t)kPixAccStride * i);
-                const double2 a0 = q2[0], a1 = q2[1];
-                const double a4 = a.pixacc[(size_t)kPixAccStride * i + 4];
-                double* q = a.A22b2 + 5 * (size_t)k;
-                const double alpha = a.alpha;
-                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * a.Gx[i]; q[4] = a4 - alpha * a.Gy[i]; }
-                else { q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4; }
-            }
-            ++k;
-        }
-    }
-}
-
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
 __global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)
 {
@@ -1226,11 +1169,11 @@ __device__ __forceinline__ void prep_block(long blk, int32_t* __restrict__ count
 }
 
 // ONE launch in front of the warp kernel (was two: prep, then pose || texel): the three jobs are independent of each other —
-//   blocks [0, n_prep)                  "prep": zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched (`count` still
-//                                       holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels), per-block boxes
-//   blocks [n_prep, n_prep + n_pose)    a2/a3 pose table (pixel order) or the K-1 segment records (tile order)
-//   the remaining n_tex blocks          texel pack inside the rectangle the boxes of the PREVIOUS launch's prep blocks span (one evaluation
-//                                       older than before; a hint only: outside it the warp kernel falls back to the stencil)
+//   n_pose blocks   a2/a3 pose table (pixel order) or the K-1 segment records (tile order)
+//   n_tex blocks    texel pack inside the rectangle the boxes of the PREVIOUS launch's prep blocks span (one evaluation older than before;
+//                   a hint only: outside it the warp kernel falls back to the stencil)
+//   n_prep blocks   "prep": zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched (`count` still holds the
+//                   previous, possibly all-reduced, counts: a superset of the locally touched pixels), per-block boxes
 // The control poses travel BY VALUE in the kernel arguments (K <= kInlineKnots: no staging copy, no dependency on another block);
 // larger K reads them from `knots_dev`, which the host has copied there before the launch.
 // err_next: the status word of the NEXT evaluation, cleared here (this launch's pose threads may already be setting bits of err).
@@ -1245,22 +1188,25 @@ struct PrepPoseTexelParams {
 
 __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexelParams p, InlineKnots kn)
 {
+    // block order = start order: the pose threads first (one long dependent chain each: the launch's critical path), then the texel
+    // blocks, the prep blocks (many, short) fill in behind
     const int b = (int)blockIdx.x;
-    if (b < p.n_prep) {
-        if (b == 0) {
-            if (threadIdx.x == 0) p.err_next[0] = 0;
-            if (p.inline_knots && p.knots_out) for (int i = threadIdx.x; i < 4 * p.K; i += 256) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
-        }
-        prep_block(b, p.count, p.npix, p.pixacc, p.W, p.blk_rect_w);
-    } else if (b < p.n_prep + p.n_pose) {
+    if (b < p.n_pose) {
         if (threadIdx.x < 64) {
             const double* knots = p.inline_knots ? kn.q : p.knots_dev;
-            const int i = (b - p.n_prep) * 64 + threadIdx.x;
+            const int i = b * 64 + threadIdx.x;
             if (p.seg) seg_thread(i, knots, p.K, p.seg);
             else pose_thread(i, p.batch_t_ns, p.nb, knots, p.K, p.t0_ns, p.dt_ns, p.pose, p.err);
         }
+    } else if (b < p.n_pose + p.n_tex) {
+        texel_rect_blocks((long)b - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.blk_rect_r, p.n_prep, p.rect_out, p.texel);
     } else {
-        texel_rect_blocks((long)b - p.n_prep - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.blk_rect_r, p.n_prep, p.rect_out, p.texel);
+        const int pb = b - p.n_pose - p.n_tex;
+        if (pb == 0) {
+            if (threadIdx.x == 0) p.err_next[0] = 0;
+            if (p.inline_knots && p.knots_out) for (int i = threadIdx.x; i < 4 * p.K; i += 256) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
+        }
+        prep_block(pb, p.count, p.npix, p.pixacc, p.W, p.blk_rect_w);
     }
 }
 
@@ -1554,6 +1500,10 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
             iterate(off, xA, xB, To, Te); off += kStride; if (off >= len) break;
             iterate(off, xB, xA, Te, To); off += kStride;
         }
+        // Tried and dropped (round 3, 1 M events): two record stages in flight per wave (three buffers of 24 records, tags / activity words
+        // one step further ahead, stage 0 fetched unmasked beside its tags): 33.0 us against 30.9.  Ablation of the 30.9 us: the MFMAs
+        // themselves ~4.7 (375 k v_mfma_f64_16x16x4 at 64 cycles on the chip's 1024 SIMDs is ~10 us of matrix-pipe time, half of it hidden),
+        // the global flush ~3.7, the stream + its dependent start the remaining ~22.
     } else {
     // No tag stream (tile order): the activity bits of a stage can only be looked up once its records are here, and loads return in
     // order.  Four stages rotate through registers: per iteration the lookups of stage i+1 (whose records arrived an iteration ago)
@@ -1626,22 +1576,6 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
 
 template <bool TAGS>
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p) { gram_body<TAGS, kGramBlock>(p, blockIdx.x); }
-
-// The fused single-GPU step's last launch: active-set write || Gram.  Both depend only on launch A (per-block counts, activity bits, cleared
-// head), so the 10-us active-set write hides behind the 30-us Gram kernel instead of standing in front of it.  Workgroups of 512 threads
-// (two fit a CU at the Gram body's register count): in the first 2 * min(n_aw, n_gram) workgroups the roles alternate, so that every CU
-// starts with one of each; the rest of the longer role follows.
-constexpr int kFusedBlock = 512;
-template <bool TAGS>
-__global__ __launch_bounds__(kFusedBlock) void emba_aw_gram_kernel(ActiveWriteParams a, GramParams g, int n_aw, int n_gram)
-{
-    const int b = (int)blockIdx.x, both = 2 * (n_aw < n_gram ? n_aw : n_gram);
-    bool is_aw; int idx;
-    if (b < both) { is_aw = (b & 1) != 0; idx = b >> 1; }
-    else { is_aw = n_aw > n_gram; idx = b - both + (both >> 1); }
-    if (is_aw) active_write_multi<kFusedBlock / 256>(idx, a);
-    else gram_body<TAGS, kFusedBlock>(g, idx);
-}
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.

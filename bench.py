@@ -120,6 +120,9 @@ def main():
                     help="uniform: SURVEY §8d's i.i.d. events (the BASELINE workload).  scene: events an ideal event camera fires while "
                          "rotating in front of an analytic scene (edge-clustered, polarity-consistent; emba_amd.synth.simulate_events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-ep", action="store_true",
+                    help="also time the step WITH the compaction of the residuals into the reference-order ep vector (what the one-shot "
+                         "drop-in entry point emba_eval_data_error always produces); reported as config.with_ep_ms_per_step, never as value")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of the N-rank launch on a ONE-GPU box: every rank uses device 0 and the collectives go through gloo "
                          "(RCCL refuses two ranks on one device); exercises the launcher, the sharding and the protocol, not xGMI")
@@ -242,6 +245,16 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    with_ep_ms = None
+    if args.with_ep:
+        barrier()
+        t_e = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            m.compact_ep()
+        barrier()
+        with_ep_ms = (time.perf_counter() - t_e) / args.steps * 1e3
+
     # the exchanges alone (same buffers, same sizes, same stream), untimed w.r.t. `value`: what a step spends in collectives
     coll_ms = None
     if use_dist:
@@ -272,7 +285,7 @@ def main():
                        "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
                                "(the host API's compacted ep vector is produced when it is asked for)",
                        "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
-                       "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms,
+                       "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms, "with_ep_ms_per_step": with_ep_ms,
                        "backend": ("gloo, all ranks on device 0 (rehearsal)" if args.one_device else "rccl") if use_dist else None,
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
                        "setup": m.setup_info()},

@@ -46,6 +46,7 @@ SIGNATURES = {
     "emba_form_normal_eq": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_double, C.c_double, _dp, _dp, _szp, _u32p,
                                       C.c_size_t, _dp, _dp, _dp]),
     "emba_get_A12_sparse": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _dp, _dp, _dp, _dp]),
+    "emba_compact_ep": (C.c_int, [C.c_void_p]),
     "emba_get_inlier_pixels": (C.c_int, [C.c_void_p, _u32p]),
     "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
     "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),

@@ -138,7 +138,7 @@ struct emba_ctx {
     hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
     bool kt_warp_valid = false, kt_accum_valid = false;
     int n_cu = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
-    int ablate = 0;  // EMBA_ABLATE diagnostics bitmask (results are WRONG when non-zero)
+    int ablate = 0;  // diagnostics builds only (-DEMBA_DIAG): EMBA_ABLATE bit mask; always 0 in the shipped library
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     int solve_info = 0;         // last Schur solve: bit 0 a 2x2 block not positive definite (error), bit 1 a pivot of S vanished (zero update, like Eigen's ldlt)
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
@@ -601,7 +601,11 @@ int emba_abi_version(void) { return EMBA_ABI_VERSION; }
 
 const char* emba_build_info(void)
 {
+#ifdef EMBA_DIAG
+    return "emba_hip: HIP/gfx950 (CDNA4, wave64) kernels, fp64, DIAGNOSTICS build (EMBA_ABLATE honoured: results may be wrong), built " __DATE__ " " __TIME__;
+#else
     return "emba_hip: HIP/gfx950 (CDNA4, wave64) kernels, fp64, built " __DATE__ " " __TIME__;
+#endif
 }
 
 const char* emba_last_error(const emba_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
@@ -634,7 +638,9 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->fx = (double)((c->W / 360.0) * 180.0 / M_PI);
     c->fy = (double)((c->H / 180.0) * 180.0 / M_PI);
     c->cx = (double)c->W / 2.0; c->cy = (double)c->H / 2.0;
-    if (const char* ab = getenv("EMBA_ABLATE")) c->ablate = atoi(ab);
+#ifdef EMBA_DIAG
+    if (const char* ab = getenv("EMBA_ABLATE")) { c->ablate = atoi(ab); if (c->ablate) fprintf(stderr, "emba_hip: DIAGNOSTICS build, EMBA_ABLATE=%d: results are WRONG\n", c->ablate); }
+#endif
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
@@ -1365,6 +1371,15 @@ emba_status emba_get_A12_sparse(emba_ctx* c, int32_t* cp_c, int32_t* cp_p, int32
     dev_free(c, d_c); dev_free(c, d_p); dev_free(c, d_x); dev_free(c, d_w); dev_free(c, d_jc); dev_free(c, d_jp); dev_free(c, d_dp);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "get_A12_sparse: %s", hipGetErrorString(e));
     return EMBA_OK;
+}
+
+emba_status emba_compact_ep(emba_ctx* c)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->inl_idx_valid = false;      // (asked for explicitly: produce it for THIS call)
+    return ensure_inl_idx(c);
 }
 
 emba_status emba_get_inlier_pixels(emba_ctx* c, uint32_t* pix_host)

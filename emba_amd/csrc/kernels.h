@@ -20,6 +20,15 @@
 
 #include "device_math.h"
 
+// Development ablations (EMBA_ABLATE bit mask: parts of a kernel switched off to see what they cost; results are WRONG when non-zero)
+// exist only in a diagnostics build (-DEMBA_DIAG, scripts/ablate*.sh build one under build_variants/): the shipped library has none of
+// the branches and does not read the variable.
+#ifdef EMBA_DIAG
+#define EMBA_ABL(word, bit) (((word) & (bit)) != 0)
+#else
+#define EMBA_ABL(word, bit) false
+#endif
+
 namespace emba {
 
 constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
@@ -358,7 +367,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
         if (COMPACT) {   // tile order: pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
             // (the K-1 segment records are cache-resident and fetched here, next to the bearing-vector gather whose latency is paid anyway:
             // prefetched with the event words they cost 24 VGPRs per pipeline stage)
-            const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * ((p.ablate & 16) ? (bi & 1u) : bi));
+            const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * (EMBA_ABL(p.ablate, 16) ? (bi & 1u) : bi));
             const double2 s0 = S2[0], s1 = S2[1], s2 = S2[2], s3 = S2[3], s4 = S2[4], s5 = S2[5];
             const double seg[kSegStride] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, s4.x, s4.y, s5.x, s5.y};
             double q[4];
@@ -438,7 +447,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
             pmx = (int)rx; pmy = (int)ry;
             pi = (uint32_t)pmy * (uint32_t)p.W + (uint32_t)pmx;
             double gx = 0.01, gy = 0.02, gxx = 0.001, gxy = 0.002, gyy = 0.003;
-            if (!(p.ablate & 4)) {
+            if (!EMBA_ABL(p.ablate, 4)) {
                 bool use_tex = p.texel != nullptr;
                 if (use_tex && p.rect_acc) {
                     int x0, y0, x1, y1;
@@ -527,10 +536,10 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
         for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
             const int rr = r0 + (t >> 3);
-            if (rr < n_rec && !(p.ablate & 2))
+            if (rr < n_rec && !EMBA_ABL(p.ablate, 2))
             {
                 typedef double v2d __attribute__((ext_vector_type(2)));
-                v2d* dst = reinterpret_cast<v2d*>(p.rec + (size_t)kRecStride * ((p.ablate & 32) ? (s_slot[rr] & 8191u) : s_slot[rr])) + c8;
+                v2d* dst = reinterpret_cast<v2d*>(p.rec + (size_t)kRecStride * (EMBA_ABL(p.ablate, 32) ? (s_slot[rr] & 8191u) : s_slot[rr])) + c8;
                 const v2d val = reinterpret_cast<const v2d*>(s_tile + rr * kRecLds)[c8];
 #if REC_NT_STORE
                 __builtin_nontemporal_store(val, dst);
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     // only receives a plain store of a non-zero MARKER here ("this pixel was touched"); emba_post_warp_a_kernel (or
     // emba_count_materialise_kernel when someone needs the map earlier) replaces markers by the counts from the lines.
     // Run sums are compacted through LDS and sent 10 pixels = 60 lanes per atomic instruction.
-    if (emit && !(p.ablate & 1)) p.count[pi] = 1;
+    if (emit && !EMBA_ABL(p.ablate, 1)) p.count[pi] = 1;
     {
         const int n_emit = __popcll(emit_mask);
         if (emit) {
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
         const int r10 = t / 6, comp = t - 6 * r10;
         for (int g = 0; g < n_emit; g += 10) {                           // wave-uniform trip count
             const int k = g + r10;
-            if (t < 60 && k < n_emit && !(p.ablate & 8))
+            if (t < 60 && k < n_emit && !EMBA_ABL(p.ablate, 8))
                 atomicAdd(p.pixacc + (size_t)kPixAccStride * s_q[k] + comp, s_acc[6 * k + comp]);
         }
     }
@@ -673,7 +682,7 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 outside = !(lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH);
                 if (!outside) {
                     const int q = ly * kTileW + lx;
-                    if (!(p.ablate & 8)) {
+                    if (!EMBA_ABL(p.ablate, 8)) {
                         atomicAdd(&s_sum[0][q], o.v0); atomicAdd(&s_sum[1][q], o.v1); atomicAdd(&s_sum[2][q], o.v2);
                         atomicAdd(&s_sum[3][q], o.v3); atomicAdd(&s_sum[4][q], o.v4); atomicAdd(&s_sum[5][q], 1.0);
                     }
@@ -714,8 +723,8 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 const int qq = s_list[wv][k];
                 const int gy = ch.y0 + qq / kTileW, gx = ch.x0 + qq % kTileW;
                 const size_t pi = (size_t)gy * p.W + gx;
-                if (comp == 0 && !(p.ablate & 1)) p.count[pi] = 1;
-                if (!(p.ablate & 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
+                if (comp == 0 && !EMBA_ABL(p.ablate, 1)) p.count[pi] = 1;
+                if (!EMBA_ABL(p.ablate, 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
             }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1235,7 +1244,7 @@ struct GramParams {
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
 __device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, double* A11, double* b1, int dim, int ablate)
 {
-    if (row >= 12 || v == 0.0 || (ablate & 32)) return;
+    if (row >= 12 || v == 0.0 || EMBA_ABL(ablate, 32)) return;
     const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
     const int grow = (row < 6) ? bc + row : bp + row - 6;
     if (col < 12) {
@@ -1361,7 +1370,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
             const uint32_t pi = rec_elem15_lo(x[u]);
             const bool in = off + 8 * u + R < len;
             const bool valid = in && rec_elem15_hi(x[u]) == p.stamp && pi != kInvalidPix;
-            act[u] = valid ? ((p.ablate & 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31) : 0u;
+            act[u] = valid ? (EMBA_ABL(p.ablate, 256) ? ~0u : p.active_bits[pi >> 5]) >> (pi & 31) : 0u;
         }
     };
     auto weight = [&](const double2& x) {
@@ -1383,7 +1392,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
                 const double ax = ok ? w * x[u].x : 0.0, ay = ok ? w * x[u].y : 0.0, bx = ok ? x[u].x : 0.0, by = ok ? x[u].y : 0.0;
                 if (__ballot(ok)) {
                     dirty = true;
-                    if (!(p.ablate & 64)) {
+                    if (!EMBA_ABL(p.ablate, 64)) {
                         acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
                         acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
                         acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
@@ -1417,7 +1426,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
                 if (__ballot(use)) {
                     dirty = true;
                     const double ax = use ? w * y[0].x : 0.0, ay = use ? w * y[0].y : 0.0, bx = use ? y[0].x : 0.0, by = use ? y[0].y : 0.0;
-                    if (!(p.ablate & 64)) {
+                    if (!EMBA_ABL(p.ablate, 64)) {
                         acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
                         acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
                         acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
@@ -1448,7 +1457,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
         };
         auto bitword = [&](int off, double tg) -> uint32_t { return p.active_bits[tagvalid(off, tg) ? ((uint32_t)__double2loint(tg) >> 5) : 0u]; };
         auto bitmask = [&](int off, double tg, uint32_t w) -> uint32_t {
-            const uint32_t bit = (((p.ablate & 256) ? ~0u : w) >> ((uint32_t)__double2loint(tg) & 31u)) & (tagvalid(off, tg) ? 1u : 0u);
+            const uint32_t bit = ((EMBA_ABL(p.ablate, 256) ? ~0u : w) >> ((uint32_t)__double2loint(tg) & 31u)) & (tagvalid(off, tg) ? 1u : 0u);
             return (uint32_t)__ballot(bit != 0);
         };
         // (GRAM_DUMMY_LOADS: a record that does not take part is "loaded" from one fixed line instead — the block's first record, a cache
@@ -1536,7 +1545,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
         for (int u = 0; u < U; ++u) {
             const uint32_t pi = rec_elem15_lo(x[u]);
             const bool valid = (off + 8 * u + R < len) && rec_elem15_hi(x[u]) == p.stamp && pi != kInvalidPix;
-            act[u] = (((p.ablate & 256) ? ~0u : w[u]) >> (pi & 31)) & (valid ? 1u : 0u);
+            act[u] = ((EMBA_ABL(p.ablate, 256) ? ~0u : w[u]) >> (pi & 31)) & (valid ? 1u : 0u);
         }
     };
     // one iteration: stage i in `cur` (its lookups in a_cur / f_cur, l_cur), stage i+1 in `nxt`, stage i+3 goes to `fre`

@@ -403,6 +403,10 @@ class LEGM:
         self._P = b_.value
         return a_.value, b_.value
 
+    def compact_ep(self):
+        """Enqueue the residual compaction into the reference-order `ep` vector on the device (emba_compact_ep)."""
+        self._check(self._L.emba_compact_ep(self._ctx))
+
     def sync(self):
         self._check(self._L.emba_sync(self._ctx))
 

@@ -155,6 +155,11 @@ emba_status emba_form_normal_eq(emba_ctx* ctx, const double* ep, int32_t thres_v
 emba_status emba_get_A12_sparse(emba_ctx* ctx, int32_t* cp_c, int32_t* cp_p, int32_t* pix, double* w,
                                 double* jc /*n*6*/, double* jp /*n*6*/, double* dp /*n*2*/);
 
+/* Enqueue the compaction of the last evaluation's residuals into the reference-order vector `ep` (model.cpp:221,256) and the per-event inlier
+ * numbers, on the device.  The resident step leaves this to whoever asks for `ep` (nothing on the device reads it); the one-shot
+ * emba_eval_data_error always pays for it.  bench.py --with-ep times a step with it. */
+emba_status emba_compact_ep(emba_ctx* ctx);
+
 /* Sensor pixel (y * sensor_w + x) of every inlier measurement of the last evaluation, in the order of ep (sensor pixel major, then time;
  * model.cpp:179-186): pix_host has capacity n_inliers.  What a multi-GPU host merges the ranks' residual vectors by (emba_group_eval). */
 emba_status emba_get_inlier_pixels(emba_ctx* ctx, uint32_t* pix_host);

@@ -1,3 +1,6 @@
+# (needs a diagnostics build: the shipped library has no ablation hooks)
+mkdir -p build_variants && [ -f build_variants/diag.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DEMBA_DIAG emba_amd/csrc/emba_hip.hip -o build_variants/diag.so
+export EMBA_LIB=$PWD/build_variants/diag.so
 # diagnostics: per-kernel times under EMBA_ABLATE bitmasks (results are wrong when non-zero; timing only)
 mkdir -p gpurun_out; rm -f gpurun_out/ablate.log
 for a in ${ABLATES:-0 1 2 4 8 15 32 64 96}; do

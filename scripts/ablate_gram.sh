@@ -1,3 +1,6 @@
+# (needs a diagnostics build: the shipped library has no ablation hooks)
+mkdir -p build_variants && [ -f build_variants/diag.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DEMBA_DIAG emba_amd/csrc/emba_hip.hip -o build_variants/diag.so
+export EMBA_LIB=$PWD/build_variants/diag.so
 # development: Gram kernel anatomy at the BASELINE workload (EMBA_ABLATE bits: 32 no flush atomics, 64 no MFMA, 256 no activity lookups; results are WRONG)
 for a in 0 32 64 256 288 352; do
   EMBA_ABLATE=$a timeout -k 10 200 python bench.py --steps ${STEPS:-200} --warmup 3 --no-cpu-baseline $ARGS 2>/dev/null | python -c "

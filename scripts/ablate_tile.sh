@@ -1,3 +1,6 @@
+# (needs a diagnostics build: the shipped library has no ablation hooks)
+mkdir -p build_variants && [ -f build_variants/diag.so ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DEMBA_DIAG emba_amd/csrc/emba_hip.hip -o build_variants/diag.so
+export EMBA_LIB=$PWD/build_variants/diag.so
 # anatomy of the tiled warp kernel by ablation (EMBA_ABLATE bits: 1 no marker, 2 no record stores, 4 no texel gather, 8 no per-pixel sums,
 # 16 static camera = pose gathers hit two records); results are WRONG when non-zero, only the kernel time is read
 mkdir -p gpurun_out; rm -f gpurun_out/ablate_tile.log

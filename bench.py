@@ -123,6 +123,11 @@ def main():
     ap.add_argument("--with-ep", action="store_true",
                     help="also time the step WITH the compaction of the residuals into the reference-order ep vector (what the one-shot "
                          "drop-in entry point emba_eval_data_error always produces); reported as config.with_ep_ms_per_step, never as value")
+    ap.add_argument("--shard-of", type=int, default=1,
+                    help="time ONE rank's shard of a window sharded over this many GPUs, on one GPU and without collectives: the global stream has "
+                         "shard-of x events-per-gpu events, the rank holds its time range + per-pixel halo (what each GPU of configs 4 / 5 computes)")
+    ap.add_argument("--shard-rank", type=int, default=0)
+    ap.add_argument("--yaw-rate", type=float, default=0.5)
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of the N-rank launch on a ONE-GPU box: every rank uses device 0 and the collectives go through gloo "
                          "(RCCL refuses two ranks on one device); exercises the launcher, the sharding and the protocol, not xGMI")
@@ -161,14 +166,14 @@ def main():
     from emba_amd.sharded import HipEngine, ShardedLEGM
     from emba_amd.synth import make_workload
 
-    n_total = args.events_per_gpu * world
+    n_total = args.events_per_gpu * world * max(args.shard_of, 1)
     sw, sh_ = (int(v) for v in args.sensor.lower().split("x"))
     if args.data == "scene":
         from emba_amd.synth import make_scene_stream
         w = make_scene_stream(n_total, pano_h=args.pano_h, K=args.knots, sensor=(sw, sh_), focal=200.0 * sw / 240.0)
         n_total = w.events.size()
     else:
-        w = make_workload(n_events=n_total, pano_h=args.pano_h, K=args.knots, sensor=(sw, sh_), focal=200.0 * sw / 240.0)
+        w = make_workload(n_events=n_total, pano_h=args.pano_h, K=args.knots, sensor=(sw, sh_), focal=200.0 * sw / 240.0, yaw_rate=args.yaw_rate)
     npix = w.pano_h * w.pano_w
 
     # One explicit (non-null) HIP stream for our kernels AND for torch/RCCL, so that launches and collectives are ordered.
@@ -193,7 +198,14 @@ def main():
     sh = ShardedLEGM(HipEngine(m), _Dist, count_t, pack_t, w.sensor_w, count_u8)
     sh.force_collectives = args.force_collectives
     t_set = time.perf_counter()
-    local = sh.set_events(w.events)
+    if args.shard_of > 1:
+        from emba_amd.sharded import shard_events
+        assert world == 1, "--shard-of times one rank's shard on one GPU"
+        local, halo = shard_events(w.events, w.sensor_w, args.shard_rank, args.shard_of)
+        sh.engine.set_events(local, halo); sh.n_local = local.size(); sh.n_max = local.size()
+        n_total = local.size()
+    else:
+        local = sh.set_events(w.events)
     m.upload_map(w.Gx, w.Gy)                                 # HBM-resident before the timed region
     m.sync()
     t_set = time.perf_counter() - t_set
@@ -284,7 +296,7 @@ def main():
                        "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
                        "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
                                "(the host API's compacted ep vector is produced when it is asked for)",
-                       "parallelism": f"time-sharded x{world}" if world > 1 else "single GPU",
+                       "parallelism": f"time-sharded x{world}" if world > 1 else (f"shard {args.shard_rank} of {args.shard_of} of the window, one GPU, no collectives" if args.shard_of > 1 else "single GPU"),
                        "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms, "with_ep_ms_per_step": with_ep_ms,
                        "backend": ("gloo, all ranks on device 0 (rehearsal)" if args.one_device else "rccl") if use_dist else None,
                        "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),

@@ -305,3 +305,66 @@ def test_eight_ranks_at_full_shard_size(oracle_mod, name, n_total, sensor, pano_
         assert results[r]["cost0"] == pytest.approx(cost0, rel=1e-9) and results[r]["cost1"] == pytest.approx(cost1, rel=1e-7)
         assert (results[r]["cost1"] < results[r]["cost0"]) == (cost1 < cost0), "LM decision differs"
     assert all(np.array_equal(results[0]["x1"], results[r]["x1"]) for r in range(1, world)), "the replicated solve must be identical on every rank"
+
+
+def test_group_of_eight_on_one_device_step_rate(oracle_mod):
+    """emba_group_* with eight ranks on ONE device (devices = {0 x 8}): the SCALE workload (8 x 1 M events) through the
+    single-process host — rank threads issue the launches side by side, P is taken once, the exchanges go through the in-library copies —
+    must give the oracle's inlier count and active set size, and a group step must not cost more than 1.3 x eight single-context steps of
+    one shard (the GPU work of eight ranks on one device is serial; the host side must hide behind it)."""
+    import ctypes as C
+    import time
+    import torch
+    assert torch.cuda.is_available()
+    from emba_amd import LEGM, _lib
+    from emba_amd.sharded import shard_events
+    from emba_amd.synth import make_workload
+    L = _lib.load()
+    world = 8
+    w = make_workload(n_events=8_000_000, pano_h=1024, K=21)
+    lut = np.ascontiguousarray(w.lut, dtype=np.float64)
+    cfg = _lib.EmbaCfg(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, lut.ctypes.data_as(_lib._dp), float(w.C_th), 100, 10.0, 0, None)
+    g = C.c_void_p()
+    dev = (C.c_int32 * world)(*([0] * world))
+    assert L.emba_group_create(C.byref(cfg), dev, world, C.byref(g)) == 0, L.emba_group_last_error(None)
+    try:
+        ev = w.events
+        x = np.ascontiguousarray(ev.x, np.uint16); y = np.ascontiguousarray(ev.y, np.uint16); pol = np.ascontiguousarray(ev.polarity, np.uint8)
+        t = np.ascontiguousarray(ev.t_ns, np.int64)
+        assert L.emba_group_set_events(g, x.ctypes.data_as(_lib._u16p), y.ctypes.data_as(_lib._u16p), pol.ctypes.data_as(_lib._u8p), t.ctypes.data_as(_lib._i64p), x.size) == 0
+        Gx = np.ascontiguousarray(w.Gx); Gy = np.ascontiguousarray(w.Gy)
+        assert L.emba_group_upload_map(g, Gx.ctypes.data_as(_lib._dp), Gy.ctypes.data_as(_lib._dp)) == 0
+        knots = np.ascontiguousarray(w.traj.knots_xyzw, np.float64)
+        n_inl, P = C.c_size_t(0), C.c_size_t(0)
+
+        def gstep():
+            st = L.emba_group_step(g, knots.ctypes.data_as(_lib._dp), w.K, int(w.traj.t0_ns), int(w.traj.dt_ns), w.thres_valid_pixel, 0, 0.0, w.alpha, C.byref(n_inl), C.byref(P))
+            assert st == 0, L.emba_group_last_error(g)
+        for _ in range(5):
+            gstep()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gstep()
+        t_group = (time.perf_counter() - t0) / 20
+    finally:
+        L.emba_group_destroy(g)
+    # eight single-context steps of one shard (rank 3's: 1 M events + halo)
+    local, halo = shard_events(w.events, w.sensor_w, 3, world)
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    m.set_events(local, halo); m.upload_map(w.Gx, w.Gy)
+    for _ in range(5):
+        m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    t0 = time.perf_counter()
+    for _ in range(40):
+        m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    t_single = (time.perf_counter() - t0) / 40
+    m.close()
+    o = oracle_mod.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+    oracle_mod.set_threads(min(oracle_mod.max_threads(), 16))
+    try:
+        ep_o, nem_o = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns)
+    finally:
+        oracle_mod.set_threads(1)
+    assert n_inl.value == ep_o.size and P.value == int((nem_o >= w.thres_valid_pixel).sum())
+    print(f"group step {t_group * 1e6:.0f} us  vs  8 x single-context shard step {8 * t_single * 1e6:.0f} us  (ratio {t_group / (8 * t_single):.2f})")
+    assert t_group <= 1.3 * 8 * t_single, (t_group, t_single)

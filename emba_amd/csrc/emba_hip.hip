@@ -145,6 +145,7 @@ struct emba_ctx {
     struct { void* p = nullptr; size_t bytes = 0; } ws[32];   // 0-15 Schur solve, 16-31 sort / order preparation
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
     double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
+    double* d_thomas = nullptr;   // Thomas factors of T_W + lambda1[i] I (W x H)
 };
 
 namespace {
@@ -1983,16 +1984,25 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
     const int H = c->H, W = c->W;
     const size_t npix = c->npix;
     emba_status st;
-    if (!c->d_SH) {   // first use: S_H, S_W, eigenvalues, two scratch planes
-        if ((st = dev_alloc(c, &c->d_SH, (size_t)H * H)) || (st = dev_alloc(c, &c->d_SW, (size_t)W * W)) || (st = dev_alloc(c, &c->d_lamH, (size_t)H)) ||
-            (st = dev_alloc(c, &c->d_lamW, (size_t)W)) || (st = dev_alloc(c, &c->d_pF, npix)) || (st = dev_alloc(c, &c->d_pT, npix))) {
-            dev_free(c, c->d_SH); dev_free(c, c->d_SW); dev_free(c, c->d_lamH); dev_free(c, c->d_lamW); dev_free(c, c->d_pF); dev_free(c, c->d_pT);
+    // EMBA_POISSON=dense: both axes by sine-matrix products (four GEMMs: the round-1/2 form, kept for comparison); default: Fourier analysis
+    // along H only + tridiagonal solves along W (poisson_kernels.h) — a third of the arithmetic, same solution to rounding.
+    const bool dense = getenv("EMBA_POISSON") && !strcmp(getenv("EMBA_POISSON"), "dense");
+    if (!c->d_SH) {   // first use: S_H, its eigenvalues, two scratch planes
+        if ((st = dev_alloc(c, &c->d_SH, (size_t)H * H)) || (st = dev_alloc(c, &c->d_lamH, (size_t)H)) || (st = dev_alloc(c, &c->d_pF, npix)) || (st = dev_alloc(c, &c->d_pT, npix))) {
+            dev_free(c, c->d_SH); dev_free(c, c->d_lamH); dev_free(c, c->d_pF); dev_free(c, c->d_pT);
             return st;
         }
         hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)H * H + 255) / 256)), dim3(256), 0, s, H, c->d_SH);
-        hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)W * W + 255) / 256)), dim3(256), 0, s, W, c->d_SW);
         hipLaunchKernelGGL(emba_dirichlet_eigen_kernel, dim3((H + 255) / 256), dim3(256), 0, s, H, c->d_lamH);
+    }
+    if (dense && !c->d_SW) {
+        if ((st = dev_alloc(c, &c->d_SW, (size_t)W * W)) || (st = dev_alloc(c, &c->d_lamW, (size_t)W))) { dev_free(c, c->d_SW); dev_free(c, c->d_lamW); return st; }
+        hipLaunchKernelGGL(emba_sine_matrix_kernel, dim3((unsigned)(((size_t)W * W + 255) / 256)), dim3(256), 0, s, W, c->d_SW);
         hipLaunchKernelGGL(emba_dirichlet_eigen_kernel, dim3((W + 255) / 256), dim3(256), 0, s, W, c->d_lamW);
+    }
+    if (!dense && !c->d_thomas) {   // Thomas factors of T_W + lambda1[i] I for every H-frequency i: W x H doubles, once
+        if ((st = dev_alloc(c, &c->d_thomas, npix))) return st;
+        hipLaunchKernelGGL(emba_thomas_coef_kernel, dim3((H + 63) / 64), dim3(64), 0, s, c->d_lamH, H, W, c->d_thomas);
     }
     const double *gx = c->d_Gx, *gy = c->d_Gy;
     if (Gx_host) {
@@ -2002,21 +2012,33 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         gx = c->d_pGx; gy = c->d_pGy;
     }
     hipLaunchKernelGGL(emba_divergence_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, gx, gy, H, W, c->d_pF);
-    auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue) {
+    auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue, double inv_norm) {
         GemmParams p{};
         p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N;
-        p.epilogue = epilogue; p.inv_norm = 1.0 / (4.0 * ((double)(H + 1) * (double)(W + 1)));   // fft_norm, laplace.cpp:648
+        p.epilogue = epilogue; p.inv_norm = inv_norm;
         p.lam1 = c->d_lamH; p.lam2 = c->d_lamW;
         p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
         const long tm = (M + kGemmBM - 1) / kGemmBM, wide = tm * ((N + 127) / 128), narrow = tm * ((N + 63) / 64);
         if (wide >= 2L * c->n_cu) hipLaunchKernelGGL(emba_dgemm_kernel<128>, dim3((unsigned)grid8(wide)), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(emba_dgemm_kernel<64>, dim3((unsigned)grid8(narrow)), dim3(256), 0, s, p);
     };
-    // rhs -> eigenvector space, solve, back (laplace.cpp:633-758):  M = S_H ((S_H F S_W) o C) S_W
-    gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0);      // T = F S_W
-    gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 1);      // U = (S_H T / fft_norm) / (lambda1 + lambda2)
-    gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0);      // T = U S_W
-    gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 0);      // M = S_H T
+    if (dense) {
+        // rhs -> eigenvector space, solve, back (laplace.cpp:633-758):  M = S_H ((S_H F S_W) o C) S_W
+        const double inv_norm = 1.0 / (4.0 * ((double)(H + 1) * (double)(W + 1)));   // fft_norm, laplace.cpp:648
+        gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0, 1.0);            // T = F S_W
+        gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 1, inv_norm);       // U = (S_H T / fft_norm) / (lambda1 + lambda2)
+        gemm(c->d_pF, c->d_SW, c->d_pT, H, W, W, 0, 1.0);            // T = U S_W
+        gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 0, 1.0);            // M = S_H T
+    } else {
+        const dim3 tg((W + 31) / 32, (H + 31) / 32), tgT((H + 31) / 32, (W + 31) / 32);
+        hipLaunchKernelGGL(emba_transpose_kernel, tg, dim3(256), 0, s, c->d_pF, H, W, c->d_pT);                       // F^T  (W x H)
+        gemm(c->d_pT, c->d_SH, c->d_pF, W, H, H, 0, 1.0);                                                                // (S_H F)^T = F^T S_H
+        const unsigned tb = (unsigned)((H + kTriSys - 1) / kTriSys);
+        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<false>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);   // (T_W + lambda1[i] I) x = g, per i
+        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<true>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);
+        gemm(c->d_pF, c->d_SH, c->d_pT, W, H, H, 2, 1.0 / (2.0 * (double)(H + 1)));                                    // M^T = X^T S_H / (2 (H+1))
+        hipLaunchKernelGGL(emba_transpose_kernel, tgT, dim3(256), 0, s, c->d_pT, W, H, c->d_pF);                      // M
+    }
     HIP_TRY(c, hipGetLastError());
     if (M_host) HIP_TRY(c, hipMemcpyAsync(M_host, c->d_pF, npix * sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));

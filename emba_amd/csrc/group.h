@@ -14,6 +14,8 @@
 #pragma once
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -36,6 +38,19 @@ __global__ void emba_add_u8_kernel(uint8_t* __restrict__ dst, const uint8_t* __r
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = (uint8_t)(dst[i] + src[i]);
+}
+
+// ranks that share a device: every buffer <- the sum of all of them, in one launch (n <= kLocalMax)
+constexpr int kLocalMax = 16;
+template <typename T> struct LocalBufs { T* p[kLocalMax]; int n; };
+template <typename T>
+__global__ void emba_sum_all_kernel(LocalBufs<T> b, long count)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    T acc = b.p[0][i];
+    for (int r = 1; r < b.n; ++r) acc = (T)(acc + b.p[r][i]);
+    for (int r = 0; r < b.n; ++r) b.p[r][i] = acc;
 }
 
 }  // namespace emba
@@ -80,10 +95,16 @@ struct RankPool {
     int n = 0;
     std::vector<std::thread> th;
     std::mutex mu;
-    std::condition_variable cv_go, cv_done;
+    std::condition_variable cv_go;
     std::function<emba_status(int)> job;
     std::vector<emba_status> st;
-    long gen = 0; int remaining = 0; bool stop = false;
+    std::atomic<long> gen{0};
+    std::atomic<int> remaining{0};
+    std::atomic<bool> stop{false};
+    // A step is a handful of fork-joins a few tens of microseconds apart: the workers spin on the generation counter for a while before they
+    // go to sleep on the condition variable (a futex wake-up per rank and phase would cost more than the phase's launches), the caller
+    // spins on the completion count.
+    static constexpr int kSpin = 20000;
     void start(int n_, const std::vector<int>& dev)
     {
         n = n_; st.assign(n, EMBA_OK);
@@ -92,25 +113,34 @@ struct RankPool {
                 (void)hipSetDevice(d);
                 long seen = 0;
                 for (;;) {
-                    std::function<emba_status(int)> f;
-                    { std::unique_lock<std::mutex> lk(mu); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
-                    const emba_status s = f(r);
-                    { std::lock_guard<std::mutex> lk(mu); st[r] = s; if (--remaining == 0) cv_done.notify_all(); }
+                    int spins = 0;
+                    while (gen.load(std::memory_order_acquire) == seen && !stop.load(std::memory_order_relaxed)) {
+                        if (++spins < kSpin) { __builtin_ia32_pause(); continue; }
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv_go.wait_for(lk, std::chrono::milliseconds(50), [&] { return stop.load() || gen.load() != seen; });
+                    }
+                    if (stop.load()) return;
+                    seen = gen.load(std::memory_order_acquire);
+                    st[r] = job(r);
+                    remaining.fetch_sub(1, std::memory_order_acq_rel);
                 }
             });
     }
     emba_status run(const std::function<emba_status(int)>& f)
     {
         if (th.empty()) { for (int r = 0; r < n; ++r) { const emba_status s = f(r); if (s) return s; } return EMBA_OK; }
-        { std::lock_guard<std::mutex> lk(mu); job = f; remaining = n; ++gen; }
+        job = f;
+        remaining.store(n, std::memory_order_release);
+        { std::lock_guard<std::mutex> lk(mu); gen.fetch_add(1, std::memory_order_acq_rel); }
         cv_go.notify_all();
-        { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return remaining == 0; }); }
+        while (remaining.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
         for (int r = 0; r < n; ++r) if (st[r]) return st[r];
         return EMBA_OK;
     }
     void shutdown()
     {
-        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        stop.store(true);
+        { std::lock_guard<std::mutex> lk(mu); }
         cv_go.notify_all();
         for (auto& t : th) if (t.joinable()) t.join();
         th.clear();
@@ -203,11 +233,20 @@ emba_status group_allreduce(emba_group* g, void* const* bufs, size_t count, XTyp
         G_NCCL(g, g_rccl.GroupEnd());
         return EMBA_OK;
     }
-    // ranks on one device: rank 0's stream sums everybody's buffer into its own once the producers are done, the others copy it back
+    // ranks on one device: rank 0's stream waits for the producers, ONE kernel leaves the sum in every rank's buffer, the others wait for it
     G_HIP(g, hipSetDevice(g->dev[0]));
     hipStream_t s0 = S(0);
     for (int r = 1; r < g->n; ++r) { G_HIP(g, hipEventRecord(ev[r], S(r))); G_HIP(g, hipStreamWaitEvent(s0, ev[r], 0)); }
     const unsigned grid = (unsigned)((count + 255) / 256);
+    if (g->n <= emba::kLocalMax) {
+        if (t == XType::F64) { emba::LocalBufs<double> b{}; b.n = g->n; for (int r = 0; r < g->n; ++r) b.p[r] = (double*)bufs[r]; hipLaunchKernelGGL(emba::emba_sum_all_kernel<double>, dim3(grid), dim3(256), 0, s0, b, (long)count); }
+        else if (t == XType::I32) { emba::LocalBufs<int32_t> b{}; b.n = g->n; for (int r = 0; r < g->n; ++r) b.p[r] = (int32_t*)bufs[r]; hipLaunchKernelGGL(emba::emba_sum_all_kernel<int32_t>, dim3(grid), dim3(256), 0, s0, b, (long)count); }
+        else { emba::LocalBufs<uint8_t> b{}; b.n = g->n; for (int r = 0; r < g->n; ++r) b.p[r] = (uint8_t*)bufs[r]; hipLaunchKernelGGL(emba::emba_sum_all_kernel<uint8_t>, dim3(grid), dim3(256), 0, s0, b, (long)count); }
+        G_HIP(g, hipGetLastError());
+        G_HIP(g, hipEventRecord(ev0, s0));
+        for (int r = 1; r < g->n; ++r) G_HIP(g, hipStreamWaitEvent(S(r), ev0, 0));
+        return EMBA_OK;
+    }
     for (int r = 1; r < g->n; ++r) {
         if (t == XType::F64) hipLaunchKernelGGL(emba::emba_add_f64_kernel, dim3(grid), dim3(256), 0, s0, (double*)bufs[0], (const double*)bufs[r], (long)count);
         else if (t == XType::I32) hipLaunchKernelGGL(emba::emba_add_i32_kernel, dim3(grid), dim3(256), 0, s0, (int32_t*)bufs[0], (const int32_t*)bufs[r], (long)count);
@@ -413,19 +452,22 @@ emba_status emba_group_set_cost(emba_group* g, int32_t irls, double eta)
 }
 
 // exchange 1 on the count maps of the last evaluation: exact int32 sums, or saturated bytes when the activity threshold allows
-emba_status group_exchange_counts(emba_group* g, int thres, bool exact)
-{
-    if (g->x1_done) return EMBA_OK;
+emba_status group_exchange_counts(emba_group* g, int thres, bool exact, const std::function<emba_status(int)>* after = nullptr)
+{   // after: per-rank work that follows the exchange directly (rides in the same fork-join as the expansion)
+    if (g->x1_done) { if (after) return gpool(g, *after); return EMBA_OK; }
     const int cap = 255 / g->n;
     if (!exact && thres >= 1 && thres <= cap) {   // sum_i min(c_i, cap) >= thres <=> sum_i c_i >= thres, and world * cap <= 255 cannot wrap
         { emba_status st = gpool(g, [&](int r) { return emba_count_compress(g->ctx[r], g->count_u8[r], cap); }); if (st) return st; }
         { emba_status st = group_allreduce(g, (void* const*)g->count_u8.data(), g->npix, XType::U8); if (st) return st; }
-        { emba_status st = gpool(g, [&](int r) { return emba_count_expand(g->ctx[r], g->count_u8[r]); }); if (st) return st; }
+        { emba_status st = gpool(g, [&](int r) { emba_status s1 = emba_count_expand(g->ctx[r], g->count_u8[r]); return (s1 || !after) ? s1 : (*after)(r); }); if (st) return st; }
+        g->x1_done = true;
+        return EMBA_OK;
     } else {
         { emba_status st = gpool(g, [&](int r) { return emba_count_map_ready(g->ctx[r]); }); if (st) return st; }
         { emba_status st = group_allreduce(g, (void* const*)g->count.data(), g->npix, XType::I32); if (st) return st; }
     }
     g->x1_done = true;
+    if (after) return gpool(g, *after);
     return EMBA_OK;
 }
 
@@ -501,12 +543,14 @@ emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double e
         if (P) *P = g->P;
         return EMBA_OK;
     }
-    { emba_status st = group_exchange_counts(g, thres, /*exact=*/false); if (st) return st; }                                               // X1
+    {   // X1, then E2 and F1 (enqueue only) in the fork-join that expands the exchanged counts
+        const std::function<emba_status(int)> e2f1 = [&](int r) {
+            emba_status s1 = emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr);
+            return s1 ? s1 : emba_form_active(g->ctx[r], thres, nullptr, nullptr); };
+        emba_status st = group_exchange_counts(g, thres, /*exact=*/false, &e2f1);
+        if (st) return st;
+    }
     g->x1_done = false;   // (consumed: the next evaluation starts a new count map)
-    { emba_status st = gpool(g, [&](int r) {                                                                                              // E2, F1 (enqueue only)
-          emba_status s1 = emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr);
-          return s1 ? s1 : emba_form_active(g->ctx[r], thres, nullptr, nullptr); });
-      if (st) return st; }
     // the active set comes from the GLOBAL counts: identical on every rank, so rank 0's P sizes exchange 2 (one host wait instead of N)
     size_t pl = 0;
     { size_t ni = 0; G_TRY(g, 0, emba_last_counts(g->ctx[0], &ni, &g->P)); pl = g->ctx[0]->pack_len; }

@@ -58,7 +58,7 @@ __global__ void emba_dirichlet_eigen_kernel(int n, double* __restrict__ lam)
 // doubles per lane).  A and B tiles go global -> registers -> LDS (k-major, so that the operand reads of the MFMA layout — lane l
 // holds element (l&15) at k = l>>4 — are consecutive 8-B words), double-buffered: the next tile's global loads are in flight
 // while the current tile's 4 k-steps x 8 MFMAs run.  12 FLOP per byte loaded from L2; MFMA-bound (fp64 matrix peak 78.6 TFLOP/s).
-// epilogue: 0 plain; 1 Poisson eigen-solve  C = (acc * inv_norm) / (lam1[row] + lam2[col])   (laplace.cpp:667-731)
+// epilogue: 0 plain; 1 Poisson eigen-solve  C = (acc * inv_norm) / (lam1[row] + lam2[col])   (laplace.cpp:667-731); 2 C = acc * inv_norm
 struct GemmParams {
     const double* A; const double* B; double* C; int M, N, K; long lda, ldb, ldc;
     int epilogue; double inv_norm; const double* lam1; const double* lam2;
@@ -168,9 +168,74 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
                 if (row < p.M && col < p.N) {
                     double v = acc[a][b][r];
                     if (p.epilogue == 1) v = (v * p.inv_norm) / (p.lam1[row] + p.lam2[col]);
+                    else if (p.epilogue == 2) v = v * p.inv_norm;
                     p.C[(size_t)p.ldc * row + col] = v;
                 }
             }
+}
+
+// ---- Fourier analysis along ONE axis + tridiagonal solves along the other ------------------------------------------------------------
+// The Dirichlet solve of laplace.cpp:587-797 is  M = S_H ((S_H F S_W) o C) S_W,  C[i][k] = 1 / (4 (H+1)(W+1) (lambda1[i] + lambda2[k])).
+// S_W / sqrt(2 (W+1)) is the orthogonal eigenbasis of the 1-D second-difference operator T_W = tridiag(1, -2, 1), eigenvalues lambda2, so
+//     S_W diag(1 / (lambda1[i] + lambda2)) S_W / (2 (W+1)) = (T_W + lambda1[i] I)^-1
+// and the W-direction transforms are a tridiagonal solve per H-frequency i:   M = S_H X / (2 (H+1)),  X[i][:] = (T_W + lambda1[i] I)^-1 (S_H F)[i][:].
+// Same solution (to rounding), a third of the arithmetic: only the two transforms along the SHORT axis remain.  Everything runs on the
+// transposed planes (W x H: index j * H + i), so that the H-transforms are row-major GEMMs / contiguous vectors and the tridiagonal
+// recurrences over j are coalesced over i.
+__global__ __launch_bounds__(256) void emba_transpose_kernel(const double* __restrict__ src, int rows, int cols, double* __restrict__ dst)
+{   // dst (cols x rows) = src (rows x cols)^T, 32 x 32 tiles through LDS
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const int y = by + r, x = bx + tx; if (y < rows && x < cols) tile[r][tx] = src[(size_t)y * cols + x]; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int y = bx + r, x = by + tx; if (y < cols && x < rows) dst[(size_t)y * rows + x] = tile[tx][r]; }
+}
+
+// Thomas factors of T_W + lambda1[i] I = tridiag(1, beta_i, 1), beta_i = -2 + lambda1[i] < -2 (strictly diagonally dominant: no pivoting):
+// cp[j][i] = 1 / (beta_i - cp[j-1][i]), cp[0][i] = 1 / beta_i.  Once per context (like the sine matrix): W x H doubles.
+__global__ void emba_thomas_coef_kernel(const double* __restrict__ lam1, int H, int W, double* __restrict__ cp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H) return;
+    const double beta = -2.0 + lam1[i];
+    double c = 1.0 / beta;
+    cp[i] = c;
+    for (int j = 1; j < W; ++j) { c = 1.0 / (beta - c); cp[(size_t)j * H + i] = c; }
+}
+
+// One sweep of the Thomas algorithm over j for every system i, in place on the transposed plane:
+//   forward   y_j = cp_j (g_j - y_{j-1}),  y_{-1} = 0          (d' of the textbook)
+//   backward  x_j = y_j - cp_j x_{j+1},    x_W   = 0
+// Both are first-order linear recurrences  y_j = a_j y_prev + b_j  (a_j = -cp_j; b_j = cp_j g_j resp. y_j): a workgroup takes kTriSys
+// systems and cuts the j range into kTriChunks chunks — (A) every thread composes its chunk's affine map, (B) one thread per system
+// chains the chunks' maps, (C) every thread replays its chunk from the now known start value and writes the result.
+constexpr int kTriSys = 8, kTriChunks = 128;
+template <bool BACKWARD>
+__global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kernel(const double* __restrict__ cp, double* __restrict__ v, int H, int W)
+{
+    __shared__ double sA[kTriChunks][kTriSys], sB[kTriChunks][kTriSys], sY[kTriChunks][kTriSys];
+    const int s = threadIdx.x % kTriSys, ch = threadIdx.x / kTriSys;
+    const int i = blockIdx.x * kTriSys + s;
+    const int q = (W + kTriChunks - 1) / kTriChunks;
+    const int j0 = ch * q, j1 = (j0 + q < W) ? j0 + q : W;
+    const bool live = i < H && j0 < W;
+    double A = 1.0, B = 0.0;
+    if (live) {
+        if (!BACKWARD) for (int j = j0; j < j1; ++j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; const double a = -c, b = c * g; B = a * B + b; A = a * A; }
+        else for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; const double a = -c; B = a * B + g; A = a * A; }
+    }
+    sA[ch][s] = A; sB[ch][s] = B;
+    __syncthreads();
+    if (ch == 0) {      // chain the chunks (in sweep order); sY[c] = value entering chunk c
+        double y = 0.0;
+        if (!BACKWARD) for (int c = 0; c < kTriChunks; ++c) { sY[c][s] = y; y = sA[c][s] * y + sB[c][s]; }
+        else for (int c = kTriChunks - 1; c >= 0; --c) { sY[c][s] = y; y = sA[c][s] * y + sB[c][s]; }
+    }
+    __syncthreads();
+    if (!live) return;
+    double y = sY[ch][s];
+    if (!BACKWARD) for (int j = j0; j < j1; ++j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = c * (g - y); v[(size_t)j * H + i] = y; }
+    else for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = g - c * y; v[(size_t)j * H + i] = y; }
 }
 
 }  // namespace emba

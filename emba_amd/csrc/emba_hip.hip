@@ -146,6 +146,8 @@ struct emba_ctx {
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
     double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
     double* d_thomas = nullptr;   // Thomas factors of T_W + lambda1[i] I (W x H)
+    double* d_Sfold = nullptr;    // the sine matrix folded by its symmetry: two (H/2 x H/2) blocks (even H)
+    double* d_pE = nullptr;       // [E | O] of the folded transform (W x H/2 each)
 };
 
 namespace {
@@ -2004,6 +2006,11 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         if ((st = dev_alloc(c, &c->d_thomas, npix))) return st;
         hipLaunchKernelGGL(emba_thomas_coef_kernel, dim3((H + 63) / 64), dim3(64), 0, s, c->d_lamH, H, W, c->d_thomas);
     }
+    const bool fold = !dense && (H % 2 == 0) && H >= 64 && !(getenv("EMBA_POISSON") && !strcmp(getenv("EMBA_POISSON"), "nofold"));
+    if (fold && !c->d_Sfold) {
+        if ((st = dev_alloc(c, &c->d_Sfold, (size_t)H * H / 2))) return st;
+        hipLaunchKernelGGL(emba_sine_folded_kernel, dim3((unsigned)(((size_t)H * H / 2 + 255) / 256)), dim3(256), 0, s, H, c->d_Sfold);
+    }
     const double *gx = c->d_Gx, *gy = c->d_Gy;
     if (Gx_host) {
         if (!c->d_pGx) { if ((st = dev_alloc(c, &c->d_pGx, npix)) || (st = dev_alloc(c, &c->d_pGy, npix))) { dev_free(c, c->d_pGx); return st; } }
@@ -2012,9 +2019,10 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         gx = c->d_pGx; gy = c->d_pGy;
     }
     hipLaunchKernelGGL(emba_divergence_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, gx, gy, H, W, c->d_pF);
-    auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue, double inv_norm) {
+    auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue, double inv_norm, long lda = 0, int a_kstride = 1, int a_koff = 0) {
         GemmParams p{};
-        p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = K; p.ldb = N; p.ldc = N;
+        p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda ? lda : K; p.ldb = N; p.ldc = N;
+        p.a_kstride = a_kstride; p.a_koff = a_koff;
         p.epilogue = epilogue; p.inv_norm = inv_norm;
         p.lam1 = c->d_lamH; p.lam2 = c->d_lamW;
         p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
@@ -2031,12 +2039,23 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         gemm(c->d_SH, c->d_pT, c->d_pF, H, W, H, 0, 1.0);            // M = S_H T
     } else {
         const dim3 tg((W + 31) / 32, (H + 31) / 32), tgT((H + 31) / 32, (W + 31) / 32);
+        // DST-I along H of every row of the transposed plane: src (W x H) -> dst (W x H), times scale.  Folded (even H): two half-size products on
+        // the even- and odd-indexed inputs + a butterfly; tmp holds [E | O] (W x H/2 each).
+        auto dst_rows = [&](const double* src, double* dst, double* tmp, double scale) {
+            if (!fold) { gemm(src, c->d_SH, dst, W, H, H, 2, scale); return; }
+            const int h = H / 2;
+            double* E = tmp; double* O = tmp + (size_t)W * h;
+            gemm(src, c->d_Sfold, E, W, h, h, 0, 1.0, H, 2, 0);
+            gemm(src, c->d_Sfold + (size_t)h * h, O, W, h, h, 0, 1.0, H, 2, 1);
+            hipLaunchKernelGGL(emba_dst_butterfly_kernel, dim3((unsigned)(((size_t)W * h + 255) / 256)), dim3(256), 0, s, E, O, W, H, scale, dst);
+        };
+        if (fold && !c->d_pE) { if ((st = dev_alloc(c, &c->d_pE, npix))) return st; }
         hipLaunchKernelGGL(emba_transpose_kernel, tg, dim3(256), 0, s, c->d_pF, H, W, c->d_pT);                       // F^T  (W x H)
-        gemm(c->d_pT, c->d_SH, c->d_pF, W, H, H, 0, 1.0);                                                                // (S_H F)^T = F^T S_H
+        dst_rows(c->d_pT, c->d_pF, c->d_pE, 1.0);                                                                        // (S_H F)^T = F^T S_H
         const unsigned tb = (unsigned)((H + kTriSys - 1) / kTriSys);
         hipLaunchKernelGGL(emba_tridiag_sweep_kernel<false>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);   // (T_W + lambda1[i] I) x = g, per i
         hipLaunchKernelGGL(emba_tridiag_sweep_kernel<true>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);
-        gemm(c->d_pF, c->d_SH, c->d_pT, W, H, H, 2, 1.0 / (2.0 * (double)(H + 1)));                                    // M^T = X^T S_H / (2 (H+1))
+        dst_rows(c->d_pF, c->d_pT, c->d_pE, 1.0 / (2.0 * (double)(H + 1)));                                            // M^T = X^T S_H / (2 (H+1))
         hipLaunchKernelGGL(emba_transpose_kernel, tgT, dim3(256), 0, s, c->d_pT, W, H, c->d_pF);                      // M
     }
     HIP_TRY(c, hipGetLastError());

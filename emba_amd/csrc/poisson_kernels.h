@@ -63,6 +63,7 @@ struct GemmParams {
     const double* A; const double* B; double* C; int M, N, K; long lda, ldb, ldc;
     int epilogue; double inv_norm; const double* lam1; const double* lam2;
     int vec;   // lda, ldb even and A, B 16-B aligned: interior tiles use 16-B loads
+    int a_kstride, a_koff;   // A's reduction index k reads column a_koff + a_kstride * k (1, 0: plain; 2, parity: every other column — the folded DST)
 };
 
 constexpr int kGemmBM = 64, kGemmBK = 16;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
     double ra[4], rb[BQ];
     auto load_tile = [&](int k0) {
         const int gr = m0 + a_row;
-        if (p.vec && gr < p.M && k0 + a_k + 3 < p.K) {           // interior: 16-B loads
+        if (p.vec && p.a_kstride == 1 && gr < p.M && k0 + a_k + 3 < p.K) {           // interior: 16-B loads
             const double2* q2 = reinterpret_cast<const double2*>(p.A + (size_t)p.lda * gr + k0 + a_k);
             const double2 v0 = q2[0], v1 = q2[1];
             ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int gk = k0 + a_k + q;
-                ra[q] = (gr < p.M && gk < p.K) ? p.A[(size_t)p.lda * gr + gk] : 0.0;
+                ra[q] = (gr < p.M && gk < p.K) ? p.A[(size_t)p.lda * gr + p.a_koff + (size_t)p.a_kstride * gk] : 0.0;
             }
         }
         const int gk = k0 + b_k;
@@ -236,6 +237,32 @@ __global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kerne
     double y = sY[ch][s];
     if (!BACKWARD) for (int j = j0; j < j1; ++j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = c * (g - y); v[(size_t)j * H + i] = y; }
     else for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = g - c * y; v[(size_t)j * H + i] = y; }
+}
+
+// ---- the sine matrix folded by its symmetry  S[n-1-k][j] = (-1)^j S[k][j]  (n even) ----------------------------------------------------
+//     y_k + y_{n-1-k} = 2 sum_{j even} S[k][j] x_j =: 2 E_k ,   y_k - y_{n-1-k} = 2 sum_{j odd} S[k][j] x_j =: 2 O_k      (k < n/2)
+// so a DST-I of length n is two (n/2 x n/2) products on the even- and odd-indexed inputs and a butterfly: half the multiplications.
+// Sf[parity][jp][k] = S[k][2 jp + parity] = 2 sin(pi (2 jp + parity + 1)(k + 1) / (n + 1)),  jp, k < n/2  (row-major, the B operand of the GEMM)
+__global__ void emba_sine_folded_kernel(int n, double* __restrict__ Sf)
+{
+    const long h = n / 2, idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * h * h) return;
+    const long parity = idx / (h * h), rem = idx % (h * h), jp = rem / h, k = rem % h, m = n + 1;
+    long r = ((2 * jp + parity + 1) * (k + 1)) % (2 * m);
+    double sgn = 2.0;
+    if (r >= m) { r -= m; sgn = -2.0; }
+    if (2 * r > m) r = m - r;
+    Sf[idx] = sgn * sin(3.14159265358979323846 * (double)r / (double)m);
+}
+// y[row][k] = (E + O) * scale, y[row][n-1-k] = (E - O) * scale from EO = [E (rows x n/2) | O (rows x n/2)] stored as two planes
+__global__ void emba_dst_butterfly_kernel(const double* __restrict__ E, const double* __restrict__ O, int rows, int n, double scale, double* __restrict__ y)
+{
+    const long h = n / 2, idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)rows * h) return;
+    const long row = idx / h, k = idx % h;
+    const double e = E[idx], o = O[idx];
+    y[row * n + k] = (e + o) * scale;
+    y[row * n + (n - 1 - k)] = (e - o) * scale;
 }
 
 }  // namespace emba

@@ -627,10 +627,12 @@ def test_lm_solver_device_matches_oracle_loop(gpu, oracle_mod, ba_kw, resident):
         assert knot_errors(rg.traj, w.traj).mean() < knot_errors(init, w.traj).mean()
 
 
-@pytest.mark.parametrize("pano_h", [75, 256, 1024])
-def test_poisson_reconstruction_matches_oracle(gpu, pano_h):
-    """reconstructFromGradient (poisson_reconstruction.cpp:9-50, laplace.cpp:587-797) on the fp64 matrix cores against
-    the numpy restatement; 75 x 150 exercises the ragged tiles and the unaligned loads, 1024 x 2048 is the BASELINE panorama."""
+@pytest.mark.parametrize("pano_h", [75, 256, 1024, 2048])
+def test_poisson_reconstruction_matches_oracle(gpu, pano_h, monkeypatch):
+    """reconstructFromGradient (poisson_reconstruction.cpp:9-50, laplace.cpp:587-797) against the numpy restatement: Fourier
+    analysis along H (sine-matrix products on the fp64 matrix cores, folded by the matrix's symmetry for even H) + tridiagonal solves along W;
+    75 x 150 exercises the ragged tiles, the unaligned loads and the unfolded odd length, 1024 x 2048 is the BASELINE panorama, 2048 x 4096
+    config 5's.  The round-1/2 form (both axes by sine-matrix products, EMBA_POISSON=dense) must give the same panorama."""
     from oracle import poisson as OP
     w = small_workload(n_events=2000, pano_h=pano_h)
     m = make_legm(w)
@@ -646,6 +648,9 @@ def test_poisson_reconstruction_matches_oracle(gpu, pano_h):
     # resident map: same result as passing it
     m.upload_map(Gx, Gy)
     assert np.array_equal(m.reconstructIntensity(), M)
+    if pano_h <= 256:
+        monkeypatch.setenv("EMBA_POISSON", "dense")
+        assert_close(m.reconstructIntensity(), Mo, "intensity panorama (dense form)", tight=1e-10)
 
 
 @pytest.mark.parametrize("declared,used", [(("huber", 0.1), ("huber", 0.1)), (("huber", 0.1), ("cauchy", 1.0)), (("cauchy", 1.0), ("quadratic", 0.0)),

@@ -1673,14 +1673,34 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     const size_t lds_bytes = (size_t)4 * 2 * n * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", n / 3);
     if (lds_bytes > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    // Block-sparse SYRK (>= 4 row blocks, i.e. K >= 64): the columns of a slice of kSyrkSlicePix consecutive active pixels — a piece of a
+    // panorama row — are non-zero only in the rows of the control poses in view while the camera looked there; over a long window
+    // (config 2: 10 s, K = 201) that is a band, and only the (row-block pair, slice) products with both blocks populated are formed.
+    // EMBA_SYRK=dense switches it off (comparison).
+    const bool sparse = nb64 >= 4 && nb64 <= 64 && !(getenv("EMBA_SYRK") && !strcmp(getenv("EMBA_SYRK"), "dense"));
     for (size_t p0 = 0; p0 < n_pix; p0 += chunk) {
         const size_t p1 = std::min(n_pix, p0 + chunk);
         bp.p0 = (long)p0; bp.p1 = (long)p1;
-        hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
         const long kc = (long)(2 * (p1 - p0));
-        const int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
+        const int n_slices = (int)((p1 - p0 + kSyrkSlicePix - 1) / kSyrkSlicePix);
+        unsigned long long* d_mask = nullptr; uint32_t *d_list = nullptr, *d_cnt = nullptr;
+        if (sparse) {
+            if ((st = ws_get(c, 3, (size_t)n_slices * 8, (void**)&d_mask)) || (st = ws_get(c, 4, (size_t)nbp * n_slices * 4, (void**)&d_list)) ||
+                (st = ws_get(c, 5, (size_t)nbp * 4, (void**)&d_cnt)))
+                return st;
+            HIP_TRY(c, hipMemsetAsync(d_mask, 0, (size_t)n_slices * 8, s));
+        }
+        bp.slice_mask = d_mask;
+        hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
+        int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
         SyrkParams sp{};
-        sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.direct = (nks == 1);
+        sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp;
+        if (sparse) {
+            hipLaunchKernelGGL(emba_syrk_lists_kernel, dim3((unsigned)nbp), dim3(64), 0, s, d_mask, n_slices, nbp, d_list, d_cnt);
+            sp.list = d_list; sp.count = d_cnt; sp.n_slices = n_slices;
+            nks = std::max(1, std::min(nks_max, n_slices));
+        }
+        sp.direct = (nks == 1);
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
         if (nks > 1)
             hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256), (unsigned)((nks + kSyrkReduceGroup - 1) / kSyrkReduceGroup)),

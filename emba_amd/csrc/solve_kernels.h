@@ -66,6 +66,14 @@ __global__ void emba_csr_fill_kernel(RecView v, long n_rec, const uint32_t* __re
 }
 
 // ---- U chunk: one wave per active pixel ---------------------------------------------------------------------------------
+// Column slices of the block-sparse SYRK: kSyrkSlicePix consecutive active pixels (ascending panorama index = a piece of a panorama row).
+// The control poses a pixel's measurements involve are those in view while the camera looks at it, so over a long window (config 2:
+// 10 s, K = 201) the columns of a slice are non-zero in a BAND of rows only and most (64-row block pair, slice) products vanish.
+#ifndef SYRK_SLICE_PIX
+#define SYRK_SLICE_PIX 128
+#endif
+constexpr int kSyrkSlicePix = SYRK_SLICE_PIX;
+
 struct SchurBuildParams {
     RecView view; const uint32_t* off; const uint32_t* bucket;
     const double* A22b2; long p0, p1;            // pixel chunk [p0, p1) in compact order
@@ -73,6 +81,7 @@ struct SchurBuildParams {
     double* U; long ldu;                         // column-major n x 2(p1-p0)
     double* yv; double* cfac;                    // per pixel: y = C^-1 b2 (2), C = {c00, c10, c11}
     int* info;                                   // set to 1 if some A22m is not positive definite
+    unsigned long long* slice_mask;              // per slice of kSyrkSlicePix pixels of the chunk: which 64-row blocks of U its columns touch (nullptr: not wanted)
 };
 
 __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams p)
@@ -93,6 +102,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
         const int el = lane & 15, kk = lane >> 4;
+        unsigned long long rows_mask = 1ull << (p.n >> 6);   // (the extra row n of the augmented block is always there)
         for (uint32_t b = b0; b < b1; b += 4) {      // four records per trip (lane l: element l&15 of record l>>4): one memory latency for four
             const uint32_t bb = b + kk;
             const bool in = bb < b1;
@@ -105,6 +115,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
             const uint32_t key = in ? rec_key(p.view, s) : 0u;
             const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
+            if (in) rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
             const double wx = w * x;                                            // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
 #pragma unroll
             for (int q = 0; q < 4; ++q) {                                       // rows of different records / of c and p may coincide: ordered steps
@@ -124,6 +135,11 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             u1[r] = (a1 - t0 * c10) / c11;
         }
         if (lane == 0) { u0[p.n] = y0; u1[p.n] = y1; }     // extra row: (U_aug U_aug^T)[r][n] = (U y)[r], the rhs update comes with the SYRK
+        if (p.slice_mask) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) rows_mask |= __shfl_xor(rows_mask, o);
+            if (lane == 0) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
+        }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
@@ -158,7 +174,32 @@ __global__ void emba_schur_rhs_kernel(const double* __restrict__ S, long lds, in
 // emba_syrk_reduce_kernel sums (many slices: all the atomics of a direct update would land on the same n^2 words).
 struct SyrkParams {
     const double* A; long lda; int n; long k; double* C; long ldc; double* slab; int nbp; int direct;
+    // block-sparse form: blockIdx.y = part; the block walks the slices list[bp * n_slices + part], + gridDim.y, ... (count[bp] of them):
+    // the column slices (2 * kSyrkSlicePix columns each) in which BOTH of its 64-row blocks have non-zeros
+    const uint32_t* list; const uint32_t* count; int n_slices;
 };
+
+// per block pair (I >= J) the slices whose columns touch both row blocks: one wave per pair, ballot-compacted
+__global__ __launch_bounds__(64) void emba_syrk_lists_kernel(const unsigned long long* __restrict__ slice_mask, int n_slices, int nbp, uint32_t* __restrict__ list,
+                                                             uint32_t* __restrict__ count)
+{
+    const int bp = blockIdx.x, lane = threadIdx.x;
+    if (bp >= nbp) return;
+    int I = (int)((sqrt(8.0 * bp + 1.0) - 1.0) * 0.5);
+    while ((long)I * (I + 1) / 2 > bp) --I;
+    while ((long)(I + 1) * (I + 2) / 2 <= bp) ++I;
+    const int J = bp - I * (I + 1) / 2;
+    const unsigned long long need = (1ull << (I & 63)) | (1ull << (J & 63));
+    uint32_t n = 0;
+    for (int s0 = 0; s0 < n_slices; s0 += 64) {
+        const int sl = s0 + lane;
+        const bool act = sl < n_slices && (slice_mask[sl] & need) == need;
+        const unsigned long long m = __ballot(act);
+        if (act) list[(size_t)bp * n_slices + n + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)sl;
+        n += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) count[bp] = n;
+}
 
 __device__ __forceinline__ void syrk_block_pair(int bp, int& I, int& J)
 {   // bp -> (I, J), I >= J, row-major over the lower triangle
@@ -176,28 +217,40 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     int I, J;
     syrk_block_pair(blockIdx.x, I, J);
     const int I0 = 64 * I, J0 = 64 * J;
-    const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
-    const long kb = (long)blockIdx.y * kslice, ke = (kb + kslice < p.k) ? kb + kslice : p.k;
     double4_t acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-    for (long c4 = kb + 4 * wv; c4 < ke; c4 += 16) {
-        const long col = c4 + kk;
-        const bool cok = col < ke;
-        const double* colp = p.A + (size_t)p.lda * (cok ? col : kb);
-        double av[4], bv[4];
+    auto range = [&](long kb, long ke) {
+        for (long c4 = kb + 4 * wv; c4 < ke; c4 += 16) {
+            const long col = c4 + kk;
+            const bool cok = col < ke;
+            const double* colp = p.A + (size_t)p.lda * (cok ? col : kb);
+            double av[4], bv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
-            av[t] = (cok && ri < p.n) ? colp[ri] : 0.0;
-            bv[t] = (cok && rj < p.n) ? colp[rj] : 0.0;
+            for (int t = 0; t < 4; ++t) {
+                const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
+                av[t] = (cok && ri < p.n) ? colp[ri] : 0.0;
+                bv[t] = (cok && rj < p.n) ? colp[rj] : 0.0;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+    };
+    if (p.list) {   // block-sparse: only the column slices in which both row blocks are populated
+        const uint32_t cnt = p.count[blockIdx.x];
+        const uint32_t* lst = p.list + (size_t)blockIdx.x * p.n_slices;
+        for (uint32_t q = blockIdx.y; q < cnt; q += gridDim.y) {
+            const long kb = (long)lst[q] * (2 * kSyrkSlicePix), ke = (kb + 2 * kSyrkSlicePix < p.k) ? kb + 2 * kSyrkSlicePix : p.k;
+            range(kb, ke);
+        }
+    } else {
+        const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
+        const long kb = (long)blockIdx.y * kslice, ke = (kb + kslice < p.k) ? kb + kslice : p.k;
+        range(kb, ke);
     }
     for (int i = threadIdx.x; i < 64 * 64; i += 256) s_tile[i] = 0.0;
     __syncthreads();

@@ -3,15 +3,15 @@
 import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-names = [r["Kernel_Name"].split("(")[0].replace("emba::", "").replace("emba_", "").replace("_kernel", "") for r in rows]
+names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("emba::", "").replace("emba_", "").replace("_kernel", "") for r in rows]
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 solves, i = [], 0
 while i < len(rows):
-    if names[i] == "csr_scan1":
+    if names[i] == "csr_count":
         j, agg = i, collections.OrderedDict()
         while j < len(rows):
             agg[names[j]] = agg.get(names[j], 0) + dur[j]
-            if names[j] == "schur_x2":
+            if names[j].startswith("schur_x2"):
                 break
             j += 1
         solves.append(((int(rows[j]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3, agg))

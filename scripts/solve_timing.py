@@ -4,7 +4,12 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emba_amd import LEGM
 from emba_amd.synth import make_workload
-for n, ph, K, dt in ((1_000_000, 1024, 21, 0.05), (1_000_000, 1024, 201, 0.005), (10_000_000, 1024, 97, 0.0104)):
+import os
+CONFIGS = ((1_000_000, 1024, 21, 0.05), (1_000_000, 1024, 201, 0.005), (10_000_000, 1024, 97, 0.0104),
+           (10_000_000, 1024, 201, 0.05))      # the last one: config 2's shape (shapes.launch: 10 s at dt = 0.05 s, K = 201) at the BASELINE event rate
+if os.environ.get("SOLVE_CONFIGS"):
+    CONFIGS = tuple(CONFIGS[int(i)] for i in os.environ["SOLVE_CONFIGS"].split(","))
+for n, ph, K, dt in CONFIGS:
     w = make_workload(n_events=n, pano_h=ph, K=K, dt_knots=dt)
     m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h)
     m.set_events(w.events); m.upload_map(w.Gx, w.Gy)

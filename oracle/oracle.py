@@ -24,7 +24,8 @@ _i32p = C.POINTER(C.c_int32)
 
 def build():
     """Compile the checker libraries (gcc/g++ only; no GPU toolchain involved)."""
-    subprocess.check_call(["make", "-s", "-C", _HERE])
+    import sys
+    subprocess.check_call(["make", "-s", "-C", _HERE], stdout=sys.stderr)      # (stdout belongs to the caller: bench.py prints ONE JSON line there)
 
 
 def _ptr(a, ty):

@@ -93,6 +93,8 @@ class OracleShardEngine:
         self.ep_pix = np.array([m["pix"] for m in self.meas], dtype=np.int64)
 
     def form_active(self, thres, sync=True):
+        self.meas_form = self.meas          # the measurements these equations consist of (a later, rejected, trial evaluation must not replace them:
+                                            # the device keeps them in its second record set, the reference in its host copies of A and b)
         cnt = self.count.numpy()
         self.active = np.nonzero(cnt >= thres)[0]
         self.compact = -np.ones(cnt.size, dtype=np.int64)
@@ -161,7 +163,7 @@ class OracleShardEngine:
         return r
 
     def _active_records(self):
-        return [(m, int(self.compact[m["pi"]])) for m in self.meas if self.compact[m["pi"]] >= 0]
+        return [(m, int(self.compact[m["pi"]])) for m in self.meas_form if self.compact[m["pi"]] >= 0]
 
     def solve_shard_size(self):
         return (3 * self.K + 1) ** 2

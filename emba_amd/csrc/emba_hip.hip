@@ -72,7 +72,6 @@ struct emba_ctx {
     int* d_err = nullptr;           // status word of the CURRENT evaluation: one of the two words of d_err2 (they alternate: an evaluation's first launch
     int* d_err2 = nullptr;          // clears the NEXT evaluation's word while its own pose threads may already be setting bits of the current one)
     uint32_t eval_seq = 0;
-    int rect_sel = 0;               // which half of d_blk_rect the next evaluation's prep blocks write (the texel blocks read the other: the previous launch's)
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
     int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P [3] step sequence number
@@ -680,13 +679,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     c->d_err = c->d_err2;
     CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_rect)] = 4 * sizeof(int);
     { const int init[4] = {0x7FFFFFFF, 0x7FFFFFFF, -1, -1}; CREATE_TRY(hipMemcpy(c->d_rect, init, sizeof init, hipMemcpyHostToDevice)); }
-    {   // two sets of per-prep-block boxes (written by one evaluation's launch, read by the next one's texel blocks), both empty to begin with
-        const size_t nbx = (c->npix + 1023) / 1024;
-        CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, 2 * nbx * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = 2 * nbx * 4 * sizeof(int);
-        std::vector<int> init(2 * nbx * 4);
-        for (size_t i = 0; i < 2 * nbx; ++i) { init[4 * i] = 0x7FFFFFFF; init[4 * i + 1] = 0x7FFFFFFF; init[4 * i + 2] = -1; init[4 * i + 3] = -1; }
-        CREATE_TRY(hipMemcpy(c->d_blk_rect, init.data(), init.size() * sizeof(int), hipMemcpyHostToDevice));
-    }
+    CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, c->n_ablk * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = c->n_ablk * 4 * sizeof(int);   // per active-count block: box of the touched pixels
     CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_total)] = 2 * sizeof(uint32_t);
     CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_scalar)] = 2 * sizeof(double);
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
@@ -1082,8 +1075,6 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         ++c->eval_seq;
         c->d_err = c->d_err2 + (c->eval_seq & 1u);
         q.count = c->d_count; q.npix = (long)c->npix; q.pixacc = c->d_pixacc; q.W = c->W; q.H = c->H; q.n_prep = n_prep_blk;
-        q.blk_rect_w = c->d_blk_rect + (size_t)c->rect_sel * n_prep_blk * 4; q.blk_rect_r = c->d_blk_rect + (size_t)(1 - c->rect_sel) * n_prep_blk * 4;
-        c->rect_sel = 1 - c->rect_sel;
         q.batch_t_ns = c->d_batch_t; q.nb = nb; q.K = (int)K; q.t0_ns = t0_ns; q.dt_ns = dt_ns; q.pose = c->d_pose; q.err = c->d_err;
         q.err_next = c->d_err2 + ((c->eval_seq + 1u) & 1u);
         q.n_pose = ((c->tile_order ? (int)K - 1 : nb) + 63) / 64;   // (tile order: K-1 segment records instead of nb batch poses)
@@ -1097,8 +1088,8 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
             HIP_TRY(c, hipMemcpyAsync(c->d_knots, c->h_knots, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
             c->knots_in_flight = true;   // cleared by the next host synchronisation
         }
-        q.n_tex = (c->use_texel == 3) ? 512 : 0;
-        q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect_out = rect_cur; q.texel = c->d_texel;
+        q.n_tex = (c->use_texel == 3) ? 1024 : 0;
+        q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect = rect_cur; q.texel = c->d_texel;
         hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_pose + q.n_tex + q.n_prep)), dim3(256), 0, s, q, kn);
     }
     if (c->use_texel == 1)
@@ -1195,6 +1186,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // and "sum every predecessor"): 38-270 us against 6.3 + 11.2 — the eight XCDs' L2s are not coherent with each other, so every flag is a
         // round trip to the memory side (and a release / acquire pair writes back / invalidates a whole L2); a kernel boundary is cheaper.
         q.active_bits = c->d_active_bits; q.pack_head = c->d_pack; q.head_len = head; aw.bits_head_done = 1;
+        q.blk_rect = c->d_blk_rect; q.W = c->W; aw.blk_rect = c->d_blk_rect; aw.rect_out = c->d_rect;   // the texel rectangle of the NEXT evaluation
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
         aw.blk_cnt = c->d_ablk_cnt; aw.fblk_cnt = c->d_fblk_cnt; aw.n_fblk = c->n_fblk; aw.total_P = q.total_P; aw.total_P_host = q.total_P_host;
         aw.total_inl = q.total_inl; aw.total_inl_host = q.total_inl_host; aw.err_dev = q.err_dev; aw.err_host = q.err_host; aw.seq = q.seq; aw.seq_host = q.seq_host;

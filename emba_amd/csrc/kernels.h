@@ -189,34 +189,11 @@ __device__ __forceinline__ void texel_rect(const int* __restrict__ acc, int W, i
 }
 
 __device__ __forceinline__ void texel_rect_blocks(long blk, long nblocks, const double* __restrict__ Gx, const double* __restrict__ Gy,
-                                                  int H, int W, const int* __restrict__ blk_rect, int n_blk_rect, int* __restrict__ rect_out,
-                                                  double* __restrict__ texel)
+                                                  int H, int W, const int* __restrict__ rect_acc, double* __restrict__ texel)
 {
-    // every texel block reduces the prep kernel's per-block boxes itself (32 KB from L2), so it does not depend on anyone
-    __shared__ int s_box[4][4];
-    __shared__ int s_rect[4];
-    int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
-    for (int i = threadIdx.x; i < n_blk_rect; i += 256) {
-        const int4 r = reinterpret_cast<const int4*>(blk_rect)[i];
-        xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
-        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
-    }
-    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        s_rect[0] = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-        s_rect[1] = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
-        s_rect[2] = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
-        s_rect[3] = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
-        if (blk == 0) { rect_out[0] = s_rect[0]; rect_out[1] = s_rect[1]; rect_out[2] = s_rect[2]; rect_out[3] = s_rect[3]; }   // for the warp kernel
-    }
-    __syncthreads();
+    // rect_acc: the box of the pixels the last formed evaluation touched (reduced by its active-write kernel's last block)
     int x0, y0, x1, y1;
-    texel_rect(s_rect, W, H, x0, y0, x1, y1);
+    texel_rect(rect_acc, W, H, x0, y0, x1, y1);
     const long rw = x1 - x0 + 1, total = rw * (long)(y1 - y0 + 1);
     for (long idx = blk * 256 + threadIdx.x; idx < total; idx += nblocks * 256) {
         const int x = x0 + (int)(idx % rw), y = y0 + (int)(idx / rw);
@@ -901,22 +878,25 @@ __global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const
 // ------------------------------------------------------------------------------------------------
 constexpr int kActivePix = 2048;
 
-__device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ count, long p0, long npix, int thres)
-{
-    uint32_t m = 0;
+__device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ count, long p0, long npix, int thres, uint32_t* touched = nullptr)
+{   // touched (optional): which of the 8 pixels have a non-zero count
+    uint32_t m = 0, tm = 0;
     if (p0 + 8 <= npix) {
         const int4 a = *reinterpret_cast<const int4*>(count + p0), b = *reinterpret_cast<const int4*>(count + p0 + 4);
         m = (a.x >= thres) | ((a.y >= thres) << 1) | ((a.z >= thres) << 2) | ((a.w >= thres) << 3) | ((b.x >= thres) << 4) |
             ((b.y >= thres) << 5) | ((b.z >= thres) << 6) | ((b.w >= thres) << 7);
+        tm = (a.x != 0) | ((a.y != 0) << 1) | ((a.z != 0) << 2) | ((a.w != 0) << 3) | ((b.x != 0) << 4) | ((b.y != 0) << 5) | ((b.z != 0) << 6) | ((b.w != 0) << 7);
     } else {
-        for (int k = 0; k < 8; ++k) if (p0 + k < npix && count[p0 + k] >= thres) m |= 1u << k;
+        for (int k = 0; k < 8; ++k) if (p0 + k < npix) { const int c = count[p0 + k]; if (c >= thres) m |= 1u << k; if (c) tm |= 1u << k; }
     }
+    if (touched) *touched = tm;
     return m;
 }
 
 // The same over a RAW count map (markers left by the warp kernel): a touched pixel's count is the sixth double of its accumulator
 // line; the counts are written back, which turns the map into the num_ev_map of model.cpp:227 for everyone downstream.
-__device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ count, const double* __restrict__ pixacc, long p0, long npix, int thres)
+__device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ count, const double* __restrict__ pixacc, long p0, long npix, int thres,
+                                                      uint32_t* touched = nullptr)
 {
     int c[8];
     const bool full = p0 + 8 <= npix;
@@ -941,9 +921,10 @@ __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ coun
             for (int k = 0; k < 8; ++k) if (p0 + k < npix) count[p0 + k] = c[k];
         }
     }
-    uint32_t m = 0;
+    uint32_t m = 0, tm = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) m |= (uint32_t)(c[k] >= thres) << k;
+    for (int k = 0; k < 8; ++k) { m |= (uint32_t)(c[k] >= thres) << k; tm |= (uint32_t)(c[k] != 0) << k; }
+    if (touched) *touched = tm;
     return m;
 }
 
@@ -954,12 +935,42 @@ __global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __
 
 __device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
                                                    uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr,
-                                                   uint8_t* __restrict__ active_bits = nullptr)
+                                                   uint8_t* __restrict__ active_bits = nullptr, int* __restrict__ blk_rect = nullptr, int W = 1)
 {
     __shared__ uint32_t s_w[4];
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
-    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres) : active_mask8(count, p0, npix, thres);
+    uint32_t tm = 0;
+    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres, &tm) : active_mask8(count, p0, npix, thres, &tm);
     if (active_bits && p0 < npix) active_bits[p0 >> 3] = (uint8_t)m8;
+    if (blk_rect) {   // bounding box of the pixels THIS evaluation touched, per block; the active-write kernel's last block reduces them
+        __shared__ int s_box[4][4];     // into the rectangle the next evaluation packs its texels in
+        int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+        if (tm) {
+            if ((W & 7) == 0) {      // the thread's 8 pixels lie in one row: one division, the ends from the lowest / highest touched bit
+                const int y = (int)(p0 / W), x = (int)(p0 - (long)y * W);
+                xmin = x + (__ffs((int)tm) - 1); xmax = x + (31 - __clz((int)tm)); ymin = y; ymax = y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (tm & (1u << k)) { const int idx = (int)(p0 + k), y = idx / W, x = idx - y * W; xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+            xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        }
+        if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int4 r;
+            r.x = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
+            r.y = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
+            r.z = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
+            r.w = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
+            reinterpret_cast<int4*>(blk_rect)[blk] = r;
+        }
+    }
     uint32_t c = __popc(m8);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
@@ -986,6 +997,7 @@ struct PostWarpParams {
     int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
     uint8_t* active_bits; double* pack_head; long head_len;   // non-null: launch A also writes the 1-bit activity map and clears A11 | b1 (the Gram kernel then
                                                               // depends on launch A only)
+    int* blk_rect; int W;                                     // non-null: per-block bounding boxes of the touched pixels (-> the next evaluation's texel rectangle)
 };
 
 struct ActiveWriteParams {
@@ -997,13 +1009,14 @@ struct ActiveWriteParams {
     const uint32_t* blk_cnt; const uint32_t* fblk_cnt; long n_fblk; uint32_t* total_P; int* total_P_host; uint32_t* total_inl; int* total_inl_host;
     const int* err_dev; int* err_host; int seq; int* seq_host;
     int bits_head_done;   // launch A has already written the activity bits and cleared the head of the pack
+    const int* blk_rect; int* rect_out;   // non-null: launch A's per-block boxes; the last block reduces them into rect_out = {xmin, ymin, xmax, ymax}
 };
 
 __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack
     if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
-    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits);
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
 }
 
@@ -1054,6 +1067,27 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
         for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) s_i[wv] = part;
         __syncthreads();
+        if (a.blk_rect) {   // the rectangle the NEXT evaluation packs its texels in (and its warp kernel trusts): the box of what this one touched
+            __shared__ int s_bx[4][4];
+            int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+            for (long j = threadIdx.x; j < a.n_ablk; j += 256) {
+                const int4 r = reinterpret_cast<const int4*>(a.blk_rect)[j];
+                xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+                xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+            }
+            if (lane == 0) { int* b = s_bx[wv]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                a.rect_out[0] = min(min(s_bx[0][0], s_bx[1][0]), min(s_bx[2][0], s_bx[3][0]));
+                a.rect_out[1] = min(min(s_bx[0][1], s_bx[1][1]), min(s_bx[2][1], s_bx[3][1]));
+                a.rect_out[2] = max(max(s_bx[0][2], s_bx[1][2]), max(s_bx[2][2], s_bx[3][2]));
+                a.rect_out[3] = max(max(s_bx[0][3], s_bx[1][3]), max(s_bx[2][3], s_bx[3][3]));
+            }
+        }
         if (threadIdx.x == 0) {
             const uint32_t P = front + (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
             const uint32_t n_inl = (s_i[0] + s_i[1]) + (s_i[2] + s_i[3]);
@@ -1135,64 +1169,42 @@ __global__ void emba_compact_map_kernel(const uint32_t* __restrict__ active_idx,
 
 // Start of an evaluation ("prep"): zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched
 // (`count` still holds the previous, possibly all-reduced, counts: a superset of the locally touched pixels).
-__device__ __forceinline__ void prep_block(long blk, int32_t* __restrict__ count, long npix, double* __restrict__ pixacc, int W, int* __restrict__ blk_rect)
+__device__ __forceinline__ void prep_block(long blk, int32_t* __restrict__ count, long npix, double* __restrict__ pixacc)
 {
     const long p0 = (blk * 256 + threadIdx.x) * 4;
-    int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
-    if (p0 < npix) {
-        int cc[4] = {0, 0, 0, 0};
-        if (p0 + 4 <= npix) {
-            const int4 c = *reinterpret_cast<const int4*>(count + p0);
-            cc[0] = c.x; cc[1] = c.y; cc[2] = c.z; cc[3] = c.w;
-            if ((c.x | c.y | c.z | c.w) != 0) *reinterpret_cast<int4*>(count + p0) = make_int4(0, 0, 0, 0);
-        } else {
-            for (int k = 0; k < 4 && p0 + k < npix; ++k) { cc[k] = count[p0 + k]; if (cc[k]) count[p0 + k] = 0; }
+    if (p0 >= npix) return;
+    int cc[4] = {0, 0, 0, 0};
+    if (p0 + 4 <= npix) {
+        const int4 c = *reinterpret_cast<const int4*>(count + p0);
+        cc[0] = c.x; cc[1] = c.y; cc[2] = c.z; cc[3] = c.w;
+        if ((c.x | c.y | c.z | c.w) != 0) *reinterpret_cast<int4*>(count + p0) = make_int4(0, 0, 0, 0);
+    } else {
+        for (int k = 0; k < 4 && p0 + k < npix; ++k) { cc[k] = count[p0 + k]; if (cc[k]) count[p0 + k] = 0; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (cc[k] != 0) {
+            double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * (p0 + k));
+            a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (cc[k] != 0) {
-                double2* a = reinterpret_cast<double2*>(pixacc + (size_t)kPixAccStride * (p0 + k));
-                a[0] = make_double2(0, 0); a[1] = make_double2(0, 0); a[2] = make_double2(0, 0);
-                const int idx = (int)(p0 + k), y = idx / W, x = idx - y * W;
-                xmin = min(xmin, x); xmax = max(xmax, x); ymin = min(ymin, y); ymax = max(ymax, y);
-            }
-    }
-    // bounding box of the touched pixels of this block -> blk_rect[block]; the texel blocks of the NEXT evaluation's launch reduce them into
-    // their texel rectangle (no global atomics: they would all land on the same four words and serialise).
-    __shared__ int s_box[4][4];
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
-        xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
-    }
-    if ((threadIdx.x & 63) == 0) { int* b = s_box[threadIdx.x >> 6]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int4 r;
-        r.x = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-        r.y = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
-        r.z = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
-        r.w = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
-        reinterpret_cast<int4*>(blk_rect)[blk] = r;
-    }
 }
 
 // ONE launch in front of the warp kernel (was two: prep, then pose || texel): the three jobs are independent of each other —
 //   n_pose blocks   a2/a3 pose table (pixel order) or the K-1 segment records (tile order)
-//   n_tex blocks    texel pack inside the rectangle the boxes of the PREVIOUS launch's prep blocks span (one evaluation older than before;
-//                   a hint only: outside it the warp kernel falls back to the stencil)
+//   n_tex blocks    texel pack inside the rectangle of the pixels the last FORMED evaluation touched (reduced by its post-warp kernels; a hint
+//                   only: outside it the warp kernel falls back to the stencil)
 //   n_prep blocks   "prep": zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched (`count` still holds the
-//                   previous, possibly all-reduced, counts: a superset of the locally touched pixels), per-block boxes
+//                   previous, possibly all-reduced, counts: a superset of the locally touched pixels)
 // The control poses travel BY VALUE in the kernel arguments (K <= kInlineKnots: no staging copy, no dependency on another block);
 // larger K reads them from `knots_dev`, which the host has copied there before the launch.
 // err_next: the status word of the NEXT evaluation, cleared here (this launch's pose threads may already be setting bits of err).
 constexpr int kInlineKnots = 104;
 struct InlineKnots { double q[4 * kInlineKnots]; };
 struct PrepPoseTexelParams {
-    int32_t* count; long npix; double* pixacc; int W, H; int* blk_rect_w; const int* blk_rect_r; int n_prep;
+    int32_t* count; long npix; double* pixacc; int W, H; int n_prep;
     const int64_t* batch_t_ns; int nb; int K; int64_t t0_ns, dt_ns; double* pose; int* err; int* err_next; int n_pose; double* seg;
     const double* knots_dev; double* knots_out; int inline_knots;
-    int n_tex; const double* Gx; const double* Gy; int* rect_out; double* texel;
+    int n_tex; const double* Gx; const double* Gy; const int* rect; double* texel;
 };
 
 __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexelParams p, InlineKnots kn)
@@ -1208,14 +1220,14 @@ __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexel
             else pose_thread(i, p.batch_t_ns, p.nb, knots, p.K, p.t0_ns, p.dt_ns, p.pose, p.err);
         }
     } else if (b < p.n_pose + p.n_tex) {
-        texel_rect_blocks((long)b - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.blk_rect_r, p.n_prep, p.rect_out, p.texel);
+        texel_rect_blocks((long)b - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.rect, p.texel);
     } else {
         const int pb = b - p.n_pose - p.n_tex;
         if (pb == 0) {
             if (threadIdx.x == 0) p.err_next[0] = 0;
             if (p.inline_knots && p.knots_out) for (int i = threadIdx.x; i < 4 * p.K; i += 256) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
         }
-        prep_block(pb, p.count, p.npix, p.pixacc, p.W, p.blk_rect_w);
+        prep_block(pb, p.count, p.npix, p.pixacc);
     }
 }
 

@@ -98,9 +98,6 @@ struct emba_ctx {
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
     double* d_seg = nullptr; int seg_cap = 0;                 // tile order: per-segment constants the tiled kernel evaluates each event's pose from (12 doubles per segment)
-    // Fused Gram sums of the tile order (EMBA_FUSE_GRAM=0 disables): the tiled warp kernel accumulates A11 | b1 over every inlier record into d_gfuse and
-    // writes each entry's panorama pixel into d_ev_pano; emba_form_accumulate copies the sums into the pack and takes the inactive pixels' records back out
-    double* d_gfuse = nullptr; uint32_t* d_ev_pano = nullptr; int use_fuse = 1; bool gf_valid = false, last_form_fused = false; int gf_irls = 0, gf_K = 0; double gf_eta = 0;
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     // Two record sets (a rejected LM trial must not cost a re-evaluation).  d_rec / d_tag / set_stamp are the WORKING set: what
@@ -648,7 +645,6 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
 #endif
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
-    if (const char* fg = getenv("EMBA_FUSE_GRAM")) c->use_fuse = atoi(fg);
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
@@ -854,13 +850,6 @@ emba_status emba_last_tile_drift(const emba_ctx* c, size_t* n_outside, int32_t* 
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (n_outside) *n_outside = c->n_outside_tile;
     if (n_rebin) *n_rebin = c->n_rebin;
-    return EMBA_OK;
-}
-
-emba_status emba_last_form_info(const emba_ctx* c, int32_t* gram_fused)
-{
-    if (!c) return EMBA_ERR_INVALID_ARG;
-    if (gram_fused) *gram_fused = c->last_form_fused ? 1 : 0;
     return EMBA_OK;
 }
 
@@ -1120,18 +1109,8 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp; c->set_stamp = p.stamp;
         p.chunks = c->d_chunks; p.n_chunks = c->n_chunks;
-        c->gf_valid = false;
-        const bool fuse = c->tile_order && c->use_fuse && c->n_cand;
-        if (fuse) {
-            const size_t head = (size_t)9 * K * K + (size_t)3 * K;
-            if ((st = dev_alloc(c, &c->d_gfuse, head)) || (st = dev_alloc(c, &c->d_ev_pano, c->n_sorted + 4))) return st;
-            HIP_TRY(c, hipMemsetAsync(c->d_gfuse, 0, head * sizeof(double), s));
-            p.gA11 = c->d_gfuse; p.gb1 = c->d_gfuse + (size_t)9 * K * K; p.gdim = 3 * (int)K; p.ev_pano = c->d_ev_pano;
-            c->gf_valid = true; c->gf_irls = c->cost_irls; c->gf_eta = c->cost_eta; c->gf_K = (int)K;
-        }
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
-        if (fuse) hipLaunchKernelGGL(emba_warp_tiled_kernel<true>, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
-        else if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel<false>, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
+        if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
         else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
         c->counts_raw = true;
@@ -1265,25 +1244,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
             hipLaunchKernelGGL(emba_a22_from_records_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec,
                                (long)c->n_cand, c->d_count, c->d_compact, c->thres, irls, eta, pack_A22b2(c), c->set_stamp);
     }
-    // tile order: the sums were formed where the records were produced (every inlier); what remains is to take the inactive pixels' records out
-    const bool fused = c->tile_order && c->gf_valid && !generic_a22 && irls == c->gf_irls && (irls == 0 || eta == c->gf_eta) && c->K == c->gf_K;
-    c->last_form_fused = fused && c->n_cand;
-    if (fused && c->n_cand) {
-        const size_t head = (size_t)9 * c->K * c->K + (size_t)3 * c->K;
-        if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
-        HIP_TRY(c, hipMemcpyAsync(c->d_pack, c->d_gfuse, head * sizeof(double), hipMemcpyDeviceToDevice, s));
-        GramCorrectParams q{};
-        q.ev_pano = c->d_ev_pano; q.ev_slot = c->d_ev_slot; q.n_entries = (long)c->n_sorted; q.rec = c->d_rec; q.slot_key = c->d_slot_key;
-        q.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits); q.irls = irls; q.eta = eta; q.A11 = pack_A11(c); q.b1 = pack_b1(c); q.dim = 3 * c->K;
-        // entries per wave: ~4 workgroups per CU in flight, whole 256-entry trips, at least 4 of them
-        const long waves_target = (long)c->n_cu * 4 * kCorrWaves;
-        long per_wave = ((long)c->n_sorted + waves_target - 1) / waves_target;
-        per_wave = std::max<long>((per_wave + 255) / 256 * 256, 1024);
-        q.per_wave = (int)per_wave;
-        const long n_waves = ((long)c->n_sorted + per_wave - 1) / per_wave;
-        hipLaunchKernelGGL(emba_gram_correct_kernel, dim3((unsigned)((n_waves + kCorrWaves - 1) / kCorrWaves)), dim3(kCorrWaves * 64), 0, s, q);
-        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
-    } else if (c->n_cand) {
+    if (c->n_cand) {
         GramParams p{};
         p.rec = c->d_rec; p.slot_key = c->d_slot_key; p.n_slots = (long)c->n_cand; p.active_bits = reinterpret_cast<const uint32_t*>(c->d_active_bits);
         p.irls = irls; p.eta = eta; p.stamp = c->set_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);

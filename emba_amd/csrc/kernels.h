@@ -272,9 +272,6 @@ struct WarpParams {
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
     uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
     const ChunkDesc* chunks; long n_chunks;   // tiled kernel only
-    // tiled kernel, fused Gram sums (nullptr: off): every inlier's w r r^T goes into gA11 | gb1 where the record is produced, and its panorama
-    // pixel into ev_pano[entry] (a coalesced 4-B stream) from which emba_gram_correct_kernel later takes the inactive pixels' records back out
-    double* gA11; double* gb1; int gdim; uint32_t* ev_pano;
 };
 
 // lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
@@ -489,97 +486,13 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
     o.v0 = v0; o.v1 = v1; o.v2 = v2; o.v3 = v3; o.v4 = v4;
 }
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
-__device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, double* A11, double* b1, int dim, int ablate)
-{
-    if (row >= 12 || v == 0.0 || EMBA_ABL(ablate, 32)) return;
-    const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
-    const int grow = (row < 6) ? bc + row : bp + row - 6;
-    if (col < 12) {
-        const int gcol = (col < 6) ? bc + col : bp + col - 6;
-        atomicAdd(A11 + (size_t)grow + (size_t)dim * gcol, v);
-    } else if (col == 14) {
-        atomicAdd(b1 + grow, v);
-    }
-}
-
-// ---- per-workgroup combine tables of 12 x 13 sums (A11 block | b1 column) per control-pose pair: the fused Gram sums of the tiled warp kernel
-// and emba_gram_correct_kernel.  Operand layout here: lane l holds element l&15 of record l>>4 of a group of four, which IS the A and
-// the B operand of v_mfma_f64_16x16x4_f64 (one instruction per four records, D = sum_k w_k r_k r_k^T); lane l owns D[(l>>4)+4r][l&15].
-constexpr int kFuseKeys = 4;            // pairs a workgroup's table holds before falling back to global atomics
-constexpr int kFuseTbl = 12 * 13;       // rows 0-11 x {cols 0-11, col 14 (e)}
-__device__ __forceinline__ void fuse_flush(double4_t acc, uint32_t key, uint32_t* s_gtag, double* s_gtbl, double* A11, double* b1, int dim, int t)
-{
-    int slot = -1;
-    if (t == 0) {
-        for (int k = 0; k < kFuseKeys; ++k) {
-            const uint32_t old = atomicCAS(&s_gtag[k], 0xFFFFFFFFu, key);
-            if (old == 0xFFFFFFFFu || old == key) { slot = k; break; }
-        }
-    }
-    slot = __builtin_amdgcn_readfirstlane(slot);
-    const int j = t & 15;
-    if (!(j < 12 || j == 14)) return;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {       // r == 3: rows 12-15, by-products
-        const int i = (t >> 4) + 4 * r;
-        const double v = acc[r];
-        if (v == 0.0) continue;
-        if (slot >= 0) atomicAdd(&s_gtbl[slot * kFuseTbl + i * 13 + (j < 12 ? j : 12)], v);
-        else gram_atomic_out(v, i, j, key, A11, b1, dim, 0);
-    }
-}
-// the workgroup's tables -> global sums (after a barrier); consecutive threads take consecutive rows of one column (A11 is column-major)
-__device__ __forceinline__ void fuse_tables_out(const uint32_t* s_gtag, const double* s_gtbl, double* A11, double* b1, int dim, int tid, int nthreads)
-{
-    for (int idx = tid; idx < kFuseKeys * kFuseTbl; idx += nthreads) {
-        const int slot = idx / kFuseTbl, e = idx - slot * kFuseTbl, jj = e / 12, i = e - 12 * jj;
-        const uint32_t key = s_gtag[slot];
-        if (key != 0xFFFFFFFFu) gram_atomic_out(s_gtbl[slot * kFuseTbl + i * 13 + jj], i, jj < 12 ? jj : 14, key, A11, b1, dim, 0);
-    }
-}
-// IRLS weight of a residual (model.cpp:599-618); the same expressions as warp_lane and the Gram kernel
-__device__ __forceinline__ double irls_weight(int irls, double eta, double e)
-{
-    if (irls == 2) return 1.0 / (1.0 + eta * e * e);
-    if (irls == 1) { const double a = fabs(e); return (a < eta) ? 1.0 : eta / a; }
-    return 1.0;
-}
-// One group of up to four records (element l&15 of record l>>4 in `val`, its pair key in `rkey`, `in` = the lane's record exists) into the
-// wave's accumulator; the accumulator belongs to ONE pair (cur_key) and is flushed to the table when another one comes along.
-struct FuseAcc { double4_t acc; uint32_t key; bool dirty; };
-__device__ __forceinline__ void fuse_group(FuseAcc& f, double val, double w, uint32_t rkey, bool in, uint32_t* s_gtag, double* s_gtbl,
-                                           double* A11, double* b1, int dim, int t)
-{
-    const double bv = ((t & 15) == 15) ? 0.0 : val;   // element 15 is the record's {pixel, stamp} word, not a number
-    unsigned long long remaining = __ballot(in);
-    while (remaining) {                               // (wave-uniform; one trip unless the four records belong to different pairs)
-        const int first = __ffsll((long long)remaining) - 1;
-        const uint32_t k0 = (uint32_t)__shfl((int)rkey, first);
-        if (k0 != f.key) {
-            if (f.dirty) { fuse_flush(f.acc, f.key, s_gtag, s_gtbl, A11, b1, dim, t); f.acc = double4_t{0.0, 0.0, 0.0, 0.0}; }
-            f.key = k0; f.dirty = false;
-        }
-        const bool mine = in && (rkey == k0);
-        const double a = mine ? w * bv : 0.0, b = mine ? bv : 0.0;
-        f.acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, f.acc, 0, 0, 0);
-        f.dirty = true;
-        remaining &= ~__ballot(mine);
-    }
-}
-
 // Record stores, issued COOPERATIVELY: a 128-B record is one contiguous line in HBM, so eight adjacent lanes write one record
 // per wave-instruction (8 full lines per instruction) instead of every lane writing into its own line (64 partial lines per
 // instruction, store-issue bound).  Only inliers have a record; they pass through a per-wave LDS tile, STAGE lanes at a time,
 // COMPACTED (rank among the stage's inliers), so that every store instruction but the last of a stage is full.
-// FUSE (tiled kernel): the staged records also feed the wave's Gram accumulator from LDS, four per MFMA (fuse_group), before they leave.
-template <int STAGE, bool FUSE = false>
+template <int STAGE>
 __device__ __forceinline__ void store_records(const WarpParams& p, int t, const LaneOut& o, uint32_t slot, unsigned long long inl_mask,
-                                              double* s_tile /* STAGE * kRecLds doubles */, uint32_t* s_slot /* STAGE */,
-                                              FuseAcc* f = nullptr, uint32_t pair_key = 0, uint32_t* s_key = nullptr /* STAGE */,
-                                              uint32_t* s_gtag = nullptr, double* s_gtbl = nullptr)
+                                              double* s_tile /* STAGE * kRecLds doubles */, uint32_t* s_slot /* STAGE */)
 {
     const int c8 = t & 7;
     // the Gram kernel's tag stream: {pano pixel, stamp} of every slot written now (one store instruction for the whole wave)
@@ -596,20 +509,8 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
             w2[6] = make_double2(o.dpx, o.dpy);
             w2[7] = make_double2(o.e, __hiloint2double((int)p.stamp, (int)o.pi));
             s_slot[rk] = slot;
-            if (FUSE) s_key[rk] = pair_key;
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS ops complete in order, no barrier needed
-        if (FUSE) {
-            for (int b0 = 0; b0 < n_rec; b0 += 4) {                      // wave-uniform trip count
-                const int ri = b0 + (t >> 4);
-                const bool in = ri < n_rec;
-                const int rc = in ? ri : 0;                              // (unconditional LDS reads from a staged record)
-                const double val = s_tile[rc * kRecLds + (t & 15)];
-                const uint32_t rkey = s_key[rc];
-                const double w = p.irls ? irls_weight(p.irls, p.eta, s_tile[rc * kRecLds + 14]) : 1.0;
-                fuse_group(*f, val, w, rkey, in, s_gtag, s_gtbl, p.gA11, p.gb1, p.gdim, t);
-            }
-        }
         for (int r0 = 0; r0 < n_rec; r0 += 8) {                          // wave-uniform trip count
             const int rr = r0 + (t >> 3);
             if (rr < n_rec && !EMBA_ABL(p.ablate, 2))
@@ -715,27 +616,17 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
 // round-robin; inlier measurements whose pixel lies inside the LDS tile (the bin plus kTileMargin pixels on every side: trial poses
 // of an LM loop move events by a few pixels) add their six terms with LDS atomics, the few outside go to HBM directly; at the end
 // every touched pixel of the tile costs ONE atomic request to its 64-B accumulator line and one marker store.
-template <bool FUSE>   // FUSE: the Gram sums of the records are accumulated here, where the records are produced (p.gA11, p.gb1, p.ev_pano)
 __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu(TILE_OCC, TILE_OCC))) void emba_warp_tiled_kernel(WarpParams p)
 {
     __shared__ double s_sum[6][kTilePx];                                                  // SoA: plane k = k-th term of every tile pixel
     __shared__ __attribute__((aligned(16))) double s_tile[kTileWaves][kTileRecStage * kRecLds];
     __shared__ uint32_t s_slot[kTileWaves][kTileRecStage];
     __shared__ uint16_t s_list[kTileWaves][64];
-    // fused Gram sums (p.gA11): pair key of every staged record, and the workgroup's combine tables
-    __shared__ uint32_t s_key[kTileWaves][kTileRecStage];
-    __shared__ uint32_t s_gtag[kFuseKeys];
-    __shared__ double s_gtbl[kFuseKeys * kFuseTbl];
 
     const long c = xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, t = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = tid; k < 6 * kTilePx; k += kTileWaves * 64) (&s_sum[0][0])[k] = 0.0;
-    constexpr bool fuse = FUSE;
-    if (fuse) {
-        for (int k = tid; k < kFuseKeys * kFuseTbl; k += kTileWaves * 64) s_gtbl[k] = 0.0;
-        if (tid < kFuseKeys) s_gtag[tid] = 0xFFFFFFFFu;
-    }
     __syncthreads();
     if (c < p.n_chunks) {   // (block-uniform)
         const ChunkDesc ch = p.chunks[c];
@@ -783,25 +674,15 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 if (om && t == 0 && p.err) atomicAdd(p.err, 2 * (int)__popcll(om));
             }
             const uint32_t slot = cur.slot;
-            // pair key of the lane's measurement: control pose of its own batch | of its predecessor's (= the previous lane's), as emba_cand_keys_kernel
-            const uint32_t pair_key = (cur.bi << 16) | ((uint32_t)dpp_shr1((int)cur.bi) & 0xFFFFu);
-            const bool own_entry = cur.valid && t >= 1;
             __builtin_amdgcn_s_waitcnt(0x0F70);   // (3) vmcnt(0): the prefetched words are in.  The builtin, not inline asm: the compiler's own wait-count bookkeeping must
                                                   // know it, or it waits again at the next iteration's first use of `cur` — behind the record stores issued below
             cur = nxt;
             __builtin_amdgcn_sched_barrier(0);
-            if (fuse) {
-                if (own_entry) __builtin_nontemporal_store(o.inl ? o.pi : kInvalidPix, &p.ev_pano[i]);   // one coalesced 4-B store per entry
-                FuseAcc f{double4_t{0.0, 0.0, 0.0, 0.0}, 0xFFFFFFFFu, false};
-                store_records<kTileRecStage, true>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv], &f, pair_key, s_key[wv], s_gtag, s_gtbl);   // (4)
-                if (f.dirty) fuse_flush(f.acc, f.key, s_gtag, s_gtbl, p.gA11, p.gb1, p.gdim, t);
-            } else
             store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)
         }
     }
     __syncthreads();
     if (c >= p.n_chunks) return;
-    if (fuse) fuse_tables_out(s_gtag, s_gtbl, p.gA11, p.gb1, p.gdim, tid, kTileWaves * 64);
     const ChunkDesc ch = p.chunks[c];
     // flush: wave by wave over the tile's pixels; touched ones are listed (LDS) and sent 10 pixels = 60 lanes per atomic instruction
     for (int q0 = wv * 64; q0 < kTilePx; q0 += kTileWaves * 64) {
@@ -1361,6 +1242,7 @@ __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexel
 // needs no cross-lane reduction: lane l owns D[(l>>4)+4r][l&15].  Records are sorted by pair, so a wave flushes (fp64
 // atomics, <= 4 per lane) only when the pair changes or its chunk ends.  IRLS weights (model.cpp:599-618) scale the A operand.
 // ------------------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
 
 struct GramParams {
     const double* rec; const uint32_t* slot_key; long n_slots; int chunk;   // chunk: record slots per wave (multiple of 8)
@@ -1370,6 +1252,20 @@ struct GramParams {
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
 };
+
+// Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
+__device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint32_t key, double* A11, double* b1, int dim, int ablate)
+{
+    if (row >= 12 || v == 0.0 || EMBA_ABL(ablate, 32)) return;
+    const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
+    const int grow = (row < 6) ? bc + row : bp + row - 6;
+    if (col < 12) {
+        const int gcol = (col < 6) ? bc + col : bp + col - 6;
+        atomicAdd(A11 + (size_t)grow + (size_t)dim * gcol, v);
+    } else if (col == 14) {
+        atomicAdd(b1 + grow, v);
+    }
+}
 
 // Operand layout of the Gram kernel.  A wave-instruction loads 8 consecutive records as 16 B per lane (1 KiB, the access width
 // HBM streams fastest at): lane l holds elements (2m, 2m+1), m = l&7, of record R = l>>3.  Fed to v_mfma_f64_16x16x4_f64 as they
@@ -1701,88 +1597,6 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
 
 template <bool TAGS>
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p) { gram_body<TAGS, kGramBlock>(p, blockIdx.x); }
-
-// ------------------------------------------------------------------------------------------------
-// Correction pass of the fused Gram sums (tile order).  emba_warp_tiled_kernel<true> has summed w r r^T over EVERY inlier record of the
-// evaluation; the normal equations take only the measurements on active pixels (model.cpp:396,409: num_ev_map >= thres, known once all
-// events — of all ranks — are counted).  This kernel streams the per-entry panorama pixels (4 B per entry, coalesced), looks the activity
-// bit up, and for the few entries on INACTIVE pixels (dense regime: ~1 %) fetches the record through the entry's slot and adds
-// -w r r^T, with the same four-records-per-MFMA grouping and combine tables as the producer.  100 M events: 0.4 GB + ~1 % of the
-// records instead of the Gram kernel's second pass over all 12.8 GB of them.
-// ------------------------------------------------------------------------------------------------
-struct GramCorrectParams {
-    const uint32_t* ev_pano; const uint32_t* ev_slot; long n_entries; int per_wave;   // per_wave: entries per wave (multiple of 256)
-    const double* rec; const uint32_t* slot_key; const uint32_t* active_bits;
-    int irls; double eta; double* A11; double* b1; int dim;
-};
-constexpr int kCorrWaves = 4, kCorrList = 320;   // waves per workgroup; entries a wave collects before it fetches their records (256 new ones may join 63)
-
-__global__ __launch_bounds__(kCorrWaves * 64) void emba_gram_correct_kernel(GramCorrectParams p)
-{
-    __shared__ uint32_t s_gtag[kFuseKeys];
-    __shared__ double s_gtbl[kFuseKeys * kFuseTbl];
-    __shared__ uint32_t s_ent[kCorrWaves][kCorrList];
-    const int tid = threadIdx.x, t = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < kFuseKeys * kFuseTbl; k += kCorrWaves * 64) s_gtbl[k] = 0.0;
-    if (tid < kFuseKeys) s_gtag[tid] = 0xFFFFFFFFu;
-    __syncthreads();
-    const long w0 = ((long)blockIdx.x * kCorrWaves + wv) * p.per_wave;
-    const long w1 = (w0 + p.per_wave < p.n_entries) ? w0 + p.per_wave : p.n_entries;
-    FuseAcc f{double4_t{0.0, 0.0, 0.0, 0.0}, 0xFFFFFFFFu, false};
-    int cnt = 0;                                                         // (wave-uniform)
-    auto drain = [&]() {                                                 // fetch the listed entries' records, 16 at a time, and take them out of the sums
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (one wave: its list writes are complete)
-        for (int b0 = 0; b0 < cnt; b0 += 16) {
-            double val[4], e14[4]; uint32_t rkey[4]; bool in[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int ri = b0 + 4 * m + (t >> 4);
-                in[m] = ri < cnt;
-                const uint32_t slot = p.ev_slot[s_ent[wv][in[m] ? ri : b0]];
-                const double* r = p.rec + (size_t)kRecStride * slot;
-                val[m] = r[t & 15];
-                e14[m] = p.irls ? r[14] : 0.0;
-                rkey[m] = p.slot_key[slot];
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                if (b0 + 4 * m >= cnt) break;                            // (uniform)
-                fuse_group(f, val[m], -irls_weight(p.irls, p.eta, e14[m]), rkey[m], in[m], s_gtag, s_gtbl, p.A11, p.b1, p.dim, t);
-            }
-        }
-        cnt = 0;
-    };
-    for (long base = w0; base < w1; base += 256) {                       // 256 entries per trip: one 16-B load per lane
-        const long i0 = base + 4 * t;
-        uint32_t pi[4];
-        if (i0 + 3 < w1 && ((reinterpret_cast<uintptr_t>(p.ev_pano + i0) & 15u) == 0)) {
-            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-            const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p.ev_pano + i0));
-            pi[0] = v.x; pi[1] = v.y; pi[2] = v.z; pi[3] = v.w;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) pi[k] = (i0 + k < w1) ? p.ev_pano[i0 + k] : kInvalidPix;
-        }
-        uint32_t word[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) word[k] = p.active_bits[pi[k] != kInvalidPix ? (pi[k] >> 5) : 0u];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool inactive = pi[k] != kInvalidPix && !((word[k] >> (pi[k] & 31u)) & 1u);
-            const unsigned long long m = __ballot(inactive);
-            if (m) {
-                if (inactive) s_ent[wv][cnt + __popcll(m & ((1ull << t) - 1ull))] = (uint32_t)(i0 + k);
-                cnt += __popcll(m);
-            }
-        }
-        if (cnt >= kCorrList - 256) drain();
-    }
-    if (cnt) drain();
-    if (f.dirty) fuse_flush(f.acc, f.key, s_gtag, s_gtbl, p.A11, p.b1, p.dim, t);
-    __syncthreads();
-    fuse_tables_out(s_gtag, s_gtbl, p.A11, p.b1, p.dim, tid, kCorrWaves * 64);
-}
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.

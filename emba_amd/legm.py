@@ -140,12 +140,6 @@ class LEGM:
         self._check(self._L.emba_last_tile_drift(self._ctx, C.byref(n), C.byref(r)))
         return n.value, r.value
 
-    def form_info(self):
-        """dict(gram_fused=...) of the last formNormalEq[IRLS]: emba_last_form_info."""
-        f = C.c_int32(0)
-        self._check(self._L.emba_last_form_info(self._ctx, C.byref(f)))
-        return dict(gram_fused=bool(f.value))
-
     def event_counts(self):
         a, b = C.c_size_t(0), C.c_size_t(0)
         self._check(self._L.emba_event_counts(self._ctx, C.byref(a), C.byref(b)))

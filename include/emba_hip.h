@@ -115,11 +115,6 @@ emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, doubl
  * No reference counterpart (the reference has no device order).  Either pointer may be NULL. */
 emba_status emba_last_tile_drift(const emba_ctx* ctx, size_t* n_outside, int32_t* n_rebin);
 
-/* How the last emba_form_accumulate / emba_step / formNormalEq[IRLS] produced A11 | b1: *gram_fused = 1 when the sums had been accumulated by
- * the tiled warp kernel where the records were produced and only the inactive pixels' records were taken back out (tile order, cost of
- * the call == declared cost, no caller-supplied ep), 0 when the Gram kernel read the records.  Diagnostics; no reference counterpart. */
-emba_status emba_last_form_info(const emba_ctx* ctx, int32_t* gram_fused);
-
 /* Number of events actually used (floor(n/100)*100) and of measurement candidates
  * (events that have a predecessor at their sensor pixel). */
 emba_status emba_event_counts(const emba_ctx* ctx, size_t* n_used, size_t* n_candidates);

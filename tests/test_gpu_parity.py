@@ -213,46 +213,6 @@ def test_tile_order_rebins_after_trajectory_drift(gpu, oracle_mod, monkeypatch):
     assert out2 == 0 and rebins2 == 1, (out2, rebins2)
 
 
-@pytest.mark.parametrize("cost", [("quadratic", 0.0), ("huber", 0.1), ("cauchy", 1.0)])
-@pytest.mark.parametrize("kw,thres", [(dict(n_events=60000, pano_h=256, K=11, sensor=(48, 36), focal=40.0), 5),
-                                      (dict(n_events=120000, pano_h=128, K=31, sensor=(32, 24), focal=30.0, dt_knots=0.01), 9),
-                                      (dict(n_events=30000, pano_h=256, K=6, sensor=(64, 48), focal=60.0), 1)])
-def test_tile_order_fused_gram_sums(gpu, oracle_mod, monkeypatch, cost, kw, thres):
-    """Tile order: A11 | b1 are summed by the tiled warp kernel where the records are produced (every inlier), and formNormalEq takes the
-    records on INACTIVE pixels back out (emba_gram_correct_kernel) instead of reading all records a second time.  Workloads with a large
-    inactive share (threshold 5 / 9 on a sparse panorama: most of the sum is taken out again), with none (threshold 1), many control-pose
-    pairs per tile (K = 31), and the three costs; a call whose cost differs from the declared one must fall back to the records."""
-    monkeypatch.setenv("EMBA_ORDER", "tile")
-    w = small_workload(**kw)
-    m = make_legm(w)
-    m.set_cost(*cost)
-    irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
-    for rep in range(2):   # (the second evaluation writes the other record set)
-        nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
-        ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, w.events if rep == 0 else None, True, nem)
-        if irls == 0:   # (ep = None: the device-resident residuals, as solver.py and the C++ adapter call it; a caller-supplied ep reads the records)
-            m.formNormalEq(None, w.K, nem, thres)
-        else:
-            m.formNormalEqIRLS(None, w.K, nem, thres, cost[0], cost[1])
-        ne = m.applyL2Reg(w.alpha)
-        assert m.setup_info()["tile_order"] and m.form_info()["gram_fused"]
-        o = oracle_run(oracle_mod, w, thres=thres, irls=irls, a=cost[1])
-        assert np.array_equal(nem, o["num_ev_map"])
-        n_in = int(o["num_ev_map"][o["num_ev_map"] >= thres].sum()); n_all = int(o["num_ev_map"].sum())
-        assert (n_in < n_all) if thres > 1 else (n_in == n_all), (n_in, n_all)      # the correction really has work to do
-        compare_normal_eq(ne, o["ne"])
-        w.Gx = w.Gx * 1.01
-    # another cost than the declared one: the records are read (and the result is still the oracle's)
-    other = ("huber", 0.3) if cost[0] != "huber" else ("cauchy", 0.5)
-    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
-    ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, None, True, nem)
-    m.formNormalEqIRLS(ep, w.K, nem, thres, other[0], other[1])
-    ne = m.applyL2Reg(w.alpha)
-    assert not m.form_info()["gram_fused"]
-    o = oracle_run(oracle_mod, w, thres=thres, irls={"huber": 1, "cauchy": 2}[other[0]], a=other[1])
-    compare_normal_eq(ne, o["ne"])
-
-
 def test_edge_cases(gpu, oracle_mod):
     from emba_amd import EmbaError
     # fewer events than one batch, and none at all

@@ -222,35 +222,70 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-    auto range = [&](long kb, long ke) {
-        for (long c4 = kb + 4 * wv; c4 < ke; c4 += 16) {
-            const long col = c4 + kk;
-            const bool cok = col < ke;
-            const double* colp = p.A + (size_t)p.lda * (cok ? col : kb);
-            double av[4], bv[4];
+    // The wave's column quads, as one flat sequence of nq: dense form — its share of the block's K slice; block-sparse form — its share of every
+    // listed slice this block takes (blockIdx.y, + gridDim.y, ...), slice after slice.  quad(it) = first column of the wave's it-th quad
+    // (all of it scalar: wave-uniform).
+    constexpr int kQuadsPerSlice = 2 * kSyrkSlicePix / 16;
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const uint32_t cnt = p.list ? p.count[blockIdx.x] : 0u;
+    const uint32_t* lst = p.list ? p.list + (size_t)blockIdx.x * p.n_slices : nullptr;
+    const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
+    const long dkb = (long)blockIdx.y * kslice, dke = (dkb + kslice < p.k) ? dkb + kslice : p.k;
+    int nq;
+    if (p.list) nq = (cnt > blockIdx.y) ? (int)((cnt - blockIdx.y + gridDim.y - 1) / gridDim.y) * kQuadsPerSlice : 0;
+    else { const long span = dke - dkb - 4 * wvs; nq = span > 0 ? (int)((span + 15) / 16) : 0; }
+    auto quad = [&](int it) -> long {
+        if (it >= nq) return -1;
+        if (p.list) return (long)lst[blockIdx.y + (uint32_t)(it / kQuadsPerSlice) * gridDim.y] * (2 * kSyrkSlicePix) + 16 * (it % kQuadsPerSlice) + 4 * wvs;
+        return dkb + 16L * it + 4 * wvs;
+    };
+    const long kend = p.list ? p.k : dke;
+    // Operand loads are UNCONDITIONAL (clamped addresses, zeros selected afterwards) and run TWO quads ahead of the MFMAs through three
+    // register buffers used round-robin: a wave's 16 MFMAs per quad are 1024 matrix-pipe cycles, two waves share a SIMD, so two quads in
+    // flight cover ~2 us of load latency.  (Before: load, wait, 16 MFMAs, next load — 26 TFLOP/s dense, 9 block-sparse.)
+    // (validity is ANDed into the operand's bits when it is USED, an iteration or two after the load: a select at the load lets the compiler
+    // sink the load under the condition — a load under a lane mask is waited for at the end of its branch, vmcnt(0) after every second
+    // load in the generated code — and a mask applied at the load is a use of the value, waited for on the spot)
+    int rma[4], rmb[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
-                av[t] = (cok && ri < p.n) ? colp[ri] : 0.0;
-                bv[t] = (cok && rj < p.n) ? colp[rj] : 0.0;
-            }
+    for (int t = 0; t < 4; ++t) { rma[t] = (I0 + 16 * t + el < p.n) ? -1 : 0; rmb[t] = (J0 + 16 * t + el < p.n) ? -1 : 0; }
+    auto load = [&](int it, double* av, double* bv, int& cm) {
+        const long c4 = quad(it);
+        const long col = c4 + kk;
+        const bool cok = c4 >= 0 && col < kend;
+        cm = cok ? -1 : 0;
+        const double* colp = p.A + (size_t)p.lda * (cok ? col : 0);
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+            const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
+            av[t] = colp[rma[t] ? ri : 0];
+            bv[t] = colp[rmb[t] ? rj : 0];
         }
     };
-    if (p.list) {   // block-sparse: only the column slices in which both row blocks are populated
-        const uint32_t cnt = p.count[blockIdx.x];
-        const uint32_t* lst = p.list + (size_t)blockIdx.x * p.n_slices;
-        for (uint32_t q = blockIdx.y; q < cnt; q += gridDim.y) {
-            const long kb = (long)lst[q] * (2 * kSyrkSlicePix), ke = (kb + 2 * kSyrkSlicePix < p.k) ? kb + 2 * kSyrkSlicePix : p.k;
-            range(kb, ke);
+    auto mma = [&](const double* av, const double* bv, int cm) {
+        double am[4], bm[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ma = cm & rma[t], mb = cm & rmb[t];
+            am[t] = __hiloint2double(__double2hiint(av[t]) & ma, __double2loint(av[t]) & ma);
+            bm[t] = __hiloint2double(__double2hiint(bv[t]) & mb, __double2loint(bv[t]) & mb);
         }
-    } else {
-        const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
-        const long kb = (long)blockIdx.y * kslice, ke = (kb + kslice < p.k) ? kb + kslice : p.k;
-        range(kb, ke);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], bm[b], acc[a][b], 0, 0, 0);
+    };
+    {
+        double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
+        int m0, m1, m2;
+        load(0, a0, b0, m0); load(1, a1, b1, m1);
+        // (one loop body of three stages and nothing else: with early exits between the stages the register allocator kept the 128 accumulator
+        // registers in different places on different paths and copied them every trip; stages past the end run on zeros)
+        for (int it = 0; it < nq; it += 3) {
+            load(it + 2, a2, b2, m2); mma(a0, b0, m0);
+            load(it + 3, a0, b0, m0); mma(a1, b1, m1);
+            load(it + 4, a1, b1, m1); mma(a2, b2, m2);
+        }
     }
     for (int i = threadIdx.x; i < 64 * 64; i += 256) s_tile[i] = 0.0;
     __syncthreads();

@@ -141,7 +141,7 @@ struct emba_ctx {
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     int solve_info = 0;         // last Schur solve: bit 0 a 2x2 block not positive definite (error), bit 1 a pivot of S vanished (zero update, like Eigen's ldlt)
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
-    struct { void* p = nullptr; size_t bytes = 0; } ws[32];   // 0-15 Schur solve, 16-31 sort / order preparation
+    struct { void* p = nullptr; size_t bytes = 0; } ws[40];   // 0-15 and 32-39 Schur solve, 16-31 sort / order preparation
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
     double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
     double* d_thomas = nullptr;   // Thomas factors of T_W + lambda1[i] I (W x H)
@@ -1652,9 +1652,9 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
                              double* d_S, long lds_, double* d_y, double* d_cf, int* d_info)
 {
     hipStream_t s = c->stream;
-    const int na = n + 1;
+    // (the SYRK covers the n rows of S; row n of the augmented matrix, the right-hand side b1 - U y, is accumulated by the build kernel itself)
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(n_pix, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
-    const int nb64 = (na + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
+    const int nb64 = (n + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
     const int nks_max = std::max(1, (4 * c->n_cu + nbp - 1) / nbp);   // enough (tile pair, K slab) blocks to fill the chip ...
     double *d_U = nullptr, *d_slab = nullptr;
     emba_status st;
@@ -1662,7 +1662,8 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     SchurBuildParams bp{};
     bp.view = view; bp.off = L.off; bp.bucket = L.bucket; bp.A22b2 = A22b2; bp.lambda = lambda;
     bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
-    const size_t lds_bytes = (size_t)4 * 2 * n * sizeof(double);
+    bp.rhs_row = d_S + n; bp.lds = lds_;
+    const size_t lds_bytes = (size_t)9 * n * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", n / 3);
     if (lds_bytes > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Block-sparse SYRK (>= 4 row blocks, i.e. K >= 64): the columns of a slice of kSyrkSlicePix consecutive active pixels — a piece of a
@@ -1675,7 +1676,9 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         bp.p0 = (long)p0; bp.p1 = (long)p1;
         const long kc = (long)(2 * (p1 - p0));
         const int n_slices = (int)((p1 - p0 + kSyrkSlicePix - 1) / kSyrkSlicePix);
-        unsigned long long* d_mask = nullptr; uint32_t *d_list = nullptr, *d_cnt = nullptr;
+        unsigned long long* d_mask = nullptr; uint32_t *d_list = nullptr, *d_cnt = nullptr; uint16_t* d_range = nullptr;
+        if ((st = ws_get(c, 32, (p1 - p0 + 8) * 2, (void**)&d_range))) return st;
+        bp.range = d_range;
         if (sparse) {
             if ((st = ws_get(c, 3, (size_t)n_slices * 8, (void**)&d_mask)) || (st = ws_get(c, 4, (size_t)nbp * n_slices * 4, (void**)&d_list)) ||
                 (st = ws_get(c, 5, (size_t)nbp * 4, (void**)&d_cnt)))
@@ -1686,7 +1689,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
         int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
         SyrkParams sp{};
-        sp.A = d_U; sp.lda = lds_; sp.n = na; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp;
+        sp.A = d_U; sp.lda = lds_; sp.n = n; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.range = d_range;
         if (sparse) {
             hipLaunchKernelGGL(emba_syrk_lists_kernel, dim3((unsigned)nbp), dim3(64), 0, s, d_mask, n_slices, nbp, d_list, d_cnt);
             sp.list = d_list; sp.count = d_cnt; sp.n_slices = n_slices;
@@ -1696,7 +1699,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
         if (nks > 1)
             hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256), (unsigned)((nks + kSyrkReduceGroup - 1) / kSyrkReduceGroup)),
-                               dim3(256), 0, s, d_slab, nks, nbp, na, d_S, lds_);
+                               dim3(256), 0, s, d_slab, nks, nbp, n, d_S, lds_);
     }
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;

@@ -82,14 +82,19 @@ struct SchurBuildParams {
     double* yv; double* cfac;                    // per pixel: y = C^-1 b2 (2), C = {c00, c10, c11}
     int* info;                                   // set to 1 if some A22m is not positive definite
     unsigned long long* slice_mask;              // per slice of kSyrkSlicePix pixels of the chunk: which 64-row blocks of U its columns touch (nullptr: not wanted)
+    uint16_t* range;                             // per pixel of the chunk: lo | hi << 8, the 64-row blocks [lo, hi] of U its two columns were WRITTEN in (lo > hi: none)
+    double* rhs_row; long lds;                   // rhs_row[lds * r] -= (U y)[r]: row n of the augmented S (the right-hand side b1 - U y), accumulated here
 };
 
 __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams p)
 {
-    extern __shared__ __attribute__((aligned(16))) double s_cols[];   // 4 waves x 2 columns x n
+    extern __shared__ __attribute__((aligned(16))) double s_cols[];   // 4 waves x 2 columns x n, then the block's n partial sums of U y
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* c0 = s_cols + (size_t)wv * 2 * p.n;
     double* c1 = c0 + p.n;
+    double* s_rhs = s_cols + (size_t)4 * 2 * p.n;
+    for (int r = threadIdx.x; r < 9 * p.n; r += 256) s_cols[r] = 0.0;   // (the columns are re-zeroed after every pixel, where they were touched)
+    __syncthreads();
     const long nwaves = (long)gridDim.x * 4;
     for (long i = p.p0 + (long)blockIdx.x * 4 + wv; i < p.p1; i += nwaves) {
         const double* q = p.A22b2 + 5 * i;
@@ -98,11 +103,9 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
         const double y0 = q[3] / c00, y1 = (q[4] - c10 * y0) / c11;
         if (lane == 0) { p.yv[2 * i] = y0; p.yv[2 * i + 1] = y1; p.cfac[3 * i] = c00; p.cfac[3 * i + 1] = c10; p.cfac[3 * i + 2] = c11; }
-        for (int r = lane; r < p.n; r += 64) { c0[r] = 0.0; c1[r] = 0.0; }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
         const int el = lane & 15, kk = lane >> 4;
-        unsigned long long rows_mask = 1ull << (p.n >> 6);   // (the extra row n of the augmented block is always there)
+        unsigned long long rows_mask = 0ull;
         for (uint32_t b = b0; b < b1; b += 4) {      // four records per trip (lane l: element l&15 of record l>>4): one memory latency for four
             const uint32_t bb = b + kk;
             const bool in = bb < b1;
@@ -125,22 +128,34 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
-        // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) rows_mask |= __shfl_xor(rows_mask, o);
+        // Only the 64-row blocks [lo, hi] between the pixel's first and last touched block are written (a band over a long window: the pixel is
+        // in view for a fraction of it); the SYRK masks every other block of these two columns out (SyrkParams::range), whatever the buffer holds.
+        const int lo = rows_mask ? (int)__ffsll((long long)rows_mask) - 1 : 1, hi = rows_mask ? 63 - (int)__clzll((long long)rows_mask) : 0;
+        const int r0 = 64 * lo, r1 = (64 * (hi + 1) < p.n) ? 64 * (hi + 1) : p.n;
+        // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11 ;  and the block's share of U y (the right-hand side b1 - U y)
         double* u0 = p.U + (size_t)p.ldu * (2 * (i - p.p0));
         double* u1 = u0 + p.ldu;
-        for (int r = lane; r < p.n; r += 64) {
+        for (int r = r0 + lane; r < r1; r += 64) {
             const double a0 = c0[r], a1 = c1[r];
-            const double t0 = a0 / c00;
+            const double t0 = a0 / c00, t1 = (a1 - t0 * c10) / c11;
             u0[r] = t0;
-            u1[r] = (a1 - t0 * c10) / c11;
+            u1[r] = t1;
+            c0[r] = 0.0; c1[r] = 0.0;
+            const double uy = t0 * y0 + t1 * y1;
+            if (uy != 0.0) atomicAdd(&s_rhs[r], uy);
         }
-        if (lane == 0) { u0[p.n] = y0; u1[p.n] = y1; }     // extra row: (U_aug U_aug^T)[r][n] = (U y)[r], the rhs update comes with the SYRK
-        if (p.slice_mask) {
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) rows_mask |= __shfl_xor(rows_mask, o);
-            if (lane == 0) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
+        if (lane == 0) {
+            p.range[i - p.p0] = (uint16_t)(lo | (hi << 8));
+            if (p.slice_mask && rows_mask) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < p.n; r += 256) {
+        const double v = s_rhs[r];
+        if (v != 0.0) atomicAdd(p.rhs_row + (size_t)p.lds * r, -v);
     }
 }
 
@@ -177,6 +192,7 @@ struct SyrkParams {
     // block-sparse form: blockIdx.y = part; the block walks the slices list[bp * n_slices + part], + gridDim.y, ... (count[bp] of them):
     // the column slices (2 * kSyrkSlicePix columns each) in which BOTH of its 64-row blocks have non-zeros
     const uint32_t* list; const uint32_t* count; int n_slices;
+    const uint16_t* range;   // per PAIR of columns (one pixel): the 64-row blocks [lo, hi] = (r & 255, r >> 8) that hold data; everything else of those columns reads as zero.  nullptr: all rows
 };
 
 // per block pair (I >= J) the slices whose columns touch both row blocks: one wave per pair, ballot-compacted
@@ -254,6 +270,7 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
         const long col = c4 + kk;
         const bool cok = c4 >= 0 && col < kend;
         cm = cok ? -1 : 0;
+        if (p.range) cm = cok ? (int)p.range[col >> 1] : 0x0001;   // (the raw range word rides with the stage; decoded in mma.  lo = 1 > hi = 0: nothing valid)
         const double* colp = p.A + (size_t)p.lda * (cok ? col : 0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -264,9 +281,11 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     };
     auto mma = [&](const double* av, const double* bv, int cm) {
         double am[4], bm[4];
+        int cma = cm, cmb = cm;
+        if (p.range) { const int lo = cm & 255, hi = cm >> 8; cma = (I >= lo && I <= hi) ? -1 : 0; cmb = (J >= lo && J <= hi) ? -1 : 0; }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ma = cm & rma[t], mb = cm & rmb[t];
+            const int ma = cma & rma[t], mb = cmb & rmb[t];
             am[t] = __hiloint2double(__double2hiint(av[t]) & ma, __double2loint(av[t]) & ma);
             bm[t] = __hiloint2double(__double2hiint(bv[t]) & mb, __double2loint(bv[t]) & mb);
         }

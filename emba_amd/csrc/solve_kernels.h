@@ -106,28 +106,42 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
         const int el = lane & 15, kk = lane >> 4;
         unsigned long long rows_mask = 0ull;
-        for (uint32_t b = b0; b < b1; b += 4) {      // four records per trip (lane l: element l&15 of record l>>4): one memory latency for four
-            const uint32_t bb = b + kk;
-            const bool in = bb < b1;
-            const uint32_t s = in ? p.bucket[bb] : 0u;
-            const double x = in ? p.view.rec[(size_t)kRecStride * s + el] : 0.0;
-            const int g = lane & 48;
-            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
-            double w = 1.0;
-            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
-            else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
-            const uint32_t key = in ? rec_key(p.view, s) : 0u;
-            const int bc = 3 * (int)(key >> 16), bp = 3 * (int)(key & 0xFFFFu);
-            if (in) rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
-            const double wx = w * x;                                            // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
+        // The pixel's record list in two dependent steps instead of two per group of four: all its bucket entries in one load (lane l: entry l),
+        // then the records of up to 16 entries in flight at a time (lane l: element l&15 of record l>>4 of each group of four).  The sums go
+        // to the LDS columns with fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
+        for (uint32_t base = b0; base < b1; base += 64) {               // (one trip unless the pixel has more than 64 records)
+            const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
+            const uint32_t s_l = p.bucket[base + (lane < m ? lane : 0)];
+            for (int t0 = 0; t0 < m; t0 += 16) {
+                double x[4]; uint32_t key[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {                                       // rows of different records / of c and p may coincide: ordered steps
-                if (in && kk == q && el < 6) { c0[bc + el] += wx * dx; c1[bc + el] += wx * dy; }
-                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (in && kk == q && el >= 6 && el < 12) { c0[bp + el - 6] += wx * dx; c1[bp + el - 6] += wx * dy; }
-                __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int u = 0; u < 4; ++u) {
+                    const int r = t0 + 4 * u + kk;
+                    const uint32_t s = (uint32_t)__shfl((int)s_l, r < m ? r : 0);
+                    x[u] = p.view.rec[(size_t)kRecStride * s + el];
+                    key[u] = rec_key(p.view, s);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (t0 + 4 * u >= m) break;                             // (uniform)
+                    const bool in = t0 + 4 * u + kk < m;
+                    const int g = lane & 48;
+                    const double dx = __shfl(x[u], g | 12), dy = __shfl(x[u], g | 13), e = __shfl(x[u], g | 14);
+                    double w = 1.0;
+                    if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
+                    else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
+                    const int bc = 3 * (int)(key[u] >> 16), bp = 3 * (int)(key[u] & 0xFFFFu);
+                    if (in) rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
+                    const double wx = w * x[u];                                 // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
+                    if (in && el < 12) {
+                        const int row = (el < 6) ? bc + el : bp + el - 6;
+                        atomicAdd(&c0[row], wx * dx);
+                        atomicAdd(&c1[row], wx * dy);
+                    }
+                }
             }
         }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) rows_mask |= __shfl_xor(rows_mask, o);
         // Only the 64-row blocks [lo, hi] between the pixel's first and last touched block are written (a band over a long window: the pixel is

@@ -380,9 +380,14 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        double v = row[j];
+        // (four partial sums: one running sum is a chain of j dependent fp64 FMAs, ~2000 of them over the block)
+        double v0 = row[j], v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-        for (int k = 0; k < j; ++k) v -= row[k] * readlane_f64(row[k], j);
+        for (int k = 0; k < j; ++k) {
+            const double t = row[k] * readlane_f64(row[k], j);
+            if ((k & 3) == 0) v0 -= t; else if ((k & 3) == 1) v1 -= t; else if ((k & 3) == 2) v2 -= t; else v3 -= t;
+        }
+        const double v = (v0 + v1) + (v2 + v3);
         const double d = readlane_f64(v, j);
         // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
         // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
@@ -390,21 +395,28 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
         // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
         const bool ok = d > 0.0;
         bad |= (j < nb) && !ok;
-        const double piv = ok ? sqrt(d) : 0.0;
-        row[j] = (r == j) ? piv : (ok ? v / piv : 0.0);     // rows above the diagonal hold garbage that is never read (k < j <= r below)
+        // (one reciprocal square root per column instead of a square root and a division: both are long dependent sequences in fp64,
+        // 64 of them in a row were half of this kernel's time)
+        const double rs = ok ? rsqrt(d) : 0.0;
+        row[j] = (r == j) ? d * rs : v * rs;                // rows above the diagonal hold garbage that is never read (k < j <= r below)
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
 #pragma unroll
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
 
-// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)
-__global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
+// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row, ONE wave per workgroup:
+// the few 256-thread workgroups of a 600-row panel sat on three CUs and their four waves queued for the LDS pipe behind 2016 broadcast
+// reads each — 35 us per panel)
+// (tried: right-looking, x[c] -= x[k] L[c][k] for all c > k with the column of L contiguous in LDS — fully unrolled the compiler hoists the
+// 2016 LDS reads and spills 15 KB per lane, with or without scheduling / memory barriers between the columns: 220 us per panel)
+__global__ __launch_bounds__(64) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
 {
     __shared__ double s[64 * 65];
-    for (int i = threadIdx.x; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+    for (int i = threadIdx.x; i < nb * nb; i += 64) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
     __syncthreads();
-    const int r = jb + nb + blockIdx.x * 256 + threadIdx.x;
+    const int r = jb + nb + blockIdx.x * 64 + threadIdx.x;
     if (r >= n) return;
     double x[64];
 #pragma unroll
@@ -412,9 +424,13 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         if (c < nb) {
-            double v = x[c];
+            double v0 = x[c], v1 = 0.0, v2 = 0.0, v3 = 0.0;
 #pragma unroll
-            for (int k = 0; k < c; ++k) v -= x[k] * s[k * 65 + c];     // L_diag[c][k]
+            for (int k = 0; k < c; ++k) {                               // L_diag[c][k]; four partial sums instead of one dependent chain
+                const double t = x[k] * s[k * 65 + c];
+                if ((k & 3) == 0) v0 -= t; else if ((k & 3) == 1) v1 -= t; else if ((k & 3) == 2) v2 -= t; else v3 -= t;
+            }
+            const double v = (v0 + v1) + (v2 + v3);
             const double dg = s[c * 65 + c];
             x[c] = (dg != 0.0) ? v / dg : 0.0;                        // zeroed column of a vanishing pivot (emba_chol_diag_kernel)
         }
@@ -426,10 +442,12 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
 // Solve L L^T x = b in place (one workgroup; 64-wide blocks: substitution inside a block by one wave in LDS, then the rest of the
 // right-hand side is updated by all threads).
 // backward_only: b already holds z = L^-1 rhs (the factorisation carried the right-hand side along as an extra row: schur_factor_solve)
+constexpr int kTrsvMaxN = 3072;   // right-hand sides up to this length stay in LDS during the backward sweep (K <= 1024)
 __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b, int backward_only)
 {
     __shared__ double s_l[64 * 65];
     __shared__ double s_x[64];
+    __shared__ double s_b[kTrsvMaxN];
     const int t = threadIdx.x;
     // forward: L z = b
     for (int jb = 0; jb < n && !backward_only; jb += 64) {
@@ -455,30 +473,38 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
         }
         __syncthreads();
     }
-    // backward: L^T x = z
+    // backward: L^T x = z.  The right-hand side lives in LDS for the whole sweep (n <= kTrsvMaxN; beyond that in global memory as before).
+    const bool in_lds = n <= kTrsvMaxN;
+    if (in_lds) { for (int i = t; i < n; i += 1024) s_b[i] = b[i]; }
+    __syncthreads();
     for (int jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {
         const int nb = (n - jb < 64) ? n - jb : 64;
         for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
-        if (t < 64) s_x[t] = (t < nb) ? b[jb + t] : 0.0;
+        if (t < 64) s_x[t] = (t < nb) ? (in_lds ? s_b[jb + t] : b[jb + t]) : 0.0;
         __syncthreads();
         if (t < 64) {
             double v = s_x[t];
+            const double dgt = s_l[t * 65 + t];
+            const double rdt = (t < nb && dgt != 0.0) ? 1.0 / dgt : 0.0;            // pseudo-inverse: zero update where the pivot vanished
             for (int j = nb - 1; j >= 0; --j) {
-                const double dg = s_l[j * 65 + j];
-                const double xj = (dg != 0.0) ? __shfl(v, j) / dg : 0.0;            // pseudo-inverse: zero update where the pivot vanished
+                const double xj = __shfl(v * rdt, j);
                 if (t == j) v = xj; else if (t < j) v -= s_l[t * 65 + j] * xj;      // L^T[t][j] = L[j][t]
             }
             s_x[t] = v;
-            if (t < nb) b[jb + t] = v;
+            if (t < nb) { if (in_lds) s_b[jb + t] = v; else b[jb + t] = v; }
         }
         __syncthreads();
-        for (int r = t; r < jb; r += 1024) {
-            double v = b[r];
-            for (int c = 0; c < nb; ++c) v -= L[(size_t)ld * r + jb + c] * s_x[c];    // L^T[r][jb+c] = L[jb+c][r]
-            b[r] = v;
+        // rows above the block: one wave per row, lanes over the block's 64 columns (one coalesced 512-B load per row), xor-shuffle sum
+        for (int r = (t >> 6); r < jb; r += 16) {
+            const int c = t & 63;
+            double d = (c < nb) ? L[(size_t)ld * r + jb + c] * s_x[c] : 0.0;      // L^T[r][jb+c] = L[jb+c][r]
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+            if (c == 0) { if (in_lds) s_b[r] -= d; else b[r] -= d; }
         }
         __syncthreads();
     }
+    if (in_lds) { for (int i = t; i < n; i += 1024) b[i] = s_b[i]; }
 }
 
 // x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,
@@ -494,20 +520,34 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
     for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < P; i += nwaves) {
         double a0 = 0.0, a1 = 0.0;
         const uint32_t b0 = off[i], b1 = off[i + 1];
-        for (uint32_t b = b0; b < b1; b += 4) {
-            const uint32_t bb = b + kk;
-            const bool in = bb < b1;
-            const uint32_t s = in ? bucket[bb] : 0u;
-            const double x = in ? view.rec[(size_t)kRecStride * s + el] : 0.0;
-            const uint32_t key = in ? rec_key(view, s) : 0u;
-            const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
-            double d = (in && el < 12) ? x * x1[row] : 0.0;
-            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
-            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
-            double w = 1.0;
-            if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
-            else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
-            if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
+        // (as in emba_schur_build_kernel: the pixel's bucket entries in one load, the records of 16 entries in flight at a time)
+        for (uint32_t base = b0; base < b1; base += 64) {
+            const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
+            const uint32_t s_l = bucket[base + (lane < m ? lane : 0)];
+            for (int t0 = 0; t0 < m; t0 += 16) {
+                double xv[4]; uint32_t key[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = t0 + 4 * u + kk;
+                    const uint32_t s = (uint32_t)__shfl((int)s_l, r < m ? r : 0);
+                    xv[u] = view.rec[(size_t)kRecStride * s + el];
+                    key[u] = rec_key(view, s);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (t0 + 4 * u >= m) break;                             // (uniform)
+                    const bool in = t0 + 4 * u + kk < m;
+                    const double x = xv[u];
+                    const int row = (el < 6) ? 3 * (int)(key[u] >> 16) + el : 3 * (int)(key[u] & 0xFFFFu) + el - 6;
+                    double d = (in && el < 12) ? x * x1[row] : 0.0;
+                    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
+                    const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
+                    double w = 1.0;
+                    if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
+                    else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
+                    if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
+                }
+            }
         }
         a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
         a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);

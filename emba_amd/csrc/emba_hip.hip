@@ -1718,7 +1718,7 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
         const int nb = std::min(64, m - jb);
         hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
         const int below = m - jb - nb;                      // matrix rows under the panel; the rhs row (index m) comes on top of them
-        hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 63) / 64), dim3(64), 0, s, Sm, lds_, m + 1, jb, nb);
+        hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 255) / 256), dim3(256), 0, s, Sm, lds_, m + 1, jb, nb);
         if (below > 0) {
             const int tb = (below + 1 + 63) / 64;
             SyrkParams tp{};

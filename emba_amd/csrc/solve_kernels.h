@@ -82,7 +82,8 @@ struct SchurBuildParams {
     double* yv; double* cfac;                    // per pixel: y = C^-1 b2 (2), C = {c00, c10, c11}
     int* info;                                   // set to 1 if some A22m is not positive definite
     unsigned long long* slice_mask;              // per slice of kSyrkSlicePix pixels of the chunk: which 64-row blocks of U its columns touch (nullptr: not wanted)
-    uint16_t* range;                             // per pixel of the chunk: lo | hi << 8, the 64-row blocks [lo, hi] of U its two columns were WRITTEN in (lo > hi: none)
+    uint16_t* range;                             // per pixel of the chunk: lo | hi << 8, the 16-ROW groups [lo, hi] its two columns of U are non-zero in (lo > hi: none);
+                                                 // the columns are WRITTEN in the 64-row blocks [lo >> 2, hi >> 2]
     double* rhs_row; long lds;                   // rhs_row[lds * r] -= (U y)[r]: row n of the augmented S (the right-hand side b1 - U y), accumulated here
 };
 
@@ -96,22 +97,40 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
     for (int r = threadIdx.x; r < 9 * p.n; r += 256) s_cols[r] = 0.0;   // (the columns are re-zeroed after every pixel, where they were touched)
     __syncthreads();
     const long nwaves = (long)gridDim.x * 4;
-    for (long i = p.p0 + (long)blockIdx.x * 4 + wv; i < p.p1; i += nwaves) {
-        const double* q = p.A22b2 + 5 * i;
-        const double mxx = q[0] + p.lambda * q[0], mxy = q[1], myy = q[2] + p.lambda * q[2];   // model.cpp:748
+    // Software pipeline over the wave's pixels: the list bounds and 2x2 block of pixel i+2 and the bucket entries of pixel i+1 are fetched
+    // while pixel i is worked on, so that a pixel costs ONE dependent round trip (its records) instead of three.
+    const long i_first = p.p0 + (long)blockIdx.x * 4 + wv, i_last = p.p1 - 1;       // (loads of pixels past the end are clamped, never used)
+    struct Hdr { uint32_t b0, b1; double q0, q1, q2, q3, q4; };
+    auto load_hdr = [&](long i, Hdr& h) {
+        const long ic = i < i_last ? i : i_last;
+        h.b0 = p.off[ic]; h.b1 = p.off[ic + 1];
+        const double* q = p.A22b2 + 5 * ic;
+        h.q0 = q[0]; h.q1 = q[1]; h.q2 = q[2]; h.q3 = q[3]; h.q4 = q[4];
+    };
+    auto load_sl = [&](const Hdr& h) -> uint32_t { const uint32_t cnt = h.b1 - h.b0; return p.bucket[h.b0 + ((uint32_t)lane < cnt ? lane : 0)]; };   // (bucket has one spare entry at its end)
+    Hdr h_cur, h_nxt;
+    load_hdr(i_first, h_cur);
+    load_hdr(i_first + nwaves, h_nxt);
+    uint32_t sl_cur = load_sl(h_cur);
+    for (long i = i_first; i < p.p1; i += nwaves) {
+        const uint32_t sl_nxt = load_sl(h_nxt);
+        Hdr h_nn;
+        load_hdr(i + 2 * nwaves, h_nn);
+        const double mxx = h_cur.q0 + p.lambda * h_cur.q0, mxy = h_cur.q1, myy = h_cur.q2 + p.lambda * h_cur.q2;   // model.cpp:748
         const double c00 = sqrt(mxx), c10 = mxy / c00, c11 = sqrt(myy - c10 * c10);
         if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
-        const double y0 = q[3] / c00, y1 = (q[4] - c10 * y0) / c11;
+        const double y0 = h_cur.q3 / c00, y1 = (h_cur.q4 - c10 * y0) / c11;
         if (lane == 0) { p.yv[2 * i] = y0; p.yv[2 * i + 1] = y1; p.cfac[3 * i] = c00; p.cfac[3 * i + 1] = c10; p.cfac[3 * i + 2] = c11; }
-        const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
+        const uint32_t b0 = h_cur.b0, b1 = h_cur.b1;
         const int el = lane & 15, kk = lane >> 4;
         unsigned long long rows_mask = 0ull;
+        int rmin = 0x7FFFFFFF, rmax = -1;                               // first / last row of U the pixel's records touch
         // The pixel's record list in two dependent steps instead of two per group of four: all its bucket entries in one load (lane l: entry l),
         // then the records of up to 16 entries in flight at a time (lane l: element l&15 of record l>>4 of each group of four).  The sums go
         // to the LDS columns with fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
         for (uint32_t base = b0; base < b1; base += 64) {               // (one trip unless the pixel has more than 64 records)
             const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
-            const uint32_t s_l = p.bucket[base + (lane < m ? lane : 0)];
+            const uint32_t s_l = (base == b0) ? sl_cur : p.bucket[base + (lane < m ? lane : 0)];
             for (int t0 = 0; t0 < m; t0 += 16) {
                 double x[4]; uint32_t key[4];
 #pragma unroll
@@ -131,7 +150,10 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
                     if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
                     else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
                     const int bc = 3 * (int)(key[u] >> 16), bp = 3 * (int)(key[u] & 0xFFFFu);
-                    if (in) rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
+                    if (in) {
+                        rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
+                        rmin = min(rmin, min(bc, bp)); rmax = max(rmax, max(bc, bp) + 5);
+                    }
                     const double wx = w * x[u];                                 // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
                     if (in && el < 12) {
                         const int row = (el < 6) ? bc + el : bp + el - 6;
@@ -143,10 +165,12 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) rows_mask |= __shfl_xor(rows_mask, o);
-        // Only the 64-row blocks [lo, hi] between the pixel's first and last touched block are written (a band over a long window: the pixel is
-        // in view for a fraction of it); the SYRK masks every other block of these two columns out (SyrkParams::range), whatever the buffer holds.
-        const int lo = rows_mask ? (int)__ffsll((long long)rows_mask) - 1 : 1, hi = rows_mask ? 63 - (int)__clzll((long long)rows_mask) : 0;
+        for (int o = 32; o >= 1; o >>= 1) { rows_mask |= __shfl_xor(rows_mask, o); rmin = min(rmin, __shfl_xor(rmin, o)); rmax = max(rmax, __shfl_xor(rmax, o)); }
+        // Only the 64-row blocks between the pixel's first and last touched row are written (a band over a long window: the pixel is in view
+        // for a fraction of it); the SYRK masks everything else of these two columns out (SyrkParams::range), whatever the buffer holds, and
+        // skips the 16 x 16 tiles in which no column of a quad has a row.
+        const int lo16 = (rmax >= 0) ? rmin >> 4 : 1, hi16 = (rmax >= 0) ? rmax >> 4 : 0;
+        const int lo = (rmax >= 0) ? lo16 >> 2 : 1, hi = (rmax >= 0) ? hi16 >> 2 : 0;
         const int r0 = 64 * lo, r1 = (64 * (hi + 1) < p.n) ? 64 * (hi + 1) : p.n;
         // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11 ;  and the block's share of U y (the right-hand side b1 - U y)
         double* u0 = p.U + (size_t)p.ldu * (2 * (i - p.p0));
@@ -161,10 +185,11 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             if (uy != 0.0) atomicAdd(&s_rhs[r], uy);
         }
         if (lane == 0) {
-            p.range[i - p.p0] = (uint16_t)(lo | (hi << 8));
+            p.range[i - p.p0] = (uint16_t)(lo16 | (hi16 << 8));
             if (p.slice_mask && rows_mask) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        h_cur = h_nxt; h_nxt = h_nn; sl_cur = sl_nxt;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < p.n; r += 256) {
@@ -206,7 +231,7 @@ struct SyrkParams {
     // block-sparse form: blockIdx.y = part; the block walks the slices list[bp * n_slices + part], + gridDim.y, ... (count[bp] of them):
     // the column slices (2 * kSyrkSlicePix columns each) in which BOTH of its 64-row blocks have non-zeros
     const uint32_t* list; const uint32_t* count; int n_slices;
-    const uint16_t* range;   // per PAIR of columns (one pixel): the 64-row blocks [lo, hi] = (r & 255, r >> 8) that hold data; everything else of those columns reads as zero.  nullptr: all rows
+    const uint16_t* range;   // per PAIR of columns (one pixel): the 16-row groups [lo, hi] = (r & 255, r >> 8) that hold data; everything else of those columns reads as zero.  nullptr: all rows
 };
 
 // per block pair (I >= J) the slices whose columns touch both row blocks: one wave per pair, ballot-compacted
@@ -295,18 +320,25 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     };
     auto mma = [&](const double* av, const double* bv, int cm) {
         double am[4], bm[4];
-        int cma = cm, cmb = cm;
-        if (p.range) { const int lo = cm & 255, hi = cm >> 8; cma = (I >= lo && I <= hi) ? -1 : 0; cmb = (J >= lo && J <= hi) ? -1 : 0; }
+        bool any_a[4], any_b[4];
+        const int lo = cm & 255, hi = (cm >> 8) & 255;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int ma = cma & rma[t], mb = cmb & rmb[t];
+            int ma = cm & rma[t], mb = cm & rmb[t];
+            if (p.range) {     // the lane's column has data in the 16-row group of this tile row?
+                ma = (4 * I + t >= lo && 4 * I + t <= hi) ? rma[t] : 0;
+                mb = (4 * J + t >= lo && 4 * J + t <= hi) ? rmb[t] : 0;
+            }
             am[t] = __hiloint2double(__double2hiint(av[t]) & ma, __double2loint(av[t]) & ma);
             bm[t] = __hiloint2double(__double2hiint(bv[t]) & mb, __double2loint(bv[t]) & mb);
+            any_a[t] = !p.range || __ballot(ma != 0) != 0ull;       // (wave-uniform) some column of the quad has rows in this 16-row group
+            any_b[t] = !p.range || __ballot(mb != 0) != 0ull;
         }
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], bm[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 4; ++b)
+                if (any_a[a] && any_b[b]) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], bm[b], acc[a][b], 0, 0, 0);
     };
     {
         double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
@@ -406,17 +438,16 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
 
-// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row, ONE wave per workgroup:
-// the few 256-thread workgroups of a 600-row panel sat on three CUs and their four waves queued for the LDS pipe behind 2016 broadcast
-// reads each — 35 us per panel)
-// (tried: right-looking, x[c] -= x[k] L[c][k] for all c > k with the column of L contiguous in LDS — fully unrolled the compiler hoists the
-// 2016 LDS reads and spills 15 KB per lane, with or without scheduling / memory barriers between the columns: 220 us per panel)
-__global__ __launch_bounds__(64) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
+// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)
+// (35 us per panel, latency-bound on 2016 LDS broadcast reads per thread.  Tried, round 3: one wave per workgroup — 60 us, the four waves
+// of a workgroup were hiding each other's LDS latency; right-looking with the column of L contiguous in LDS — fully unrolled the compiler
+// hoists all 2016 reads and spills 15 KB per lane whatever barriers sit between the columns: 220 us; four partial sums: no change.)
+__global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
 {
     __shared__ double s[64 * 65];
-    for (int i = threadIdx.x; i < nb * nb; i += 64) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+    for (int i = threadIdx.x; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
     __syncthreads();
-    const int r = jb + nb + blockIdx.x * 64 + threadIdx.x;
+    const int r = jb + nb + blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
     double x[64];
 #pragma unroll
@@ -517,13 +548,24 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
     // one wave per pixel, four records per trip (lane l: element l&15 of record l>>4), 12-term dot products by xor-shuffles
     const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4, g = lane & 48;
     const long nwaves = (long)gridDim.x * 4;
-    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < P; i += nwaves) {
+    // (pipelined over the wave's pixels like emba_schur_build_kernel: list bounds of pixel i+2 and bucket entries of pixel i+1 in flight)
+    const long i_first = (long)blockIdx.x * 4 + (threadIdx.x >> 6), i_last = P - 1;
+    auto load_b = [&](long i, uint32_t& b0, uint32_t& b1) { const long ic = i < i_last ? i : i_last; b0 = off[ic]; b1 = off[ic + 1]; };
+    auto load_sl = [&](uint32_t b0, uint32_t b1) -> uint32_t { return bucket[b0 + ((uint32_t)lane < b1 - b0 ? lane : 0)]; };
+    uint32_t cb0, cb1, nb0, nb1;
+    load_b(i_first, cb0, cb1);
+    load_b(i_first + nwaves, nb0, nb1);
+    uint32_t sl_cur = load_sl(cb0, cb1);
+    for (long i = i_first; i < P; i += nwaves) {
+        const uint32_t sl_nxt = load_sl(nb0, nb1);
+        uint32_t nnb0, nnb1;
+        load_b(i + 2 * nwaves, nnb0, nnb1);
         double a0 = 0.0, a1 = 0.0;
-        const uint32_t b0 = off[i], b1 = off[i + 1];
+        const uint32_t b0 = cb0, b1 = cb1;
         // (as in emba_schur_build_kernel: the pixel's bucket entries in one load, the records of 16 entries in flight at a time)
         for (uint32_t base = b0; base < b1; base += 64) {
             const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
-            const uint32_t s_l = bucket[base + (lane < m ? lane : 0)];
+            const uint32_t s_l = (base == b0) ? sl_cur : bucket[base + (lane < m ? lane : 0)];
             for (int t0 = 0; t0 < m; t0 += 16) {
                 double xv[4]; uint32_t key[4];
 #pragma unroll
@@ -559,6 +601,7 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
             x2[2 * i + 1] = bq;
             x2[2 * i] = (t0 - c10 * bq) / c00;
         }
+        cb0 = nb0; cb1 = nb1; nb0 = nnb0; nb1 = nnb1; sl_cur = sl_nxt;
     }
 }
 

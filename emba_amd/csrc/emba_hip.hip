@@ -1624,25 +1624,28 @@ emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 // ---- f1: the solvers (solve_kernels.h) ------------------------------------------------------------------------------------------
 namespace {
 
-struct SolveLists { uint32_t* off = nullptr; uint32_t* bucket = nullptr; };
+struct SolveLists { uint32_t* off = nullptr; RecView sorted{}; };   // sorted: the participating records in pixel order; off[i]: first record of pixel i
 
 // per-pixel record lists over `n_pix` pixels of `view` (n_rec records): counts from the records themselves, exclusive scan, fill.
-// Workspaces 0 (off), 1 (cursor), 2 (bucket).
+// Workspaces 0 (off), 1 (cursor), 33 (the records in pixel order).
 emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n_pix, SolveLists* out)
 {
     hipStream_t s = c->stream;
-    uint32_t *d_off = nullptr, *d_cursor = nullptr, *d_bucket = nullptr;
+    uint32_t *d_off = nullptr, *d_cursor = nullptr; double* d_sorted = nullptr;
     emba_status st;
     if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
-        (st = ws_get(c, 2, (n_rec + 1) * 4, (void**)&d_bucket)))
+        (st = ws_get(c, 33, (n_rec + 1) * kRecStride * sizeof(double), (void**)&d_sorted)))
         return st;
     HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
     if (n_rec) hipLaunchKernelGGL(emba_csr_count_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_cursor);
     if ((st = dev_scan(c, d_cursor, d_off, n_pix, d_off + n_pix))) return st;
     HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
-    if (n_rec) hipLaunchKernelGGL(emba_csr_fill_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_off, d_cursor, d_bucket);
+    // the participating records, copied into pixel order (the passes over them — U build, x2, every CG iteration — then stream)
+    if (n_rec) hipLaunchKernelGGL(emba_csr_fill_sorted_kernel, dim3(nblocks(n_rec, 32)), dim3(256), 0, s, view, (long)n_rec, d_off, d_cursor, d_sorted);
     HIP_TRY(c, hipGetLastError());
-    out->off = d_off; out->bucket = d_bucket;
+    out->off = d_off;
+    out->sorted = RecView{};
+    out->sorted.rec = d_sorted; out->sorted.packed = 1; out->sorted.pix_base = 0;
     return EMBA_OK;
 }
 
@@ -1660,7 +1663,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     emba_status st;
     if ((st = ws_get(c, 8, (size_t)lds_ * 2 * chunk * 8, (void**)&d_U)) || (st = ws_get(c, 12, (size_t)nks_max * nbp * 4096 * 8, (void**)&d_slab))) return st;
     SchurBuildParams bp{};
-    bp.view = view; bp.off = L.off; bp.bucket = L.bucket; bp.A22b2 = A22b2; bp.lambda = lambda;
+    bp.view = view; bp.off = L.off; bp.A22b2 = A22b2; bp.lambda = lambda;
     bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
     bp.rhs_row = d_S + n; bp.lds = lds_;
     const size_t lds_bytes = (size_t)9 * n * sizeof(double);
@@ -1768,11 +1771,11 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     SolveLists L;
     if ((st = build_lists(c, view, M, P, &L))) return st;
     hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
-    if ((st = schur_accumulate(c, view, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info))) return st;
+    if ((st = schur_accumulate(c, L.sorted, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info))) return st;
     if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)
-        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, view, L.off, L.bucket, d_y,
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, L.sorted, L.off, d_y,
                            d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2);
     HIP_TRY(c, hipGetLastError());
     int info = 0;
@@ -1868,7 +1871,7 @@ extern "C" emba_status emba_solve_shard_partial(emba_ctx* c, int32_t rank, int32
     view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
     SolveLists L;
     if ((st = build_lists(c, view, n_recv, n_pix, &L))) return st;
-    return schur_accumulate(c, view, L, n_pix, pack_A22b2(c) + 5 * lo, lambda, n, S_part_dev, lds_, d_y, d_cf, d_info);
+    return schur_accumulate(c, L.sorted, L, n_pix, pack_A22b2(c) + 5 * lo, lambda, n, S_part_dev, lds_, d_y, d_cf, d_info);
 }
 
 extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda,
@@ -1892,11 +1895,11 @@ extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_
     if ((st = schur_factor_solve(c, S_dev, lds_, n, skip, d_rhs, d_info))) return st;
     if (x2_full_dev) {
         HIP_TRY(c, hipMemsetAsync(x2_full_dev, 0, 2 * c->P * sizeof(double), s));
-        RecView view{};
-        view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
+        RecView view{};       // the received records in pixel order, as emba_solve_shard_partial's build_lists left them
+        view.rec = (const double*)c->ws[33].p; view.packed = 1; view.pix_base = 0;
         if (n_pix)
             hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((n_pix + 3) / 4, 8192)), dim3(256), 0, s, view, (const uint32_t*)c->ws[0].p,
-                               (const uint32_t*)c->ws[2].p, d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo);
+                               d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo);
     }
     HIP_TRY(c, hipGetLastError());
     int info = 0;
@@ -1942,7 +1945,7 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
         return EMBA_OK;
     };
     CgPixParams pp{};
-    pp.view = view; pp.off = L.off; pp.bucket = L.bucket; pp.A22b2 = pack_A22b2(c); pp.lambda = lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = skip;
+    pp.view = L.sorted; pp.off = L.off; pp.A22b2 = pack_A22b2(c); pp.lambda = lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = skip;
     pp.P = (long)P;
     auto apply = [&](const double* v, double* y) {   // y = [A11m A12; A12^T A22m] v
         hipLaunchKernelGGL(emba_cg_a11_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pack_A11(c), n, lambda, skip, v, y);

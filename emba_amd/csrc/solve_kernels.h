@@ -46,6 +46,17 @@ __device__ __forceinline__ uint32_t rec_key(const RecView& v, uint32_t s)
     return v.packed ? (uint32_t)__double2hiint(v.rec[(size_t)kRecStride * s + 15]) : v.slot_key[s];
 }
 
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// DPP row rotation of a double inside its row of 16 lanes (VALU moves, no LDS crossbar)
+template <int N> __device__ __forceinline__ double dpp_row_ror(double v)      // lane l <- lane (l - N) mod 16 of its row
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, true));
+}
+
 __global__ void emba_csr_count_kernel(RecView v, long n_rec, uint32_t* __restrict__ cnt)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,15 +65,30 @@ __global__ void emba_csr_count_kernel(RecView v, long n_rec, uint32_t* __restric
     if (rec_pixel(v, s, k)) atomicAdd(cnt + k, 1u);
 }
 
-// bucket fill: every participating record takes a ticket in its pixel's list
-__global__ void emba_csr_fill_kernel(RecView v, long n_rec, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor, uint32_t* __restrict__ bucket)
+// Sorted fill: every participating record takes a ticket in its pixel's list and is COPIED there (eight lanes per 128-B record: coalesced
+// reads in slot order, one full line written per record), with the tail rewritten to the packed form {pixel of the list, pair key}.  The
+// U build, the x2 kernel and every iteration of the CG solver then stream a pixel's records from consecutive lines instead of gathering
+// random 128-B lines through an index list (config 2's shape: 7.5 M records, each pass ran at the ~2 TB/s of that gather).
+__global__ __launch_bounds__(256) void emba_csr_fill_sorted_kernel(RecView v, long n_rec, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
+                                                                   double* __restrict__ out)
 {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_rec) return;
-    int32_t k;
-    if (!rec_pixel(v, s, k)) return;
-    const uint32_t pos = off[k] + atomicAdd(cursor + k, 1u);
-    bucket[pos] = (uint32_t)s;
+    const long s = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int lane = threadIdx.x & 63, c8 = threadIdx.x & 7;
+    const long sc = s < n_rec ? s : n_rec - 1;                       // (n_rec >= 1 whenever this is launched; every lane stays for the shuffles)
+    const double2 val = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * sc)[c8];
+    int32_t k = -1; uint32_t pos = 0, key = 0;
+    if (c8 == 7 && s < n_rec) {                                      // the lane that holds the tail word
+        bool ok;
+        if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(val.y) - v.pix_base); ok = true; }
+        else { uint32_t pi; ok = record_valid(val.y, v.stamp, pi); if (ok) { k = v.compact[pi]; ok = k >= 0; } }
+        if (ok) { pos = off[k] + atomicAdd(cursor + k, 1u); key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s]; }
+        else k = -1;
+    }
+    k = __shfl(k, lane | 7); pos = (uint32_t)__shfl((int)pos, lane | 7); key = (uint32_t)__shfl((int)key, lane | 7);
+    if (k < 0) return;
+    double2 o = val;
+    if (c8 == 7) o.y = __hiloint2double((int)key, k);
+    reinterpret_cast<double2*>(out + (size_t)kRecStride * pos)[c8] = o;
 }
 
 // ---- U chunk: one wave per active pixel ---------------------------------------------------------------------------------
@@ -75,7 +101,7 @@ __global__ void emba_csr_fill_kernel(RecView v, long n_rec, const uint32_t* __re
 constexpr int kSyrkSlicePix = SYRK_SLICE_PIX;
 
 struct SchurBuildParams {
-    RecView view; const uint32_t* off; const uint32_t* bucket;
+    RecView view; const uint32_t* off;            // view: the records in pixel order (build_lists); off: first record of every pixel
     const double* A22b2; long p0, p1;            // pixel chunk [p0, p1) in compact order
     double lambda; int irls; double eta; int n;  // n = 3K
     double* U; long ldu;                         // column-major n x 2(p1-p0)
@@ -97,8 +123,8 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
     for (int r = threadIdx.x; r < 9 * p.n; r += 256) s_cols[r] = 0.0;   // (the columns are re-zeroed after every pixel, where they were touched)
     __syncthreads();
     const long nwaves = (long)gridDim.x * 4;
-    // Software pipeline over the wave's pixels: the list bounds and 2x2 block of pixel i+2 and the bucket entries of pixel i+1 are fetched
-    // while pixel i is worked on, so that a pixel costs ONE dependent round trip (its records) instead of three.
+    // Software pipeline over the wave's pixels: the list bounds and 2x2 block of pixel i+1 are fetched while pixel i is worked on; the pixel's
+    // records are consecutive (emba_csr_fill_sorted_kernel), so a pixel costs ONE dependent round trip.
     const long i_first = p.p0 + (long)blockIdx.x * 4 + wv, i_last = p.p1 - 1;       // (loads of pixels past the end are clamped, never used)
     struct Hdr { uint32_t b0, b1; double q0, q1, q2, q3, q4; };
     auto load_hdr = [&](long i, Hdr& h) {
@@ -107,15 +133,10 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const double* q = p.A22b2 + 5 * ic;
         h.q0 = q[0]; h.q1 = q[1]; h.q2 = q[2]; h.q3 = q[3]; h.q4 = q[4];
     };
-    auto load_sl = [&](const Hdr& h) -> uint32_t { const uint32_t cnt = h.b1 - h.b0; return p.bucket[h.b0 + ((uint32_t)lane < cnt ? lane : 0)]; };   // (bucket has one spare entry at its end)
     Hdr h_cur, h_nxt;
     load_hdr(i_first, h_cur);
-    load_hdr(i_first + nwaves, h_nxt);
-    uint32_t sl_cur = load_sl(h_cur);
     for (long i = i_first; i < p.p1; i += nwaves) {
-        const uint32_t sl_nxt = load_sl(h_nxt);
-        Hdr h_nn;
-        load_hdr(i + 2 * nwaves, h_nn);
+        load_hdr(i + nwaves, h_nxt);
         const double mxx = h_cur.q0 + p.lambda * h_cur.q0, mxy = h_cur.q1, myy = h_cur.q2 + p.lambda * h_cur.q2;   // model.cpp:748
         const double c00 = sqrt(mxx), c10 = mxy / c00, c11 = sqrt(myy - c10 * c10);
         if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
@@ -125,31 +146,32 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const int el = lane & 15, kk = lane >> 4;
         unsigned long long rows_mask = 0ull;
         int rmin = 0x7FFFFFFF, rmax = -1;                               // first / last row of U the pixel's records touch
-        // The pixel's record list in two dependent steps instead of two per group of four: all its bucket entries in one load (lane l: entry l),
-        // then the records of up to 16 entries in flight at a time (lane l: element l&15 of record l>>4 of each group of four).  The sums go
-        // to the LDS columns with fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
-        for (uint32_t base = b0; base < b1; base += 64) {               // (one trip unless the pixel has more than 64 records)
-            const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
-            const uint32_t s_l = (base == b0) ? sl_cur : p.bucket[base + (lane < m ? lane : 0)];
+        // 16 records in flight at a time (lane l: element l&15 of record l>>4 of each group of four).  The sums go to the LDS columns with
+        // fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
+        {
+            const uint32_t base = b0; const int m = (int)(b1 - b0);
             for (int t0 = 0; t0 < m; t0 += 16) {
-                double x[4]; uint32_t key[4];
+                double x[4]; double2 dxy[4], et[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = t0 + 4 * u + kk;
-                    const uint32_t s = (uint32_t)__shfl((int)s_l, r < m ? r : 0);
-                    x[u] = p.view.rec[(size_t)kRecStride * s + el];
-                    key[u] = rec_key(p.view, s);
+                    const double* rp = p.view.rec + (size_t)kRecStride * (base + (uint32_t)(r < m ? r : 0));
+                    x[u] = rp[el];
+                    // dp, the residual and the tail word straight from the record's line (same address in the record's 16 lanes: one cached
+                    // request) rather than broadcast from lanes 12-14 through the LDS crossbar, which this kernel's atomics already load
+                    dxy[u] = reinterpret_cast<const double2*>(rp)[6];
+                    et[u] = reinterpret_cast<const double2*>(rp)[7];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (t0 + 4 * u >= m) break;                             // (uniform)
                     const bool in = t0 + 4 * u + kk < m;
-                    const int g = lane & 48;
-                    const double dx = __shfl(x[u], g | 12), dy = __shfl(x[u], g | 13), e = __shfl(x[u], g | 14);
+                    const double dx = dxy[u].x, dy = dxy[u].y, e = et[u].x;
+                    const uint32_t keyu = (uint32_t)__double2hiint(et[u].y);      // (packed view: tail = {pixel, pair key})
                     double w = 1.0;
                     if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
                     else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
-                    const int bc = 3 * (int)(key[u] >> 16), bp = 3 * (int)(key[u] & 0xFFFFu);
+                    const int bc = 3 * (int)(keyu >> 16), bp = 3 * (int)(keyu & 0xFFFFu);
                     if (in) {
                         rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
                         rmin = min(rmin, min(bc, bp)); rmax = max(rmax, max(bc, bp) + 5);
@@ -189,7 +211,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             if (p.slice_mask && rows_mask) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        h_cur = h_nxt; h_nxt = h_nn; sl_cur = sl_nxt;
+        h_cur = h_nxt;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < p.n; r += 256) {
@@ -398,10 +420,6 @@ __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks
 // where L[j][k] is lane j's register k, broadcast with v_readlane (j is uniform).  Both loops are fully unrolled so that every
 // register index is static; no LDS and no barrier on the 64-step critical path (the 256-thread right-looking version spent
 // ~1.2 us per column in barriers: 76 us per panel; the LDS left-looking one 56; this one ~12).
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
 
 __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
 {
@@ -540,59 +558,53 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
 
 // x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,
 // then z = C^-1 (A12_i^T x1)  (since U^T x1 = C^-1 A12^T x1)                                                       model.cpp:791
-__global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
-                                                            const uint32_t* __restrict__ off, const uint32_t* __restrict__ bucket,
+__global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view, const uint32_t* __restrict__ off,
                                                             const double* __restrict__ yv, const double* __restrict__ cfac,
                                                             const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
 {
-    // one wave per pixel, four records per trip (lane l: element l&15 of record l>>4), 12-term dot products by xor-shuffles
-    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4, g = lane & 48;
+    // One wave per pixel; the pixel's records are consecutive (emba_csr_fill_sorted_kernel), 16 of them in flight (lane l: element l&15 of record
+    // l>>4 of each group of four).  The 12-term dot product of a record and its weight stay inside the record's DPP row of 16 lanes — row shifts
+    // on the VALU, no LDS crossbar: with xor-shuffles and broadcasts (14 ds_bpermute per group) the kernel ran at the LDS pipe's rate.
+    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4;
     const long nwaves = (long)gridDim.x * 4;
-    // (pipelined over the wave's pixels like emba_schur_build_kernel: list bounds of pixel i+2 and bucket entries of pixel i+1 in flight)
     const long i_first = (long)blockIdx.x * 4 + (threadIdx.x >> 6), i_last = P - 1;
     auto load_b = [&](long i, uint32_t& b0, uint32_t& b1) { const long ic = i < i_last ? i : i_last; b0 = off[ic]; b1 = off[ic + 1]; };
-    auto load_sl = [&](uint32_t b0, uint32_t b1) -> uint32_t { return bucket[b0 + ((uint32_t)lane < b1 - b0 ? lane : 0)]; };
     uint32_t cb0, cb1, nb0, nb1;
     load_b(i_first, cb0, cb1);
-    load_b(i_first + nwaves, nb0, nb1);
-    uint32_t sl_cur = load_sl(cb0, cb1);
     for (long i = i_first; i < P; i += nwaves) {
-        const uint32_t sl_nxt = load_sl(nb0, nb1);
-        uint32_t nnb0, nnb1;
-        load_b(i + 2 * nwaves, nnb0, nnb1);
-        double a0 = 0.0, a1 = 0.0;
+        load_b(i + nwaves, nb0, nb1);                                  // (the next pixel's list bounds: in flight during this one)
+        double acc = 0.0;                                              // lane 12 of a row: sum of w (v . x1) dx over its records; lane 13: ... dy
         const uint32_t b0 = cb0, b1 = cb1;
-        // (as in emba_schur_build_kernel: the pixel's bucket entries in one load, the records of 16 entries in flight at a time)
-        for (uint32_t base = b0; base < b1; base += 64) {
-            const int m = (int)((b1 - base < 64u) ? b1 - base : 64u);
-            const uint32_t s_l = (base == b0) ? sl_cur : bucket[base + (lane < m ? lane : 0)];
-            for (int t0 = 0; t0 < m; t0 += 16) {
-                double xv[4]; uint32_t key[4];
+        for (uint32_t base = b0; base < b1; base += 16) {
+            double xv[4], ev[4]; uint32_t key[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = t0 + 4 * u + kk;
-                    const uint32_t s = (uint32_t)__shfl((int)s_l, r < m ? r : 0);
-                    xv[u] = view.rec[(size_t)kRecStride * s + el];
-                    key[u] = rec_key(view, s);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t r = base + 4 * u + kk;
+                const uint32_t s = r < b1 ? r : b0;
+                xv[u] = view.rec[(size_t)kRecStride * s + el];
+                ev[u] = irls ? view.rec[(size_t)kRecStride * s + 14] : 0.0;     // the residual, for the IRLS weight (same line: one cached request per record)
+                key[u] = rec_key(view, s);
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (t0 + 4 * u >= m) break;                             // (uniform)
-                    const bool in = t0 + 4 * u + kk < m;
-                    const double x = xv[u];
-                    const int row = (el < 6) ? 3 * (int)(key[u] >> 16) + el : 3 * (int)(key[u] & 0xFFFFu) + el - 6;
-                    double d = (in && el < 12) ? x * x1[row] : 0.0;
-                    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
-                    const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
-                    double w = 1.0;
-                    if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
-                    else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
-                    if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
-                }
+            for (int u = 0; u < 4; ++u) {
+                if (base + 4 * u >= b1) break;                             // (uniform)
+                const bool in = base + 4 * u + kk < b1;
+                const double x = xv[u];
+                const int row = (el < 6) ? 3 * (int)(key[u] >> 16) + el : 3 * (int)(key[u] & 0xFFFFu) + el - 6;
+                double d = (in && el < 12) ? x * x1[row] : 0.0;
+                // rotations inside the row: every lane ends with the whole dot product.  (NOT a shift-scan with the total handed to lanes 12 / 13 by
+                // two different shifts behind a select: the compiler turns that select into two branches with one DPP move in each, and a DPP
+                // move reads zero from lanes its branch has masked off)
+                d += dpp_row_ror<1>(d); d += dpp_row_ror<2>(d); d += dpp_row_ror<4>(d); d += dpp_row_ror<8>(d);
+                const double dot = d, e = ev[u];
+                double w = 1.0;
+                if (irls == 2) w = 1.0 / (1.0 + eta * e * e);
+                else if (irls == 1) { const double a = fabs(e); w = (a < eta) ? 1.0 : eta / a; }
+                if (in && (el == 12 || el == 13)) acc += w * dot * x;      // x = dp_x in lane 12, dp_y in lane 13
             }
         }
-        a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
-        a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
+        acc += __shfl_xor(acc, 16); acc += __shfl_xor(acc, 32);
+        const double a0 = readlane_f64(acc, 12), a1 = readlane_f64(acc, 13);
         if (lane == 0) {
             const double c00 = cfac[3 * i], c10 = cfac[3 * i + 1], c11 = cfac[3 * i + 2];
             const double z0 = a0 / c00, z1 = (a1 - c10 * z0) / c11;          // z = C^-1 (A12_i^T x1)
@@ -601,7 +613,7 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view,
             x2[2 * i + 1] = bq;
             x2[2 * i] = (t0 - c10 * bq) / c00;
         }
-        cb0 = nb0; cb1 = nb1; nb0 = nnb0; nb1 = nnb1; sl_cur = sl_nxt;
+        cb0 = nb0; cb1 = nb1;
     }
 }
 
@@ -625,7 +637,7 @@ __global__ __launch_bounds__(256) void emba_cg_a11_kernel(const double* __restri
 }
 
 struct CgPixParams {
-    RecView view; const uint32_t* off; const uint32_t* bucket; const double* A22b2; double lambda; int irls; double eta; int n, skip; long P;
+    RecView view; const uint32_t* off; const double* A22b2; double lambda; int irls; double eta; int n, skip; long P;
     const double* v; double* y;
 };
 
@@ -644,7 +656,7 @@ __global__ __launch_bounds__(256) void emba_cg_pixel_kernel(CgPixParams p)
         for (uint32_t b = b0; b < b1; b += 4) {
             const uint32_t bb = b + kk;
             const bool in = bb < b1;
-            const uint32_t s = in ? p.bucket[bb] : 0u;
+            const uint32_t s = in ? bb : 0u;                           // (the records are in pixel order)
             const double x = in ? p.view.rec[(size_t)kRecStride * s + el] : 0.0;
             const uint32_t key = in ? rec_key(p.view, s) : 0u;
             const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;

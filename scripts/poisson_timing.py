@@ -2,7 +2,7 @@
 solves along W) and EMBA_POISSON=dense (four sine-matrix GEMMs), with the error against the numpy/scipy oracle."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emba_amd import LEGM
 from emba_amd.synth import pinhole_bearing_lut
 from oracle import poisson as OP

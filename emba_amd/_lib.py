@@ -62,6 +62,7 @@ SIGNATURES = {
     "emba_solve_shard_finish": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_void_p, _dp, C.c_void_p]),
     "emba_solve_normal_eq_cg": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _i32p, _dp]),
     "emba_update_map": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "emba_update_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double]),
     "emba_map_accept": (C.c_int, [C.c_void_p]),
     "emba_map_reject": (C.c_int, [C.c_void_p]),
     "emba_trial_reject": (C.c_int, [C.c_void_p]),

@@ -55,7 +55,7 @@ struct emba_ctx {
     const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // the map planes the next evaluation reads (current or trial)
     const double* d_Gx_cur = nullptr; const double* d_Gy_cur = nullptr;   // current (accepted) map: own upload, bound, or accepted trial
     double* d_Gx_trial = nullptr; double* d_Gy_trial = nullptr; bool map_is_trial = false;
-    double* d_x2 = nullptr; size_t x2_cap = 0;
+    double* d_x2 = nullptr; size_t x2_cap = 0; size_t x2_resident_P = (size_t)-1;   // x2_resident_P: d_x2 holds the x2 of the last solve on this context (for that many pixels)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     bool counts_raw = false;   // the count map holds the warp kernel's markers, not yet the counts (see ensure_counts)
     double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
@@ -898,7 +898,19 @@ emba_status emba_bind_map_dev(emba_ctx* c, const double* Gx_dev, const double* G
     return EMBA_OK;
 }
 
-emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping)
+namespace {
+emba_status ensure_x2(emba_ctx* c, size_t P)
+{
+    if (c->x2_cap < 2 * P || !c->d_x2) {
+        dev_free(c, c->d_x2);
+        emba_status st = dev_alloc(c, &c->d_x2, std::max<size_t>(2 * P, 2));
+        if (st) return st;
+        c->x2_cap = std::max<size_t>(2 * P, 2);
+    }
+    return EMBA_OK;
+}
+// src_kind: 0 host pointer, 1 device pointer, 2 the x2 the last solve left in d_x2
+emba_status update_map_impl(emba_ctx* c, const double* x2, int src_kind, double damping)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
@@ -906,27 +918,40 @@ emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping)
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;
-    if (c->P && !x2_host) return fail(c, EMBA_ERR_INVALID_ARG, "x2 NULL");
+    if (src_kind == 2 && c->P && c->x2_resident_P != c->P) return fail(c, EMBA_ERR_STATE, "x2 NULL: no solve of the current normal equations has left its x2 on the device");
+    if (src_kind != 2 && c->P && !x2) return fail(c, EMBA_ERR_INVALID_ARG, "x2 NULL");
     if (!c->d_Gx_trial) {
         if ((st = dev_alloc(c, &c->d_Gx_trial, c->npix))) return st;
         if ((st = dev_alloc(c, &c->d_Gy_trial, c->npix))) return st;
     }
-    if (c->x2_cap < 2 * c->P) {
-        dev_free(c, c->d_x2);
-        if ((st = dev_alloc(c, &c->d_x2, 2 * c->P))) return st;
-        c->x2_cap = 2 * c->P;
-    }
+    if ((st = ensure_x2(c, c->P))) return st;
     hipStream_t s = c->stream;
     if ((st = ensure_compact(c))) return st;
-    if (c->P) HIP_TRY(c, hipMemcpyAsync(c->d_x2, x2_host, 2 * c->P * sizeof(double), hipMemcpyHostToDevice, s));
+    if (c->P && src_kind != 2) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_x2, x2, 2 * c->P * sizeof(double), src_kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+        c->x2_resident_P = (size_t)-1;      // (whatever a solve left there is overwritten)
+    }
     hipLaunchKernelGGL(emba_update_map_kernel, dim3((unsigned)((c->npix + 255) / 256)), dim3(256), 0, s, c->d_Gx_cur, c->d_Gy_cur, c->d_compact,
                        c->d_x2, damping, (long)c->npix, c->d_Gx_trial, c->d_Gy_trial);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(s));   // x2_host may be freed by the caller
+    if (src_kind == 0) HIP_TRY(c, hipStreamSynchronize(s));   // x2_host may be freed by the caller
     c->d_Gx = c->d_Gx_trial; c->d_Gy = c->d_Gy_trial;
     c->map_is_trial = true;
     return EMBA_OK;
 }
+// the solvers leave their x2 in d_x2 (device to device: 2P doubles), so that updateMap needs no trip through the host
+emba_status keep_x2(emba_ctx* c, const double* d_src, size_t P)
+{
+    emba_status st = ensure_x2(c, P);
+    if (st) return st;
+    if (P) HIP_TRY(c, hipMemcpyAsync(c->d_x2, d_src, 2 * P * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    c->x2_resident_P = P;
+    return EMBA_OK;
+}
+}  // namespace
+
+emba_status emba_update_map(emba_ctx* c, const double* x2_host, double damping) { return update_map_impl(c, x2_host, x2_host ? 0 : 2, damping); }
+emba_status emba_update_map_dev(emba_ctx* c, const double* x2_dev, double damping) { return update_map_impl(c, x2_dev, x2_dev ? 1 : 2, damping); }
 
 emba_status emba_map_accept(emba_ctx* c)
 {
@@ -1207,6 +1232,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->thres = thres;
     c->eq_in_alt = false;   // new equations are being formed from the working set: the other set's are obsolete
     c->P_pending = true; c->active_done = false; c->accum_done = false;
+    c->x2_resident_P = (size_t)-1;   // (a solve of the PREVIOUS equations may have left its x2 on the device)
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
     emba_status st = resolve_pending(c, true);   // counts only: a sharded host sizes exchange 2 from P while the gather still runs
     if (st) return st;
@@ -1782,6 +1808,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
     if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_rhs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (x2_host && P) HIP_TRY(c, hipMemcpyAsync(x2_host, d_x2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if ((st = keep_x2(c, d_x2, P))) return st;
     HIP_TRY(c, hipStreamSynchronize(s));
     c->solve_info = info;
     // bit 0: a 2x2 block A22m_i is not positive definite — the reference's A22m_i.inverse() (model.cpp:750) returns inf / nan there and the
@@ -1987,6 +2014,7 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
     HIP_TRY(c, hipGetLastError());
     if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, d_x, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
     if (x2_host && P) HIP_TRY(c, hipMemcpyAsync(x2_host, d_x + n, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s));
+    if ((st = keep_x2(c, d_x + n, P))) return st;
     HIP_TRY(c, hipStreamSynchronize(s));
     if (iterations) *iterations = it;
     if (error) *error = err;

@@ -169,6 +169,7 @@ struct emba_group {
     int decl_irls = 0; double decl_eta = 0.0;   // robust cost declared for the evaluations (emba_group_set_cost)
     // grow-only scratch of the sharded solve, per rank (an LM loop calls it every iteration)
     std::vector<double*> sv_send, sv_recv, sv_S, sv_x2; std::vector<size_t> cap_send, cap_recv, cap_S, cap_x2;
+    bool x2_on_ranks = false;   // sv_x2[r] holds the all-reduced x2 of the last emba_group_solve (emba_group_update_map with x2_host == NULL)
     RankPool pool;
     int sw_ = 0;
     std::vector<uint16_t> ev_x, ev_y;    // sensor coordinates of the window's events (host copy): the merged residual vector of emba_group_eval is ordered by sensor pixel
@@ -530,6 +531,7 @@ emba_status emba_group_eval(emba_group* g, const double* knots, int32_t K, int64
 emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
+    g->x2_on_ranks = false;     // (what a solve of the previous equations left on the ranks)
     if (g->n == 1 && !g->use_rccl) {
         emba_ctx* c = g->ctx[0];
         G_TRY(g, 0, emba_eval_finish(c, nullptr, nullptr, nullptr));
@@ -650,6 +652,7 @@ emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alp
 // Cholesky, x2 exchanged.  x1_host: 3K, x2_host: 2P (either may be NULL).
 emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
 {
+    if (g) g->x2_on_ranks = false;
     if (!g) return EMBA_ERR_INVALID_ARG;
     if (g->n == 1 && !g->use_rccl) { G_TRY(g, 0, emba_solve_normal_eq(g->ctx[0], lambda, fix_first_pose, x1_host, x2_host)); return EMBA_OK; }
     const int n = g->n;
@@ -683,6 +686,7 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
     if (x2_host && g->P) G_HIP(g, hipMemcpyAsync(x2_host, g->sv_x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
     for (int r = 0; r < n; ++r) { G_HIP(g, hipSetDevice(g->dev[r])); G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream)); }
     for (int r = 0; r < n; ++r) if (fin[r]) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
+    g->x2_on_ranks = true;
     return EMBA_OK;
 }
 
@@ -700,6 +704,13 @@ emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_
 emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
+    // x2_host == NULL: every rank applies the x2 the last emba_group_solve left in ITS device memory (the all-reduced vector) — nothing crosses
+    // to the host and back, and not once per rank
+    if (!x2_host && (g->n > 1 || g->use_rccl)) {
+        if (!g->x2_on_ranks) return gfail(g, EMBA_ERR_STATE, "x2 NULL: emba_group_solve has not left an x2 on the ranks (after emba_group_solve_cg pass the host vector)");
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_update_map_dev(g->ctx[r], g->sv_x2[r], damping));
+        return EMBA_OK;
+    }
     for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_update_map(g->ctx[r], x2_host, damping));
     return EMBA_OK;
 }

@@ -53,6 +53,8 @@ struct LegmHipState {
     std::vector<double> trial_sample;
     bool trial_pending = false;          // the last evaluation was on the trial map and its fate is not known yet
     bool map_is_trial = false;           // the device holds a trial map nobody has decided about
+    // the x2 of the last Schur solve stays on the ranks' devices: updateMap recognises it (size + a strided sample) and skips the upload
+    std::vector<double> x2_sample; size_t x2_size = 0; bool x2_on_device = false;
 };
 static std::map<const LEGM*, LegmHipState> g_state;   // or a member `LegmHipState hip_;` added to class LEGM
 
@@ -176,7 +178,7 @@ void LEGM::formNormalEq(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, 
 {
     auto& st = g_state[this];
     CHECK((size_t)ep.size() == st.n_ep) << "formNormalEq expects the residual vector evaluateDataError returned (solver.cpp:99-102: the model state is that call's)";
-    legm_hip_detail::settle_trial(st, true);        // formNormalEq after a trial evaluation: the step was accepted (solver.cpp:93-131)
+    legm_hip_detail::settle_trial(st, true); st.x2_on_device = false;        // formNormalEq after a trial evaluation: the step was accepted (solver.cpp:93-131)
     try { st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel); }
     catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
@@ -189,7 +191,7 @@ void LEGM::formNormalEqIRLS(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_bloc
 {
     auto& st = g_state[this];
     CHECK((size_t)ep.size() == st.n_ep) << "formNormalEqIRLS expects the residual vector evaluateDataError returned";
-    legm_hip_detail::settle_trial(st, true);
+    legm_hip_detail::settle_trial(st, true); st.x2_on_device = false;
     try {
         st.impl->setCost(cost_type, a);             // later evaluations accumulate the weighted per-pixel sums directly (speed only)
         st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel, cost_type, a);
@@ -224,6 +226,8 @@ void LEGM::solveNormalEq(const MatXd& A11, const MatXd& A12, const std::vector<M
     const int skip = fix_first_pose ? 3 : 0;
     x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
     x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());
+    st.x2_sample.clear(); legm_hip_detail::sample_plane(v2.data(), v2.size(), st.x2_sample);
+    st.x2_size = v2.size(); st.x2_on_device = true;
 }
 
 std::pair<int, double> LEGM::solveNormalEqCG(const MatXd& A11, const MatXd& A12, const std::vector<Mat2d>& A22_blocks, const VecXd& b1,
@@ -237,6 +241,7 @@ std::pair<int, double> LEGM::solveNormalEqCG(const MatXd& A11, const MatXd& A12,
     std::vector<double> v1, v2;
     std::pair<int, double> res(0, 0.0);
     try { res = st.impl->solveNormalEqCG(lambda, fix_first_pose, v1, v2); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    st.x2_on_device = false;     // (the CG solve runs on rank 0 only: updateMap uploads x2 to every rank)
     const int skip = fix_first_pose ? 3 : 0;
     x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
     x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());
@@ -254,9 +259,16 @@ void LEGM::updateMap(cv::Mat& Gx_new, cv::Mat& Gy_new, const VecXd& x2, const do
     CHECK(active_pix_idxes.size() == st.ne.num_active_pixels && (size_t)x2.size() == 2 * st.ne.num_active_pixels);
     CHECK(Gx_new.isContinuous() && Gy_new.isContinuous() && Gx_new.type() == CV_64FC1);
     legm_hip_detail::settle_trial(st, false);       // (a trial nobody evaluated or decided about is dropped)
-    std::vector<double> v2(x2.data(), x2.data() + x2.size());
+    // x2 is what solveNormalEq has just returned (solver.cpp:193-239)?  Then every rank still holds it: no upload.
+    bool resident = false;
+    if (st.x2_on_device && (size_t)x2.size() == st.x2_size && x2.size() > 0) {
+        std::vector<double> s2;
+        legm_hip_detail::sample_plane(x2.data(), (size_t)x2.size(), s2);
+        resident = s2.size() == st.x2_sample.size() && std::memcmp(s2.data(), st.x2_sample.data(), s2.size() * sizeof(double)) == 0;
+    }
     try {
-        st.impl->updateMap(v2, damping_factor);
+        if (resident) st.impl->updateMapResident(damping_factor);
+        else { std::vector<double> v2(x2.data(), x2.data() + x2.size()); st.impl->updateMap(v2, damping_factor); }
         st.impl->downloadMap(Gx_new.ptr<double>(), Gy_new.ptr<double>());
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     st.map_is_trial = true; st.trial_pending = false;

@@ -123,6 +123,8 @@ public:
 
     // updateMap (model.cpp:863-903) into the trial map; the LM decision (solver.cpp:299-352)
     void updateMap(const std::vector<double>& x2, double damping_factor) { check(emba_group_update_map(g_, x2.data(), damping_factor)); }
+    // ... with the x2 the last solveNormalEq left on every rank's device (no upload)
+    void updateMapResident(double damping_factor) { check(emba_group_update_map(g_, nullptr, damping_factor)); }
     void acceptMap() { check(emba_group_map_accept(g_)); }
     void rejectMap() { check(emba_group_map_reject(g_)); }
     void downloadMap(double* Gx, double* Gy) { check(emba_group_download_map(g_, Gx, Gy)); }

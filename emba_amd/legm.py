@@ -219,13 +219,17 @@ class LEGM:
         """model.cpp:689-719, applied to the device-resident pack; returns the updated blocks (call once per formNormalEq)."""
         return self._finish(alpha, dense_A12)
 
-    def solveNormalEq(self, lam, fix_first_pose=False):
+    supports_resident_x2 = True    # solveNormalEq[CG](..., resident_x2=True) returns x2 = None; updateMap(None, damping) applies the device copy
+
+    def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
         """model.cpp:721-792 on the device-resident, L2-regularised normal equations (call after applyL2Reg, solver.cpp:130,190):
-        returns (x1 [3K, zeros for a fixed first pose], x2 [2P])."""
+        returns (x1 [3K, zeros for a fixed first pose], x2 [2P]).  resident_x2: x2 stays on the device (returned as None) for the
+        updateMap(None, ...) that follows — the reference hands it from the solver to updateMap and nowhere else (solver.cpp:193-239)."""
         self.last_counts()     # (P may have been left on the device by form_active(sync=False): the output buffer is sized from it)
-        x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
-        self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), _p(x2, _dp)))
-        return x1, x2[:2 * self._P]
+        x1 = np.zeros(3 * self.K)
+        x2 = None if resident_x2 else np.zeros(2 * max(self._P, 1))
+        self._check(self._L.emba_solve_normal_eq(self._ctx, float(lam), 1 if fix_first_pose else 0, _p(x1, _dp), None if resident_x2 else _p(x2, _dp)))
+        return x1, (None if resident_x2 else x2[:2 * self._P])
 
     def last_solve_info(self):
         """bit 0: a 2x2 block was not positive definite (the solve raised EMBA_ERR_NUMERIC); bit 1: a pivot of S vanished (zero update)."""
@@ -256,20 +260,29 @@ class LEGM:
                                                     1 if fix_first_pose else 0, C.c_void_p(S_ptr), _p(x1, _dp), C.c_void_p(x2_ptr)))
         return x1
 
-    def solveNormalEqCG(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6):
-        """model.cpp:794-840 (Eigen ConjugateGradient, 100 iterations, tolerance 1e-6) on the device: returns (x1, x2, iterations, error)."""
+    def solveNormalEqCG(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6, resident_x2=False):
+        """model.cpp:794-840 (Eigen ConjugateGradient, 100 iterations, tolerance 1e-6) on the device: returns (x1, x2, iterations, error);
+        resident_x2 as in solveNormalEq."""
         self.last_counts()
-        x1 = np.zeros(3 * self.K); x2 = np.zeros(2 * max(self._P, 1))
+        x1 = np.zeros(3 * self.K)
+        x2 = None if resident_x2 else np.zeros(2 * max(self._P, 1))
         it = C.c_int32(0); err = C.c_double(0)
-        self._check(self._L.emba_solve_normal_eq_cg(self._ctx, float(lam), 1 if fix_first_pose else 0, int(max_iter), float(tol), _p(x1, _dp), _p(x2, _dp),
-                                                    C.byref(it), C.byref(err)))
-        return x1, x2[:2 * self._P], it.value, err.value
+        self._check(self._L.emba_solve_normal_eq_cg(self._ctx, float(lam), 1 if fix_first_pose else 0, int(max_iter), float(tol), _p(x1, _dp),
+                                                    None if resident_x2 else _p(x2, _dp), C.byref(it), C.byref(err)))
+        return x1, (None if resident_x2 else x2[:2 * self._P]), it.value, err.value
 
     def updateMap(self, x2, damping_factor):
         """model.cpp:863-903 on the device-resident map: builds the TRIAL map (active += damping*x2, all other pixels 0) that
-        the following evaluateDataError(traj, None, None) uses; report the LM decision with acceptMap() / rejectMap()."""
-        x2 = np.ascontiguousarray(x2, dtype=np.float64)
-        self._check(self._L.emba_update_map(self._ctx, _p(x2, _dp), float(damping_factor)))
+        the following evaluateDataError(traj, None, None) uses; report the LM decision with acceptMap() / rejectMap().
+        x2: a host array; None = the x2 the last solveNormalEq[CG] left on the device (resident_x2=True there saves the download
+        too); or an int = device address of 2P doubles (a sharded host's all-reduced x2)."""
+        if x2 is None:
+            self._check(self._L.emba_update_map(self._ctx, None, float(damping_factor)))
+        elif isinstance(x2, int):
+            self._check(self._L.emba_update_map_dev(self._ctx, C.c_void_p(x2), float(damping_factor)))
+        else:
+            x2 = np.ascontiguousarray(x2, dtype=np.float64)
+            self._check(self._L.emba_update_map(self._ctx, _p(x2, _dp), float(damping_factor)))
 
     def acceptMap(self):
         self._check(self._L.emba_map_accept(self._ctx))

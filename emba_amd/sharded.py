@@ -171,12 +171,13 @@ class ShardedLEGM:
         n_inl, self.P = e.last_counts()
         return n_inl, out
 
-    def solveNormalEq(self, lam, fix_first_pose=False):
+    def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
         """LEGM::solveNormalEq (model.cpp:721-792) over all ranks, after iteration(): the sparse A12 factors are time-sharded, a pixel's
         columns are sums over several ranks' records, so the records are first sent to the rank that owns their pixel (contiguous
         ranges of the active set), each rank forms the Schur sums of ITS pixels, one all-reduce of the (3K+1)^2 block follows, the
         Cholesky is replicated and the per-pixel x2 are exchanged.  Three collectives: all-to-all (records), all-reduce (S), all-reduce
-        (x2, disjoint supports).  Returns (x1 [3K], x2 [2P]) — identical on every rank."""
+        (x2, disjoint supports).  Returns (x1 [3K], x2 [2P]) — identical on every rank.  resident_x2: x2 is returned as the DEVICE tensor
+        the all-reduce left on this rank (for ShardedModel.updateMap: no trip through the host)."""
         import torch
         e, dist, w, r = self.engine, self.dist, self.world, self.rank
         dev = self.pack.device
@@ -222,7 +223,7 @@ class ShardedLEGM:
         if float(x2[n2].item()) != 0.0:
             raise failure if failure is not None else EmbaError(_ERR_NUMERIC, "the damped normal equations are not positive definite on another rank")
         x1 = x2[n2 + 1:].cpu().numpy().copy()
-        return x1, x2[: 2 * self.P].cpu().numpy()
+        return x1, (x2[: 2 * self.P] if resident_x2 else x2[: 2 * self.P].cpu().numpy())
 
 
 class ShardedModel:
@@ -273,14 +274,23 @@ class ShardedModel:
     def form_finish(self, alpha):
         self.sh.form(self._thres, alpha, *self.cost)
 
-    def solveNormalEq(self, lam, fix_first_pose=False):
-        return self.sh.solveNormalEq(lam, fix_first_pose)
+    supports_resident_x2 = True     # solver.solve_time_window: x2 stays a device tensor between solveNormalEq and updateMap
+
+    def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
+        return self.sh.solveNormalEq(lam, fix_first_pose, resident_x2=resident_x2)
 
     def solveNormalEqCG(self, lam, fix_first_pose=False):
         raise NotImplementedError("solveNormalEqCG is single-GPU (emba_solve_normal_eq_cg); the sharded loop uses the Schur solve")
 
     def updateMap(self, x2, damping):
-        self.m.updateMap(x2, damping)
+        if hasattr(x2, "data_ptr"):            # the tensor of solveNormalEq(resident_x2=True)
+            if x2.is_cuda and getattr(self.m, "supports_resident_x2", False):
+                self._x2_keep = x2             # (kept alive until the next update: the copy is enqueued, not finished)
+                self.m.updateMap(int(x2.data_ptr()) if x2.numel() else None, damping)      # (no active pixel: nothing to apply)
+            else:
+                self.m.updateMap(x2.cpu().numpy(), damping)
+        else:
+            self.m.updateMap(x2, damping)
 
     def acceptMap(self):
         self.m.acceptMap()

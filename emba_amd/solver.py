@@ -89,11 +89,13 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             if it == 0:                                                              # :69-91, uploads the initial map once
                 cost_min = ph.evaluate(traj, Gx, Gy)
             ph.form(traj.size())                                                     # :93-131
+        # x2 goes from the solver to updateMap and nowhere else (solver.cpp:193-239): a device model keeps it in HBM (x2 is None here)
+        rkw = dict(resident_x2=True) if getattr(model, "supports_resident_x2", False) else {}
         try:
             if ba.use_CG:
-                x1, x2 = model.solveNormalEqCG(lam, fix_first_pose=ba.first_time_window)[:2]   # :196-202
+                x1, x2 = model.solveNormalEqCG(lam, fix_first_pose=ba.first_time_window, **rkw)[:2]   # :196-202
             else:
-                x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window)         # :190-194
+                x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window, **rkw)         # :190-194
         except Exception as e:   # noqa: BLE001
             # EMBA_ERR_NUMERIC: a 2x2 block A22_i + lambda*diag(A22_i) is not positive definite.  The reference's A22m_i.inverse()
             # (model.cpp:750) returns inf / nan there, x1 / x2 and the trial cost become NaN, `cost_new < cost_min` is false and the step is

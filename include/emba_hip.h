@@ -187,9 +187,12 @@ emba_status emba_bind_map_dev(emba_ctx* ctx, const double* Gx_dev, const double*
  * the device-resident map with the active set of the last emba_form_active: trial = current; trial[active_i] += damping*x2[2i],
  * x2[2i+1]; trial[every other pixel] = 0.  From then on evaluations use the TRIAL map (pass Gx = Gy = NULL to
  * emba_eval_data_error, or call emba_eval_launch) until the caller reports the LM decision: emba_map_accept makes the trial map
- * current (solver.cpp:299-339), emba_map_reject drops it (:340-352).  x2_host: 2P doubles.  emba_download_map copies the map
- * the next evaluation would use. */
+ * current (solver.cpp:299-339), emba_map_reject drops it (:340-352).  x2_host: 2P doubles, or NULL: the x2 the last
+ * emba_solve_normal_eq[_cg] on this context left on the device (the reference hands x2 from the solver straight to updateMap,
+ * solver.cpp:193-239 — 2P doubles that need not cross to the host and back).  emba_update_map_dev: x2 in device memory (a sharded
+ * host's all-reduced x2), NULL as above.  emba_download_map copies the map the next evaluation would use. */
 emba_status emba_update_map(emba_ctx* ctx, const double* x2_host, double damping);
+emba_status emba_update_map_dev(emba_ctx* ctx, const double* x2_dev, double damping);
 emba_status emba_map_accept(emba_ctx* ctx);
 emba_status emba_map_reject(emba_ctx* ctx);
 /* A rejected LM trial without a re-evaluation (solver.cpp:340-352 simply reuses A and b).  An evaluation that follows emba_form_* writes its
@@ -366,6 +369,7 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
 /* LEGM::solveNormalEqCG: one-rank groups only (EMBA_ERR_STATE otherwise: a sharded window uses the Schur solve) */
 emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host, double* x2_host,
                                 int32_t* iterations, double* error);
+/* x2_host == NULL: every rank applies the (all-reduced) x2 the last emba_group_solve left in its own device memory. */
 emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping);
 emba_status emba_group_map_accept(emba_group* g);
 emba_status emba_group_map_reject(emba_group* g);

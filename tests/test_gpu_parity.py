@@ -749,3 +749,50 @@ def test_randomised_small_configurations(gpu, oracle_mod):
         assert np.array_equal(nem, o2["num_ev_map"]), tag + " (second evaluation)"
         if o2["ep"].size:
             assert_close(ep2, o2["ep"], "ep2 " + tag)
+
+
+@pytest.mark.parametrize("use_cg", [False, True])
+def test_update_map_from_the_solvers_resident_x2(gpu, oracle_mod, use_cg):
+    """solver.cpp:193-239 hands x2 from solveNormalEq[CG] straight to updateMap: with resident_x2 the 2P doubles stay on the device
+    (solve returns None, updateMap(None) applies the device copy).  Same trial map as through the host, bit for bit; a NULL x2 with no
+    solve of the CURRENT equations behind it is refused; the device-pointer form (a sharded host's all-reduced x2) gives the same map."""
+    import torch
+    from emba_amd import EmbaError
+    w = small_workload(n_events=20000)
+    m = make_legm(w)
+    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+    m.evaluateDataError(w.traj, w.Gx, w.Gy, w.events, True, nem)
+    m.formNormalEq(None, w.K, nem, w.thres_valid_pixel)
+    ne = m.applyL2Reg(w.alpha)
+    with pytest.raises(EmbaError):
+        m.updateMap(None, 0.7)                               # nothing solved yet
+    solve = (lambda **kw: m.solveNormalEqCG(1e-2, True, **kw)[:2]) if use_cg else (lambda **kw: m.solveNormalEq(1e-2, True, **kw))
+    x1h, x2h = solve()
+    m.updateMap(x2h, 0.7)
+    via_host = m.downloadMap()
+    m.rejectMap()
+    x1r, x2r = solve(resident_x2=True)
+    # (two solves of the same system agree to rounding only: the product's partial tiles are combined with LDS atomics)
+    # (... and two CG runs to the solver's own tolerance, model.cpp:830-836: the matrix is applied with atomics)
+    rel = 1e-4 if use_cg else 1e-9
+    assert x2r is None and np.allclose(x1r, x1h, rtol=rel, atol=rel * np.abs(x1h).max())
+    m.updateMap(None, 0.7)
+    via_dev = m.downloadMap()
+    tol = rel * np.abs(x2h).max()
+    assert np.allclose(via_dev[0], via_host[0], rtol=0, atol=tol) and np.allclose(via_dev[1], via_host[1], rtol=0, atol=tol)
+    assert not np.array_equal(via_dev[0], w.Gx)              # (the trial map really is a different map)
+    Gx_t, Gy_t = oracle_mod.update_map(ne["active"], x2h, 0.7, w.Gx, w.Gy)
+    assert np.allclose(via_dev[0], Gx_t, rtol=0, atol=tol) and np.allclose(via_dev[1], Gy_t, rtol=0, atol=tol)
+    m.rejectMap()
+    t = torch.from_numpy(x2h).to("cuda:0")
+    torch.cuda.synchronize()
+    m.updateMap(int(t.data_ptr()), 0.7)
+    via_ptr = m.downloadMap()
+    assert np.array_equal(via_ptr[0], via_host[0]) and np.array_equal(via_ptr[1], via_host[1])
+    m.rejectMap()
+    # new equations: what the previous solve left on the device is not theirs
+    m.evaluateDataError(w.traj, None, None, None, True, nem)
+    m.formNormalEq(None, w.K, nem, w.thres_valid_pixel)
+    m.applyL2Reg(w.alpha)
+    with pytest.raises(EmbaError):
+        m.updateMap(None, 0.7)

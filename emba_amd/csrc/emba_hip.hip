@@ -55,6 +55,9 @@ struct emba_ctx {
     const double* d_Gx = nullptr; const double* d_Gy = nullptr;   // the map planes the next evaluation reads (current or trial)
     const double* d_Gx_cur = nullptr; const double* d_Gy_cur = nullptr;   // current (accepted) map: own upload, bound, or accepted trial
     double* d_Gx_trial = nullptr; double* d_Gy_trial = nullptr; bool map_is_trial = false;
+    // the per-pixel record lists + pixel-ordered records of the last LOCAL solve (workspaces 0, 33): a re-solve of the same equations with another
+    // lambda (a rejected LM trial, solver.cpp:340-352) reuses them
+    bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
     double* d_x2 = nullptr; size_t x2_cap = 0; size_t x2_resident_P = (size_t)-1;   // x2_resident_P: d_x2 holds the x2 of the last solve on this context (for that many pixels)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     bool counts_raw = false;   // the count map holds the warp kernel's markers, not yet the counts (see ensure_counts)
@@ -1233,6 +1236,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->eq_in_alt = false;   // new equations are being formed from the working set: the other set's are obsolete
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     c->x2_resident_P = (size_t)-1;   // (a solve of the PREVIOUS equations may have left its x2 on the device)
+    c->lists_valid = false;          // (new active set)
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
     emba_status st = resolve_pending(c, true);   // counts only: a sharded host sizes exchange 2 from P while the gather still runs
     if (st) return st;
@@ -1659,6 +1663,13 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
     hipStream_t s = c->stream;
     uint32_t *d_off = nullptr, *d_cursor = nullptr; double* d_sorted = nullptr;
     emba_status st;
+    if (!view.packed && c->lists_valid && c->lists_stamp == view.stamp && c->lists_P == n_pix && c->lists_nrec == n_rec && c->ws[0].p && c->ws[33].p) {
+        out->off = (uint32_t*)c->ws[0].p;
+        out->sorted = RecView{};
+        out->sorted.rec = (const double*)c->ws[33].p; out->sorted.packed = 1; out->sorted.pix_base = 0;
+        return EMBA_OK;
+    }
+    c->lists_valid = false;
     if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
         (st = ws_get(c, 33, (n_rec + 1) * kRecStride * sizeof(double), (void**)&d_sorted)))
         return st;
@@ -1672,6 +1683,7 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
     out->off = d_off;
     out->sorted = RecView{};
     out->sorted.rec = d_sorted; out->sorted.packed = 1; out->sorted.pix_base = 0;
+    if (!view.packed) { c->lists_valid = true; c->lists_stamp = view.stamp; c->lists_P = n_pix; c->lists_nrec = n_rec; }
     return EMBA_OK;
 }
 

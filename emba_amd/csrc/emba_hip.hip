@@ -2076,7 +2076,7 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         HIP_TRY(c, hipMemcpyAsync(c->d_pGy, Gy_host, npix * sizeof(double), hipMemcpyHostToDevice, s));
         gx = c->d_pGx; gy = c->d_pGy;
     }
-    hipLaunchKernelGGL(emba_divergence_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, gx, gy, H, W, c->d_pF);
+    if (dense) hipLaunchKernelGGL(emba_divergence_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, gx, gy, H, W, c->d_pF);
     auto gemm = [&](const double* A, const double* B, double* C, int M, int N, int K, int epilogue, double inv_norm, long lda = 0, int a_kstride = 1, int a_koff = 0) {
         GemmParams p{};
         p.A = A; p.B = B; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda ? lda : K; p.ldb = N; p.ldc = N;
@@ -2099,22 +2099,29 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         const dim3 tg((W + 31) / 32, (H + 31) / 32), tgT((H + 31) / 32, (W + 31) / 32);
         // DST-I along H of every row of the transposed plane: src (W x H) -> dst (W x H), times scale.  Folded (even H): two half-size products on
         // the even- and odd-indexed inputs + a butterfly; tmp holds [E | O] (W x H/2 each).
-        auto dst_rows = [&](const double* src, double* dst, double* tmp, double scale) {
-            if (!fold) { gemm(src, c->d_SH, dst, W, H, H, 2, scale); return; }
+        // transposed_out: dst receives the result TRANSPOSED (H x W) — the folded form's butterfly writes it that way, saving the last transpose pass
+        auto dst_rows = [&](const double* src, double* dst, double* tmp, double scale, bool transposed_out) -> bool {
+            if (!fold) { gemm(src, c->d_SH, dst, W, H, H, 2, scale); return false; }
             const int h = H / 2;
             double* E = tmp; double* O = tmp + (size_t)W * h;
             gemm(src, c->d_Sfold, E, W, h, h, 0, 1.0, H, 2, 0);
             gemm(src, c->d_Sfold + (size_t)h * h, O, W, h, h, 0, 1.0, H, 2, 1);
-            hipLaunchKernelGGL(emba_dst_butterfly_kernel, dim3((unsigned)(((size_t)W * h + 255) / 256)), dim3(256), 0, s, E, O, W, H, scale, dst);
+            if (transposed_out) hipLaunchKernelGGL(emba_dst_butterfly_T_kernel, dim3((h + 31) / 32, (W + 31) / 32), dim3(256), 0, s, E, O, W, H, scale, dst);
+            else hipLaunchKernelGGL(emba_dst_butterfly_kernel, dim3((unsigned)(((size_t)W * h + 255) / 256)), dim3(256), 0, s, E, O, W, H, scale, dst);
+            return transposed_out;
         };
         if (fold && !c->d_pE) { if ((st = dev_alloc(c, &c->d_pE, npix))) return st; }
-        hipLaunchKernelGGL(emba_transpose_kernel, tg, dim3(256), 0, s, c->d_pF, H, W, c->d_pT);                       // F^T  (W x H)
-        dst_rows(c->d_pT, c->d_pF, c->d_pE, 1.0);                                                                        // (S_H F)^T = F^T S_H
+        hipLaunchKernelGGL(emba_divergence_T_kernel, tg, dim3(256), 0, s, gx, gy, H, W, c->d_pT);                     // F^T  (W x H), straight from the gradient maps
+        dst_rows(c->d_pT, c->d_pF, c->d_pE, 1.0, false);                                                                 // (S_H F)^T = F^T S_H
         const unsigned tb = (unsigned)((H + kTriSys - 1) / kTriSys);
-        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<false>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);   // (T_W + lambda1[i] I) x = g, per i
-        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<true>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_pF, H, W);
-        dst_rows(c->d_pF, c->d_pT, c->d_pE, 1.0 / (2.0 * (double)(H + 1)));                                            // M^T = X^T S_H / (2 (H+1))
-        hipLaunchKernelGGL(emba_transpose_kernel, tgT, dim3(256), 0, s, c->d_pT, W, H, c->d_pF);                      // M
+        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<false>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_lamH, c->d_pF, H, W);   // (T_W + lambda1[i] I) x = g, per i
+        hipLaunchKernelGGL(emba_tridiag_sweep_kernel<true>, dim3(tb), dim3(kTriSys * kTriChunks), 0, s, c->d_thomas, c->d_lamH, c->d_pF, H, W);
+        // M^T = X^T S_H / (2 (H+1)).  Folded: the butterfly writes M itself into d_pF (its input X^T is dead once E and O exist)
+        if (fold) dst_rows(c->d_pF, c->d_pF, c->d_pE, 1.0 / (2.0 * (double)(H + 1)), true);
+        else {
+            dst_rows(c->d_pF, c->d_pT, c->d_pE, 1.0 / (2.0 * (double)(H + 1)), false);
+            hipLaunchKernelGGL(emba_transpose_kernel, tgT, dim3(256), 0, s, c->d_pT, W, H, c->d_pF);                  // M
+        }
     }
     HIP_TRY(c, hipGetLastError());
     if (M_host) HIP_TRY(c, hipMemcpyAsync(M_host, c->d_pF, npix * sizeof(double), hipMemcpyDeviceToHost, s));

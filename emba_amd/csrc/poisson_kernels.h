@@ -192,6 +192,46 @@ __global__ __launch_bounds__(256) void emba_transpose_kernel(const double* __res
     for (int r = ty; r < 32; r += 8) { const int y = bx + r, x = by + tx; if (y < cols && x < rows) dst[(size_t)y * rows + x] = tile[tx][r]; }
 }
 
+// F^T straight from the gradient maps (the divergence of emba_divergence_kernel, written transposed: one pass instead of two)
+__global__ __launch_bounds__(256) void emba_divergence_T_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, int H, int W, double* __restrict__ FT)
+{
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = by + r, j = bx + tx;
+        double f = 0.0;
+        if (i < H - 1 && j < W - 1) { const size_t idx = (size_t)i * W + j; f = Gx[idx + 1] - Gx[idx] + Gy[idx + W] - Gy[idx]; }   // same association as the reference
+        tile[r][tx] = f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int j = bx + r, i = by + tx; if (j < W && i < H) FT[(size_t)j * H + i] = tile[tx][r]; }
+}
+
+// Butterfly of the folded DST written TRANSPOSED: out (n x rows)[k][row] = (E[row][k] +- O[row][k]) * scale — the last step of the solve hands the
+// panorama back in its own layout without a separate transpose pass
+__global__ __launch_bounds__(256) void emba_dst_butterfly_T_kernel(const double* __restrict__ E, const double* __restrict__ O, int rows, int n, double scale,
+                                                                    double* __restrict__ out)
+{
+    __shared__ double te[32][33], to[32][33];
+    const int h = n / 2;
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // bx over k (< h), by over rows
+    for (int r = ty; r < 32; r += 8) {
+        const int row = by + r, k = bx + tx;
+        const bool in = row < rows && k < h;
+        te[r][tx] = in ? E[(size_t)row * h + k] : 0.0;
+        to[r][tx] = in ? O[(size_t)row * h + k] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = bx + r, row = by + tx;
+        if (k < h && row < rows) {
+            const double e = te[tx][r], o = to[tx][r];
+            out[(size_t)k * rows + row] = (e + o) * scale;
+            out[(size_t)(n - 1 - k) * rows + row] = (e - o) * scale;
+        }
+    }
+}
+
 // Thomas factors of T_W + lambda1[i] I = tridiag(1, beta_i, 1), beta_i = -2 + lambda1[i] < -2 (strictly diagonally dominant: no pivoting):
 // cp[j][i] = 1 / (beta_i - cp[j-1][i]), cp[0][i] = 1 / beta_i.  Once per context (like the sine matrix): W x H doubles.
 __global__ void emba_thomas_coef_kernel(const double* __restrict__ lam1, int H, int W, double* __restrict__ cp)
@@ -211,8 +251,13 @@ __global__ void emba_thomas_coef_kernel(const double* __restrict__ lam1, int H, 
 // systems and cuts the j range into kTriChunks chunks — (A) every thread composes its chunk's affine map, (B) one thread per system
 // chains the chunks' maps, (C) every thread replays its chunk from the now known start value and writes the result.
 constexpr int kTriSys = 8, kTriChunks = 128;
+constexpr int kTriMaxQ = 32;    // elements per chunk the recomputing backward replay supports (W <= kTriChunks * kTriMaxQ = 4096; wider planes read the table)
+// The Thomas factors are RECOMPUTED inside a chunk from the chunk's first stored one (c_j = 1 / (beta_i - c_{j-1}): one division per element,
+// on an otherwise idle VALU) instead of being streamed: a sweep read cp and the plane twice each — 335 MB at 2048 x 4096 — now 67 x 2 + 67 MB
+// of plane traffic and 128 factors per system.  (Same values: the table itself was filled by this recurrence, emba_thomas_coef_kernel.)
 template <bool BACKWARD>
-__global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kernel(const double* __restrict__ cp, double* __restrict__ v, int H, int W)
+__global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kernel(const double* __restrict__ cp, const double* __restrict__ lam1,
+                                                                                  double* __restrict__ v, int H, int W)
 {
     __shared__ double sA[kTriChunks][kTriSys], sB[kTriChunks][kTriSys], sY[kTriChunks][kTriSys];
     const int s = threadIdx.x % kTriSys, ch = threadIdx.x / kTriSys;
@@ -220,10 +265,20 @@ __global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kerne
     const int q = (W + kTriChunks - 1) / kTriChunks;
     const int j0 = ch * q, j1 = (j0 + q < W) ? j0 + q : W;
     const bool live = i < H && j0 < W;
+    const double beta = live ? -2.0 + lam1[i] : -3.0;
+    // c_{j0-1} (0 in front of the first element: c_0 = 1 / beta), then c_j for the chunk by the recurrence — forwards in both sweeps
+    const double c_in = (live && j0 > 0) ? cp[(size_t)(j0 - 1) * H + i] : 0.0;
     double A = 1.0, B = 0.0;
     if (live) {
-        if (!BACKWARD) for (int j = j0; j < j1; ++j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; const double a = -c, b = c * g; B = a * B + b; A = a * A; }
-        else for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; const double a = -c; B = a * B + g; A = a * A; }
+        if (!BACKWARD) {
+            double c = c_in;
+            for (int j = j0; j < j1; ++j) { c = 1.0 / (beta - c); const double g = v[(size_t)j * H + i]; const double a = -c, b = c * g; B = a * B + b; A = a * A; }
+        } else {
+            // x_j = y_j - c_j x_{j+1}, j descending: the chunk's affine map in terms of x entering from above needs c_j in DESCENDING order; the
+            // composition is associative, so build it ascending instead:  (x_{j1} -> x_{j0})  =  f_{j0} o f_{j0+1} o ... o f_{j1-1},  f_j(x) = g_j - c_j x
+            double c = c_in;
+            for (int j = j0; j < j1; ++j) { c = 1.0 / (beta - c); const double g = v[(size_t)j * H + i]; B = B + A * g; A = A * (-c); }
+        }
     }
     sA[ch][s] = A; sB[ch][s] = B;
     __syncthreads();
@@ -235,8 +290,22 @@ __global__ __launch_bounds__(kTriSys * kTriChunks) void emba_tridiag_sweep_kerne
     __syncthreads();
     if (!live) return;
     double y = sY[ch][s];
-    if (!BACKWARD) for (int j = j0; j < j1; ++j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = c * (g - y); v[(size_t)j * H + i] = y; }
-    else for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = g - c * y; v[(size_t)j * H + i] = y; }
+    if (!BACKWARD) {
+        double c = c_in;
+        for (int j = j0; j < j1; ++j) { c = 1.0 / (beta - c); const double g = v[(size_t)j * H + i]; y = c * (g - y); v[(size_t)j * H + i] = y; }
+    } else {
+        // descending replay needs c_j descending: the chunk's factors are kept from one ascending pass (q <= kTriMaxQ of them; longer chunks read the table)
+        if (q <= kTriMaxQ) {
+            double cs[kTriMaxQ];
+            double c = c_in;
+#pragma unroll
+            for (int k = 0; k < kTriMaxQ; ++k) { if (j0 + k < j1) { c = 1.0 / (beta - c); cs[k] = c; } }
+#pragma unroll
+            for (int k = kTriMaxQ - 1; k >= 0; --k) { if (j0 + k < j1) { const int j = j0 + k; const double g = v[(size_t)j * H + i]; y = g - cs[k] * y; v[(size_t)j * H + i] = y; } }
+        } else {
+            for (int j = j1 - 1; j >= j0; --j) { const double c = cp[(size_t)j * H + i], g = v[(size_t)j * H + i]; y = g - c * y; v[(size_t)j * H + i] = y; }
+        }
+    }
 }
 
 // ---- the sine matrix folded by its symmetry  S[n-1-k][j] = (-1)^j S[k][j]  (n even) ----------------------------------------------------

@@ -2085,7 +2085,10 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         p.lam1 = c->d_lamH; p.lam2 = c->d_lamW;
         p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
         const long tm = (M + kGemmBM - 1) / kGemmBM, wide = tm * ((N + 127) / 128), narrow = tm * ((N + 63) / 64);
-        if (wide >= 2L * c->n_cu) hipLaunchKernelGGL(emba_dgemm_kernel<128>, dim3((unsigned)grid8(wide)), dim3(256), 0, s, p);
+        const long big = ((M + kGemmBM2 - 1) / kGemmBM2) * ((N + kGemmBN2 - 1) / kGemmBN2);
+        const bool use_big = big >= (long)c->n_cu && !(getenv("EMBA_GEMM") && !strcmp(getenv("EMBA_GEMM"), "64"));
+        if (use_big) hipLaunchKernelGGL(emba_dgemm128_kernel, dim3((unsigned)grid8(big)), dim3(512), 0, s, p);
+        else if (wide >= 2L * c->n_cu) hipLaunchKernelGGL(emba_dgemm_kernel<128>, dim3((unsigned)grid8(wide)), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(emba_dgemm_kernel<64>, dim3((unsigned)grid8(narrow)), dim3(256), 0, s, p);
     };
     if (dense) {

@@ -175,6 +175,107 @@ __global__ __launch_bounds__(256) void emba_dgemm_kernel(GemmParams p)
             }
 }
 
+// The same product with a 128 x 128 x 16 block tile and 512 threads (8 waves, 4 x 2, wave tile 32 x 64 as above): a third less operand traffic
+// from L2 per flop (the 64 x 128 tile above moves 0.8 GB through L2 for the 8.6 GFLOP of one folded DST product at 2048 x 4096 — 4 TB/s at its
+// 200 us).  Used when the output gives every CU a tile of this size.
+constexpr int kGemmBM2 = 128, kGemmBN2 = 128;
+__global__ __launch_bounds__(512) void emba_dgemm128_kernel(GemmParams p)
+{
+    constexpr int LdA = kGemmBM2 + 16, LdB = kGemmBN2 + 16, NB = 4;
+    __shared__ __attribute__((aligned(16))) double sA[2][kGemmBK * LdA];
+    __shared__ __attribute__((aligned(16))) double sB[2][kGemmBK * LdB];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int el = lane & 15, kk = lane >> 4;
+    const int tiles_n = (p.N + kGemmBN2 - 1) / kGemmBN2, tiles_m = (p.M + kGemmBM2 - 1) / kGemmBM2;
+    const long n_tiles = (long)tiles_m * tiles_n;
+    long bid = blockIdx.x;
+    {
+        const long per = (n_tiles + 7) / 8;
+        bid = (bid & 7) * per + (bid >> 3);
+        if (bid >= n_tiles) return;
+    }
+    const int m0 = (int)(bid / tiles_n) * kGemmBM2, n0 = (int)(bid % tiles_n) * kGemmBN2;
+    const int wm = (wv & 3) * 32, wn = (wv >> 2) * 64;
+    // staging: A tile 128 x 16 (4 doubles per thread: row t/4, k (t%4)*4..+3), B tile 16 x 128 (4 per thread: k t/32, cols (t%32)*4..+3)
+    const int a_row = t >> 2, a_k = (t & 3) * 4;
+    const int b_k = t >> 5, b_col = (t & 31) * 4;
+    double ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+        const int gr = m0 + a_row;
+        if (p.vec && p.a_kstride == 1 && gr < p.M && k0 + a_k + 3 < p.K) {
+            const double2* q2 = reinterpret_cast<const double2*>(p.A + (size_t)p.lda * gr + k0 + a_k);
+            const double2 v0 = q2[0], v1 = q2[1];
+            ra[0] = v0.x; ra[1] = v0.y; ra[2] = v1.x; ra[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gk = k0 + a_k + q;
+                ra[q] = (gr < p.M && gk < p.K) ? p.A[(size_t)p.lda * gr + p.a_koff + (size_t)p.a_kstride * gk] : 0.0;
+            }
+        }
+        const int gk = k0 + b_k;
+        if (p.vec && gk < p.K && n0 + b_col + 3 < p.N) {
+            const double2* q2 = reinterpret_cast<const double2*>(p.B + (size_t)p.ldb * gk + n0 + b_col);
+            const double2 v0 = q2[0], v1 = q2[1];
+            rb[0] = v0.x; rb[1] = v0.y; rb[2] = v1.x; rb[3] = v1.y;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int gc = n0 + b_col + q;
+                rb[q] = (gk < p.K && gc < p.N) ? p.B[(size_t)p.ldb * gk + gc] : 0.0;
+            }
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sA[buf][(a_k + q) * LdA + a_row] = ra[q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sB[buf][b_k * LdB + b_col + q] = rb[q];
+    };
+    pdouble4_t acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[a][b] = pdouble4_t{0.0, 0.0, 0.0, 0.0};
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < p.K; k0 += kGemmBK) {
+        const bool more = k0 + kGemmBK < p.K;
+        if (more) load_tile(k0 + kGemmBK);
+#pragma unroll
+        for (int ks = 0; ks < kGemmBK; ks += 4) {
+            double av[2], bv[NB];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) av[a] = sA[buf][(ks + kk) * LdA + wm + 16 * a + el];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) bv[b] = sB[buf][(ks + kk) * LdB + wn + 16 * b + el];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + 16 * a + kk + 4 * r, col = n0 + wn + 16 * b + el;
+                if (row < p.M && col < p.N) {
+                    double v = acc[a][b][r];
+                    if (p.epilogue == 1) v = (v * p.inv_norm) / (p.lam1[row] + p.lam2[col]);
+                    else if (p.epilogue == 2) v = v * p.inv_norm;
+                    p.C[(size_t)p.ldc * row + col] = v;
+                }
+            }
+}
+
 // ---- Fourier analysis along ONE axis + tridiagonal solves along the other ------------------------------------------------------------
 // The Dirichlet solve of laplace.cpp:587-797 is  M = S_H ((S_H F S_W) o C) S_W,  C[i][k] = 1 / (4 (H+1)(W+1) (lambda1[i] + lambda2[k])).
 // S_W / sqrt(2 (W+1)) is the orthogonal eigenbasis of the 1-D second-difference operator T_W = tridiag(1, -2, 1), eigenvalues lambda2, so

@@ -430,14 +430,9 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
-        // (four partial sums: one running sum is a chain of j dependent fp64 FMAs, ~2000 of them over the block)
-        double v0 = row[j], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        double v = row[j];
 #pragma unroll
-        for (int k = 0; k < j; ++k) {
-            const double t = row[k] * readlane_f64(row[k], j);
-            if ((k & 3) == 0) v0 -= t; else if ((k & 3) == 1) v1 -= t; else if ((k & 3) == 2) v2 -= t; else v3 -= t;
-        }
-        const double v = (v0 + v1) + (v2 + v3);
+        for (int k = 0; k < j; ++k) v -= row[k] * readlane_f64(row[k], j);
         const double d = readlane_f64(v, j);
         // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
         // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
@@ -445,11 +440,8 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
         // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
         const bool ok = d > 0.0;
         bad |= (j < nb) && !ok;
-        // (one reciprocal square root per column instead of a square root and a division: both are long dependent sequences in fp64,
-        // 64 of them in a row were half of this kernel's time)
-        const double rs = ok ? rsqrt(d) : 0.0;
-        row[j] = (r == j) ? d * rs : v * rs;                // rows above the diagonal hold garbage that is never read (k < j <= r below)
-        __builtin_amdgcn_sched_barrier(0);
+        const double piv = ok ? sqrt(d) : 0.0;
+        row[j] = (r == j) ? piv : (ok ? v / piv : 0.0);     // rows above the diagonal hold garbage that is never read (k < j <= r below)
     }
     if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
 #pragma unroll
@@ -473,13 +465,9 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
 #pragma unroll
     for (int c = 0; c < 64; ++c) {
         if (c < nb) {
-            double v0 = x[c], v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            double v = x[c];
 #pragma unroll
-            for (int k = 0; k < c; ++k) {                               // L_diag[c][k]; four partial sums instead of one dependent chain
-                const double t = x[k] * s[k * 65 + c];
-                if ((k & 3) == 0) v0 -= t; else if ((k & 3) == 1) v1 -= t; else if ((k & 3) == 2) v2 -= t; else v3 -= t;
-            }
-            const double v = (v0 + v1) + (v2 + v3);
+            for (int k = 0; k < c; ++k) v -= x[k] * s[k * 65 + c];     // L_diag[c][k]
             const double dg = s[c * 65 + c];
             x[c] = (dg != 0.0) ? v / dg : 0.0;                        // zeroed column of a vanishing pivot (emba_chol_diag_kernel)
         }

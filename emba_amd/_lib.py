@@ -50,6 +50,9 @@ SIGNATURES = {
     "emba_get_inlier_pixels": (C.c_int, [C.c_void_p, _u32p]),
     "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
     "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),
+    "emba_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dp, _dp]),
+    "emba_costs_launch": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int32]),
+    "emba_costs_finish": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dp, _dp]),
     "emba_dump_state": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _i32p, _i32p, _dp, _dp, _dp]),
     "emba_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_bind_map_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -58,6 +58,7 @@ struct emba_ctx {
     // the per-pixel record lists + pixel-ordered records of the last LOCAL solve (workspaces 0, 33): a re-solve of the same equations with another
     // lambda (a rejected LM trial, solver.cpp:340-352) reuses them
     bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
+    double* h_cost = nullptr;           // pinned: {data cost sum, reg cost sum} of emba_costs
     double* d_x2 = nullptr; size_t x2_cap = 0; size_t x2_resident_P = (size_t)-1;   // x2_resident_P: d_x2 holds the x2 of the last solve on this context (for that many pixels)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     bool counts_raw = false;   // the count map holds the warp kernel's markers, not yet the counts (see ensure_counts)
@@ -704,6 +705,7 @@ void emba_destroy(emba_ctx* c)
     free_window(c);
     free_all_buffers(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_cost) (void)hipHostFree(c->h_cost);
     if (c->h_knots) (void)hipHostFree(c->h_knots);
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
@@ -1444,6 +1446,49 @@ emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)
     else if (irls == 2) v *= 0.5 / eta;
     *cost = v;
     return EMBA_OK;
+}
+
+// Both cost terms of a trial point (solver.cpp:88-91, 265-268) with ONE host synchronisation: the two reductions are enqueued, their results
+// come back in one pinned 16-byte copy.  emba_costs_launch / _finish split it so that a group can enqueue every rank before it waits for any.
+emba_status emba_costs_launch(emba_ctx* c, int32_t irls, double eta, int32_t with_reg)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no residuals yet");
+    if (with_reg && !c->have_map) return fail(c, EMBA_ERR_STATE, "no map");
+    HIP_TRY(c, hipSetDevice(c->device));
+    { emba_status st0 = resolve_pending(c); if (st0) return st0; }
+    if (!c->h_cost) HIP_TRY(c, hipHostMalloc((void**)&c->h_cost, 2 * sizeof(double), hipHostMallocDefault));
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->d_scalar, 0, 2 * sizeof(double), s));
+    if (c->n_sorted) {
+        const unsigned grid = (unsigned)std::min<size_t>((c->n_pm + 255) / 256, 2048);
+        hipLaunchKernelGGL(emba_data_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (long)c->n_pm, (int)irls, eta, c->d_scalar);
+    }
+    if (with_reg) {
+        const unsigned grid = (unsigned)std::min<size_t>((c->npix + 255) / 256, 2048);
+        hipLaunchKernelGGL(emba_reg_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_Gx, c->d_Gy, (long)c->npix, c->d_scalar + 1);
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->h_cost, c->d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+emba_status emba_costs_finish(emba_ctx* c, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost)
+{
+    if (!c || !c->h_cost) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double v = c->h_cost[0];
+    if (irls == 0) v *= 0.5;
+    else if (irls == 2) v *= 0.5 / eta;
+    if (data_cost) *data_cost = v;
+    if (reg_cost) *reg_cost = 0.5 * alpha * c->h_cost[1];
+    return EMBA_OK;
+}
+emba_status emba_costs(emba_ctx* c, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost)
+{
+    emba_status st = emba_costs_launch(c, irls, eta, reg_cost ? 1 : 0);
+    if (st) return st;
+    return emba_costs_finish(c, irls, eta, alpha, data_cost, reg_cost);
 }
 
 emba_status emba_reg_cost(emba_ctx* c, double alpha, double* cost)

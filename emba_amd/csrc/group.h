@@ -641,10 +641,11 @@ emba_status emba_group_download(emba_group* g, double* A11, double* b1, uint32_t
 emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
+    // every rank's reductions are enqueued before any is waited for (rank 0 also reduces the replicated map): N overlapping waits, not 2N serial ones
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_costs_launch(g->ctx[r], irls, eta, (r == 0 && reg_cost) ? 1 : 0));
     double d = 0;
-    for (int r = 0; r < g->n; ++r) { double v = 0; G_TRY(g, r, emba_data_cost(g->ctx[r], irls, eta, &v)); d += v; }
+    for (int r = 0; r < g->n; ++r) { double v = 0, rg = 0; G_TRY(g, r, emba_costs_finish(g->ctx[r], irls, eta, alpha, &v, &rg)); d += v; if (r == 0 && reg_cost) *reg_cost = rg; }
     if (data_cost) *data_cost = d;
-    if (reg_cost) G_TRY(g, 0, emba_reg_cost(g->ctx[0], alpha, reg_cost));
     return EMBA_OK;
 }
 

@@ -176,6 +176,12 @@ class LEGM:
         self._check(self._L.emba_data_cost(self._ctx, COST_TYPES[cost_type], float(a), C.byref(v)))
         return v.value
 
+    def costs(self, cost_type="quadratic", a=0.0, alpha=0.0):
+        """(dataCost, regCost) with one host synchronisation: emba_costs."""
+        d, r = C.c_double(0), C.c_double(0)
+        self._check(self._L.emba_costs(self._ctx, COST_TYPES[cost_type], float(a), float(alpha), C.byref(d), C.byref(r)))
+        return d.value, r.value
+
     def regCost(self, alpha):
         """alpha*0.5*|evaluateRegError|^2 (model.cpp:260-277, solver.cpp:90), reduced on the device."""
         v = C.c_double(0)

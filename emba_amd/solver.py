@@ -57,6 +57,9 @@ class _Phases:
             m.eval_finish()
         else:
             m.evaluateDataError(traj, Gx, Gy, None, True, self.nem)
+        if hasattr(m, "costs"):      # both reductions, one synchronisation
+            d, r = m.costs(self.cost_type, self.ba.eta, self.ba.alpha)
+            return d + r
         return m.dataCost(self.cost_type, self.ba.eta) + m.regCost(self.ba.alpha)
 
     def form(self, K):

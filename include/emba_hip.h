@@ -169,6 +169,12 @@ emba_status emba_get_inlier_pixels(emba_ctx* ctx, uint32_t* pix_host);
  * reg = 0.5*alpha*sum(Gx^2+Gy^2) over all pixels (model.cpp:260-277). */
 emba_status emba_data_cost(emba_ctx* ctx, int32_t irls, double eta, double* cost);
 emba_status emba_reg_cost(emba_ctx* ctx, double alpha, double* cost);
+/* Both terms with one host synchronisation (the LM loop asks for them together at every trial point, solver.cpp:88-91, 265-268).
+ * reg_cost may be NULL (a rank of a sharded host whose map is a replica).  emba_costs_launch / emba_costs_finish: the same in two halves, so
+ * that a multi-GPU host can enqueue every rank's reductions before it waits for any. */
+emba_status emba_costs(emba_ctx* ctx, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost);
+emba_status emba_costs_launch(emba_ctx* ctx, int32_t irls, double eta, int32_t with_reg);
+emba_status emba_costs_finish(emba_ctx* ctx, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost);
 
 /* Per-event state dump in ORIGINAL (time) order for parity tests: what State_LEGM holds after
  * evaluateDataError (state.h:56-83).  All host, capacity n; any may be NULL.

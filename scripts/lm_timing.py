@@ -26,7 +26,7 @@ def timed(name):
     def g(*x, **k):
         t = time.perf_counter(); r = f(*x, **k); T[name] = T.get(name, 0.0) + time.perf_counter() - t; return r
     setattr(m, name, g)
-for nm in ("set_events", "upload_map", "eval_launch", "eval_finish", "dataCost", "regCost", "form_active", "form_accumulate", "form_finish", "solveNormalEq", "updateMap",
+for nm in ("set_events", "upload_map", "eval_launch", "eval_finish", "costs", "dataCost", "regCost", "form_active", "form_accumulate", "form_finish", "solveNormalEq", "updateMap",
            "acceptMap", "rejectMap"):
     if hasattr(m, nm): timed(nm)
 t0 = time.perf_counter()

@@ -796,3 +796,17 @@ def test_update_map_from_the_solvers_resident_x2(gpu, oracle_mod, use_cg):
     m.applyL2Reg(w.alpha)
     with pytest.raises(EmbaError):
         m.updateMap(None, 0.7)
+
+
+@pytest.mark.parametrize("cost", [("quadratic", 0.0), ("huber", 0.1), ("cauchy", 1.0)])
+def test_costs_in_one_call(gpu, oracle_mod, cost):
+    """emba_costs = (emba_data_cost, emba_reg_cost) of the same state with one host synchronisation (solver.cpp:88-91, 265-268)."""
+    w = small_workload(n_events=20000)
+    m = make_legm(w)
+    nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+    ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, w.events, True, nem)
+    d, r = m.costs(cost[0], cost[1], w.alpha)
+    assert d == pytest.approx(m.dataCost(*cost), rel=1e-13) and r == pytest.approx(m.regCost(w.alpha), rel=1e-13)
+    irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
+    assert d == pytest.approx(oracle_mod.data_cost(ep, irls, cost[1]), rel=1e-10)
+    assert r == pytest.approx(oracle_mod.reg_cost(w.Gx, w.Gy, w.alpha), rel=1e-12)

@@ -977,7 +977,9 @@ emba_status emba_trial_reject(emba_ctx* c)
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->eq_in_alt) return EMBA_OK;     // nothing was evaluated since the equations were formed (or they have been re-formed)
     HIP_TRY(c, hipSetDevice(c->device));
-    if (c->P_pending || c->inl_pending || c->ep_deferred) { emba_status st = resolve_pending(c); if (st) return st; }
+    // (a trial that was only launched: its compacted residual vector and inlier numbers will never be asked for — nothing to resolve)
+    if (c->ep_deferred && !c->P_pending && !c->inl_pending) c->ep_deferred = false;
+    else if (c->P_pending || c->inl_pending || c->ep_deferred) { emba_status st = resolve_pending(c); if (st) return st; }
     std::swap(c->d_rec, c->d_rec2); std::swap(c->d_tag, c->d_tag2); std::swap(c->set_stamp, c->set_stamp2);
     std::swap(c->caps[reinterpret_cast<void**>(&c->d_rec)], c->caps[reinterpret_cast<void**>(&c->d_rec2)]);
     std::swap(c->caps[reinterpret_cast<void**>(&c->d_tag)], c->caps[reinterpret_cast<void**>(&c->d_tag2)]);
@@ -1456,8 +1458,11 @@ emba_status emba_costs_launch(emba_ctx* c, int32_t irls, double eta, int32_t wit
     if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no residuals yet");
     if (with_reg && !c->have_map) return fail(c, EMBA_ERR_STATE, "no map");
     HIP_TRY(c, hipSetDevice(c->device));
-    { emba_status st0 = resolve_pending(c); if (st0) return st0; }
-    if (!c->h_cost) HIP_TRY(c, hipHostMalloc((void**)&c->h_cost, 2 * sizeof(double), hipHostMallocDefault));
+    // An evaluation that has only been launched stays that way: the reductions read the per-event residuals and flags the warp kernel wrote,
+    // not the compacted vector — so the formNormalEq that follows an accepted trial still finds the post-warp work fused (emba_form_active), and
+    // a rejected trial never pays for a residual vector nobody asks for.  The step's status word comes back with the sums (emba_costs_finish).
+    if (!c->ep_deferred) { emba_status st0 = resolve_pending(c); if (st0) return st0; }
+    if (!c->h_cost) HIP_TRY(c, hipHostMalloc((void**)&c->h_cost, 4 * sizeof(double), hipHostMallocDefault));
     hipStream_t s = c->stream;
     HIP_TRY(c, hipMemsetAsync(c->d_scalar, 0, 2 * sizeof(double), s));
     if (c->n_sorted) {
@@ -1469,6 +1474,7 @@ emba_status emba_costs_launch(emba_ctx* c, int32_t irls, double eta, int32_t wit
         hipLaunchKernelGGL(emba_reg_cost_kernel, dim3(grid), dim3(256), 0, s, c->d_Gx, c->d_Gy, (long)c->npix, c->d_scalar + 1);
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_cost, c->d_scalar, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_cost + 2, c->d_err, sizeof(int), hipMemcpyDeviceToHost, s));      // bit 0: a batch outside the knots
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }
@@ -1477,6 +1483,7 @@ emba_status emba_costs_finish(emba_ctx* c, int32_t irls, double eta, double alph
     if (!c || !c->h_cost) return EMBA_ERR_INVALID_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int w = 0; memcpy(&w, c->h_cost + 2, sizeof(int)); if (w & 1) return fail(c, EMBA_ERR_TIME_RANGE, "a batch midpoint lies outside the spline's knots"); }
     double v = c->h_cost[0];
     if (irls == 0) v *= 0.5;
     else if (irls == 2) v *= 0.5 / eta;

@@ -54,7 +54,10 @@ class _Phases:
             if Gx is not None:
                 m.upload_map(Gx, Gy)
             m.eval_launch(traj)
-            m.eval_finish()
+            if getattr(m, "async_phases", False) and hasattr(m, "costs"):
+                m.eval_finish(sync=False)      # nothing is resolved on the host: the costs below are the synchronisation
+            else:
+                m.eval_finish()
         else:
             m.evaluateDataError(traj, Gx, Gy, None, True, self.nem)
         if hasattr(m, "costs"):      # both reductions, one synchronisation
@@ -65,7 +68,10 @@ class _Phases:
     def form(self, K):
         m, ba = self.m, self.ba
         if self.resident:
-            m.form_active(ba.thres_valid_pixel)
+            if getattr(m, "async_phases", False):
+                m.form_active(ba.thres_valid_pixel, sync=False)      # P is resolved by the solve
+            else:
+                m.form_active(ba.thres_valid_pixel)
             m.form_accumulate(self.cost_type, ba.eta)
             m.form_finish(ba.alpha)
         else:

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
 #include "kernels.h"
 
 namespace emba {
@@ -326,43 +327,48 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     int rma[4], rmb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { rma[t] = (I0 + 16 * t + el < p.n) ? -1 : 0; rmb[t] = (J0 + 16 * t + el < p.n) ? -1 : 0; }
-    auto load = [&](int it, double* av, double* bv, int& cm) {
-        const long c4 = quad(it);
-        const long col = c4 + kk;
-        const bool cok = c4 >= 0 && col < kend;
-        cm = cok ? -1 : 0;
-        if (p.range) cm = cok ? (int)p.range[col >> 1] : 0x0001;   // (the raw range word rides with the stage; decoded in mma.  lo = 1 > hi = 0: nothing valid)
-        const double* colp = p.A + (size_t)p.lda * (cok ? col : 0);
+    // DIAG (I == J): the B operand IS the A operand — half the loads of such a pair (4 of the 10 pairs of a 4-block band) — and the tiles above
+    // the diagonal are not formed
+    auto run = [&](auto diag_c) {
+        constexpr bool DIAG = decltype(diag_c)::value;
+        auto load = [&](int it, double* av, double* bv, int& cm) {
+            const long c4 = quad(it);
+            const long col = c4 + kk;
+            const bool cok = c4 >= 0 && col < kend;
+            cm = cok ? -1 : 0;
+            if (p.range) cm = cok ? (int)p.range[col >> 1] : 0x0001;   // (the raw range word rides with the stage; decoded in mma.  lo = 1 > hi = 0: nothing valid)
+            const double* colp = p.A + (size_t)p.lda * (cok ? col : 0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
-            av[t] = colp[rma[t] ? ri : 0];
-            bv[t] = colp[rmb[t] ? rj : 0];
-        }
-    };
-    auto mma = [&](const double* av, const double* bv, int cm) {
-        double am[4], bm[4];
-        bool any_a[4], any_b[4];
-        const int lo = cm & 255, hi = (cm >> 8) & 255;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int ma = cm & rma[t], mb = cm & rmb[t];
-            if (p.range) {     // the lane's column has data in the 16-row group of this tile row?
-                ma = (4 * I + t >= lo && 4 * I + t <= hi) ? rma[t] : 0;
-                mb = (4 * J + t >= lo && 4 * J + t <= hi) ? rmb[t] : 0;
+            for (int t = 0; t < 4; ++t) {
+                const int ri = I0 + 16 * t + el, rj = J0 + 16 * t + el;
+                av[t] = colp[rma[t] ? ri : 0];
+                if (!DIAG) bv[t] = colp[rmb[t] ? rj : 0];
             }
-            am[t] = __hiloint2double(__double2hiint(av[t]) & ma, __double2loint(av[t]) & ma);
-            bm[t] = __hiloint2double(__double2hiint(bv[t]) & mb, __double2loint(bv[t]) & mb);
-            any_a[t] = !p.range || __ballot(ma != 0) != 0ull;       // (wave-uniform) some column of the quad has rows in this 16-row group
-            any_b[t] = !p.range || __ballot(mb != 0) != 0ull;
-        }
+        };
+        auto mma = [&](const double* av, const double* bv, int cm) {
+            double am[4], bm[4];
+            bool any_a[4], any_b[4];
+            const int lo = cm & 255, hi = (cm >> 8) & 255;
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int t = 0; t < 4; ++t) {
+                int ma = cm & rma[t], mb = cm & rmb[t];
+                if (p.range) {     // the lane's column has data in the 16-row group of this tile row?
+                    ma = (4 * I + t >= lo && 4 * I + t <= hi) ? rma[t] : 0;
+                    mb = (4 * J + t >= lo && 4 * J + t <= hi) ? rmb[t] : 0;
+                }
+                am[t] = __hiloint2double(__double2hiint(av[t]) & ma, __double2loint(av[t]) & ma);
+                if (!DIAG) bm[t] = __hiloint2double(__double2hiint(bv[t]) & mb, __double2loint(bv[t]) & mb);
+                any_a[t] = !p.range || __ballot(ma != 0) != 0ull;       // (wave-uniform) some column of the quad has rows in this 16-row group
+                any_b[t] = DIAG ? any_a[t] : (!p.range || __ballot(mb != 0) != 0ull);
+            }
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                if (any_a[a] && any_b[b]) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], bm[b], acc[a][b], 0, 0, 0);
-    };
-    {
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (DIAG && a < b) continue;
+                    if (any_a[a] && any_b[b]) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(am[a], DIAG ? am[b] : bm[b], acc[a][b], 0, 0, 0);
+                }
+        };
         double a0[4], b0[4], a1[4], b1[4], a2[4], b2[4];
         int m0, m1, m2;
         load(0, a0, b0, m0); load(1, a1, b1, m1);
@@ -373,7 +379,8 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
             load(it + 3, a0, b0, m0); mma(a1, b1, m1);
             load(it + 4, a1, b1, m1); mma(a2, b2, m2);
         }
-    }
+    };
+    if (I == J) run(std::true_type{}); else run(std::false_type{});
     for (int i = threadIdx.x; i < 64 * 64; i += 256) s_tile[i] = 0.0;
     __syncthreads();
 #pragma unroll

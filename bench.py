@@ -238,20 +238,25 @@ def main():
     for _ in range(n_extra):
         step()
     barrier()
-    # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region: each event record
-    # opens a ~6 us bubble in front of the next kernel and reading the events back makes the host wait for the Gram kernel,
-    # so timing every step would distort the very throughput being measured.
-    warp_ms, accum_ms = [], []
+    # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region (at most 16 samples), each sample in
+    # its own set of events that is read AFTER the loop: an event record opens a bubble of a few us in front of the next kernel, and reading one
+    # back inside the loop would make the host wait for the Gram kernel — timing every step would distort the very throughput being measured.
+    every = max(8, (args.steps + 15) // 16)
+    slots = []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        timed = (i % 8 == 0)
-        m.enable_kernel_timing(timed)
-        n_inl, _ = step()
+        timed = (i % every == 0)
         if timed:
-            a, b = m.last_kernel_ms()
-            warp_ms.append(a); accum_ms.append(b)
+            slots.append(len(slots))
+        m.enable_kernel_timing(timed, slots[-1] if timed else 0)
+        n_inl, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    m.enable_kernel_timing(False)
+    warp_ms, accum_ms = [], []
+    for sl in slots:
+        a, b = m.kernel_ms_slot(sl)
+        warp_ms.append(a); accum_ms.append(b)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

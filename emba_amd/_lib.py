@@ -89,6 +89,7 @@ SIGNATURES = {
     "emba_timer_elapsed_ms": (C.c_int, [C.c_void_p, C.c_int32, _fp]),
     "emba_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "emba_last_kernel_ms": (C.c_int, [C.c_void_p, _fp, _fp]),
+    "emba_kernel_ms_slot": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp]),
     # single-process multi-GPU host
     "emba_group_create": (C.c_int, [C.POINTER(EmbaCfg), _i32p, C.c_int32, C.POINTER(C.c_void_p)]),
     "emba_group_destroy": (None, [C.c_void_p]),

@@ -138,7 +138,8 @@ struct emba_ctx {
     // timing
     hipEvent_t ev_start[8]{}, ev_stop[8]{};
     bool kernel_timing = false;
-    hipEvent_t kt[4]{};  // warp start/stop, accum start/stop
+    hipEvent_t kt_sets[16][4]{}; hipEvent_t* kt = kt_sets[0]; int kt_slot = 0;  // per slot: warp start/stop, accum start/stop (emba_enable_kernel_timing)
+    bool kt_valid[16][2]{};
     bool kt_warp_valid = false, kt_accum_valid = false;
     int n_cu = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int ablate = 0;  // diagnostics builds only (-DEMBA_DIAG): EMBA_ABLATE bit mask; always 0 in the shipped library
@@ -690,7 +691,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     memset(c->h_pinned, 0, 64);
     CREATE_TRY(hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0));
     for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
-    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt[i]));
+    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt_sets[0][i]));
     CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = c;
@@ -709,7 +710,7 @@ void emba_destroy(emba_ctx* c)
     if (c->h_knots) (void)hipHostFree(c->h_knots);
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
-    for (int i = 0; i < 4; ++i) if (c->kt[i]) (void)hipEventDestroy(c->kt[i]);
+    for (int k = 0; k < 16; ++k) for (int i = 0; i < 4; ++i) if (c->kt_sets[k][i]) (void)hipEventDestroy(c->kt_sets[k][i]);
     for (auto& w : c->ws) if (w.p) (void)hipFree(w.p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1144,7 +1145,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
         else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
-        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; }
+        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; c->kt_valid[c->kt_slot][0] = true; }
         c->counts_raw = true;
     } else {
         c->counts_raw = false;
@@ -1300,7 +1301,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         constexpr long wpb = kGramBlock / 64;
         if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
         else hipLaunchKernelGGL(emba_gram_kernel<false>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
-        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; }
+        if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
     HIP_TRY(c, hipGetLastError());
     c->accum_done = true; c->finish_done = false;
@@ -1681,24 +1682,37 @@ emba_status emba_timer_elapsed_ms(emba_ctx* c, int32_t slot, float* ms)
 
 emba_status emba_enable_kernel_timing(emba_ctx* c, int32_t on)
 {
-    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c || on < 0 || on > 16) return EMBA_ERR_INVALID_ARG;
     c->kernel_timing = on != 0;
+    if (on) {       // on = 1 + slot: the next evaluation / form record their events in that slot, to be read later (emba_kernel_ms_slot)
+        const int slot = on - 1;
+        for (int i = 0; i < 4; ++i) if (!c->kt_sets[slot][i]) HIP_TRY(c, hipEventCreate(&c->kt_sets[slot][i]));
+        c->kt = c->kt_sets[slot]; c->kt_slot = slot;
+        c->kt_valid[slot][0] = c->kt_valid[slot][1] = false;
+    }
     c->kt_warp_valid = c->kt_accum_valid = false;
+    return EMBA_OK;
+}
+
+emba_status emba_kernel_ms_slot(emba_ctx* c, int32_t slot, float* warp_ms, float* accum_ms)
+{
+    if (!c || slot < 0 || slot >= 16) return EMBA_ERR_INVALID_ARG;
+    hipEvent_t* k = c->kt_sets[slot];
+    if (warp_ms) {
+        *warp_ms = -1.f;
+        if (c->kt_valid[slot][0]) { HIP_TRY(c, hipEventSynchronize(k[1])); HIP_TRY(c, hipEventElapsedTime(warp_ms, k[0], k[1])); }
+    }
+    if (accum_ms) {
+        *accum_ms = -1.f;
+        if (c->kt_valid[slot][1]) { HIP_TRY(c, hipEventSynchronize(k[3])); HIP_TRY(c, hipEventElapsedTime(accum_ms, k[2], k[3])); }
+    }
     return EMBA_OK;
 }
 
 emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
-    if (warp_ms) {
-        *warp_ms = -1.f;
-        if (c->kt_warp_valid) { HIP_TRY(c, hipEventSynchronize(c->kt[1])); HIP_TRY(c, hipEventElapsedTime(warp_ms, c->kt[0], c->kt[1])); }
-    }
-    if (accum_ms) {
-        *accum_ms = -1.f;
-        if (c->kt_accum_valid) { HIP_TRY(c, hipEventSynchronize(c->kt[3])); HIP_TRY(c, hipEventElapsedTime(accum_ms, c->kt[2], c->kt[3])); }
-    }
-    return EMBA_OK;
+    return emba_kernel_ms_slot(c, c->kt_slot, warp_ms, accum_ms);
 }
 
 }  // extern "C"

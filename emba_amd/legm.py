@@ -441,8 +441,15 @@ class LEGM:
         self._check(self._L.emba_timer_elapsed_ms(self._ctx, slot, C.byref(ms)))
         return ms.value
 
-    def enable_kernel_timing(self, on=True):
-        self._check(self._L.emba_enable_kernel_timing(self._ctx, 1 if on else 0))
+    def enable_kernel_timing(self, on=True, slot=0):
+        """on: the next step's warp / Gram kernels are bracketed by HIP events in `slot` (< 16); read them with last_kernel_ms() at once or with
+        kernel_ms_slot(slot) after the loop (no host wait inside it)."""
+        self._check(self._L.emba_enable_kernel_timing(self._ctx, (1 + int(slot)) if on else 0))
+
+    def kernel_ms_slot(self, slot):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self._L.emba_kernel_ms_slot(self._ctx, int(slot), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def last_kernel_ms(self):
         a, b = C.c_float(0), C.c_float(0)

@@ -330,8 +330,10 @@ emba_status emba_timer_elapsed_ms(emba_ctx* ctx, int32_t slot, float* ms); /* sy
 /* Device-measured duration (ms, HIP events around the launch) of the dominant kernel
  * (warp+residual+record kernel, "emba_warp_residual_kernel") in the most recent emba_eval_launch,
  * valid after a sync when kernel timing was enabled with emba_enable_kernel_timing(ctx, 1). */
-emba_status emba_enable_kernel_timing(emba_ctx* ctx, int32_t on);
+emba_status emba_enable_kernel_timing(emba_ctx* ctx, int32_t on);      /* on = 0: off; 1 + slot (slot < 16): the events of the next step go to that slot */
 emba_status emba_last_kernel_ms(emba_ctx* ctx, float* warp_ms, float* accum_ms);
+/* ... read LATER, after the timed loop: sampled steps then cost their event records only, not a host wait each (bench.py) */
+emba_status emba_kernel_ms_slot(emba_ctx* ctx, int32_t slot, float* warp_ms, float* accum_ms);
 
 /* ---- Several GPUs behind ONE host thread ------------------------------------------------------------------------
  * The reference front-end is one process that owns one LEGM (src/emba/emba.cpp:378; solver.cpp:63-353 calls it).  An emba_group is

@@ -358,7 +358,9 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // Measured (profiles/r02c_order_sweep.txt): the tile order wins once the working set has left the Infinity Cache (3 M events, 1024x2048:
         // 374 vs 394 us per step; 5 M / K=97: 558 vs 618; 100 M: 4.8 vs 8.7 ms warp) and loses below it (1 M events, 24 per pixel: 82 vs 52 us
         // — every entry of the tile order is a warp, lead-ins included, and a workgroup's LDS tile is zeroed and flushed for a handful of groups).
-        tile = (c->order_mode == 2) || (c->n_used >= 3000000 && per_px >= 8.0 && lead_frac <= 0.35);
+        // (round 3, with at least 5 groups per wave and chunk: 2 M events 220 vs 246 us per step, 1.5 M 188 vs 155 — the pixel order falls off a cliff
+        // between 1.5 M and 2 M events, where its 128-B records stop fitting the 256-MB Infinity Cache)
+        tile = (c->order_mode == 2) || (c->n_used >= 2000000 && per_px >= 8.0 && lead_frac <= 0.35);
     }
 
     if (!tile) {
@@ -396,7 +398,12 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // chunk size: enough workgroups for ~8 rounds of the chip, at most 16 groups of 63 entries per wave
         const size_t slots = (size_t)c->n_cu * 2;
         size_t chunk = (nd + slots * 8 - 1) / (slots * 8);
-        chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves), (size_t)kWarpNew * kTileWaves * 16);
+        // (at least 5 groups per wave: a workgroup zeroes and flushes its 55-KB LDS tile whatever it has to do — 3 M events: 902 -> 2520 entries per
+        // chunk, warp kernel 191 -> 174 us; 5 M: 280 -> 271; from 10 M on the first rule gives more than that anyway)
+#ifndef TILE_MIN_GROUPS
+#define TILE_MIN_GROUPS 5
+#endif
+        chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves * TILE_MIN_GROUPS), (size_t)kWarpNew * kTileWaves * 16);
         std::vector<ChunkDesc> h_chunks;
         for (size_t k = 0; k < occ.size(); ++k) {
             const uint32_t b = occ[k].first, b0 = occ[k].second, b1 = (k + 1 < occ.size()) ? occ[k + 1].second : (uint32_t)nd;

@@ -289,7 +289,9 @@ def main():
         value = n_total / (elapsed / args.steps)
         wk = float(np.mean(warp_ms))
         n_launch = local.size()
-        tr = pmc_traffic(w.describe()) if world == 1 else None
+        # (a shard-of-N run times one rank's part of the stream: its traffic summary is keyed by the shard, not by the whole window's description)
+        wkey = w.describe() if args.shard_of == 1 else f"{w.describe()} shard {args.shard_rank} of {args.shard_of}"
+        tr = pmc_traffic(wkey) if world == 1 else None
         achieved = ALGO_BYTES_PER_EVENT * n_launch / (wk * 1e-3) / 1e9
         counter = (tr["hbm_bytes_per_launch"] / (wk * 1e-3) / 1e9) if tr else None   # the bytes the counters saw, over the same time
         out = {

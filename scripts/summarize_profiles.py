@@ -29,8 +29,16 @@ with open(f"profiles/{tag}_pmc_summary.csv", "w") as fo:
 cand = [r for r in rows if "emba_warp_tiled_kernel" in r[0]] or [r for r in rows if "emba_warp_residual_kernel" in r[0] and "true" not in r[0]]
 dom = cand[0]
 bench = json.loads([l for l in open(f"{src}/bench_trace.log") if l.startswith("{")][-1])
+wkey = bench["config"]["workload"]
+par = bench["config"].get("parallelism", "")
+if par.startswith("shard "):      # bench.py --shard-of N: one rank's part of the stream (bench.py looks the summary up under this key)
+    t = par.split()
+    wkey = f"{wkey} shard {t[1]} of {t[3]}"
 json.dump({"kernel": "emba_warp_tiled_kernel" if "tiled" in dom[0] else "emba_warp_residual_kernel", "hbm_bytes_per_launch": dom[4], "FETCH_SIZE_KiB": dom[2], "WRITE_SIZE_KiB": dom[3],
-           "atomic_requests_per_launch": dom[5], "correction": "gfx950: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "workload": bench["config"]["workload"], "tag": tag},
+           "atomic_requests_per_launch": dom[5], "correction": "gfx950: 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes", "workload": wkey, "tag": tag},
           open(f"profiles/{tag}_traffic.json", "w"), indent=1)
+# the run itself could only look up an OLDER summary of this workload (or none): put the counters of THIS profile next to its kernel time
+r = bench["roofline"]
+r["traffic"] = dom[4]; r["counter_GBs"] = dom[4] / (r["kernel_ms"] * 1e-3) / 1e9; r["counter_frac"] = r["counter_GBs"] / r["peak"]
 json.dump(bench, open(f"profiles/{tag}_bench_profiled.json", "w"))
 print(open(f"profiles/{tag}_pmc_summary.csv").read())

@@ -63,6 +63,11 @@ struct emba_ctx {
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
     bool counts_raw = false;   // the count map holds the warp kernel's markers, not yet the counts (see ensure_counts)
     double* d_pixacc = nullptr; bool pix_dirty_all = true;   // per-pixel A22/b2 accumulator lines (64 B each)
+    bool pixacc_clean = false;     // every accumulator line is zero: the last evaluation's sums were gathered AND cleared by the resident step (no prep blocks needed)
+    bool pixacc_consumed = false;  // ... so a second formNormalEq on the same evaluation rebuilds A22 | b2 from the records instead
+    bool step_consume = false;     // set by emba_step around its emba_form_active: this gather is the sums' only reader
+    bool force_generic_a22 = false;
+    int32_t count_mark = 0;        // count_marker(stamp) of the last evaluation: what its touched pixels hold in a raw count map
     int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (EMBA_TEXEL=auto|pack|fly|rect)
     int use_texel = 0;    // what the current evaluation uses: 0 fly, 1 full pack, 3 rectangle
     int* d_rect = nullptr;       // {xmin,ymin,xmax,ymax} of the pixels the previous evaluation touched
@@ -102,6 +107,12 @@ struct emba_ctx {
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
     double* d_seg = nullptr; int seg_cap = 0;                 // tile order: per-segment constants the tiled kernel evaluates each event's pose from (12 doubles per segment)
+    int step_gather = 2;    // EMBA_STEP_GATHER: how emba_step writes its active set + A22 | b2 rows — 0 the sweeping kernel (emba_active_write_kernel), 1 the list-driven
+                            // gather as a kernel of its own, 2 (default) the list-driven gather as the head of the compact Gram kernel
+    uint16_t* d_seg_act = nullptr;   // launch A's per-unit active lists (offsets inside the unit), n_ablk * kActivePix entries
+    bool aw_in_gram = false; ActiveWriteParams aw_saved{};   // the gather of the running step, to be issued with its Gram launch (emba_form_accumulate)
+    int step_fast = 1;   // EMBA_STEP_FAST=0: emba_step keeps the clearing pass in front of every evaluation (A/B)
+    int gram_mode = 0;   // EMBA_GRAM=stream|compact (1 | 2; 0 = by size): which form of the tag-stream Gram kernel runs
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     // Two record sets (a rejected LM trial must not cost a re-evaluation).  d_rec / d_tag / set_stamp are the WORKING set: what
@@ -463,6 +474,17 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     return EMBA_OK;
 }
 
+// Which form of the tag-stream Gram kernel emba_form_accumulate launches for the current window: a record set that is still cache-resident (what
+// the warp kernel wrote microseconds ago: up to ~200 MB of slots) takes the compact form (live records only, half the stages);
+// EMBA_GRAM=stream|compact overrides.  Shared with emba_form_active, which leaves its gather to that kernel's head in the resident step.
+bool gram_uses_tags(const emba_ctx* c, bool ep_host) { return c->use_tags && !c->tile_order && !ep_host; }
+bool gram_is_compact(const emba_ctx* c, bool ep_host)
+{
+    if (!gram_uses_tags(c, ep_host) || !c->n_cand) return false;
+    if (c->gram_mode) return c->gram_mode == 2;
+    return (size_t)c->n_cand * kRecStride * sizeof(double) <= ((size_t)200 << 20);
+}
+
 emba_status ensure_pack(emba_ctx* c, int K)
 {
     const size_t need = (size_t)9 * K * K + (size_t)3 * K + 5 * c->npix;
@@ -510,7 +532,7 @@ emba_status ensure_counts(emba_ctx* c)
 {
     if (!c->counts_raw) return EMBA_OK;
     c->counts_raw = false;
-    hipLaunchKernelGGL(emba_count_materialise_kernel, dim3((unsigned)((c->npix + 2047) / 2048)), dim3(256), 0, c->stream, c->d_count, c->d_pixacc, (long)c->npix);
+    hipLaunchKernelGGL(emba_count_materialise_kernel, dim3((unsigned)((c->npix + 2047) / 2048)), dim3(256), 0, c->stream, c->d_count, c->d_pixacc, (long)c->npix, c->count_mark);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }
@@ -657,6 +679,9 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
 #endif
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
     if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
+    if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
+    if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
+    if (const char* gm = getenv("EMBA_GRAM")) c->gram_mode = !strcmp(gm, "stream") ? 1 : !strcmp(gm, "compact") ? 2 : 0;
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
@@ -684,6 +709,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipMalloc((void**)&c->d_active_bits, (c->npix + 31) / 32 * 4 + 8)); c->caps[reinterpret_cast<void**>(&c->d_active_bits)] = (c->npix + 31) / 32 * 4 + 8;
     CREATE_TRY(hipMalloc((void**)&c->d_active, c->npix * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_active)] = c->npix * sizeof(uint32_t);
     c->n_ablk = (c->npix + kActivePix - 1) / kActivePix;
+    CREATE_TRY(hipMalloc((void**)&c->d_seg_act, c->n_ablk * kActivePix * sizeof(uint16_t))); c->caps[reinterpret_cast<void**>(&c->d_seg_act)] = c->n_ablk * kActivePix * sizeof(uint16_t);
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_cnt, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_cnt)] = c->n_ablk * sizeof(uint32_t);
     CREATE_TRY(hipMalloc((void**)&c->d_ablk_off, c->n_ablk * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_ablk_off)] = c->n_ablk * sizeof(uint32_t);
     CREATE_TRY(hipMalloc((void**)&c->d_err2, 2 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_err2)] = 2 * sizeof(int);
@@ -1025,6 +1051,7 @@ emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, doub
     if (!c) return EMBA_ERR_INVALID_ARG;
     c->d_count = count_map_dev ? count_map_dev : c->d_count_own;
     c->pix_dirty_all = true;   // the new count buffer says nothing about which pixacc lines are dirty
+    c->pixacc_clean = false;
     if (pack_dev) { c->d_pack = pack_dev; c->pack_cap = pack_cap; c->pack_bound = true; }
     else { c->pack_bound = false; c->d_pack = c->d_pack_own; c->pack_cap = c->pack_own_cap; }
     return EMBA_OK;
@@ -1101,9 +1128,12 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
         c->pix_dirty_all = false;
+        c->pixacc_clean = true;
     }
     int* rect_cur = c->d_rect;
-    const int n_prep_blk = (int)((c->npix + 1023) / 1024);
+    // the clearing pass over count map + accumulator lines is only needed when the previous evaluation's sums are still in their lines (it was
+    // never formed by the resident step, whose gather clears them behind itself); the count map's entries are stamped and need no clearing
+    const int n_prep_blk = c->pixacc_clean ? 0 : (int)((c->npix + 1023) / 1024);
     // Hessian source: with several events per panorama pixel (measured break-even: ~4) the full texel pack (one 48-B gather per
     // measurement instead of an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels an
     // earlier evaluation touched, and the warp kernel falls back to the stencil outside it.
@@ -1130,6 +1160,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         }
         q.n_tex = (c->use_texel == 3) ? 1024 : 0;
         q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect = rect_cur; q.texel = c->d_texel;
+        if (q.n_pose + q.n_tex + q.n_prep == 0) q.n_prep = 1;   // (an empty window on clean lines: block 0 still clears the next status word)
         hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_pose + q.n_tex + q.n_prep)), dim3(256), 0, s, q, kn);
     }
     if (c->use_texel == 1)
@@ -1148,6 +1179,8 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.ablate = c->ablate;
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp; c->set_stamp = p.stamp;
+        p.marker = c->count_mark = count_marker(p.stamp);
+        c->pixacc_clean = false; c->pixacc_consumed = false;
         p.chunks = c->d_chunks; p.n_chunks = c->n_chunks;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
@@ -1205,7 +1238,11 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     ActiveWriteParams aw{};
     aw.count = c->d_count; aw.npix = npix; aw.thres = thres; aw.blk_off = c->d_ablk_off; aw.compact = nullptr; aw.active_idx = c->d_active; aw.pixacc = c->d_pixacc;
     aw.A22b2 = pack_A22b2(c); aw.pack_head = c->d_pack; aw.head_len = head; aw.alpha = c->fused_alpha; aw.Gx = c->d_Gx; aw.Gy = c->d_Gy;
-    aw.active_bits = c->d_active_bits; aw.max_P = (long)((c->pack_cap - (size_t)head) / 5); aw.n_ablk = (long)c->n_ablk;
+    aw.active_bits = c->d_active_bits; aw.max_P = (long)((c->pack_cap - (size_t)head) / 5); aw.n_ablk = (long)c->n_ablk; aw.ablate = c->ablate;
+    // the resident step cleared this evaluation's per-pixel sums behind its gather: a second formNormalEq on the same evaluation takes A22 | b2
+    // from the records (the generic path of emba_form_accumulate), and its L2 term from emba_form_finish
+    c->force_generic_a22 = c->pixacc_consumed;
+    if (c->force_generic_a22) { aw.A22b2 = nullptr; aw.alpha = 0.0; c->fused_alpha = 0.0; }
     if (c->ep_deferred && c->n_sorted) {
         c->ep_deferred = false;
         PostWarpParams q{};
@@ -1216,7 +1253,11 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = nullptr;   // (inlier numbers: on demand, ensure_inl_idx)
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
-        if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; c->counts_raw = false; }   // launch A turns the markers into counts
+        if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; q.marker = c->count_mark; c->counts_raw = false; }   // launch A turns the markers into counts
+        const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
+        const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count;
+        if (consume) { aw.clear_pixacc = c->d_pixacc; c->pixacc_clean = true; c->pixacc_consumed = true; }
+        if (lists) { q.seg = c->d_seg_act; aw.seg = c->d_seg_act; if (consume) q.clear_inactive = c->d_pixacc; }
         // launch A: {active counts (+ markers -> counts, activity bits, cleared A11 | b1) || inlier-flag counts}; launch B: the active-set write,
         // whose blocks take their own prefix over launch A's per-block counts and whose last block publishes P, the inlier total, the status
         // word and the sequence words the host polls.  (Nothing on the device reads the compacted residual vector `ep` — costs, Gram and solvers
@@ -1230,7 +1271,14 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
         aw.blk_cnt = c->d_ablk_cnt; aw.fblk_cnt = c->d_fblk_cnt; aw.n_fblk = c->n_fblk; aw.total_P = q.total_P; aw.total_P_host = q.total_P_host;
         aw.total_inl = q.total_inl; aw.total_inl_host = q.total_inl_host; aw.err_dev = q.err_dev; aw.err_host = q.err_host; aw.seq = q.seq; aw.seq_host = q.seq_host;
-        hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
+        // (round 4, measured and dropped: this write on a side stream beside the Gram kernel — both only depend on launch A — costs more than it
+        // hides: each cross-stream event edge opens a 7-12 us bubble on this stack, 114.5 vs 107.6 us per step)
+        // The resident one-GPU step (lists): the write is list-driven and balanced (active_gather_block) and rides in the head of the compact Gram
+        // kernel — emba_form_accumulate issues it — or runs as a kernel of its own (EMBA_STEP_GATHER=1, or where the Gram kernel is another form)
+        c->aw_in_gram = false;
+        if (lists && c->step_gather == 2 && gram_is_compact(c, false)) { c->aw_saved = aw; c->aw_in_gram = true; }
+        else if (lists) hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, aw);
+        else hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
         c->inl_pending = true;
     } else {
         { emba_status st0 = launch_ep_compaction(c); if (st0) return st0; }
@@ -1266,7 +1314,11 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     hipStream_t s = c->stream;
     // the per-pixel sums of the evaluation already carry this cost's weights (emba_set_cost / emba_step)?  Then they ARE A22/b2.
     const bool acc_matches = (irls == c->acc_irls) && (irls == 0 || eta == c->acc_eta);
-    const bool generic_a22 = !acc_matches || (ep_host != nullptr);
+    const bool generic_a22 = !acc_matches || (ep_host != nullptr) || c->force_generic_a22;
+    if (c->aw_in_gram && (generic_a22 || !gram_is_compact(c, ep_host != nullptr))) {   // (not what emba_step does: the deferred gather as a launch of its own after all)
+        hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, c->aw_saved);
+        c->aw_in_gram = false;
+    }
     if (generic_a22) { emba_status st = resolve_pending(c); if (st) return st; }   // needs n_inliers / P on the host (rare path)
     if (ep_host && c->n_inliers) {
         { emba_status st = ensure_inl_idx(c); if (st) return st; }
@@ -1292,7 +1344,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         p.irls = irls; p.eta = eta; p.stamp = c->set_stamp; p.A11 = pack_A11(c); p.b1 = pack_b1(c);
         // the tag stream pays where slots are dead (pixel order: about half of them at the BASELINE workload); in the tile order (dense regime:
         // nearly every slot is live) the warp kernel's scattered 8-B tag stores cost more than the Gram kernel saves (40 M events: +370 vs -180 us)
-        p.tag = (c->use_tags && !c->tile_order && !ep_host) ? c->d_tag : nullptr;
+        p.tag = gram_uses_tags(c, ep_host != nullptr) ? c->d_tag : nullptr;
         p.dim = 3 * c->K;
         p.ablate = c->ablate;
         // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),
@@ -1306,7 +1358,39 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         const long waves = ((long)c->n_cand + chunk - 1) / chunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
         constexpr long wpb = kGramBlock / 64;
-        if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
+        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+#ifdef EMBA_DIAG
+        static int trace_left = getenv("EMBA_GRAM_TRACE") ? 3 : 0;     // diagnostics: anatomy of the 50th..52nd compact launch (s_memtime stamps per wave)
+        static int trace_skip = 50;
+        unsigned long long* d_trace = nullptr;
+        if (trace_left && gram_is_compact(c, ep_host != nullptr) && trace_skip-- <= 0) {
+            if (ws_get(c, 39, (size_t)grid * wpb * 64, (void**)&d_trace) == EMBA_OK) { (void)hipMemsetAsync(d_trace, 0, (size_t)grid * wpb * 64, s); p.trace = d_trace; }
+        }
+#endif
+        if (gram_is_compact(c, ep_host != nullptr)) {
+            if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_compact_kernel<GRAM_U, true>), dim3(grid), dim3(kGramBlock), 0, s, p, c->aw_saved);
+            else hipLaunchKernelGGL((emba_gram_compact_kernel<GRAM_U, false>), dim3(grid), dim3(kGramBlock), 0, s, p, ActiveWriteParams{});
+            c->aw_in_gram = false;
+        }
+#ifdef EMBA_DIAG
+        if (d_trace) {
+            --trace_left;
+            std::vector<unsigned long long> h((size_t)grid * wpb * 8);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
+            unsigned long long t0 = ~0ull, t1 = 0; double seg[7] = {0}; double lat_first = 0, lat_last = 0; size_t nw = 0;
+            for (size_t w = 0; w < (size_t)grid * wpb; ++w) { const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[6]) continue; t0 = std::min(t0, q[0]); t1 = std::max(t1, q[6]); }
+            for (size_t w = 0; w < (size_t)grid * wpb; ++w) {
+                const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[6]) continue;
+                ++nw; lat_first += (double)(q[0] - t0); lat_last += (double)(t1 - q[6]);
+                unsigned long long prev = q[0];
+                for (int k = 1; k <= 6; ++k) { const unsigned long long v = q[k] ? q[k] : prev; seg[k] += (double)(v - prev); prev = v; }
+            }
+            fprintf(stderr, "gram trace (s_memtime ticks, mean over %zu waves; span first start -> last end %llu): start skew %.0f | init+barrier %.0f | phase A %.0f | phase B %.0f | wave flush %.0f | barrier %.0f | block flush %.0f | tail skew %.0f\n",
+                    nw, t1 - t0, lat_first / nw, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw, seg[6] / nw, lat_last / nw);
+        }
+#endif
+        else if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3(grid), dim3(kGramBlock), 0, s, p);
         else hipLaunchKernelGGL(emba_gram_kernel<false>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
@@ -1620,7 +1704,10 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     }
     if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
     c->fused_alpha = alpha;   // A22/b2 come from the accumulator, so applyL2Reg rides along with the gather
-    if ((st = emba_form_active(c, thres, nullptr, nullptr))) return st;
+    c->step_consume = (c->step_fast != 0);   // ... which is their only reader: it zeroes the lines behind itself and the next evaluation needs no clearing pass
+    st = emba_form_active(c, thres, nullptr, nullptr);
+    c->step_consume = false;
+    if (st) return st;
     if ((st = emba_form_accumulate(c, nullptr, irls, eta))) return st;
     if ((st = emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr))) return st;
     if (n_inliers) *n_inliers = c->n_inliers;

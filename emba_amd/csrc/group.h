@@ -563,7 +563,11 @@ emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double e
     // few million events per rank; EMBA_X2_SPLIT=0/1 overrides)
     size_t n_max = 0;
     for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
-    const bool rows_final = (irls == g->decl_irls) && (irls == 0 || eta == g->decl_eta);
+    // "final" is decided from the cost the LAST EVALUATION weighted its per-pixel sums with (acc_irls / acc_eta, recorded by emba_eval_launch),
+    // not from the cost last declared: a cost declared after the evaluation (the IRLS form's first iteration) leaves gathered rows that
+    // emba_form_accumulate is about to rebuild from the records — they must not be on their way through a collective meanwhile.
+    bool rows_final = true;
+    for (int r = 0; r < g->n; ++r) rows_final = rows_final && (irls == g->ctx[r]->acc_irls) && (irls == 0 || eta == g->ctx[r]->acc_eta);
     bool split = n_max >= 3000000;
     if (const char* v = getenv("EMBA_X2_SPLIT")) split = atoi(v) != 0;
     split = split && rows_final;

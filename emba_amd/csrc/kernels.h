@@ -41,6 +41,10 @@ __device__ __forceinline__ bool record_valid(double tail_y, uint32_t stamp, uint
     pano_idx = (uint32_t)__double2loint(tail_y);
     return (uint32_t)__double2hiint(tail_y) == stamp && pano_idx != kInvalidPix;
 }
+// The count-map entry of a pixel the evaluation with this stamp touched, until the next dense pass replaces it by the pixel's count
+// (materialise_mask8): negative, so it is never a count, and stamped, so that whatever an EARLIER evaluation left in the map — its
+// counts, or markers nobody materialised — reads as "not touched" without the map having been cleared in between.
+__host__ __device__ __forceinline__ int32_t count_marker(uint32_t stamp) { return (int32_t)(0x80000000u | (stamp & 0x3FFFFFFFu)); }
 constexpr int kPoseStride = 14;    // doubles per pose record: q[4] J1[9] cp  (112 B = 7 x 16-B gathers per event)
 #ifndef TEXEL_STRIDE
 #define TEXEL_STRIDE 6
@@ -271,6 +275,7 @@ struct WarpParams {
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count marker, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
     uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
+    int32_t marker;         // what a touched pixel's count-map entry is set to: count_marker(stamp), negative — never a count, never another evaluation's marker
     const ChunkDesc* chunks; long n_chunks;   // tiled kernel only
 };
 
@@ -589,7 +594,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     // only receives a plain store of a non-zero MARKER here ("this pixel was touched"); emba_post_warp_a_kernel (or
     // emba_count_materialise_kernel when someone needs the map earlier) replaces markers by the counts from the lines.
     // Run sums are compacted through LDS and sent 10 pixels = 60 lanes per atomic instruction.
-    if (emit && !EMBA_ABL(p.ablate, 1)) p.count[pi] = 1;
+    if (emit && !EMBA_ABL(p.ablate, 1)) p.count[pi] = p.marker;
     {
         const int n_emit = __popcll(emit_mask);
         if (emit) {
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                     }
                 } else {   // moved out of the tile since the order was built: still correct, just not aggregated
                     double* a = p.pixacc + (size_t)kPixAccStride * o.pi;
-                    p.count[o.pi] = 1;
+                    p.count[o.pi] = p.marker;
                     atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
                 }
             }
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
                 const int qq = s_list[wv][k];
                 const int gy = ch.y0 + qq / kTileW, gx = ch.x0 + qq % kTileW;
                 const size_t pi = (size_t)gy * p.W + gx;
-                if (comp == 0 && !EMBA_ABL(p.ablate, 1)) p.count[pi] = 1;
+                if (comp == 0 && !EMBA_ABL(p.ablate, 1)) p.count[pi] = p.marker;
                 if (!EMBA_ABL(p.ablate, 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
             }
         }
@@ -896,8 +901,10 @@ __device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ cou
 // The same over a RAW count map (markers left by the warp kernel): a touched pixel's count is the sixth double of its accumulator
 // line; the counts are written back, which turns the map into the num_ev_map of model.cpp:227 for everyone downstream.
 __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ count, const double* __restrict__ pixacc, long p0, long npix, int thres,
-                                                      uint32_t* touched = nullptr)
+                                                      int32_t marker, uint32_t* touched = nullptr)
 {
+    // entry == marker: touched by THIS evaluation -> its count from the accumulator line; anything else that is not zero is what an earlier
+    // evaluation left behind (counts, or markers nobody asked about) -> zero.  The map needs no clearing pass between evaluations.
     int c[8];
     const bool full = p0 + 8 <= npix;
     if (full) {
@@ -911,8 +918,13 @@ __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ coun
 #pragma unroll
     for (int k = 0; k < 8; ++k) any |= c[k];
     if (any) {
+        // (unconditional loads — an entry that is not this evaluation's marker re-reads the thread's first pixel: eight loads under eight lane
+        // masks are eight dependent round trips for a lane in the middle of the footprint)
+        double n8[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (c[k]) c[k] = (int)pixacc[(size_t)kPixAccStride * (p0 + k) + 5];
+        for (int k = 0; k < 8; ++k) n8[k] = pixacc[(size_t)kPixAccStride * (p0 + ((c[k] == marker) ? k : 0)) + 5];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c[k] = (c[k] == marker) ? (int)n8[k] : 0;
         if (full) {
             *reinterpret_cast<int4*>(count + p0) = make_int4(c[0], c[1], c[2], c[3]);
             *reinterpret_cast<int4*>(count + p0 + 4) = make_int4(c[4], c[5], c[6], c[7]);
@@ -928,19 +940,24 @@ __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ coun
     return m;
 }
 
-__global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __restrict__ count, const double* __restrict__ pixacc, long npix)
+__global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __restrict__ count, const double* __restrict__ pixacc, long npix, int32_t marker)
 {
-    (void)materialise_mask8(count, pixacc, ((long)blockIdx.x * 256 + threadIdx.x) * 8, npix, 1);
+    (void)materialise_mask8(count, pixacc, ((long)blockIdx.x * 256 + threadIdx.x) * 8, npix, 1, marker);
 }
 
 __device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
                                                    uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr,
-                                                   uint8_t* __restrict__ active_bits = nullptr, int* __restrict__ blk_rect = nullptr, int W = 1)
+                                                   uint8_t* __restrict__ active_bits = nullptr, int* __restrict__ blk_rect = nullptr, int W = 1, int32_t marker = 0,
+                                                   uint16_t* __restrict__ seg = nullptr, double* __restrict__ clear_inactive = nullptr)
 {
+    // seg (the resident one-GPU step): the unit's active pixels, ascending, as offsets inside the unit at seg[blk * kActivePix + rank] — the
+    // gather that follows (active_gather_block) then works from lists, balanced over the whole grid, instead of sweeping the count map again.
+    // clear_inactive (same step): the accumulator lines of touched pixels that did NOT become active are zeroed here (their count has just been
+    // read; nobody else reads them), the active ones by the gather, so that the next evaluation starts on clean lines without a clearing pass.
     __shared__ uint32_t s_w[4];
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
     uint32_t tm = 0;
-    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres, &tm) : active_mask8(count, p0, npix, thres, &tm);
+    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres, marker, &tm) : active_mask8(count, p0, npix, thres, &tm);
     if (active_bits && p0 < npix) active_bits[p0 >> 3] = (uint8_t)m8;
     if (blk_rect) {   // bounding box of the pixels THIS evaluation touched, per block; the active-write kernel's last block reduces them
         __shared__ int s_box[4][4];     // into the rectangle the next evaluation packs its texels in
@@ -971,12 +988,30 @@ __device__ __forceinline__ void active_count_block(long blk, const int32_t* __re
             reinterpret_cast<int4*>(blk_rect)[blk] = r;
         }
     }
-    uint32_t c = __popc(m8);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t mine = __popc(m8);
+    uint32_t x = mine;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_w[wv] = x;
     __syncthreads();
     if (threadIdx.x == 0) blk_cnt[blk] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (seg) {
+        uint32_t r = x - mine;
+        for (int w = 0; w < wv; ++w) r += s_w[w];
+        uint16_t* sg = seg + (size_t)blk * kActivePix;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (m8 & (1u << k)) sg[r++] = (uint16_t)(8 * threadIdx.x + k);
+    }
+    if (clear_inactive) {
+        const uint32_t z = tm & ~m8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (z & (1u << k)) {
+                double2* q = reinterpret_cast<double2*>(clear_inactive + (size_t)kPixAccStride * (p0 + k));
+                q[0] = make_double2(0, 0); q[1] = make_double2(0, 0); q[2] = make_double2(0, 0);
+            }
+    }
 }
 
 __global__ __launch_bounds__(256) void emba_active_count_kernel(const int32_t* __restrict__ count, long npix, int thres,
@@ -994,10 +1029,11 @@ struct PostWarpParams {
     uint32_t* fblk_cnt; uint32_t* fblk_off; long n_fblk; const uint32_t* perm; long n_pm; uint32_t* total_inl; int* total_inl_host; const int* err_dev; int* err_host;
     const double* e_sorted; const uint8_t* flag; double* ep; int32_t* inl_idx;
     int seq; int* seq_host;   // step sequence number, written to pinned host memory AFTER the counts (two words: [0] behind P, [1] behind the inlier count): the host may poll them instead of waiting for the stream
-    int32_t* raw_count; const double* pixacc;   // non-null: the count map still holds the warp kernel's markers; launch A materialises it
+    int32_t* raw_count; const double* pixacc; int32_t marker;   // non-null: the count map still holds the warp kernel's markers (count_marker of its stamp); launch A materialises it
     uint8_t* active_bits; double* pack_head; long head_len;   // non-null: launch A also writes the 1-bit activity map and clears A11 | b1 (the Gram kernel then
                                                               // depends on launch A only)
     int* blk_rect; int W;                                     // non-null: per-block bounding boxes of the touched pixels (-> the next evaluation's texel rectangle)
+    uint16_t* seg; double* clear_inactive;                    // the resident one-GPU step (active_count_block): per-unit active lists; zero the lines of touched, inactive pixels
 };
 
 struct ActiveWriteParams {
@@ -1009,6 +1045,10 @@ struct ActiveWriteParams {
     const uint32_t* blk_cnt; const uint32_t* fblk_cnt; long n_fblk; uint32_t* total_P; int* total_P_host; uint32_t* total_inl; int* total_inl_host;
     const int* err_dev; int* err_host; int seq; int* seq_host;
     int bits_head_done;   // launch A has already written the activity bits and cleared the head of the pack
+    const uint16_t* seg;  // active_gather_block: launch A's per-unit active lists
+    int ablate;           // diagnostics builds only: 2048 no gather / row stores, 4096 no clearing stores, 8192 no lists / active set, 16384 return right after the count loads
+    double* clear_pixacc; // non-null (the resident one-GPU step): the per-pixel sums have one reader, this gather — every touched line is zeroed behind it,
+                          // so that the next evaluation starts on clean lines without a clearing pass (emba_prep_pose_texel_kernel: no prep blocks)
     const int* blk_rect; int* rect_out;   // non-null: launch A's per-block boxes; the last block reduces them into rect_out = {xmin, ymin, xmax, ymax}
 };
 
@@ -1016,7 +1056,7 @@ __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack
     if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
-    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W);
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W, p.marker, p.seg, p.clear_inactive);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
 }
 
@@ -1026,15 +1066,35 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
     // alpha != 0: applyL2Reg (model.cpp:689-719) fused into the gather — only legal when no all-reduce follows (single GPU);
     // max_P: rows of A22b2 the (possibly caller-bound) pack has room for — rows past it are not written, the host reports
     // EMBA_ERR_CAPACITY once it has read P.
+    // Round 4: the gather is COOPERATIVE.  A lane used to walk its (up to 8) active pixels one after the other — load the line, wait, store the
+    // row: as many dependent round trips as the busiest lane of the wave has active pixels, and the zeroing of consumed lines (clear_pixacc)
+    // added three scattered stores per touched pixel to the same walk.  Now every wave lists its active pixels by compact rank and its touched
+    // pixels in LDS and works through the lists together: 12 pixels x 5 sums per load instruction, two instructions in flight, the rows
+    // written as contiguous runs; 10 lines x 6 doubles per clearing store.  The per-block counts in front of the block are fetched in one
+    // round trip, issued before the count-map loads.  Same expressions as before: identical values.
     __shared__ uint32_t s_w[4];
+    __shared__ uint16_t s_list[4][1024];      // per wave: [0, 512) active pixels by compact rank, [512, 1024) touched pixels
     const int32_t* __restrict__ count = a.count; const double* __restrict__ pixacc = a.pixacc; int32_t* __restrict__ compact = a.compact;
     const long npix = a.npix;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // exclusive prefix of this block over the per-block counts of launch A: up to four independent loads per thread and 1024 blocks
+    uint32_t part = 0;
+    if (a.blk_cnt) {
+        for (long j0 = 0; j0 < blk; j0 += 1024) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const long j = j0 + threadIdx.x + 256 * u; v[u] = a.blk_cnt[j < a.n_ablk ? j : a.n_ablk - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + threadIdx.x + 256 * u < blk) part += v[u];
+        }
+    }
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack, cleared here so the step needs no memset node
     if (!a.bits_head_done) for (long i = blk * 256 + threadIdx.x; i < a.head_len; i += a.n_ablk * 256) a.pack_head[i] = 0.0;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
-    const uint32_t m = active_mask8(count, p0, npix, a.thres);
+    uint32_t tm = 0;
+    const uint32_t m = active_mask8(count, p0, npix, a.thres, &tm);
     if (!a.bits_head_done && p0 < npix) a.active_bits[p0 >> 3] = (uint8_t)m;
+    if (EMBA_ABL(a.ablate, 16384) && !(a.blk_cnt && blk == a.n_ablk - 1)) { if (m == 0xFFFFFFFFu) a.active_idx[0] = part; return; }
     const uint32_t mine = __popc(m);
     uint32_t x = mine;
 #pragma unroll
@@ -1044,10 +1104,8 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
     }
     if (lane == 63) s_w[wv] = x;
     uint32_t front = 0;
-    if (a.blk_cnt) {   // exclusive prefix of this block over the per-block counts of launch A
+    if (a.blk_cnt) {
         __shared__ uint32_t s_f[4];
-        uint32_t part = 0;
-        for (long j = threadIdx.x; j < blk; j += 256) part += a.blk_cnt[j];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
         if (lane == 0) s_f[wv] = part;
@@ -1057,15 +1115,16 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
         __syncthreads();
         front = a.blk_off[blk];
     }
-    uint32_t k = front + x - mine;
-    for (int w = 0; w < wv; ++w) k += s_w[w];
+    uint32_t wave_base = front;
+    for (int w = 0; w < wv; ++w) wave_base += s_w[w];
+    uint32_t k = wave_base + x - mine;
     if (a.blk_cnt && blk == a.n_ablk - 1) {   // the last block publishes the step's counts (what launch B did)
         __shared__ uint32_t s_i[4];
-        uint32_t part = 0;
-        for (long j = threadIdx.x; j < a.n_fblk; j += 256) part += a.fblk_cnt[j];
+        uint32_t parti = 0;
+        for (long j = threadIdx.x; j < a.n_fblk; j += 256) parti += a.fblk_cnt[j];
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-        if (lane == 0) s_i[wv] = part;
+        for (int o = 32; o >= 1; o >>= 1) parti += __shfl_xor(parti, o);
+        if (lane == 0) s_i[wv] = parti;
         __syncthreads();
         if (a.blk_rect) {   // the rectangle the NEXT evaluation packs its texels in (and its warp kernel trusts): the box of what this one touched
             __shared__ int s_bx[4][4];
@@ -1079,7 +1138,7 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
                 xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
                 xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
             }
-            if (lane == 0) { int* b = s_bx[wv]; b[0] = xmin; b[1] = ymin; b[2] = xmax; b[3] = ymax; }
+            if (lane == 0) { int* bx = s_bx[wv]; bx[0] = xmin; bx[1] = ymin; bx[2] = xmax; bx[3] = ymax; }
             __syncthreads();
             if (threadIdx.x == 0) {
                 a.rect_out[0] = min(min(s_bx[0][0], s_bx[1][0]), min(s_bx[2][0], s_bx[3][0]));
@@ -1110,30 +1169,204 @@ __device__ __forceinline__ void active_write_block(long blk, const ActiveWritePa
         reinterpret_cast<int4*>(compact + p0)[0] = make_int4(cv[0], cv[1], cv[2], cv[3]);
         reinterpret_cast<int4*>(compact + p0)[1] = make_int4(cv[4], cv[5], cv[6], cv[7]);
     }
+    // the active set, and the wave's lists
+    uint16_t* const list = s_list[wv];
+    if (!EMBA_ABL(a.ablate, 8192)) {
+        uint32_t kk = x - mine;                                               // rank inside the wave
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const long i = p0 + j;
-        if (i >= npix) break;
-        if (m & (1u << j)) {
-            if (compact && p0 + 8 > npix) compact[i] = (int32_t)k;
-            a.active_idx[k] = (uint32_t)i;
-            if (a.A22b2 && (long)k < a.max_P) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
-                const double2* q2 = reinterpret_cast<const double2*>(pixacc + (size_t)kPixAccStride * i);
-                const double2 a0 = q2[0], a1 = q2[1];
-                const double a4 = pixacc[(size_t)kPixAccStride * i + 4];
-                double* q = a.A22b2 + 5 * (size_t)k;
-                const double alpha = a.alpha;
-                if (alpha != 0.0) { q[0] = a0.x + alpha; q[1] = a0.y; q[2] = a1.x + alpha; q[3] = a1.y - alpha * a.Gx[i]; q[4] = a4 - alpha * a.Gy[i]; }
-                else { q[0] = a0.x; q[1] = a0.y; q[2] = a1.x; q[3] = a1.y; q[4] = a4; }
+        for (int j = 0; j < 8; ++j) {
+            const long i = p0 + j;
+            if (m & (1u << j)) {
+                if (compact && p0 + 8 > npix) compact[i] = (int32_t)(wave_base + kk);
+                a.active_idx[wave_base + kk] = (uint32_t)i;
+                list[kk] = (uint16_t)(lane * 8 + j);
+                ++kk;
+            } else if (compact && p0 + 8 > npix && i < npix) {
+                compact[i] = -1;
             }
-            ++k;
-        } else if (compact && p0 + 8 > npix) {
-            compact[i] = -1;
+        }
+    }
+    const int n_act = __shfl((int)x, 63);
+    int n_t = 0;
+    if (a.clear_pixacc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // touched pixels (any order)
+            const bool t = (tm >> j) & 1u;
+            const unsigned long long mk = __ballot(t);
+            if (t) list[512 + n_t + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(lane * 8 + j);
+            n_t += (int)__popcll(mk);
+        }
+    }
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS operations complete in order
+    const long wave_p0 = blk * kActivePix + 512L * wv;
+    if (a.A22b2 && n_act > 0 && !EMBA_ABL(a.ablate, 2048)) {   // quadratic cost: the per-pixel sums of the warp kernel ARE A22/b2 of the active pixels
+        const double alpha = a.alpha;
+        const int e5 = lane / 5, comp = lane - 5 * e5;
+        for (int g = 0; g < n_act; g += 24) {                         // two instructions of 12 pixels x 5 sums in flight
+            const int ea = g + e5, eb = g + 12 + e5;
+            const bool oka = lane < 60 && ea < n_act, okb = lane < 60 && eb < n_act;
+            const long pa = wave_p0 + list[oka ? ea : 0], pb = wave_p0 + list[okb ? eb : 0];
+            // (unconditional loads — a lane without an entry re-reads the wave's first active pixel: a load under a lane mask is waited for
+            // at the end of its branch, and the two instructions would run one after the other)
+            double va = pixacc[(size_t)kPixAccStride * pa + comp], vb = pixacc[(size_t)kPixAccStride * pb + comp];
+            if (alpha != 0.0) {                                       // (wave-uniform) applyL2Reg, model.cpp:689-719
+                const double* G = (comp == 4) ? a.Gy : a.Gx;
+                const double ga = G[pa], gb = G[pb];
+                if (comp == 0 || comp == 2) { va = va + alpha; vb = vb + alpha; }
+                else if (comp >= 3) { va = va - alpha * ga; vb = vb - alpha * gb; }
+            }
+            if (oka && (long)(wave_base + ea) < a.max_P) a.A22b2[5 * (size_t)(wave_base + ea) + comp] = va;
+            if (okb && (long)(wave_base + eb) < a.max_P) a.A22b2[5 * (size_t)(wave_base + eb) + comp] = vb;
+        }
+    }
+    if (a.clear_pixacc && n_t > 0 && !EMBA_ABL(a.ablate, 4096)) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): the gathers above have returned before their lines are zeroed
+        const int e6 = lane / 6, comp = lane - 6 * e6;
+        for (int g = 0; g < n_t; g += 10) {
+            const int e = g + e6;
+            if (lane < 60 && e < n_t) a.clear_pixacc[(size_t)kPixAccStride * (wave_p0 + list[512 + e]) + comp] = 0.0;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParams a) { active_write_block(blockIdx.x, a); }
+
+// ------------------------------------------------------------------------------------------------
+// a8 + the A22 | b2 gather of the resident one-GPU step, LIST-DRIVEN.  Round 4, measured (scripts/r04_exp5.sh): of the 15 us of the
+// sweeping write kernel above, 7.7 are its launch + one pass over the 8-MB count map, and 5.8 the gather — the active pixels sit in the
+// ~8 % of the panorama the camera looked at, so a few dozen of the 1024 blocks do all of it, one dependent round trip per 24 pixels of a
+// wave that has hundreds.  Launch A (active_count_block) now leaves every unit's active pixels as a list; here a block takes an EQUAL slice
+// [k0, k1) of the compact index range: prefix of the per-unit counts in LDS, binary search k -> (unit, rank), list entry -> pixel, then 8
+// lanes fetch one pixel's 64-B accumulator line (all of a slice's lines in flight at once), write its row of the pack (applyL2Reg folded in,
+// model.cpp:689-719) and the active-set entry, and zero the line behind the gather.  Work proportional to P, balanced, no count-map pass.
+// Used as the head of the Gram kernel (no launch of its own) or as a kernel of its own.  s_pre: kGatherMaxUnits + 1 words, s_ws: NT / 64.
+// ------------------------------------------------------------------------------------------------
+constexpr int kGatherMaxUnits = 4096;    // panoramas up to 8 M pixels (2048 x 4096); beyond that the host keeps the sweeping form
+// part 1: the prefix of the per-unit counts in s_pre (two barriers), what block 0 publishes; returns P.
+template <int NT>
+__device__ __forceinline__ uint32_t active_gather_prefix(const ActiveWriteParams& a, long blk, uint32_t* s_pre, uint32_t* s_ws)
+{
+    constexpr int NW = NT / 64, PER = kGatherMaxUnits / NT;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int s_pub[NW][5];
+    if (blk == 0) {   // (block-uniform) block 0 also publishes what the host polls for: the inlier total and the next evaluation's texel rectangle ride
+                      // through the same two barriers as the prefix below — every thread fetches its share at once (a single wave walking the
+                      // per-block arrays, one dependent load after the other, held this block back by ~8 us)
+        uint32_t ni = 0;
+        for (long j = tid; j < a.n_fblk; j += NT) ni += a.fblk_cnt[j];
+        int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+        if (a.blk_rect)
+            for (long j = tid; j < a.n_ablk; j += NT) {
+                const int4 r = reinterpret_cast<const int4*>(a.blk_rect)[j];
+                xmin = min(xmin, r.x); ymin = min(ymin, r.y); xmax = max(xmax, r.z); ymax = max(ymax, r.w);
+            }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ni += __shfl_xor(ni, o);
+            xmin = min(xmin, __shfl_xor(xmin, o)); ymin = min(ymin, __shfl_xor(ymin, o));
+            xmax = max(xmax, __shfl_xor(xmax, o)); ymax = max(ymax, __shfl_xor(ymax, o));
+        }
+        if (lane == 0) { s_pub[wv][0] = (int)ni; s_pub[wv][1] = xmin; s_pub[wv][2] = ymin; s_pub[wv][3] = xmax; s_pub[wv][4] = ymax; }
+    }
+    // exclusive prefix of launch A's per-unit counts -> s_pre[0 .. n_ablk], s_pre[n_ablk] = P
+    uint32_t v[PER], mine = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { const long j = (long)tid * PER + u; v[u] = a.blk_cnt[j < a.n_ablk ? j : a.n_ablk - 1]; }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) { if ((long)tid * PER + u >= a.n_ablk) v[u] = 0; mine += v[u]; }
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) s_ws[wv] = x;
+    __syncthreads();
+    uint32_t woff = 0, P = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { const uint32_t t = s_ws[w]; P += t; if (w < wv) woff += t; }
+    {
+        uint32_t run = woff + x - mine;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const long j = (long)tid * PER + u; if (j < a.n_ablk) s_pre[j] = run; run += v[u]; }
+        if (tid == 0) s_pre[a.n_ablk] = P;
+    }
+    if (blk == 0 && tid == 0) {
+        uint32_t ni = 0; int xmin = 0x7FFFFFFF, ymin = 0x7FFFFFFF, xmax = -1, ymax = -1;
+        for (int w = 0; w < NW; ++w) { ni += (uint32_t)s_pub[w][0]; xmin = min(xmin, s_pub[w][1]); ymin = min(ymin, s_pub[w][2]); xmax = max(xmax, s_pub[w][3]); ymax = max(ymax, s_pub[w][4]); }
+        if (a.blk_rect) { a.rect_out[0] = xmin; a.rect_out[1] = ymin; a.rect_out[2] = xmax; a.rect_out[3] = ymax; }
+        a.total_P[0] = P; a.total_inl[0] = ni;
+        if (a.total_P_host) a.total_P_host[0] = (int)P;
+        if (a.total_inl_host) a.total_inl_host[0] = (int)ni;
+        if (a.err_host) a.err_host[0] = a.err_dev[0];
+        if (a.seq_host) {
+            __threadfence_system();
+            __hip_atomic_store(a.seq_host + 0, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(a.seq_host + 1, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    __syncthreads();
+    return P;
+}
+
+// part 2: the block's slice of the compact index range (see above)
+template <int NT>
+__device__ __forceinline__ void active_gather_slice(const ActiveWriteParams& a, long blk, long nblk, uint32_t P, const uint32_t* s_pre)
+{
+    constexpr int Q = 4, PIX = NT / 8;   // PIX pixels per pass of the block (8 lanes each), Q passes in flight
+    const int tid = threadIdx.x;
+    const long per = ((long)P + nblk - 1) / nblk;
+    const long k0 = blk * per, k1 = (k0 + per < (long)P) ? k0 + per : (long)P;
+    const int comp = tid & 7;
+    const double alpha = a.alpha;
+    const int n_units = (int)a.n_ablk;
+    for (long base = k0; base < k1; base += (long)Q * PIX) {       // block-uniform; one trip at the BASELINE workload (P / grid = 270 pixels)
+        long kq[Q]; bool ok[Q]; int lo[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const long k = base + (long)q * PIX + (tid >> 3); ok[q] = k < k1; kq[q] = ok[q] ? k : k0; lo[q] = 0; }
+        // the unit of k: the LAST u with s_pre[u] <= k (units in front of it may be empty) — a fixed-length, branch-free search, the Q of them
+        // side by side (a data-dependent loop per pass runs its dozen LDS round trips one pass after the other)
+#pragma unroll
+        for (int step = kGatherMaxUnits / 2; step >= 1; step >>= 1)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { const int cand = lo[q] + step; if (cand < n_units && (long)s_pre[cand < n_units ? cand : 0] <= kq[q]) lo[q] = cand; }
+        long pix[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) pix[q] = (long)lo[q] * kActivePix + a.seg[(size_t)lo[q] * kActivePix + (kq[q] - (long)s_pre[lo[q]])];
+        double val[Q], g[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) val[q] = a.pixacc[(size_t)kPixAccStride * pix[q] + comp];   // 8 lanes = one 64-B line; every pass in flight
+        if (alpha != 0.0) {
+            const double* G = (comp == 4) ? a.Gy : a.Gx;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) g[q] = G[pix[q]];
+        }
+        if (a.clear_pixacc) {   // the lines are zeroed behind the gather — FIRST, while only the loads above are outstanding (the wait does not include a store)
+            __builtin_amdgcn_s_waitcnt(0x0F70);                       // vmcnt(0): every lane of every pass has its value
+#pragma unroll
+            for (int q = 0; q < Q; ++q) if (ok[q] && comp < 6) a.clear_pixacc[(size_t)kPixAccStride * pix[q] + comp] = 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            double w = val[q];
+            if (alpha != 0.0) {
+                if (comp == 0 || comp == 2) w = w + alpha;
+                else if (comp == 3 || comp == 4) w = w - alpha * g[q];
+            }
+            if (ok[q] && !EMBA_ABL(a.ablate, 2048)) {
+                if (comp < 5 && kq[q] < a.max_P) a.A22b2[5 * (size_t)kq[q] + comp] = w;
+                if (comp == 5) a.active_idx[kq[q]] = (uint32_t)pix[q];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void emba_active_gather_kernel(ActiveWriteParams a)
+{
+    __shared__ uint32_t s_pre[kGatherMaxUnits + 1];
+    __shared__ uint32_t s_ws[4];
+    const uint32_t P = active_gather_prefix<256>(a, blockIdx.x, s_pre, s_ws);
+    active_gather_slice<256>(a, blockIdx.x, gridDim.x, P, s_pre);
+}
+
+
 
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
 __global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)
@@ -1194,7 +1427,9 @@ __device__ __forceinline__ void prep_block(long blk, int32_t* __restrict__ count
 //   n_tex blocks    texel pack inside the rectangle of the pixels the last FORMED evaluation touched (reduced by its post-warp kernels; a hint
 //                   only: outside it the warp kernel falls back to the stencil)
 //   n_prep blocks   "prep": zero the count map (model.cpp:85) and the pixacc lines the previous evaluation touched (`count` still holds the
-//                   previous, possibly all-reduced, counts: a superset of the locally touched pixels)
+//                   previous, possibly all-reduced, counts or that evaluation's markers: a superset of the locally touched pixels).  NONE when
+//                   the previous evaluation's sums were consumed and cleared by the resident step's gather (ActiveWriteParams::clear_pixacc):
+//                   the count map itself never needs clearing — its entries are stamped (count_marker)
 // The control poses travel BY VALUE in the kernel arguments (K <= kInlineKnots: no staging copy, no dependency on another block);
 // larger K reads them from `knots_dev`, which the host has copied there before the launch.
 // err_next: the status word of the NEXT evaluation, cleared here (this launch's pose threads may already be setting bits of err).
@@ -1212,6 +1447,10 @@ __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexel
     // block order = start order: the pose threads first (one long dependent chain each: the launch's critical path), then the texel
     // blocks, the prep blocks (many, short) fill in behind
     const int b = (int)blockIdx.x;
+    if (b == 0) {   // (whatever block 0's role is; none of the roles below has a barrier)
+        if (threadIdx.x == 255) p.err_next[0] = 0;
+        if (p.inline_knots && p.knots_out) for (int i = (int)threadIdx.x - 64; i >= 0 && i < 4 * p.K; i += 192) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
+    }
     if (b < p.n_pose) {
         if (threadIdx.x < 64) {
             const double* knots = p.inline_knots ? kn.q : p.knots_dev;
@@ -1222,12 +1461,7 @@ __global__ __launch_bounds__(256) void emba_prep_pose_texel_kernel(PrepPoseTexel
     } else if (b < p.n_pose + p.n_tex) {
         texel_rect_blocks((long)b - p.n_pose, p.n_tex, p.Gx, p.Gy, p.H, p.W, p.rect, p.texel);
     } else {
-        const int pb = b - p.n_pose - p.n_tex;
-        if (pb == 0) {
-            if (threadIdx.x == 0) p.err_next[0] = 0;
-            if (p.inline_knots && p.knots_out) for (int i = threadIdx.x; i < 4 * p.K; i += 256) p.knots_out[i] = kn.q[i];   // (for whoever reads the device copy later)
-        }
-        prep_block(pb, p.count, p.npix, p.pixacc);
+        prep_block(b - p.n_pose - p.n_tex, p.count, p.npix, p.pixacc);
     }
 }
 
@@ -1251,6 +1485,7 @@ struct GramParams {
     const double* tag;                                                    // per slot {pano pixel, stamp} (8 B), or nullptr: decide from the records themselves
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
+    unsigned long long* trace;   // diagnostics builds only (EMBA_GRAM_TRACE): 8 s_memtime stamps per wave of the compact kernel
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
@@ -1468,14 +1703,14 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
             return lane < 8 * U && off + lane < len && (uint32_t)__double2hiint(tg) == p.stamp && (uint32_t)__double2loint(tg) != kInvalidPix;
         };
         auto bitword = [&](int off, double tg) -> uint32_t { return p.active_bits[tagvalid(off, tg) ? ((uint32_t)__double2loint(tg) >> 5) : 0u]; };
-        auto bitmask = [&](int off, double tg, uint32_t w) -> uint32_t {
+        auto bitmask = [&](int off, double tg, uint32_t w) -> unsigned long long {   // one bit per slot of the stage (8 U <= 64 slots = lanes)
             const uint32_t bit = ((EMBA_ABL(p.ablate, 256) ? ~0u : w) >> ((uint32_t)__double2loint(tg) & 31u)) & (tagvalid(off, tg) ? 1u : 0u);
-            return (uint32_t)__ballot(bit != 0);
+            return (unsigned long long)__ballot(bit != 0);
         };
         // (GRAM_DUMMY_LOADS: a record that does not take part is "loaded" from one fixed line instead — the block's first record, a cache
         // hit shared by all such lanes — so that the load is unconditional and the wait counts stay exact)
         const double2* dummy = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * start) + (lane & 7);
-        auto load_masked = [&](int off, uint32_t m, double2* x) {
+        auto load_masked = [&](int off, unsigned long long m, double2* x) {
             const double2* q = rec0 + 8 * off;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1496,11 +1731,12 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
         const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)key0;
         auto keys = [&](int off) { k_first = key_s[off]; k_last = key_s[(off + 8 * U < len ? off + 8 * U : len) - 1]; };
         // iteration i: Tb = tags of stage i+1 (here), Tn = tags of stage i+2 (arriving), W = activity words of stage i+1 (arriving)
-        uint32_t Mc, W;
+        static_assert(8 * U <= 64, "a stage's live mask is one wave ballot");
+        unsigned long long Mc; uint32_t W;
         double Te, To;
         auto iterate = [&](int off, double2* cur, double2* nxt, double& Tb, double& Tn) {
             const bool h1 = off + kStride < len;
-            const uint32_t Mn = h1 ? bitmask(off + kStride, Tb, W) : 0u;
+            const unsigned long long Mn = h1 ? bitmask(off + kStride, Tb, W) : 0ull;
             W = bitword(off + 2 * kStride, Tn);
             Tb = tagload(off + 3 * kStride);                 // (Tb's stage is done with: its register takes stage i+3)
             load_masked(h1 ? off + kStride : off, Mn, nxt);     // (Mn == 0 past the end: dummy loads only)
@@ -1597,6 +1833,180 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
 
 template <bool TAGS>
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p) { gram_body<TAGS, kGramBlock>(p, blockIdx.x); }
+
+// The same contraction for a CACHE-RESIDENT record set with a tag stream (pixel order up to ~1.5 M slots: the records the warp kernel wrote
+// microseconds ago are still in the Infinity Cache).  There the streaming form above is bound by its dependent chain, not by bytes: a wave
+// walks 8 stages of 32 SLOTS, half of them dead (stale, an outlier's, or on an inactive pixel), each stage one memory round trip behind
+// the previous one, plus three round trips of pipeline fill — 27.8 us for 84 MB at the BASELINE workload (round 3).  Here a wave owns ONE
+// contiguous chunk of slots and works in two phases:
+//   A  all the chunk's tags at once (one round trip), all their activity words at once (a second), ballots -> the LIVE slots' offsets,
+//      compacted, into the wave's LDS list;
+//   B  the live records only, 8 U per stage, every lane of every load instruction useful (lane -> list entry -> 16 B of its record's line),
+//      stage s+1 in flight while stage s runs through the matrix cores.
+// Half the stages, no dead lanes, two dependent trips in front of the first record instead of three.  The pair key is checked once per chunk
+// (slots are sorted by pair: a chunk of a few hundred slots almost never holds two); a chunk that does takes the grouping path per stage.
+// GATHER (the resident one-GPU step): the block first does its slice of the list-driven active-set write + A22 | b2 gather
+// (active_gather_block) — it only depends on launch A, like the Gram sums, and as a prologue it costs three short round trips instead of a launch.
+template <int U, bool GATHER>
+__global__ __launch_bounds__(kGramBlock) void emba_gram_compact_kernel(GramParams p, ActiveWriteParams aw)
+{
+    constexpr int kWaves = kGramBlock / 64, kStage = 8 * U;
+    __shared__ uint32_t s_tag[kGramKeys];
+    __shared__ double s_tile[kGramKeys * 256];
+    __shared__ uint16_t s_list[kWaves][kGramChunk];
+    __shared__ uint32_t s_pre[GATHER ? kGatherMaxUnits + 1 : 1];
+    __shared__ uint32_t s_ws[kWaves];
+#ifdef EMBA_DIAG
+#define GRAM_STAMP(k) do { if (p.trace && (threadIdx.x & 63) == 0) p.trace[8 * ((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GRAM_STAMP(k) do { } while (0)
+#endif
+    GRAM_STAMP(0);
+    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
+    if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m = lane & 7, R = lane >> 3;
+    const long w_start = ((long)blockIdx.x * kWaves + wv) * (long)p.chunk;
+    const long left = p.n_slots - w_start;
+    const int len = left <= 0 ? 0 : (left < (long)p.chunk ? (int)left : p.chunk);   // wave-uniform, <= kGramChunk
+    uint16_t* const list = s_list[wv];
+    int n_live = 0;
+    // ---- phase A: tags -> activity words -> compacted list of live slot offsets, in rounds of 256 slots (one round at the BASELINE workload).
+    // Three steps, so that the FIRST round's two round trips can be issued around the gather head below and hide behind its own three.
+    const double* tag0 = p.tag + (len > 0 ? w_start : 0);
+    const long tag_lim = len > 0 ? p.n_slots + kGramPad - 1 - w_start : 0;       // (the tag buffer is padded like the records)
+    auto issue_tags = [&](int base, double* tg) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const long idx = base + 64 * q + lane; tg[q] = tag0[idx < tag_lim ? idx : tag_lim]; }
+    };
+    auto issue_words = [&](int base, const double* tg, uint32_t* wd) {   // unconditional gathers from a safe word; validity is applied when the bit is extracted
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t pi = (uint32_t)__double2loint(tg[q]);
+            const bool valid = base + 64 * q + lane < len && (uint32_t)__double2hiint(tg[q]) == p.stamp && pi != kInvalidPix;
+            wd[q] = p.active_bits[valid ? (pi >> 5) : 0u];
+        }
+    };
+    auto finish_round = [&](int base, const double* tg, const uint32_t* wd) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t pi = (uint32_t)__double2loint(tg[q]);
+            const bool valid = base + 64 * q + lane < len && (uint32_t)__double2hiint(tg[q]) == p.stamp && pi != kInvalidPix;
+            const bool live = valid && (((EMBA_ABL(p.ablate, 256) ? ~0u : wd[q]) >> (pi & 31u)) & 1u);     // model.cpp:396,409
+            const unsigned long long mk = __ballot(live);
+            if (live) list[n_live + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(base + 64 * q + lane);
+            n_live += (int)__popcll(mk);
+        }
+    };
+    double tg[4]; uint32_t wd[4];
+    issue_tags(0, tg);
+    uint32_t P_act = 0;
+    if (GATHER) P_act = active_gather_prefix<kGramBlock>(aw, blockIdx.x, s_pre, s_ws);   // (its two barriers also publish the cleared combine table)
+    else __syncthreads();
+    GRAM_STAMP(1);
+    issue_words(0, tg, wd);
+    if (GATHER) active_gather_slice<kGramBlock>(aw, blockIdx.x, gridDim.x, P_act, s_pre);
+    if (len > 0) {
+        finish_round(0, tg, wd);
+#pragma unroll 1
+        for (int base = 256; base < len; base += 256) { issue_tags(base, tg); issue_words(base, tg, wd); finish_round(base, tg, wd); }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS operations complete in order
+    }
+    GRAM_STAMP(2);
+    if (n_live > 0) {
+        // ---- phase B
+        typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
+        const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)(p.slot_key + w_start);
+        const uint32_t k_a = key_s[0], k_b = key_s[len - 1];
+        const bool uniform = (k_a == k_b);                               // the whole chunk belongs to one control-pose pair
+        uint32_t cur_key = k_a;
+        bool dirty = false;
+        double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
+        auto flush = [&]() {
+            gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, p.dim, p.ablate, s_tag, s_tile);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
+        };
+        const double2* rec0 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * w_start) + m;
+        const int n_st = (n_live + kStage - 1) / kStage;
+        auto load_stage = [&](int s, double2* x) {       // (unconditional: an entry past the end re-reads the first live record and is zeroed below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) { const int e = kStage * s + 8 * u + R; x[u] = rec0[8 * (int)list[e < n_live ? e : 0]]; }
+        };
+        auto weight = [&](const double2& x) {
+            double w = 1.0;
+            if (p.irls) {
+                const double e = rec_elem14(x);
+                if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);          // cauchy, model.cpp:603
+                else { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }   // huber, :608-616
+            }
+            return w;
+        };
+        auto mfma3 = [&](bool use, double w, const double2& x) {
+            // selects, not multiplies: a lane past the end holds a copy of somebody else's record
+            const double ax = use ? w * x.x : 0.0, ay = use ? w * x.y : 0.0, bx = use ? x.x : 0.0, by = use ? x.y : 0.0;
+            if (!EMBA_ABL(p.ablate, 64)) {
+                acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
+                acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
+                acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
+            }
+        };
+        if (uniform) {
+            auto consume = [&](int s, const double2* x) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = kStage * s + 8 * u + R < n_live;
+                    if (__ballot(ok)) { dirty = true; mfma3(ok, weight(x[u]), x[u]); }
+                }
+            };
+            double2 xA[U], xB[U];
+            load_stage(0, xA);
+            int s = 0;
+            for (; s + 2 < n_st; s += 2) {       // (both prefetches exist: no load sits under a branch inside the loop)
+                load_stage(s + 1, xB); consume(s, xA);
+                load_stage(s + 2, xA); consume(s + 1, xB);
+            }
+            // the last one or two stages, peeled: nothing is fetched that is not consumed — the wave's flush below is a real call, in front of
+            // which everything outstanding is waited for (a redundant prefetch of the last stage cost every wave one more round trip: 2.3 us)
+            if (s + 1 < n_st) { load_stage(s + 1, xB); consume(s, xA); consume(s + 1, xB); }
+            else consume(s, xA);
+        } else {
+            // the chunk holds a pair boundary (a few dozen waves per launch): 8 live records at a time, grouped by pair — a small rolled loop
+            // of its own, so that its registers and branches stay out of the pipelined loop above
+#pragma unroll 1
+            for (int e0 = 0; e0 < n_live; e0 += 8) {
+                const int e = e0 + R;
+                const bool in = e < n_live;
+                const int sl = list[in ? e : 0];
+                const double2 y = rec0[8 * sl];
+                const uint32_t key = in ? p.slot_key[w_start + sl] : 0xFFFFFFFFu;
+                const double w = weight(y);
+                unsigned long long remaining = __ballot(in);
+                while (remaining) {
+                    const int first = __ffsll((long long)remaining) - 1;
+                    const uint32_t k0 = (uint32_t)__shfl((int)key, first);
+                    if (k0 != cur_key) { if (dirty) flush(); cur_key = k0; dirty = false; }
+                    const bool mine = in && (key == k0);
+                    if (__ballot(mine)) { dirty = true; mfma3(mine, w, y); }
+                    remaining &= ~__ballot(mine);
+                }
+            }
+        }
+        GRAM_STAMP(3);
+        if (dirty) flush();
+    }
+    GRAM_STAMP(4);
+    __syncthreads();
+    GRAM_STAMP(5);
+    // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
+    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
+        const uint32_t key = s_tag[i >> 8];
+        if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
+    }
+    GRAM_STAMP(6);
+#undef GRAM_STAMP
+}
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.

@@ -810,3 +810,56 @@ def test_costs_in_one_call(gpu, oracle_mod, cost):
     irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
     assert d == pytest.approx(oracle_mod.data_cost(ep, irls, cost[1]), rel=1e-10)
     assert r == pytest.approx(oracle_mod.reg_cost(w.Gx, w.Gy, w.alpha), rel=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_events=30000),                                       # small: 64 units of 2048 pixels over 27 Gram blocks
+    dict(n_events=20000, pano_h=75, sensor=(48, 36), focal=45.0),   # 75 x 150 panorama: 11 250 pixels, neither a multiple of 2048 nor of 8
+    dict(n_events=60000, pano_h=256, K=9, sensor=(64, 48), focal=60.0, thres_valid_pixel=2),
+    "baseline",                                                 # 1 M events, 1024 x 2048, K = 21: what bench.py steps
+])
+@pytest.mark.parametrize("fast,gather", [("1", "2"), ("1", "1"), ("1", "0"), ("0", "2"), ("0", "0")])
+def test_resident_step_sequences(gpu, oracle_mod, cfg, fast, gather, monkeypatch):
+    """The resident one-GPU step (emba_step) in the sequences a host produces.  Round 4: its active-set write + A22 | b2 gather is list-driven and rides in the head
+    of the Gram kernel (EMBA_STEP_GATHER=2; 1: a kernel of its own; 0: the sweeping kernel of the other paths), the accumulator lines are zeroed
+    behind their readers so that the next evaluation has no clearing pass (EMBA_STEP_FAST=0 keeps the pass), and the count map's entries are stamped instead of cleared — each of which could leak one evaluation's state into the
+    next.  Checked against the oracle after: two steps in a row; an evaluation that is never formed (a rejected trial) in between; a second
+    formNormalEq, with another threshold, on the evaluation a step has consumed (A22 | b2 then come from the records)."""
+    from emba_amd.synth import make_workload
+    monkeypatch.setenv("EMBA_STEP_FAST", fast); monkeypatch.setenv("EMBA_STEP_GATHER", gather)
+    w = make_workload() if cfg == "baseline" else small_workload(**cfg)
+    m = make_legm(w)
+    m.set_events(w.events)
+    m.upload_map(w.Gx, w.Gy)
+    o = oracle_run(oracle_mod, w)
+
+    def check(tag):
+        ne = m._finish(w.alpha, False)                     # download only: L2 was applied inside the step
+        compare_normal_eq(ne, o["ne"])
+        _, ep, nem = m.eval_finish(want_ep=True, want_map=True)
+        assert np.array_equal(nem, o["num_ev_map"]), tag
+        assert_close(ep, o["ep"], "ep " + tag)
+
+    for it in range(2):
+        n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+        assert n_inl == o["ep"].size and P == o["ne"]["P"]
+        check(f"step {it}")
+    # an evaluation at other poses that nobody forms: its markers and per-pixel sums must not reach the next step
+    import copy
+    traj2 = copy.deepcopy(w.traj)
+    k = traj2.knots_xyzw.copy(); k[:, 0] += 0.01; k /= np.linalg.norm(k, axis=1, keepdims=True); traj2.knots_xyzw = k
+    m.eval_launch(traj2); m.eval_finish(sync=False)
+    assert m.dataCost() > 0
+    m.eval_launch(traj2); m.eval_finish(sync=False)           # twice: markers of two stamps nobody materialised
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert n_inl == o["ep"].size and P == o["ne"]["P"]
+    check("step after unformed evaluations")
+    # a second formNormalEq on the evaluation the step has consumed, with a lower threshold and without the L2 term
+    th2 = max(1, w.thres_valid_pixel - 1)
+    o2 = oracle_run(oracle_mod, w, thres=th2, alpha=0.0)
+    ne2 = m.formNormalEq(None, w.K, None, th2)             # (ep = None: the device-resident residuals, like solver.cpp's call pattern)
+    compare_normal_eq(ne2, o2["ne"])
+    # ... and the step after that is clean again
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert P == o["ne"]["P"]
+    check("step after a re-form")

@@ -1255,7 +1255,10 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; q.marker = c->count_mark; c->counts_raw = false; }   // launch A turns the markers into counts
         const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
-        const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count;
+        // list-driven gather: where it rides in the head of the compact Gram kernel (as a kernel of its own it is no faster than the sweeping write:
+        // 109.6 vs 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison)
+        const bool lists_ok = c->step_consume && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count;
+        const bool lists = lists_ok && (c->step_gather == 1 || (c->step_gather == 2 && gram_is_compact(c, false)));
         if (consume) { aw.clear_pixacc = c->d_pixacc; c->pixacc_clean = true; c->pixacc_consumed = true; }
         if (lists) { q.seg = c->d_seg_act; aw.seg = c->d_seg_act; if (consume) q.clear_inactive = c->d_pixacc; }
         // launch A: {active counts (+ markers -> counts, activity bits, cleared A11 | b1) || inlier-flag counts}; launch B: the active-set write,
@@ -1378,16 +1381,15 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
             std::vector<unsigned long long> h((size_t)grid * wpb * 8);
             (void)hipStreamSynchronize(s);
             (void)hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
-            unsigned long long t0 = ~0ull, t1 = 0; double seg[7] = {0}; double lat_first = 0, lat_last = 0; size_t nw = 0;
-            for (size_t w = 0; w < (size_t)grid * wpb; ++w) { const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[6]) continue; t0 = std::min(t0, q[0]); t1 = std::max(t1, q[6]); }
+            double seg[8] = {0}; size_t nw = 0;
             for (size_t w = 0; w < (size_t)grid * wpb; ++w) {
-                const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[6]) continue;
-                ++nw; lat_first += (double)(q[0] - t0); lat_last += (double)(t1 - q[6]);
+                const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[7]) continue;
+                ++nw;
                 unsigned long long prev = q[0];
-                for (int k = 1; k <= 6; ++k) { const unsigned long long v = q[k] ? q[k] : prev; seg[k] += (double)(v - prev); prev = v; }
+                for (int k = 1; k <= 7; ++k) { const unsigned long long v = q[k] ? q[k] : prev; seg[k] += (double)(v - prev); prev = v; }
             }
-            fprintf(stderr, "gram trace (s_memtime ticks, mean over %zu waves; span first start -> last end %llu): start skew %.0f | init+barrier %.0f | phase A %.0f | phase B %.0f | wave flush %.0f | barrier %.0f | block flush %.0f | tail skew %.0f\n",
-                    nw, t1 - t0, lat_first / nw, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw, seg[6] / nw, lat_last / nw);
+            fprintf(stderr, "gram trace (s_memtime ticks, mean over %zu waves): init+prefix %.0f | words+slice %.0f | phase A rest %.0f | phase B %.0f | wave flush %.0f | barrier %.0f | block flush %.0f | total %.0f\n",
+                    nw, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw, seg[6] / nw, seg[7] / nw, (seg[1] + seg[2] + seg[3] + seg[4] + seg[5] + seg[6] + seg[7]) / nw);
         }
 #endif
         else if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3(grid), dim3(kGramBlock), 0, s, p);

@@ -87,7 +87,8 @@ template <class T> __device__ __forceinline__ T stream_load(const T* p, bool nt)
 constexpr int kGramPad = 256;     // record slots allocated past the last one: the Gram kernel's stages read whole 8-record groups
 constexpr int kGramChunkMin = 64; // smallest share of record slots a wave of the Gram kernel is given
 constexpr int kGramChunk = 1024;   // most record slots a wave of the Gram (A11/b1) kernel is given (multiple of 8)
-constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table)
+constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table).  Round 4, compact form at 1 M events: 8 waves
+                                   // per CU 52 us, 4 waves 93 us, 24 waves (768 x 2, 80 VGPRs, 13 spilled) 39.6 us, 32 waves (64 VGPRs, 81 spilled) 52-66 us; 16: 37 us
 constexpr int kGramKeys = 4;       // control-pose pairs the block-level LDS table can hold before falling back to global atomics
 
 // Blocks are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md "Workgroup dispatch"); give each
@@ -1246,7 +1247,7 @@ constexpr int kGatherMaxUnits = 4096;    // panoramas up to 8 M pixels (2048 x 4
 template <int NT>
 __device__ __forceinline__ uint32_t active_gather_prefix(const ActiveWriteParams& a, long blk, uint32_t* s_pre, uint32_t* s_ws)
 {
-    constexpr int NW = NT / 64, PER = kGatherMaxUnits / NT;
+    constexpr int NW = NT / 64, PER = (kGatherMaxUnits + NT - 1) / NT;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ int s_pub[NW][5];
     if (blk == 0) {   // (block-uniform) block 0 also publishes what the host polls for: the inlier total and the next evaluation's texel rectangle ride
@@ -1907,13 +1908,14 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_compact_kernel(GramParam
     GRAM_STAMP(1);
     issue_words(0, tg, wd);
     if (GATHER) active_gather_slice<kGramBlock>(aw, blockIdx.x, gridDim.x, P_act, s_pre);
+    GRAM_STAMP(2);
     if (len > 0) {
         finish_round(0, tg, wd);
 #pragma unroll 1
         for (int base = 256; base < len; base += 256) { issue_tags(base, tg); issue_words(base, tg, wd); finish_round(base, tg, wd); }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS operations complete in order
     }
-    GRAM_STAMP(2);
+    GRAM_STAMP(3);
     if (n_live > 0) {
         // ---- phase B
         typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
@@ -1993,18 +1995,18 @@ __global__ __launch_bounds__(kGramBlock) void emba_gram_compact_kernel(GramParam
                 }
             }
         }
-        GRAM_STAMP(3);
+        GRAM_STAMP(4);
         if (dirty) flush();
     }
-    GRAM_STAMP(4);
-    __syncthreads();
     GRAM_STAMP(5);
+    __syncthreads();
+    GRAM_STAMP(6);
     // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
         const uint32_t key = s_tag[i >> 8];
         if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
     }
-    GRAM_STAMP(6);
+    GRAM_STAMP(7);
 #undef GRAM_STAMP
 }
 

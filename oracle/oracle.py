@@ -162,6 +162,25 @@ def ref_cg_solve(n, rows, cols, vals, b, max_iter=100, tol=1e-6):
     return x, it.value, float(err[0])
 
 
+def ref_solve_normal_eq_cg(A11, A12, A22, b1, b2, lam):
+    """LEGM::solveNormalEqCG (model.cpp:794-840) end to end by the reference's own code: eigen_utils::diagMat / diagSpMat / catSpMat
+    (src/utils/eigen_utils.cpp, compiled unmodified) + Eigen's ConjugateGradient.  A11 n x n, A12 n x 2P (dense), A22 P x 2 x 2.
+    Returns (x1, x2, iterations, error, (rows, cols, vals) of the assembled system)."""
+    A11 = np.asfortranarray(A11, dtype=np.float64); A12 = np.asfortranarray(A12, dtype=np.float64)
+    n = A11.shape[0]; P = A12.shape[1] // 2
+    A22 = _f64(A22).reshape(P, 4); b1 = _f64(b1); b2 = _f64(b2)
+    x1 = np.zeros(n); x2 = np.zeros(max(2 * P, 1)); it = C.c_int(0); err = np.zeros(1)
+    cap = n * n + 2 * n * 2 * P + 4 * P + 8
+    rows = np.zeros(cap, np.int32); cols = np.zeros(cap, np.int32); vals = np.zeros(cap); nnz = C.c_long(0)
+    f = ref_eigen().ref_solve_normal_eq_cg
+    f.restype = None
+    f(C.c_int(n), C.c_long(P), A11.ctypes.data_as(_dp), A12.ctypes.data_as(_dp), _ptr(A22, _dp), _ptr(b1, _dp), _ptr(b2, _dp), C.c_double(lam),
+      _ptr(x1, _dp), _ptr(x2, _dp), C.byref(it), _ptr(err, _dp), C.c_long(cap), _ptr(rows, _i32p), _ptr(cols, _i32p), _ptr(vals, _dp), C.byref(nnz))
+    k = nnz.value
+    assert k <= cap
+    return x1, x2[: 2 * P], it.value, float(err[0]), (rows[:k].copy(), cols[:k].copy(), vals[:k].copy())
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 

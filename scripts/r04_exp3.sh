@@ -1,4 +1,4 @@
-# round 4, experiment 3: anatomy of the compact Gram kernel (diag build: s_memtime stamps + ablations)
+# round 4: anatomy of the compact Gram kernel (diag build: s_memtime stamps per wave)
 mkdir -p gpurun_out && rm -f gpurun_out/r04_exp3.log
 L=gpurun_out/r04_exp3.log
 one() {  # label, env...
@@ -9,6 +9,5 @@ d=json.loads(sys.stdin.readline()); r=d['roofline']; print('%-34s step %7.1f us 
   grep "gram trace" gpurun_out/r04_exp3.err | tee -a $L
 }
 D=$PWD/build_variants/diag.so
-one "diag default" EMBA_LIB=$D EMBA_GRAM_TRACE=1
-one "diag stream form" EMBA_LIB=$D EMBA_GRAM=stream
-for a in 32 64 96 256; do one "compact ablate $a" EMBA_LIB=$D EMBA_ABLATE=$a EMBA_GRAM_TRACE=1; done
+one "diag gather in head" EMBA_LIB=$D EMBA_GRAM_TRACE=1
+one "diag gather standalone" EMBA_LIB=$D EMBA_GRAM_TRACE=1 EMBA_STEP_GATHER=1

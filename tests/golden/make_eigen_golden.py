@@ -6,6 +6,10 @@ reference's solvers on matrices the oracle produces —
     A22m_i.inverse()   (Eigen::Matrix2d)                 src/emba/model.cpp:750
     ConjugateGradient<SpMat, Lower|Upper>(100, 1e-6)     src/emba/model.cpp:828-836
 
+Round 4: the CG systems are ASSEMBLED by the reference's own code too — eigen_utils::diagMat / diagSpMat / catSpMat of
+src/utils/eigen_utils.cpp (compiled unmodified into libref_eigen.so) in the order of model.cpp:805-821, from the blocks formNormalEq +
+applyL2Reg export (ref_solve_normal_eq_cg); full_system_triplets below (Python) stays as the cross-check of that assembly.
+
 Run in the authoring container only:   make -C oracle && python tests/golden/make_eigen_golden.py
 The fixture holds inputs and Eigen's outputs; it is data, not source."""
 import os
@@ -101,11 +105,22 @@ def main():
     wc = small_workload(n_events=2400, pano_h=64, K=5, sensor=(12, 8), focal=10.0)
     nec = oracle_run(O, wc, dense_A12=True)["ne"]
     for name, lam, skip in (("trimmed", 1e-3, 3), ("full", 1e-2, 0)):
-        n, rows, cols, vals, b = full_system_triplets(nec, lam, skip)
-        x, it, err = O.ref_cg_solve(n, rows, cols, vals, b, 100, 1e-6)
+        # the blocks as solver.cpp hands them to solveNormalEqCG (first-window trim :156-165 when skip = 3)
+        A11 = nec["A11"][skip:, skip:]; A12 = nec["A12"][skip:, :]; b1 = nec["b1"][skip:]
+        x1, x2, it, err, (rows, cols, vals) = O.ref_solve_normal_eq_cg(A11, A12, nec["A22"], b1, nec["b2"], lam)
+        x = np.concatenate([x1, x2]); b = np.concatenate([b1, nec["b2"]]); n = x.size
+        # cross-check 1: the Python assembly gives the same matrix (as a dense array: triplet order is Eigen's column-major one)
+        n_py, r_py, c_py, v_py, b_py = full_system_triplets(nec, lam, skip)
+        M_ref = np.zeros((n, n)); np.add.at(M_ref, (rows, cols), vals)
+        M_py = np.zeros((n, n)); np.add.at(M_py, (r_py, c_py), v_py)
+        assert n_py == n and np.array_equal(M_ref, M_py) and np.array_equal(b, b_py), "the reference's catSpMat assembly differs from the Python one"
+        # cross-check 2: Eigen's CG on the triplets alone reproduces the end-to-end call bit for bit
+        xt, itt, errt = O.ref_cg_solve(n, rows, cols, vals, b, 100, 1e-6)
+        assert itt == it and np.array_equal(xt, x) and errt == err
         out[f"cg_{name}_rows"] = rows; out[f"cg_{name}_cols"] = cols; out[f"cg_{name}_vals"] = vals; out[f"cg_{name}_b"] = b
         out[f"cg_{name}_x"] = x; out[f"cg_{name}_iters"] = np.int32(it); out[f"cg_{name}_err"] = err
         out[f"cg_{name}_lam"] = lam; out[f"cg_{name}_skip"] = np.int32(skip)
+        out[f"cg_{name}_A11"] = A11; out[f"cg_{name}_A12"] = A12; out[f"cg_{name}_A22"] = nec["A22"]; out[f"cg_{name}_b1"] = b1; out[f"cg_{name}_b2"] = nec["b2"]
     path = os.path.join(HERE, "eigen_solvers.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", {k: (int(out[f'cg_{k}_iters']), float(out[f'cg_{k}_err'])) for k in ("trimmed", "full")})

@@ -421,10 +421,16 @@ def test_cg_matches_the_reference_eigen_golden(oracle_mod):
     ne, o = r["ne"], r["oracle"]
     for name in ("trimmed", "full"):
         lam, skip = float(g[f"cg_{name}_lam"]), int(g[f"cg_{name}_skip"])
+        # the fixture's system was assembled by the REFERENCE's own eigen_utils::catSpMat / diagMat / diagSpMat (model.cpp:805-821, round 4) from
+        # these blocks — which are the oracle's (the workload generator and the oracle are deterministic) ...
+        assert np.allclose(ne["A11"][skip:, skip:], g[f"cg_{name}_A11"], rtol=1e-13, atol=0) and np.allclose(ne["A12"][skip:, :], g[f"cg_{name}_A12"], rtol=1e-13, atol=0)
+        assert np.allclose(ne["A22"], g[f"cg_{name}_A22"], rtol=1e-13, atol=0) and np.allclose(ne["b2"], g[f"cg_{name}_b2"], rtol=1e-13, atol=0)
+        # ... and the Python assembly of the same system (what the tests used before) is the same matrix
         n, rows, cols, vals, b = full_system_triplets(ne, lam, skip)
-        # the fixture's input IS this system (the workload generator and the oracle are deterministic)
-        assert np.array_equal(rows, g[f"cg_{name}_rows"]) and np.array_equal(cols, g[f"cg_{name}_cols"])
-        assert np.allclose(vals, g[f"cg_{name}_vals"], rtol=1e-13, atol=0) and np.allclose(b, g[f"cg_{name}_b"], rtol=1e-13, atol=0)
+        M_py = np.zeros((n, n)); np.add.at(M_py, (rows, cols), vals)
+        M_ref = np.zeros((n, n)); np.add.at(M_ref, (g[f"cg_{name}_rows"], g[f"cg_{name}_cols"]), g[f"cg_{name}_vals"])
+        assert np.allclose(M_py, M_ref, rtol=1e-13, atol=0) and np.allclose(b, g[f"cg_{name}_b"], rtol=1e-13, atol=0)
+        assert np.array_equal(M_ref, M_ref.T)
         x1, x2, it, err = o.solve_cg_sparse(ne, r["ep"], w.K, r["num_ev_map"], w.thres_valid_pixel, 0, 0.0, lam, bool(skip))
         ex = g[f"cg_{name}_x"]
         assert it == int(g[f"cg_{name}_iters"]), (it, int(g[f"cg_{name}_iters"]))
@@ -460,3 +466,13 @@ def test_solver_restatements_live_against_the_reference_eigen_build(oracle_mod):
     for _ in range(100):
         A = rng.normal(size=4)
         assert np.array_equal(O.inverse2(A), O.ref_inverse2(A))
+    # solveNormalEqCG end to end by the reference's own assembly code (eigen_utils.cpp) on a system that is not in the golden file
+    w = small_workload(n_events=3000, pano_h=64, K=6, sensor=(12, 8), focal=10.0, seed=11)
+    r = oracle_run(O, w, dense_A12=True)
+    ne, o = r["ne"], r["oracle"]
+    for lam, skip in ((1e-3, 3), (1e-1, 0)):
+        x1r, x2r, itr, errr, _ = O.ref_solve_normal_eq_cg(ne["A11"][skip:, skip:], ne["A12"][skip:, :], ne["A22"], ne["b1"][skip:], ne["b2"], lam)
+        x1, x2, it, err = o.solve_cg_sparse(ne, r["ep"], w.K, r["num_ev_map"], w.thres_valid_pixel, 0, 0.0, lam, bool(skip))
+        assert it == itr and err == pytest.approx(errr, rel=1e-6)
+        ex = np.concatenate([x1r, x2r]); got = np.concatenate([x1[skip:], x2])
+        assert np.allclose(got, ex, rtol=1e-7, atol=1e-9 * np.abs(ex).max())

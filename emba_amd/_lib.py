@@ -70,6 +70,7 @@ SIGNATURES = {
     "emba_map_reject": (C.c_int, [C.c_void_p]),
     "emba_trial_reject": (C.c_int, [C.c_void_p]),
     "emba_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_get_map_active": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
     "emba_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_reconstruct_intensity": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "emba_bind_exchange_buffers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "emba_group_map_accept": (C.c_int, [C.c_void_p]),
     "emba_group_map_reject": (C.c_int, [C.c_void_p]),
     "emba_group_download_map": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_group_get_map_active": (C.c_int, [C.c_void_p, _dp, C.c_size_t]),
 }
 
 

@@ -111,6 +111,9 @@ struct emba_ctx {
                             // gather as a kernel of its own, 2 (default) the list-driven gather as the head of the compact Gram kernel
     uint16_t* d_seg_act = nullptr;   // launch A's per-unit active lists (offsets inside the unit), n_ablk * kActivePix entries
     bool aw_in_gram = false; ActiveWriteParams aw_saved{};   // the gather of the running step, to be issued with its Gram launch (emba_form_accumulate)
+    int step_one_set = 1;      // EMBA_STEP_ONE_SET=0: emba_step alternates between two record sets like an LM loop's evaluations (A/B)
+    bool no_alt_set = false;   // set by emba_step around its evaluation: the step re-forms the equations itself, nothing of the previous ones can be gone back to —
+                               // no second record set (+12.8 GB at 100 M events for callers that can never reject)
     int step_fast = 1;   // EMBA_STEP_FAST=0: emba_step keeps the clearing pass in front of every evaluation (A/B)
     int gram_mode = 0;   // EMBA_GRAM=stream|compact (1 | 2; 0 = by size): which form of the tag-stream Gram kernel runs
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
@@ -681,6 +684,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
     if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
+    if (const char* sf = getenv("EMBA_STEP_ONE_SET")) c->step_one_set = atoi(sf);
     if (const char* gm = getenv("EMBA_GRAM")) c->gram_mode = !strcmp(gm, "stream") ? 1 : !strcmp(gm, "compact") ? 2 : 0;
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
@@ -1046,6 +1050,25 @@ emba_status emba_download_map(emba_ctx* c, double* Gx_host, double* Gy_host)
     return EMBA_OK;
 }
 
+emba_status emba_get_map_active(emba_ctx* c, double* gxy_host, size_t cap_P)
+{
+    if (!c || !gxy_host) return c ? fail(c, EMBA_ERR_INVALID_ARG, "gxy_host NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
+    if (!c->active_done && !c->P_pending) return fail(c, EMBA_ERR_STATE, "no active set (formNormalEq) yet");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st = resolve_pending(c);
+    if (st) return st;
+    if (cap_P < c->P) return fail(c, EMBA_ERR_CAPACITY, "cap_P=%zu < P=%zu", cap_P, c->P);
+    if (!c->P) return EMBA_OK;
+    double* d_out = nullptr;
+    if ((st = ws_get(c, 15, 2 * c->P * sizeof(double), (void**)&d_out))) return st;
+    hipLaunchKernelGGL(emba_map_active_kernel, dim3(nblocks(c->P)), dim3(256), 0, c->stream, c->d_Gx, c->d_Gy, c->d_active, (long)c->P, d_out);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(gxy_host, d_out, 2 * c->P * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return EMBA_OK;
+}
+
 emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, double* pack_dev, size_t pack_cap)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
@@ -1103,7 +1126,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->h_knots_cap = K;
     }
     hipStream_t s = c->stream;
-    if (c->accum_done) {
+    if (c->accum_done && !c->no_alt_set) {
         // The working record set is what the current normal equations were formed from: this evaluation (an LM trial, or simply the next
         // step) writes the OTHER set, so that a rejection can go back to untouched equations (emba_trial_reject).
         if (c->P_pending || c->inl_pending) { if ((st = resolve_pending(c, true))) return st; }
@@ -1700,7 +1723,9 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     {   // the evaluation weights its per-pixel sums with THIS step's cost (whatever emba_set_cost declared for other callers)
         const int keep_irls = c->cost_irls; const double keep_eta = c->cost_eta;
         c->cost_irls = irls; c->cost_eta = irls ? eta : 0.0;
+        c->no_alt_set = (c->step_one_set != 0);
         st = emba_eval_launch(c, knots, K, t0_ns, dt_ns);
+        c->no_alt_set = false;
         c->cost_irls = keep_irls; c->cost_eta = keep_eta;
         if (st) return st;
     }
@@ -1989,6 +2014,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     // step is lost (NaN cost: rejected); reported as EMBA_ERR_NUMERIC.  bit 1: a pivot of S vanished — handled like Eigen's ldlt (zero
     // update in that component), not an error.
     if (info & 1) return fail(c, EMBA_ERR_NUMERIC, "a 2x2 block of A22 + lambda*diag(A22) is not positive definite (the reference's inverse() gives inf/nan)");
+    if (info & 4) return fail(c, EMBA_ERR_NUMERIC, "the Schur complement is indefinite or not finite (a pivot clearly below zero, or NaN): no update is returned");
     return EMBA_OK;
 }
 
@@ -2109,6 +2135,7 @@ extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_
     HIP_TRY(c, hipStreamSynchronize(s));
     c->solve_info = info;
     if (info & 1) return fail(c, EMBA_ERR_NUMERIC, "a 2x2 block of A22 + lambda*diag(A22) is not positive definite (the reference's inverse() gives inf/nan)");
+    if (info & 4) return fail(c, EMBA_ERR_NUMERIC, "the Schur complement is indefinite or not finite (a pivot clearly below zero, or NaN): no update is returned");
     return EMBA_OK;
 }
 

@@ -737,6 +737,12 @@ emba_status emba_group_download_map(emba_group* g, double* Gx, double* Gy)
     G_TRY(g, 0, emba_download_map(g->ctx[0], Gx, Gy));
     return EMBA_OK;
 }
+emba_status emba_group_get_map_active(emba_group* g, double* gxy_host, size_t cap_P)
+{
+    if (!g) return EMBA_ERR_INVALID_ARG;
+    G_TRY(g, 0, emba_get_map_active(g->ctx[0], gxy_host, cap_P));
+    return EMBA_OK;
+}
 // the last evaluation was a rejected trial that involved no map update: the equations formed before it are current again on every rank
 emba_status emba_group_trial_reject(emba_group* g)
 {

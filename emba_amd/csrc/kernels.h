@@ -2062,6 +2062,16 @@ __global__ void emba_update_map_kernel(const double* __restrict__ Gx, const doub
     Gy_new[i] = (k >= 0) ? Gy[i] + damping * x2[2 * (size_t)k + 1] : 0.0;     // :875 / :898
 }
 
+// the map at the active pixels only (emba_get_map_active): out[2k] = Gx[active_k], out[2k+1] = Gy[active_k]
+__global__ void emba_map_active_kernel(const double* __restrict__ Gx, const double* __restrict__ Gy, const uint32_t* __restrict__ active_idx, long P,
+                                       double* __restrict__ out)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    const uint32_t i = active_idx[k];
+    reinterpret_cast<double2*>(out)[k] = make_double2(Gx[i], Gy[i]);
+}
+
 // pack -> boundary layout: A22 P*4 ([xx xy; xy yy]) and b2 2P.
 __global__ void emba_unpack_kernel(const double* __restrict__ A22b2, long P, double* __restrict__ A22, double* __restrict__ b2)
 {

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
     double row[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
-    bool bad = false;
+    bool bad = false, bad_sign = false;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
         double v = row[j];
@@ -445,12 +445,21 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
         // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
         // The case that occurs in practice is a control pose no event constrains: its rows and columns of S are exactly zero, so d == 0
         // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
+        // (round 4) Only a VANISHING pivot is that case: d == 0, or a non-positive value within rounding of it — 64 ulp of the
+        // diagonal entry it was eliminated from.  A pivot that is clearly negative, or not finite, means S is indefinite or carries a NaN: Eigen
+        // factors the former with a negative D entry and propagates the latter; a Cholesky factorisation can do neither, and a finite, partly
+        // zeroed x1 with EMBA_OK would hide corrupted equations — info bit 2 (4), which the solve returns as EMBA_ERR_NUMERIC (the LM loop then
+        // rejects the step, as it does for the NaN cost the reference would see).
+        const double d0 = readlane_f64(row[j], j);                 // lane j's column j is still the original diagonal entry here (left-looking)
         const bool ok = d > 0.0;
+        const bool vanishing = !ok && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
         bad |= (j < nb) && !ok;
+        bad_sign |= (j < nb) && !ok && !vanishing;
         const double piv = ok ? sqrt(d) : 0.0;
         row[j] = (r == j) ? piv : (ok ? v / piv : 0.0);     // rows above the diagonal hold garbage that is never read (k < j <= r below)
     }
     if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
+    if (bad_sign && r == 0) atomicOr(info, 4);
 #pragma unroll
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }

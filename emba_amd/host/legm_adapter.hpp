@@ -30,6 +30,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 
@@ -44,17 +45,23 @@ namespace EMBA {
 struct LegmHipState {
     std::unique_ptr<emba_host::ShardedLEGM> impl;
     emba_host::EventPacket packet;       // dvs_msgs::Event -> {x, y, t_ns, polarity}; rebuilt only when the CONTENT of `events` changes
-    const dvs_msgs::Event* src = nullptr; size_t n = 0; uint64_t t_first = 0, t_mid = 0, t_last = 0;
+    const dvs_msgs::Event* src = nullptr; size_t n = 0; uint64_t src_key = 0;     // allocation, size and a sampled content hash of the caller's packet
     emba_host::NormalEquations ne;
     int K = 0;                           // control poses of the last evaluation
     size_t n_ep = 0;                     // size of the ep vector the last evaluateDataError returned
-    // the trial map: the Mats updateMap filled last (data pointers + a strided sample of their content)
+    // the trial map: the Mats updateMap filled last (data pointers + what it wrote into them)
     const unsigned char* trial_gx = nullptr; const unsigned char* trial_gy = nullptr;
-    std::vector<double> trial_sample;
+    std::vector<uint32_t> trial_active;  // the pixels updateMap wrote (the trial map is zero everywhere else, model.cpp:892-901) ...
+    std::vector<double> trial_gxy;       // ... and the values: gxy[2i], gxy[2i+1] at trial_active[i]
+    std::vector<double> trial_sample;    // a strided sample of the planes outside them
     bool trial_pending = false;          // the last evaluation was on the trial map and its fate is not known yet
     bool map_is_trial = false;           // the device holds a trial map nobody has decided about
+    // the caller's CURRENT map is zero outside these pixels (the active set of the accepted trial it came from): the next updateMap zeroes
+    // just them instead of two whole planes.  Invalid until a trial of this object has been accepted, and after any map it did not produce.
+    std::vector<uint32_t> cur_nonzero; bool cur_nonzero_valid = false;
     // the x2 of the last Schur solve stays on the ranks' devices: updateMap recognises it (size + a strided sample) and skips the upload
     std::vector<double> x2_sample; size_t x2_size = 0; bool x2_on_device = false;
+    bool numeric_failure = false;        // the last solve met a 2x2 block that is not positive definite: x1 / x2 are NaN like the reference's (model.cpp:750)
 };
 static std::map<const LEGM*, LegmHipState> g_state;   // or a member `LegmHipState hip_;` added to class LEGM
 
@@ -74,7 +81,21 @@ inline std::vector<int> devices_from_env()
     return dev;
 }
 
-constexpr size_t kSample = 97;           // values compared to recognise the trial Mats (a stride over the plane)
+// allocation + size + a hash over 4096 events spread through the packet (all four fields) + the last one: see ShardedLEGM::packetKey
+inline uint64_t packet_key(const EventPacket& ev)
+{
+    uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)ev.size();
+    auto mix = [&](const dvs_msgs::Event& e) {
+        h ^= (uint64_t)e.ts.toNSec(); h *= 0x100000001B3ull; h ^= ((uint64_t)e.x << 32) | ((uint64_t)e.y << 8) | (e.polarity ? 1u : 0u); h *= 0x100000001B3ull;
+    };
+    if (ev.empty()) return h;
+    const size_t step = ev.size() / 4096 ? ev.size() / 4096 : 1;
+    for (size_t i = 0; i < ev.size(); i += step) mix(ev[i]);
+    mix(ev.back());
+    return h;
+}
+
+constexpr size_t kSample = 4099;         // values compared to recognise the trial Mats outside the pixels updateMap wrote (a prime stride count over the plane)
 inline void sample_plane(const double* p, size_t n, std::vector<double>& out)
 {
     const size_t step = n / kSample ? n / kSample : 1;
@@ -88,7 +109,8 @@ inline void settle_trial(LegmHipState& st, bool accepted)
     try { if (accepted) st.impl->acceptMap(); else st.impl->rejectMap(); }
     catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     st.map_is_trial = false; st.trial_pending = false;
-    if (!accepted) { st.trial_gx = st.trial_gy = nullptr; }
+    if (accepted) { st.cur_nonzero = st.trial_active; st.cur_nonzero_valid = true; }     // solver.cpp:304-305: Gx_new.copyTo(Gx)
+    else { st.trial_gx = st.trial_gy = nullptr; }
 }
 
 inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2,
@@ -127,6 +149,9 @@ LEGM::LEGM(const sensor_msgs::CameraInfo& camera_info_msg, double C_th, int pano
     std::vector<double> lut(3 * bv.size());
     for (size_t i = 0; i < bv.size(); ++i) { lut[3 * i] = bv[i].x; lut[3 * i + 1] = bv[i].y; lut[3 * i + 2] = bv[i].z; }
     try {
+        // ~LEGM is inline in the reference header (model.h:80): the adapter cannot hook it, so an object at a reused address finds the
+        // previous one's entry — every field of it is reset here, not only the engine
+        g_state[this] = LegmHipState();
         g_state[this].impl.reset(new emba_host::ShardedLEGM(camera_info_msg.width, camera_info_msg.height, lut.data(), C_th, pano_width, pano_height,
                                                             legm_hip_detail::devices_from_env()));
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
@@ -137,14 +162,21 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
 {
     auto& st = g_state[this];
     CHECK(Gx.isContinuous() && Gy.isContinuous() && Gx.type() == CV_64FC1 && num_ev_map.type() == CV_32SC1);
+    if (st.numeric_failure) {
+        // The solve this trial point comes from met a 2x2 block A22m_i that is not positive definite: the reference's inverse() gives inf / nan
+        // there (model.cpp:750), x1 and x2 are NaN, and so are the trajectory and the map handed in here.  Its trial cost is NaN and the step is
+        // rejected (solver.cpp:299, 340-352: lambda *= 10); nothing is evaluated — one NaN residual says the same.
+        st.numeric_failure = false; st.trial_pending = false; st.n_ep = 1;
+        num_ev_map.setTo(0);
+        return VecXd::Constant(1, std::numeric_limits<double>::quiet_NaN());
+    }
     // the sliding window hands the same packet to every LM trial; a new window may reuse the allocation: keyed on content
-    const uint64_t tf = events.empty() ? 0 : events.front().ts.toNSec(), tl = events.empty() ? 0 : events.back().ts.toNSec(),
-                   tm = events.empty() ? 0 : events[events.size() / 2].ts.toNSec();
-    if (st.src != events.data() || st.n != events.size() || st.t_first != tf || st.t_last != tl || st.t_mid != tm) {
+    const uint64_t key = legm_hip_detail::packet_key(events);
+    if (st.src != events.data() || st.n != events.size() || st.src_key != key) {
         st.packet.resize(events.size());
         for (size_t k = 0; k < events.size(); ++k)
             st.packet[k] = {events[k].x, events[k].y, (int64_t)events[k].ts.toNSec(), (bool)events[k].polarity};
-        st.src = events.data(); st.n = events.size(); st.t_first = tf; st.t_last = tl; st.t_mid = tm;
+        st.src = events.data(); st.n = events.size(); st.src_key = key;
     }
     // control poses as quaternions (x,y,z,w) + spline timing exactly as LinearTrajectory stores them (trajectory.cpp:59-64)
     const int K = (int)traj_ptr->size();
@@ -158,10 +190,20 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
     const size_t npix = (size_t)Gx.rows * Gx.cols;
     bool resident = false;
     if (st.map_is_trial && Gx.ptr<unsigned char>() == st.trial_gx && Gy.ptr<unsigned char>() == st.trial_gy) {
-        std::vector<double> s;
-        legm_hip_detail::sample_plane(Gx.ptr<double>(), npix, s); legm_hip_detail::sample_plane(Gy.ptr<double>(), npix, s);
-        resident = (s.size() == st.trial_sample.size()) && std::memcmp(s.data(), st.trial_sample.data(), s.size() * sizeof(double)) == 0;
+        // every value updateMap wrote is compared, and a strided sample of the (zero) rest of the planes
+        const double* gx = Gx.ptr<double>(); const double* gy = Gy.ptr<double>();
+        resident = true;
+        for (size_t i = 0; i < st.trial_active.size() && resident; ++i) {
+            const uint32_t p = st.trial_active[i];
+            resident = std::memcmp(&gx[p], &st.trial_gxy[2 * i], sizeof(double)) == 0 && std::memcmp(&gy[p], &st.trial_gxy[2 * i + 1], sizeof(double)) == 0;
+        }
+        if (resident) {
+            std::vector<double> smp;
+            legm_hip_detail::sample_plane(gx, npix, smp); legm_hip_detail::sample_plane(gy, npix, smp);
+            resident = (smp.size() == st.trial_sample.size()) && std::memcmp(smp.data(), st.trial_sample.data(), smp.size() * sizeof(double)) == 0;
+        }
     }
+    if (!resident) st.cur_nonzero_valid = false;    // a map this object did not produce: nothing is known about where it is zero
     if (!resident && st.map_is_trial) legm_hip_detail::settle_trial(st, false);   // some other map: the pending trial is void
     try {
         std::vector<double> ep = st.impl->evaluateDataError(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
@@ -222,12 +264,23 @@ void LEGM::solveNormalEq(const MatXd& A11, const MatXd& A12, const std::vector<M
     const bool fix_first_pose = A11.rows() == 3 * st.K - 3;          // solver.cpp:156-165 dropped the first control pose
     legm_hip_detail::settle_trial(st, false);       // solveNormalEq again without a formNormalEq in between: the trial was rejected
     std::vector<double> v1, v2;
-    try { st.impl->solveNormalEq(lambda, fix_first_pose, v1, v2); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    st.numeric_failure = false;
+    try { st.impl->solveNormalEq(lambda, fix_first_pose, v1, v2); }
+    catch (const emba_host::StatusError& e) {
+        // EMBA_ERR_NUMERIC: a 2x2 block A22m_i is not positive definite.  The reference does not stop there: A22m_i.inverse() yields inf / nan
+        // (model.cpp:750), S and with it x1 and x2 become NaN, the trial cost is NaN, the step is rejected and lambda grows (solver.cpp:340-352).
+        // Same here: NaN updates, the trial evaluation short-circuited (evaluateDataError above).  Every other status stays fatal.
+        if (e.status != EMBA_ERR_NUMERIC) LOG(FATAL) << e.what();
+        v1.assign(3 * (size_t)st.K, std::numeric_limits<double>::quiet_NaN());
+        v2.assign(2 * st.ne.num_active_pixels, std::numeric_limits<double>::quiet_NaN());
+        st.numeric_failure = true;
+    }
+    catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     const int skip = fix_first_pose ? 3 : 0;
     x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
     x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());
     st.x2_sample.clear(); legm_hip_detail::sample_plane(v2.data(), v2.size(), st.x2_sample);
-    st.x2_size = v2.size(); st.x2_on_device = true;
+    st.x2_size = v2.size(); st.x2_on_device = !st.numeric_failure;
 }
 
 std::pair<int, double> LEGM::solveNormalEqCG(const MatXd& A11, const MatXd& A12, const std::vector<Mat2d>& A22_blocks, const VecXd& b1,
@@ -266,16 +319,30 @@ void LEGM::updateMap(cv::Mat& Gx_new, cv::Mat& Gy_new, const VecXd& x2, const do
         legm_hip_detail::sample_plane(x2.data(), (size_t)x2.size(), s2);
         resident = s2.size() == st.x2_sample.size() && std::memcmp(s2.data(), st.x2_sample.data(), s2.size() * sizeof(double)) == 0;
     }
+    double* gx = Gx_new.ptr<double>(); double* gy = Gy_new.ptr<double>();
+    const size_t npix = (size_t)Gx_new.rows * Gx_new.cols;
+    // zero the planes: everything (two memsets of H x W doubles), or — when the clones are known to be the map an accepted trial of this
+    // object produced — just that trial's active pixels, the only places where they are not zero already
+    if (st.cur_nonzero_valid) for (uint32_t p : st.cur_nonzero) { gx[p] = 0.0; gy[p] = 0.0; }
+    else { std::memset(gx, 0, npix * sizeof(double)); std::memset(gy, 0, npix * sizeof(double)); }
+    if (st.numeric_failure) {
+        // x2 is NaN (see solveNormalEq): the reference's loop writes Gx + damping * NaN into the active pixels and zero elsewhere
+        // (model.cpp:863-903); the device is not touched, the trial evaluation that follows is short-circuited
+        for (size_t p : active_pix_idxes) { gx[p] = std::numeric_limits<double>::quiet_NaN(); gy[p] = std::numeric_limits<double>::quiet_NaN(); }
+        return;       // (these clones are dropped with the rejected step; the caller's current map is what it was)
+    }
     try {
         if (resident) st.impl->updateMapResident(damping_factor);
         else { std::vector<double> v2(x2.data(), x2.data() + x2.size()); st.impl->updateMap(v2, damping_factor); }
-        st.impl->downloadMap(Gx_new.ptr<double>(), Gy_new.ptr<double>());
+        // the trial map is zero outside the active pixels (model.cpp:892-901): 16 B x P cross PCIe instead of 16 B x H x W
+        st.impl->mapAtActive(st.trial_gxy);
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    st.trial_active = st.ne.active_pix_idxes;
+    for (size_t i = 0; i < st.trial_active.size(); ++i) { gx[st.trial_active[i]] = st.trial_gxy[2 * i]; gy[st.trial_active[i]] = st.trial_gxy[2 * i + 1]; }
     st.map_is_trial = true; st.trial_pending = false;
     st.trial_gx = Gx_new.ptr<unsigned char>(); st.trial_gy = Gy_new.ptr<unsigned char>();
     st.trial_sample.clear();
-    const size_t npix = (size_t)Gx_new.rows * Gx_new.cols;
-    legm_hip_detail::sample_plane(Gx_new.ptr<double>(), npix, st.trial_sample); legm_hip_detail::sample_plane(Gy_new.ptr<double>(), npix, st.trial_sample);
+    legm_hip_detail::sample_plane(gx, npix, st.trial_sample); legm_hip_detail::sample_plane(gy, npix, st.trial_sample);
 }
 
 }  // namespace EMBA

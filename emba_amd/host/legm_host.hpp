@@ -18,6 +18,13 @@
 
 namespace emba_host {
 
+// what check() throws: the status of the C ABI call rides along, so that a caller can tell EMBA_ERR_NUMERIC (a 2x2 block that is not positive
+// definite: the reference carries on with inf / nan and loses the step) from a real failure
+struct StatusError : std::runtime_error {
+    emba_status status;
+    StatusError(emba_status st, const std::string& msg) : std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + msg), status(st) {}
+};
+
 struct Event {              // dvs_msgs::Event: uint16 x, uint16 y, time ts, bool polarity
     uint16_t x, y;
     int64_t t_ns;           // ts.toNSec()
@@ -107,7 +114,7 @@ private:
 
     [[noreturn]] static void fatal(emba_status st, const char* msg)
     {   // the reference aborts through glog CHECK / LOG(FATAL); callers that link glog can catch and LOG(FATAL)
-        throw std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + (msg ? msg : ""));
+        throw StatusError(st, msg ? msg : "");
     }
     void check(emba_status st) { if (st != EMBA_OK) fatal(st, emba_last_error(ctx_)); }
 

@@ -26,7 +26,7 @@ public:
         cfg.bearing_lut = bearing_lut; cfg.C_th = C_th; cfg.event_batch = 100; cfg.outlier_px = 10.0;
         std::vector<int32_t> dev(devices.begin(), devices.end());
         const emba_status st = emba_group_create(&cfg, dev.data(), (int32_t)dev.size(), &g_);
-        if (st != EMBA_OK) throw std::runtime_error("emba_group_create status " + std::to_string((int)st) + ": " + emba_last_error(nullptr));
+        if (st != EMBA_OK) throw StatusError(st, std::string("emba_group_create: ") + emba_last_error(nullptr));
     }
     ~ShardedLEGM() { emba_group_destroy(g_); }
     ShardedLEGM(const ShardedLEGM&) = delete;
@@ -128,6 +128,8 @@ public:
     void acceptMap() { check(emba_group_map_accept(g_)); }
     void rejectMap() { check(emba_group_map_reject(g_)); }
     void downloadMap(double* Gx, double* Gy) { check(emba_group_download_map(g_, Gx, Gy)); }
+    // the trial map at the active pixels only — it is zero everywhere else (model.cpp:892-901): gxy[2i] = Gx[active_i], gxy[2i+1] = Gy[active_i]
+    void mapAtActive(std::vector<double>& gxy) { gxy.assign(P_ ? 2 * P_ : 1, 0.0); check(emba_group_get_map_active(g_, gxy.data(), P_)); gxy.resize(2 * P_); }
 
     emba_group* group() { return g_; }
 
@@ -135,22 +137,35 @@ private:
     static int irls_code(const std::string& t) { return t == "cauchy" ? 2 : t == "huber" ? 1 : 0; }
     void check(emba_status st)
     {   // the reference aborts through glog CHECK / LOG(FATAL); callers that link glog can catch and LOG(FATAL)
-        if (st != EMBA_OK) throw std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + emba_group_last_error(g_));
+        if (st != EMBA_OK) throw StatusError(st, emba_group_last_error(g_));
     }
-    // the sliding window hands the same packet to every LM trial: registered once per CONTENT (allocation, size, first / last timestamp —
-    // a window that reuses the allocation with new events of equal count differs in its timestamps)
+    // the sliding window hands the same packet to every LM trial: registered once per CONTENT.  The key is the allocation, the size and a hash
+    // over 4096 events spread evenly through the packet (all four fields) plus the first and the last one: a window that reuses the allocation
+    // with other events of equal count — a re-subsampled window, say — differs at nearly every position, so it cannot hide from the sample;
+    // hashing every event would cost more per call (16 MB at 1 M events) than the evaluation it guards.
+    static uint64_t packetKey(const EventPacket& ev)
+    {
+        uint64_t h = 0xCBF29CE484222325ull ^ (uint64_t)ev.size();
+        auto mix = [&](const Event& e) {
+            h ^= (uint64_t)e.t_ns; h *= 0x100000001B3ull; h ^= ((uint64_t)e.x << 32) | ((uint64_t)e.y << 8) | (e.polarity ? 1u : 0u); h *= 0x100000001B3ull;
+        };
+        if (ev.empty()) return h;
+        const size_t step = ev.size() / 4096 ? ev.size() / 4096 : 1;
+        for (size_t i = 0; i < ev.size(); i += step) mix(ev[i]);
+        mix(ev.back());
+        return h;
+    }
     void ensureEvents(const EventPacket& ev)
     {
-        const Event* d = ev.data();
-        const int64_t tf = ev.empty() ? 0 : ev.front().t_ns, tl = ev.empty() ? 0 : ev.back().t_ns, tm = ev.empty() ? 0 : ev[ev.size() / 2].t_ns;
-        if (have_ev_ && d == ev_ptr_ && ev.size() == ev_n_ && tf == ev_t0_ && tl == ev_t1_ && tm == ev_tm_) return;
+        const uint64_t key = packetKey(ev);
+        if (have_ev_ && ev.data() == ev_ptr_ && ev.size() == ev_n_ && key == ev_key_) return;
         setEvents(ev);
-        have_ev_ = true; ev_ptr_ = d; ev_n_ = ev.size(); ev_t0_ = tf; ev_t1_ = tl; ev_tm_ = tm;
+        have_ev_ = true; ev_ptr_ = ev.data(); ev_n_ = ev.size(); ev_key_ = key;
     }
     emba_group* g_ = nullptr;
     int W_, H_, K_ = 0;
     size_t P_ = 0, n_inliers_ = 0;
-    bool have_ev_ = false; const Event* ev_ptr_ = nullptr; size_t ev_n_ = 0; int64_t ev_t0_ = 0, ev_t1_ = 0, ev_tm_ = 0;
+    bool have_ev_ = false; const Event* ev_ptr_ = nullptr; size_t ev_n_ = 0; uint64_t ev_key_ = 0;
 };
 
 }  // namespace emba_host

@@ -225,6 +225,7 @@ class LEGM:
         """model.cpp:689-719, applied to the device-resident pack; returns the updated blocks (call once per formNormalEq)."""
         return self._finish(alpha, dense_A12)
 
+    keeps_equations_on_reject = True   # rejectMap / rejectTrial make the equations formed before the trial current again (second record set)
     async_phases = True            # eval_finish(sync=False) / form_active(thres, sync=False): the LM loop's only synchronisations are costs() and the solve
     supports_resident_x2 = True    # solveNormalEq[CG](..., resident_x2=True) returns x2 = None; updateMap(None, damping) applies the device copy
 

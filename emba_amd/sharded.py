@@ -274,6 +274,7 @@ class ShardedModel:
     def form_finish(self, alpha):
         self.sh.form(self._thres, alpha, *self.cost)
 
+    keeps_equations_on_reject = True
     supports_resident_x2 = True     # solver.solve_time_window: x2 stays a device tensor between solveNormalEq and updateMap
 
     def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):

@@ -39,6 +39,50 @@ class LMResult:
     log: list = field(default_factory=list)      # (iter, log10(lambda), cost_min, cost_new, accepted)
 
 
+class RuntimeLog:
+    """The run-time records EMBA::solveTimeWindow appends under <result_dir>/final_results (solver.cpp:105-151 runtime_formEqs.txt,
+    :205-223 runtime_solveEqs.txt, :271-291 runtime_objFuncs.txt, :196-202 CG_iterations.txt, :170-178 + emba.cpp:223 iterations.txt),
+    in the reference's line formats.  Like its function-static counters, the totals run over all the windows of a process: keep ONE object per
+    run and pass it to every solve_time_window.  The reference casts each duration to whole milliseconds before summing; the device path's
+    phases are shorter than that, so the sums here are of the unrounded seconds (stated, not hidden: same fields, finer values)."""
+
+    def __init__(self, result_dir):
+        import os
+        self.dir = os.path.join(result_dir, "final_results")
+        os.makedirs(self.dir, exist_ok=True)
+        self.n = dict(formEqs=0, solveEqs=0, obj_func=0)
+        self.t = dict(formEqs=0.0, solveEqs=0.0, obj_func=0.0)
+        self.window = 0
+        open(os.path.join(self.dir, "iterations.txt"), "w").close()          # emba.cpp:223 opens it afresh
+
+    def _app(self, name, line):
+        import os
+        with open(os.path.join(self.dir, name), "a") as f:
+            f.write(line + "\n")
+
+    def new_window(self):                                                    # solver.cpp:55-59
+        self.window += 1
+        self._app("iterations.txt", f"window #{self.window}")
+        self._app("iterations.txt", "---------------------------------------------------------")
+
+    def add(self, key, it, seconds, Np=None):
+        self.n[key] += 1; self.t[key] += seconds
+        n, tot = self.n[key], self.t[key]
+        if key == "formEqs":
+            self._app("runtime_formEqs.txt", f"iter #{it} count_formEqs = {n} sec_total_formEqs = {tot:.6g} sec_average_formEqs = {tot / n:.6g}")
+        elif key == "solveEqs":
+            self._app("runtime_solveEqs.txt", f"iter #{it} count_solveEqs = {n} sec_total_solveEqs = {tot:.9g} sec_average_solveEqs = {tot / n:.9g}")
+        else:
+            self._app("runtime_objFuncs.txt", f"iter #{it} count_obj_func = {n} sec_total_obj_func = {tot:.9g} sec_average_obj_func = {tot / n:.9g} Np = {Np}")
+
+    def iteration(self, it, lam, cost_min, cost_new, cost_data, cost_reg):
+        self._app("iterations.txt", f"iter #{it}:  log10(lambda) = {np.log10(lam):g}  cost_min^2 = {cost_min:g}  cost_new^2 = {cost_new:g}"
+                                    f"  cost_data = {cost_data:g}  cost_reg = {cost_reg:g}")
+
+    def cg(self, it, iters, err):
+        self._app("CG_iterations.txt", f"iter #{it} iter_times = {iters} error = {err:g}")
+
+
 class _Phases:
     """The three things the loop asks of the model, through the reference-shaped methods (evaluateDataError returns ep and the count
     map to the host, as LEGM::evaluateDataError does) or, with resident=True, through the phase-level calls that leave both in HBM."""
@@ -62,8 +106,10 @@ class _Phases:
             m.evaluateDataError(traj, Gx, Gy, None, True, self.nem)
         if hasattr(m, "costs"):      # both reductions, one synchronisation
             d, r = m.costs(self.cost_type, self.ba.eta, self.ba.alpha)
-            return d + r
-        return m.dataCost(self.cost_type, self.ba.eta) + m.regCost(self.ba.alpha)
+        else:
+            d, r = m.dataCost(self.cost_type, self.ba.eta), m.regCost(self.ba.alpha)
+        self.last_costs = (d, r)
+        return d + r
 
     def form(self, K):
         m, ba = self.m, self.ba
@@ -82,9 +128,25 @@ class _Phases:
             m.applyL2Reg(ba.alpha)                                                   # :130
 
 
-def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSettings(), verbose=False, resident=False):
+def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSettings(), verbose=False, resident=False, runtime_log=None):
     """model: emba_amd.LEGM.  The refined map stays on the device (model.downloadMap()); returns LMResult.
-    resident=True keeps residuals and count map in HBM too (only costs, counts and the 3K pose increments reach the host)."""
+    resident=True keeps residuals and count map in HBM too (only costs, counts and the 3K pose increments reach the host).
+    runtime_log: a RuntimeLog — the reference's runtime_*.txt / iterations.txt records (each timed phase then ends in a host synchronisation,
+    as it does in the reference's synchronous calls)."""
+    import time
+    rl = runtime_log
+    if rl is not None:
+        rl.new_window()
+
+    def timed(key, it_, fn, Np=None):
+        if rl is None:
+            return fn()
+        t0 = time.perf_counter()
+        out = fn()
+        if hasattr(model, "sync"):
+            model.sync()
+        rl.add(key, it_, time.perf_counter() - t0, Np() if callable(Np) else Np)
+        return out
     lam, lam_max, lam_min = 1e-3, 1e3, 1e-300                                       # solver.cpp:15-17
     cost_min_old = cost_new = cost_min = 1e99
     it, count_tol, decreased = 0, 0, True
@@ -97,14 +159,20 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
         if decreased:
             if it == 0:                                                              # :69-91, uploads the initial map once
                 cost_min = ph.evaluate(traj, Gx, Gy)
-            ph.form(traj.size())                                                     # :93-131
+                cost_parts = ph.last_costs
+            timed("formEqs", it, lambda: ph.form(traj.size()))                       # :93-131 (+ :105-151 runtime_formEqs.txt)
+        if rl is not None:                                                           # :170-178
+            rl.iteration(it, lam, cost_min, cost_new, *cost_parts)
         # x2 goes from the solver to updateMap and nowhere else (solver.cpp:193-239): a device model keeps it in HBM (x2 is None here)
         rkw = dict(resident_x2=True) if getattr(model, "supports_resident_x2", False) else {}
         try:
             if ba.use_CG:
-                x1, x2 = model.solveNormalEqCG(lam, fix_first_pose=ba.first_time_window, **rkw)[:2]   # :196-202
+                res = timed("solveEqs", it, lambda: model.solveNormalEqCG(lam, fix_first_pose=ba.first_time_window, **rkw))   # :196-202
+                x1, x2 = res[:2]
+                if rl is not None and len(res) >= 4:
+                    rl.cg(it, res[2], res[3])
             else:
-                x1, x2 = model.solveNormalEq(lam, fix_first_pose=ba.first_time_window, **rkw)         # :190-194
+                x1, x2 = timed("solveEqs", it, lambda: model.solveNormalEq(lam, fix_first_pose=ba.first_time_window, **rkw))   # :190-194
         except Exception as e:   # noqa: BLE001
             # EMBA_ERR_NUMERIC: a 2x2 block A22_i + lambda*diag(A22_i) is not positive definite.  The reference's A22m_i.inverse()
             # (model.cpp:750) returns inf / nan there, x1 / x2 and the trial cost become NaN, `cost_new < cost_min` is false and the step is
@@ -120,7 +188,9 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             continue
         traj_new = emba_io.incremental_update(traj, x1, ba.first_time_window)        # :226-234
         model.updateMap(x2, ba.damping_factor)                                       # :237-240 (trial map, on the device)
-        cost_new = ph.evaluate(traj_new)                                             # :251-268
+        n_act = (lambda: model.last_counts()[1]) if hasattr(model, "last_counts") else None
+        cost_new = timed("obj_func", it + 1, lambda: ph.evaluate(traj_new), n_act)   # :251-268 (+ :271-291 runtime_objFuncs.txt, after iter += 1)
+        cost_parts_new = ph.last_costs
         it += 1
         accepted = cost_new < cost_min
         log.append((it, float(np.log10(lam)), cost_min, cost_new, accepted))
@@ -132,6 +202,7 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             model.acceptMap()
             lam /= 10
             cost_min_old, cost_min = cost_min, cost_new
+            cost_parts = cost_parts_new
             if abs(1 - cost_min / (cost_min_old + 1e-10)) < lm.tol_fun:
                 count_tol += 1
                 if count_tol >= lm.num_times_tol_fun_sat:
@@ -142,6 +213,11 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             # trial evaluation wrote a SECOND record set; rejectMap (emba_map_reject) makes the set the equations were formed from current
             # again — pack, active set and records untouched — so a rejection costs one evaluation, like in the reference.
             model.rejectMap()
+            if not getattr(model, "keeps_equations_on_reject", False):
+                # a model written to the older contract (its trial evaluation overwrites the state its equations were formed from): back to
+                # the accepted point the long way — evaluate there again and re-form
+                ph.evaluate(traj)
+                ph.form(traj.size())
             lam *= 10
             count_tol = 0
     return LMResult(traj, cost_min, it, False, log)

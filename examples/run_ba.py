@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from emba_amd import LEGM, io as eio, so3, synth                      # noqa: E402
 from emba_amd.legm import LinearTrajectory                            # noqa: E402
-from emba_amd.solver import BASettings, LMSettings, solve_time_window  # noqa: E402
+from emba_amd.solver import BASettings, LMSettings, RuntimeLog, solve_time_window  # noqa: E402
 
 
 def main():
@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--eta", type=float, default=0.1)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--runtime-log", action="store_true", help="write the reference's run-time records under <out>/final_results (every timed phase then ends in a host synchronisation)")
     ap.add_argument("--sharded", action="store_true", help="go through the multi-GPU host (ShardedLEGM / ShardedModel) even with one rank")
     a = ap.parse_args()
     if a.alpha is None:
@@ -94,7 +95,9 @@ def main():
     if rank == 0:
         print(f"{events.size()} events, {traj.size()} control poses, panorama {H}x{W}" + (f", {world} rank(s) through the sharded host" if legm is not model else ""))
     t0 = time.time()
-    res = solve_time_window(model, traj, events, Gx, Gy, ba, LMSettings(max_num_iter=a.max_iter), verbose=a.verbose, resident=True)
+    # the reference's run-time records (final_results/runtime_{formEqs,solveEqs,objFuncs}.txt, iterations.txt: solver.cpp:105-151, 170-178, 205-223, 271-291)
+    rlog = RuntimeLog(a.out) if (a.runtime_log and rank == 0) else None
+    res = solve_time_window(model, traj, events, Gx, Gy, ba, LMSettings(max_num_iter=a.max_iter), verbose=a.verbose, resident=True, runtime_log=rlog)
     dt = time.time() - t0
     if rank != 0:                                           # every rank holds the same result; rank 0 writes it
         import torch.distributed as dist

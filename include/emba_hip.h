@@ -209,6 +209,10 @@ emba_status emba_map_reject(emba_ctx* ctx);
  * formNormalEq needs a new evaluation first (count map and per-pixel sums are the trial's). */
 emba_status emba_trial_reject(emba_ctx* ctx);
 emba_status emba_download_map(emba_ctx* ctx, double* Gx_host, double* Gy_host);
+/* The map the next evaluation would use (the trial map after emba_update_map), at the P pixels of the current active set only:
+ * gxy_host[2i] = Gx[active_i], gxy_host[2i+1] = Gy[active_i].  By model.cpp:892-901 the trial map is ZERO at every other pixel, so this is the
+ * whole result of LEGM::updateMap in 16 B x P instead of 16 B x H x W (the drop-in adapter zero-fills the caller's Mats around it). */
+emba_status emba_get_map_active(emba_ctx* ctx, double* gxy_host, size_t cap_P);
 
 /* Intensity panorama from the gradient map: poisson_reconstruction::reconstructFromGradient,
  * src/image_rec/poisson_reconstruction.cpp:9-50 + pde::poisolve (Dirichlet, zero boundary), src/image_rec/laplace.cpp:587-797,
@@ -382,6 +386,7 @@ emba_status emba_group_update_map(emba_group* g, const double* x2_host, double d
 emba_status emba_group_map_accept(emba_group* g);
 emba_status emba_group_map_reject(emba_group* g);
 emba_status emba_group_download_map(emba_group* g, double* Gx_host, double* Gy_host);
+emba_status emba_group_get_map_active(emba_group* g, double* gxy_host, size_t cap_P);   /* emba_get_map_active on rank 0's replica */
 emba_status emba_group_trial_reject(emba_group* g);   /* emba_trial_reject on every rank (emba_group_map_reject includes it) */
 
 #ifdef __cplusplus

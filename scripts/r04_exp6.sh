@@ -6,6 +6,8 @@ one() {  # label, env...
 import sys,json
 d=json.loads(sys.stdin.readline()); r=d['roofline']; print('%-34s step %7.1f us  warp %6.1f us  gram %6.1f us'%('$lbl', d['ms_per_step']*1e3, r['kernel_ms']*1e3, r['accumulate_kernel_ms']*1e3))" | tee -a $L
 }
-one "default" X=1
-for v in $(ls build_variants/u*.so); do one "$v" EMBA_LIB=$PWD/$v; done
-one "default again" X=1
+one "default (one set)" X=1
+one "two sets" EMBA_STEP_ONE_SET=0
+one "one set, 100 steps" STEPS=100
+one "two sets, 100 steps" EMBA_STEP_ONE_SET=0 STEPS=100
+one "two sets, 20 steps" EMBA_STEP_ONE_SET=0 STEPS=20

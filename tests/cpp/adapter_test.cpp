@@ -10,9 +10,11 @@
 #define EMBA_LEGM_ADAPTER_SKETCH
 #include "emba_amd/host/legm_adapter.hpp"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 #include <vector>
 
 template <class T> static std::vector<T> rd(FILE* f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
@@ -85,15 +87,44 @@ int main(int argc, char** argv)
     table.resize((size_t)sw * sh);
     for (size_t i = 0; i < table.size(); ++i) table[i] = {lut[3 * i], lut[3 * i + 1], lut[3 * i + 2]};
     sensor_msgs::CameraInfo info; info.width = sw; info.height = sh;
-    EMBA::LEGM model(info, C_th, W, H);
 
     EMBA::EventPacket events(n);
-    for (int64_t k = 0; k < n; ++k) { events[k].x = x[k]; events[k].y = y[k]; events[k].ts.sec = (uint32_t)(t[k] / 1000000000LL); events[k].ts.nsec = (uint32_t)(t[k] % 1000000000LL); events[k].polarity = pol[k]; }
+    auto fill_events = [&](bool scrambled) {
+        for (int64_t k = 0; k < n; ++k) {
+            events[k].x = x[k]; events[k].y = y[k]; events[k].ts.sec = (uint32_t)(t[k] / 1000000000LL); events[k].ts.nsec = (uint32_t)(t[k] % 1000000000LL); events[k].polarity = pol[k];
+            // "another window in the same allocation": same count, same first / middle / last event, other pixels in between
+            if (scrambled && k > 0 && k != n / 2 && k != n - 1) { events[k].x = (uint16_t)((x[k] + 7) % sw); events[k].y = (uint16_t)((y[k] + 3) % sh); }
+        }
+    };
     LinTraj* traj = new LinTraj();
     for (int i = 0; i < K; ++i) traj->q.emplace_back(knots[4 * i + 3], knots[4 * i], knots[4 * i + 1], knots[4 * i + 2]);
     traj->mockSetTiming(t0, dt);
     cv::Mat Gx = cv::Mat::zeros(H, W, CV_64FC1), Gy = cv::Mat::zeros(H, W, CV_64FC1);
     std::memcpy(Gx.ptr<double>(), gx.data(), gx.size() * 8); std::memcpy(Gy.ptr<double>(), gy.data(), gy.size() * 8);
+
+    // ---- a PREDECESSOR at the address the model under test will live at (a sliding-window host that re-creates its model): it evaluates another
+    // packet in the same allocation, forms, solves and leaves a trial map + a resident x2 behind, then goes away.  ~LEGM is inline in the
+    // reference header, so the adapter never sees the destruction: whatever it keyed by `this` must not reach the successor.
+    alignas(EMBA::LEGM) static unsigned char slot[sizeof(EMBA::LEGM)];
+    {
+        fill_events(true);
+        EMBA::LEGM* pre = new (slot) EMBA::LEGM(info, C_th, W, H);
+        cv::Mat nm = cv::Mat::zeros(H, W, CV_32SC1);
+        EMBA::MatXd a11, a12; std::vector<EMBA::Mat2d> a22; EMBA::VecXd c1, c2, y1, y2;
+        std::set<size_t> act, inact;
+        EMBA::VecXd e0 = pre->evaluateDataError(traj, Gx, Gy, events, true, nm);
+        pre->formNormalEq(a11, a12, a22, c1, c2, e0, K, nm, thres, act, inact);
+        pre->applyL2Reg(a22, c2, act, alpha, Gx, Gy);
+        pre->solveNormalEq(a11, a12, a22, c1, c2, 1e-2, y1, y2);
+        cv::Mat gxn = Gx.clone(), gyn = Gy.clone();
+        pre->updateMap(gxn, gyn, y2, 1.0, act, inact);
+        pre->~LEGM();
+    }
+    fill_events(false);                              // the real packet, in the SAME allocation (same size, same first / middle / last timestamp)
+    EMBA::LEGM& model = *new (slot) EMBA::LEGM(info, C_th, W, H);
+    const bool timing = getenv("ADAPTER_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_iter = now();
 
     // ---- solveTimeWindow's state (solver.cpp:15-61)
     double lambda = 1e-3; const double lambda_max = 1e3, lambda_min = 1e-300;
@@ -134,6 +165,7 @@ int main(int argc, char** argv)
         iter += 1;
         const bool accepted = cost_new < cost_min;
         printf("LM %d %.1f %.17g %.17g %d %zu %d\n", iter, std::log10(lambda), cost_min, cost_new, accepted ? 1 : 0, active.size(), cg_it);
+        if (timing) { const auto t1 = now(); printf("TIME %d %.3f ms (whole LM iteration through the adapter, incl. the loop's own Mat clones / copies)\n", iter, std::chrono::duration<double, std::milli>(t1 - t_iter).count()); }
         if (accepted) {                                                                                      // :299-339
             cost_has_decreased = true;
             delete traj; traj = traj_new;
@@ -144,6 +176,7 @@ int main(int argc, char** argv)
             cost_has_decreased = false; delete traj_new;
             lambda *= 10; count_tol = 0;
         }
+        t_iter = now();
     }
     printf("END %d %d %.17g\n", iter, converged ? 1 : 0, cost_min);
     for (int i = 0; i < K; ++i) printf("KNOT %.17g %.17g %.17g %.17g\n", traj->q[i].x(), traj->q[i].y(), traj->q[i].z(), traj->q[i].w());
@@ -151,5 +184,6 @@ int main(int argc, char** argv)
     for (size_t i = 0; i < np; ++i) { sx += Gx.ptr<double>()[i] * (double)((i % 7) + 1); sy += Gy.ptr<double>()[i] * (double)((i % 5) + 1); }
     printf("MAP %.17g %.17g\n", sx, sy);
     delete traj;
+    model.~LEGM();
     return 0;
 }

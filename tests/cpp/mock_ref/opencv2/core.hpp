@@ -25,6 +25,7 @@ public:
         if (dst.buf_ && buf_ && dst.buf_->size() == buf_->size() && dst.type_ == type_) { std::memcpy(dst.buf_->data(), buf_->data(), buf_->size()); dst.rows = rows; dst.cols = cols; }
         else dst = clone();
     }
+    void setTo(int v) { if (buf_) std::memset(buf_->data(), v, buf_->size()); }     // (cv::Mat::setTo(Scalar): the tests only use 0)
     bool isContinuous() const { return true; }
     int type() const { return type_; }
     template <class T> T* ptr() { return buf_ ? reinterpret_cast<T*>(buf_->data()) : nullptr; }

@@ -47,6 +47,8 @@ class OracleModel:
     """The CPU oracle behind the method names emba_amd.solver.solve_time_window drives, so the SAME LM loop can run on the
     oracle and on the device path and their iteration logs compared (test infrastructure only)."""
 
+    keeps_equations_on_reject = True     # (rejectMap below brings the oracle's state back itself where it has to)
+
     def __init__(self, O, w, sparse=False, use_cg=False):
         """sparse: solve from the sparse A12 factors (sizes where the dense 3K x 2P matrix does not fit); use_cg: solveNormalEqCG."""
         self.O = O

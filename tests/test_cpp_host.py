@@ -119,6 +119,11 @@ def test_adapter_runs_the_reference_call_order(tmp_path, hip_lib, oracle_mod, de
     _write_case(p, wi, o)           # (only the inputs are read by adapter_test)
     max_iter = 8
     env = dict(os.environ); env["EMBA_HIP_DEVICES"] = devices
+    if devices == "0,0" and use_irls:
+        # formNormalEqIRLS declares its cost AFTER the first evaluation — the gathered (quadratic) A22 | b2 rows are then NOT final and
+        # must not travel through the split exchange 2 while emba_form_accumulate rebuilds them from the records: forced on here (it only switches
+        # itself on from 3 M events per rank)
+        env["EMBA_X2_SPLIT"] = "1"
     r = subprocess.run([ADAPTER_EXE, str(p), str(max_iter), "1" if use_irls else "0", "1" if use_cg else "0"], capture_output=True, text=True, timeout=300, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr

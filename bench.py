@@ -238,22 +238,25 @@ def main():
     for _ in range(n_extra):
         step()
     barrier()
-    # ... and until the step time has SETTLED: a fresh box has been seen to run its first few hundred steps at half speed (206 vs 103 us per step
-    # in the first bench process after the box came up: clocks, lazily loaded code objects).  Blocks of steps are timed between barriers until two
-    # consecutive blocks agree within 3 % (at most 30 blocks: ~1 s); the block time is all-reduced (MAX), so every rank runs the same count.
+    # ... and until the step time has SETTLED, and at least 1000 steps have run in all.  Round 4 (scripts/r04_dbg.py): the HIP runtime stalls the
+    # launching thread ONCE per process for 32-68 ms at a fixed number of kernel launches — step 848-850 of this loop, whatever the step's size or
+    # the stream (and for ~1.2 ms at step 460-462); nothing like it in the following 3000 steps.  A 20-step timed region that happens to contain
+    # it reads 3 ms per step instead of 0.1.  Blocks of steps are timed between barriers until two consecutive blocks agree within 3 % AND the
+    # thousand is complete; the block time is all-reduced (MAX), so every rank runs the same count.
     n_blk = int(min(max(np.ceil(0.02 / max(t_w, 1e-6)), 8), 400))
-    prev = None
-    for _ in range(30):
+    prev, done = None, args.warmup + 3 + n_extra
+    for _ in range(200):
         t_b = time.perf_counter()
         for _ in range(n_blk):
             step()
         barrier()
+        done += n_blk
         t_b = (time.perf_counter() - t_b) / n_blk
         if use_dist:
             tt = torch.tensor([t_b], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_b = float(tt.item())
-        if prev is not None and abs(t_b - prev) <= 0.03 * prev:
+        if prev is not None and abs(t_b - prev) <= 0.03 * prev and done >= 1000:
             break
         prev = t_b
     # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region (at most 16 samples), each sample in
@@ -267,7 +270,11 @@ def main():
         if timed:
             slots.append(len(slots))
         m.enable_kernel_timing(timed, slots[-1] if timed else 0)
-        n_inl, _ = step()
+        if os.environ.get("BENCH_DEBUG"):
+            t_s = time.perf_counter(); n_inl, _ = step(); t_s = time.perf_counter() - t_s
+            if t_s > 1e-3: print(f"[bench debug] step {i} took {t_s * 1e3:.2f} ms (timed={timed})", file=sys.stderr)
+        else:
+            n_inl, _ = step()
     barrier()
     elapsed = time.perf_counter() - t0
     m.enable_kernel_timing(False)

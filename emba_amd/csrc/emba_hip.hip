@@ -103,6 +103,7 @@ struct emba_ctx {
     uint16_t* d_cp = nullptr; double* d_batch_u = nullptr;                                          // control-pose index (= spline segment) and spline parameter per batch
     double* d_ev_u = nullptr; uint16_t* d_ev_seg = nullptr;                                         // tile order: the same per entry of the device order
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
+    bool chunks_lpt = false;   // the chunk list is sorted longest first and walked in grid order (no XCD-contiguous remapping)
     bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
@@ -415,7 +416,7 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // (at least 5 groups per wave: a workgroup zeroes and flushes its 55-KB LDS tile whatever it has to do — 3 M events: 902 -> 2520 entries per
         // chunk, warp kernel 191 -> 174 us; 5 M: 280 -> 271; from 10 M on the first rule gives more than that anyway)
 #ifndef TILE_MIN_GROUPS
-#define TILE_MIN_GROUPS 5
+#define TILE_MIN_GROUPS 8
 #endif
         chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves * TILE_MIN_GROUPS), (size_t)kWarpNew * kTileWaves * 16);
         std::vector<ChunkDesc> h_chunks;
@@ -430,6 +431,11 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
                 if (d.begin < d.end) h_chunks.push_back(d);
             }
         }
+        // Chunk sizes differ (every bin is cut on its own) and the grid is a few rounds of the chip's workgroup slots: with the longest chunks FIRST the
+        // last round is made of the short ones (longest-processing-time order; workgroups are dispatched in grid order as slots free up).
+        // EMBA_CHUNK_ORDER=bin keeps the bins' order (neighbouring chunks on one XCD).
+        c->chunks_lpt = !(getenv("EMBA_CHUNK_ORDER") && !strcmp(getenv("EMBA_CHUNK_ORDER"), "bin"));
+        if (c->chunks_lpt) std::stable_sort(h_chunks.begin(), h_chunks.end(), [](const ChunkDesc& a, const ChunkDesc& b) { return a.end - a.begin > b.end - b.begin; });
         c->n_chunks = (long)h_chunks.size();
         if ((st = dev_alloc(c, &c->d_chunks, h_chunks.size()))) return st;
         HIP_TRY(c, hipMemcpyAsync(c->d_chunks, h_chunks.data(), h_chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
@@ -728,7 +734,9 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     memset(c->h_pinned, 0, 64);
     CREATE_TRY(hipHostGetDevicePointer((void**)&c->h_pinned_dev, c->h_pinned, 0));
     for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
-    for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt_sets[0][i]));
+    // every slot of the kernel-timing events up front: creating one later can stall the calling thread for tens of milliseconds (round 4: a 38-51 ms
+    // pause inside bench.py's timed loop, once per process, at the first use of a new slot — the runtime growing its signal pool)
+    for (int k = 0; k < 16; ++k) for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt_sets[k][i]));
     CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = c;
@@ -1204,7 +1212,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.stamp = ++c->rec_stamp; c->set_stamp = p.stamp;
         p.marker = c->count_mark = count_marker(p.stamp);
         c->pixacc_clean = false; c->pixacc_consumed = false;
-        p.chunks = c->d_chunks; p.n_chunks = c->n_chunks;
+        p.chunks = c->d_chunks; p.n_chunks = c->n_chunks; p.chunks_linear = c->chunks_lpt ? 1 : 0;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
         else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);

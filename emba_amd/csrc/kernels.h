@@ -277,7 +277,7 @@ struct WarpParams {
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
     uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
     int32_t marker;         // what a touched pixel's count-map entry is set to: count_marker(stamp), negative — never a count, never another evaluation's marker
-    const ChunkDesc* chunks; long n_chunks;   // tiled kernel only
+    const ChunkDesc* chunks; long n_chunks; int chunks_linear;   // tiled kernel only; chunks_linear: chunk = blockIdx (the list is in dispatch order: longest first)
 };
 
 // lane l <- lane l-1 (lane 0 <- 0): one v_mov_b32_dpp wave_shr:1 per dword, no LDS
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
     __shared__ uint32_t s_slot[kTileWaves][kTileRecStage];
     __shared__ uint16_t s_list[kTileWaves][64];
 
-    const long c = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const long c = p.chunks_linear ? (long)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, t = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = tid; k < 6 * kTilePx; k += kTileWaves * 64) (&s_sum[0][0])[k] = 0.0;

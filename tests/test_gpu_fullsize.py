@@ -1,8 +1,11 @@
 """GPU parity at the per-GPU FULL sizes of BASELINE.json's configurations 3-5 (-m gpu), against the CPU oracle:
 
+  config 1  playroom.launch on the shipped calibration (calib/DVS-playroom.yaml: 128x128, f = 91.4015; K = 47, 512x1024 panorama), ~1 M events:
+            * one evaluation + form on 1 M uniform events (tests/test_gpu_parity.py::test_other_configurations_against_oracle)
+            * a short LM loop on ~1 M events simulated from a scene with that camera
   config 3  city.launch shape: 640x480 sensor, K = 97 (4.8 s), 1024x2048 panorama
             * one evaluateDataError + formNormalEq + applyL2Reg on 10 M events
-            * solveTimeWindow to convergence (device-resident LM loop) + Poisson reconstruction on a simulated scene of that shape
+            * solveTimeWindow to convergence (device-resident LM loop) + Poisson reconstruction on >= 10 M events simulated from a scene of that shape
   config 4  town.launch: 40 M events over 8 GPUs -> rank r of 8 holds 5 M events + its per-pixel halo (K = 97)
   config 5  synthetic: 100 M events, K = 256, 2048x4096, 8 GPUs -> rank r of 8 holds 12.5 M events + halo
 
@@ -111,25 +114,26 @@ def test_one_rank_of_eight_at_full_shard_size(gpu, oracle_mod, name, n_total, se
     _compare_blocks(ne, ne_o)
 
 
-def test_city_shape_lm_to_convergence_and_poisson(gpu, oracle_mod):
-    """Config 3 end to end: EMBA::solveTimeWindow (solver.cpp:11-368) to convergence on > 2 M events simulated from a scene with the city
-    shape (640x480, K = 97, 1024x2048), device-resident, then reconstructIntensity — against the same loop on the oracle (Schur solve
-    on the sparse factors), decision for decision."""
-    from emba_amd import synth
-    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+def _lm_against_oracle(oracle_mod, w, ba, lm, poisson):
+    """EMBA::solveTimeWindow on the device (resident) and on the oracle (Schur solve on the sparse factors, evaluation on the host's cores — the
+    omp mode equals the one-thread mode: tests/test_oracle_pinned.py), compared decision for decision."""
+    from emba_amd.solver import solve_time_window
     from helpers import OracleModel
     from oracle import poisson as OP
     from test_lm_solver_cpu import perturbed
-    w = synth.make_scene_workload(pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240, n_steps=200, amp=3.0, n_terms=6, yaw_rate=0.02, max_freq=(40, 20))
-    assert w.events.size() >= 2_000_000, w.events.size()
+    O = oracle_mod
     init = perturbed(w)
-    ba, lm = BASettings(), LMSettings(max_num_iter=8)
     m = _legm(w)
     rg = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, lm, resident=True)
     Gx_d, Gy_d = m.downloadMap()
-    M = m.reconstructIntensity()
-    om = OracleModel(oracle_mod, w, sparse=True)
-    ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, lm)
+    M = m.reconstructIntensity() if poisson else None
+    m.close()
+    O.set_threads(min(O.max_threads(), 16))
+    try:
+        om = OracleModel(O, w, sparse=True)
+        ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, lm)
+    finally:
+        O.set_threads(1)
     assert [e[4] for e in rg.log] == [e[4] for e in ro.log], "accept/reject sequence differs"
     assert rg.iterations == ro.iterations and rg.converged == ro.converged
     for g, o in zip(rg.log, ro.log):
@@ -138,4 +142,29 @@ def test_city_shape_lm_to_convergence_and_poisson(gpu, oracle_mod):
     Gx_o, Gy_o = om.downloadMap()
     assert np.abs(Gx_d - Gx_o).max() < 1e-7 * np.abs(Gx_o).max() and np.abs(Gy_d - Gy_o).max() < 1e-7 * np.abs(Gy_o).max()
     assert rg.cost_min < rg.log[0][2]
-    assert_close(M, OP.reconstruct_from_gradient(Gx_d, Gy_d), "intensity panorama", tight=1e-9)
+    if poisson:
+        assert_close(M, OP.reconstruct_from_gradient(Gx_d, Gy_d), "intensity panorama", tight=1e-9)
+    return rg
+
+
+def test_city_shape_lm_to_convergence_and_poisson(gpu, oracle_mod):
+    """Config 3 end to end AT ITS SIZE (round 4): EMBA::solveTimeWindow (solver.cpp:11-368) to convergence on >= 10 M events simulated from a scene
+    with the city shape (640x480, K = 97, 1024x2048), device-resident, then reconstructIntensity — against the same loop on the oracle."""
+    from emba_amd import synth
+    from emba_amd.solver import BASettings, LMSettings
+    w = synth.make_scene_workload(pano_h=1024, K=97, sensor=(640, 480), focal=200.0 * 640 / 240, n_steps=200, amp=6.6, n_terms=6, yaw_rate=0.02, max_freq=(40, 20))
+    assert w.events.size() >= 10_000_000, w.events.size()
+    rg = _lm_against_oracle(oracle_mod, w, BASettings(), LMSettings(max_num_iter=8), poisson=True)
+    print("city shape:", w.events.size(), "events,", rg.iterations, "LM iterations, converged", rg.converged)
+
+
+def test_playroom_calibration_lm_on_1M_events(gpu, oracle_mod):
+    """Config 1 on the calibration the reference ships (calib/DVS-playroom.yaml:1-7: 128 x 128, fx = fy = 91.4015; launch/playroom.launch: 512 x 1024
+    panorama; a 2.3-s window at dt_knots = 0.05: K = 47) at ~1 M events simulated from a scene seen by that camera: a short LM loop, decision for
+    decision against the oracle loop."""
+    from emba_amd import synth
+    from emba_amd.solver import BASettings, LMSettings
+    w = synth.make_scene_workload(pano_h=512, K=47, sensor=(128, 128), focal=91.4015, n_steps=400, amp=1.65, n_terms=8, yaw_rate=0.5, max_freq=(40, 20))
+    assert 900_000 <= w.events.size() <= 1_400_000, w.events.size()
+    rg = _lm_against_oracle(oracle_mod, w, BASettings(), LMSettings(max_num_iter=5), poisson=False)
+    print("playroom calibration:", w.events.size(), "events,", rg.iterations, "LM iterations")

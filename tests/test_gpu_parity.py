@@ -348,7 +348,7 @@ def test_baseline_size_against_oracle(gpu, oracle_mod):
 
 @pytest.mark.parametrize("cfg", [
     dict(n_events=1500000, pano_h=2048, K=256, sensor=(640, 480), focal=520.0, dt_knots=0.004, thres_valid_pixel=2),   # city/synthetic-like: big sensor, big pano, many knots
-    dict(n_events=300000, pano_h=512, K=47, sensor=(128, 128), focal=91.4015, dt_knots=0.05, t_beg=0.1),  # playroom.launch shape (2.3 s window)
+    dict(n_events=1000000, pano_h=512, K=47, sensor=(128, 128), focal=91.4015, dt_knots=0.05, t_beg=0.1),  # config 1: playroom.launch on calib/DVS-playroom.yaml (128x128, f = 91.4015), 2.3-s window, ~1 M events
     dict(n_events=400000, pano_h=256, K=6, sensor=(32, 24), focal=30.0),                         # dense stream: ~500 events per sensor pixel
     dict(n_events=600000, pano_h=1024, K=201, sensor=(240, 180), focal=200.0, dt_knots=0.05, thres_valid_pixel=2),   # shapes.launch shape: 10 s window, 5 rad sweep (footprint as wide as the panorama)
 ])

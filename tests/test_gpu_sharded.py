@@ -255,6 +255,7 @@ def _rank8_main(shared, rank, w, init, lam, damping, results):
 @pytest.mark.parametrize("name,n_total,sensor,pano_h,K,yaw", [
     ("SCALE workload: 8 x 1 M events", 8_000_000, (240, 180), 1024, 21, 0.5),
     ("town.launch shape: 8 x 5 M events", 40_000_000, (640, 480), 1024, 97, 0.1),
+    ("synthetic 100 M: 8 x 12.5 M events, K = 256, 2048 x 4096", 100_000_000, (240, 180), 2048, 256, 0.5),      # config 5 as a whole protocol (round 4)
 ])
 def test_eight_ranks_at_full_shard_size(oracle_mod, name, n_total, sensor, pano_h, K, yaw):
     """world = 8 through emba_amd.sharded with the real engine (eight contexts on one MI355X, the collectives through the thread stand-in):

@@ -116,7 +116,6 @@ struct emba_ctx {
     bool no_alt_set = false;   // set by emba_step around its evaluation: the step re-forms the equations itself, nothing of the previous ones can be gone back to —
                                // no second record set (+12.8 GB at 100 M events for callers that can never reject)
     int step_fast = 1;   // EMBA_STEP_FAST=0: emba_step keeps the clearing pass in front of every evaluation (A/B)
-    int gram_mode = 0;   // EMBA_GRAM=stream|compact (1 | 2; 0 = by size): which form of the tag-stream Gram kernel runs
     double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     // Two record sets (a rejected LM trial must not cost a re-evaluation).  d_rec / d_tag / set_stamp are the WORKING set: what
@@ -415,10 +414,10 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         size_t chunk = (nd + slots * 8 - 1) / (slots * 8);
         // (at least 5 groups per wave: a workgroup zeroes and flushes its 55-KB LDS tile whatever it has to do — 3 M events: 902 -> 2520 entries per
         // chunk, warp kernel 191 -> 174 us; 5 M: 280 -> 271; from 10 M on the first rule gives more than that anyway)
-#ifndef TILE_MIN_GROUPS
-#define TILE_MIN_GROUPS 8
-#endif
-        chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves * TILE_MIN_GROUPS), (size_t)kWarpNew * kTileWaves * 16);
+        // round 4, with the chunks dispatched longest first: 8 groups per wave up to ~8 M entries (3 M events: 1339 chunks, warp kernel 160 -> 153 us;
+        // 5 M: 257 -> 242), 5 beyond (10 M: 8 groups 493 us, 5 groups 464 — there the first rule decides most chunks anyway)
+        const size_t min_groups = nd < (size_t)8000000 ? 8 : 5;
+        chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves * min_groups), (size_t)kWarpNew * kTileWaves * 16);
         std::vector<ChunkDesc> h_chunks;
         for (size_t k = 0; k < occ.size(); ++k) {
             const uint32_t b = occ[k].first, b0 = occ[k].second, b1 = (k + 1 < occ.size()) ? occ[k + 1].second : (uint32_t)nd;
@@ -483,16 +482,9 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     return EMBA_OK;
 }
 
-// Which form of the tag-stream Gram kernel emba_form_accumulate launches for the current window: a record set that is still cache-resident (what
-// the warp kernel wrote microseconds ago: up to ~200 MB of slots) takes the compact form (live records only, half the stages);
-// EMBA_GRAM=stream|compact overrides.  Shared with emba_form_active, which leaves its gather to that kernel's head in the resident step.
+// the tag stream pays where slots are dead (pixel order: about half of them at the BASELINE workload); in the tile order (dense regime: nearly every
+// slot is live) the warp kernel's scattered 8-B tag stores cost more than the Gram kernel saves (40 M events: +370 vs -180 us)
 bool gram_uses_tags(const emba_ctx* c, bool ep_host) { return c->use_tags && !c->tile_order && !ep_host; }
-bool gram_is_compact(const emba_ctx* c, bool ep_host)
-{
-    if (!gram_uses_tags(c, ep_host) || !c->n_cand) return false;
-    if (c->gram_mode) return c->gram_mode == 2;
-    return (size_t)c->n_cand * kRecStride * sizeof(double) <= ((size_t)200 << 20);
-}
 
 emba_status ensure_pack(emba_ctx* c, int K)
 {
@@ -691,7 +683,6 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_ONE_SET")) c->step_one_set = atoi(sf);
-    if (const char* gm = getenv("EMBA_GRAM")) c->gram_mode = !strcmp(gm, "stream") ? 1 : !strcmp(gm, "compact") ? 2 : 0;
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
 
@@ -1286,10 +1277,13 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
         if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; q.marker = c->count_mark; c->counts_raw = false; }   // launch A turns the markers into counts
         const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
-        // list-driven gather: where it rides in the head of the compact Gram kernel (as a kernel of its own it is no faster than the sweeping write:
-        // 109.6 vs 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison)
-        const bool lists_ok = c->step_consume && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count;
-        const bool lists = lists_ok && (c->step_gather == 1 || (c->step_gather == 2 && gram_is_compact(c, false)));
+        // list-driven gather: it rides in the head of the Gram kernel (as a kernel of its own it is no faster than the sweeping write: 109.6 vs
+        // 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison, 0 the sweeping kernel)
+        // Where it pays (measured, same box, step time with the head vs with the sweeping kernel): 1 M events 101.2 vs 105.7 us, the 1 M-event shard of
+        // the 8 M-event stream 121.8 vs 127, scene-driven 1.17 M events 121 vs 135 — but 1.5 M events 161 vs 154, 3 M (tile order) 289 vs 281, 10 M 833
+        // vs 817: with more active pixels per block the head's dependent trips grow past what the launch saved.  Pixel order up to 1.3 M slots.
+        const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count && c->n_cand &&
+                           (c->step_gather == 3 || (!c->tile_order && c->n_cand <= 1300000));    // (EMBA_STEP_GATHER=3: everywhere, for comparison)
         if (consume) { aw.clear_pixacc = c->d_pixacc; c->pixacc_clean = true; c->pixacc_consumed = true; }
         if (lists) { q.seg = c->d_seg_act; aw.seg = c->d_seg_act; if (consume) q.clear_inactive = c->d_pixacc; }
         // launch A: {active counts (+ markers -> counts, activity bits, cleared A11 | b1) || inlier-flag counts}; launch B: the active-set write,
@@ -1310,7 +1304,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // The resident one-GPU step (lists): the write is list-driven and balanced (active_gather_block) and rides in the head of the compact Gram
         // kernel — emba_form_accumulate issues it — or runs as a kernel of its own (EMBA_STEP_GATHER=1, or where the Gram kernel is another form)
         c->aw_in_gram = false;
-        if (lists && c->step_gather == 2 && gram_is_compact(c, false)) { c->aw_saved = aw; c->aw_in_gram = true; }
+        if (lists && c->step_gather >= 2) { c->aw_saved = aw; c->aw_in_gram = true; }
         else if (lists) hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, aw);
         else hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
         c->inl_pending = true;
@@ -1349,7 +1343,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
     // the per-pixel sums of the evaluation already carry this cost's weights (emba_set_cost / emba_step)?  Then they ARE A22/b2.
     const bool acc_matches = (irls == c->acc_irls) && (irls == 0 || eta == c->acc_eta);
     const bool generic_a22 = !acc_matches || (ep_host != nullptr) || c->force_generic_a22;
-    if (c->aw_in_gram && (generic_a22 || !gram_is_compact(c, ep_host != nullptr))) {   // (not what emba_step does: the deferred gather as a launch of its own after all)
+    if (c->aw_in_gram && (generic_a22 || !c->n_cand)) {   // (not what emba_step does: the deferred gather as a launch of its own after all)
         hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, c->aw_saved);
         c->aw_in_gram = false;
     }
@@ -1393,38 +1387,15 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
         constexpr long wpb = kGramBlock / 64;
         const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
-#ifdef EMBA_DIAG
-        static int trace_left = getenv("EMBA_GRAM_TRACE") ? 3 : 0;     // diagnostics: anatomy of the 50th..52nd compact launch (s_memtime stamps per wave)
-        static int trace_skip = 50;
-        unsigned long long* d_trace = nullptr;
-        if (trace_left && gram_is_compact(c, ep_host != nullptr) && trace_skip-- <= 0) {
-            if (ws_get(c, 39, (size_t)grid * wpb * 64, (void**)&d_trace) == EMBA_OK) { (void)hipMemsetAsync(d_trace, 0, (size_t)grid * wpb * 64, s); p.trace = d_trace; }
+        const ActiveWriteParams aw = c->aw_in_gram ? c->aw_saved : ActiveWriteParams{};
+        if (p.tag) {
+            if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_kernel<true, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
+            else hipLaunchKernelGGL((emba_gram_kernel<true, false>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
+        } else {
+            if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_kernel<false, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
+            else hipLaunchKernelGGL((emba_gram_kernel<false, false>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
         }
-#endif
-        if (gram_is_compact(c, ep_host != nullptr)) {
-            if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_compact_kernel<GRAM_U, true>), dim3(grid), dim3(kGramBlock), 0, s, p, c->aw_saved);
-            else hipLaunchKernelGGL((emba_gram_compact_kernel<GRAM_U, false>), dim3(grid), dim3(kGramBlock), 0, s, p, ActiveWriteParams{});
-            c->aw_in_gram = false;
-        }
-#ifdef EMBA_DIAG
-        if (d_trace) {
-            --trace_left;
-            std::vector<unsigned long long> h((size_t)grid * wpb * 8);
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h.data(), d_trace, h.size() * 8, hipMemcpyDeviceToHost);
-            double seg[8] = {0}; size_t nw = 0;
-            for (size_t w = 0; w < (size_t)grid * wpb; ++w) {
-                const unsigned long long* q = &h[8 * w]; if (!q[0] || !q[7]) continue;
-                ++nw;
-                unsigned long long prev = q[0];
-                for (int k = 1; k <= 7; ++k) { const unsigned long long v = q[k] ? q[k] : prev; seg[k] += (double)(v - prev); prev = v; }
-            }
-            fprintf(stderr, "gram trace (s_memtime ticks, mean over %zu waves): init+prefix %.0f | words+slice %.0f | phase A rest %.0f | phase B %.0f | wave flush %.0f | barrier %.0f | block flush %.0f | total %.0f\n",
-                    nw, seg[1] / nw, seg[2] / nw, seg[3] / nw, seg[4] / nw, seg[5] / nw, seg[6] / nw, seg[7] / nw, (seg[1] + seg[2] + seg[3] + seg[4] + seg[5] + seg[6] + seg[7]) / nw);
-        }
-#endif
-        else if (p.tag) hipLaunchKernelGGL(emba_gram_kernel<true>, dim3(grid), dim3(kGramBlock), 0, s, p);
-        else hipLaunchKernelGGL(emba_gram_kernel<false>, dim3((unsigned)((waves + wpb - 1) / wpb)), dim3(kGramBlock), 0, s, p);
+        c->aw_in_gram = false;
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
     HIP_TRY(c, hipGetLastError());

@@ -1240,7 +1240,11 @@ __global__ __launch_bounds__(256) void emba_active_write_kernel(ActiveWriteParam
 // [k0, k1) of the compact index range: prefix of the per-unit counts in LDS, binary search k -> (unit, rank), list entry -> pixel, then 8
 // lanes fetch one pixel's 64-B accumulator line (all of a slice's lines in flight at once), write its row of the pack (applyL2Reg folded in,
 // model.cpp:689-719) and the active-set entry, and zero the line behind the gather.  Work proportional to P, balanced, no count-map pass.
-// Used as the head of the Gram kernel (no launch of its own) or as a kernel of its own.  s_pre: kGatherMaxUnits + 1 words, s_ws: NT / 64.
+// Used as the head of the Gram kernel (gram_body<.., GATHER>: no launch of its own) or as a kernel of its own.  s_pre: kGatherMaxUnits + 1 words,
+// s_ws: NT / 64.  (Round 4 also tried a "compact" Gram kernel under it — a wave lists its chunk's live slots first and then fetches only those,
+// every lane of every load useful, half the stages: 27.3 vs 27.8 us at 1 M events, 62.6 vs 45.6 us at 1.5 M: the stream form's time is the
+// records' 7 TB/s burst plus fixed costs, not its chain of stages — s_memtime stamps per wave: phase A 2.6 us, records 9.1, wave flush 3.2,
+// final barrier 2.8 of a 17.8-us wave in a 27-us kernel.  Dropped.)
 // ------------------------------------------------------------------------------------------------
 constexpr int kGatherMaxUnits = 4096;    // panoramas up to 8 M pixels (2048 x 4096); beyond that the host keeps the sweeping form
 // part 1: the prefix of the per-unit counts in s_pre (two barriers), what block 0 publishes; returns P.
@@ -1486,7 +1490,6 @@ struct GramParams {
     const double* tag;                                                    // per slot {pano pixel, stamp} (8 B), or nullptr: decide from the records themselves
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
-    unsigned long long* trace;   // diagnostics builds only (EMBA_GRAM_TRACE): 8 s_memtime stamps per wave of the compact kernel
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
@@ -1560,14 +1563,24 @@ __device__ __forceinline__ uint32_t rec_elem15_hi(double2 v)
     return (uint32_t)__builtin_amdgcn_ds_swizzle(__double2hiint(v.y), (7 << 5) | 0x18);
 }
 
-template <bool TAGS, int kGramBlock>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
-__device__ __forceinline__ void gram_body(const GramParams& p, const long gram_blk)
+// GATHER (the resident one-GPU step): every block first does its slice of the list-driven active-set write + A22 | b2 gather (active_gather_*): it
+// only depends on launch A of the post-warp pair, like the Gram sums, and as a prologue it costs three short round trips instead of a launch of
+// its own with a pass over the count map (round 4, 1 M events: 27.5 + 15 us -> 34.5 us).
+template <bool TAGS, int kGramBlock, bool GATHER>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
+__device__ __forceinline__ void gram_body(const GramParams& p, const long gram_blk, const ActiveWriteParams& aw)
 {
     __shared__ uint32_t s_tag[kGramKeys];
     __shared__ double s_tile[kGramKeys * 256];
+    __shared__ uint32_t s_pre[GATHER ? kGatherMaxUnits + 1 : 1];
+    __shared__ uint32_t s_ws[kGramBlock / 64];
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
     if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
-    __syncthreads();
+    if (GATHER) {   // (its two barriers also publish the cleared combine table)
+        const uint32_t P_act = active_gather_prefix<kGramBlock>(aw, gram_blk, s_pre, s_ws);
+        active_gather_slice<kGramBlock>(aw, gram_blk, gridDim.x, P_act, s_pre);
+    } else {
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // The block's 16 waves walk ONE contiguous range of 16 x chunk record slots together, stage by stage (wave w takes stages
@@ -1832,183 +1845,8 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     }
 }
 
-template <bool TAGS>
-__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p) { gram_body<TAGS, kGramBlock>(p, blockIdx.x); }
-
-// The same contraction for a CACHE-RESIDENT record set with a tag stream (pixel order up to ~1.5 M slots: the records the warp kernel wrote
-// microseconds ago are still in the Infinity Cache).  There the streaming form above is bound by its dependent chain, not by bytes: a wave
-// walks 8 stages of 32 SLOTS, half of them dead (stale, an outlier's, or on an inactive pixel), each stage one memory round trip behind
-// the previous one, plus three round trips of pipeline fill — 27.8 us for 84 MB at the BASELINE workload (round 3).  Here a wave owns ONE
-// contiguous chunk of slots and works in two phases:
-//   A  all the chunk's tags at once (one round trip), all their activity words at once (a second), ballots -> the LIVE slots' offsets,
-//      compacted, into the wave's LDS list;
-//   B  the live records only, 8 U per stage, every lane of every load instruction useful (lane -> list entry -> 16 B of its record's line),
-//      stage s+1 in flight while stage s runs through the matrix cores.
-// Half the stages, no dead lanes, two dependent trips in front of the first record instead of three.  The pair key is checked once per chunk
-// (slots are sorted by pair: a chunk of a few hundred slots almost never holds two); a chunk that does takes the grouping path per stage.
-// GATHER (the resident one-GPU step): the block first does its slice of the list-driven active-set write + A22 | b2 gather
-// (active_gather_block) — it only depends on launch A, like the Gram sums, and as a prologue it costs three short round trips instead of a launch.
-template <int U, bool GATHER>
-__global__ __launch_bounds__(kGramBlock) void emba_gram_compact_kernel(GramParams p, ActiveWriteParams aw)
-{
-    constexpr int kWaves = kGramBlock / 64, kStage = 8 * U;
-    __shared__ uint32_t s_tag[kGramKeys];
-    __shared__ double s_tile[kGramKeys * 256];
-    __shared__ uint16_t s_list[kWaves][kGramChunk];
-    __shared__ uint32_t s_pre[GATHER ? kGatherMaxUnits + 1 : 1];
-    __shared__ uint32_t s_ws[kWaves];
-#ifdef EMBA_DIAG
-#define GRAM_STAMP(k) do { if (p.trace && (threadIdx.x & 63) == 0) p.trace[8 * ((size_t)blockIdx.x * kWaves + (threadIdx.x >> 6)) + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GRAM_STAMP(k) do { } while (0)
-#endif
-    GRAM_STAMP(0);
-    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
-    if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int m = lane & 7, R = lane >> 3;
-    const long w_start = ((long)blockIdx.x * kWaves + wv) * (long)p.chunk;
-    const long left = p.n_slots - w_start;
-    const int len = left <= 0 ? 0 : (left < (long)p.chunk ? (int)left : p.chunk);   // wave-uniform, <= kGramChunk
-    uint16_t* const list = s_list[wv];
-    int n_live = 0;
-    // ---- phase A: tags -> activity words -> compacted list of live slot offsets, in rounds of 256 slots (one round at the BASELINE workload).
-    // Three steps, so that the FIRST round's two round trips can be issued around the gather head below and hide behind its own three.
-    const double* tag0 = p.tag + (len > 0 ? w_start : 0);
-    const long tag_lim = len > 0 ? p.n_slots + kGramPad - 1 - w_start : 0;       // (the tag buffer is padded like the records)
-    auto issue_tags = [&](int base, double* tg) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const long idx = base + 64 * q + lane; tg[q] = tag0[idx < tag_lim ? idx : tag_lim]; }
-    };
-    auto issue_words = [&](int base, const double* tg, uint32_t* wd) {   // unconditional gathers from a safe word; validity is applied when the bit is extracted
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t pi = (uint32_t)__double2loint(tg[q]);
-            const bool valid = base + 64 * q + lane < len && (uint32_t)__double2hiint(tg[q]) == p.stamp && pi != kInvalidPix;
-            wd[q] = p.active_bits[valid ? (pi >> 5) : 0u];
-        }
-    };
-    auto finish_round = [&](int base, const double* tg, const uint32_t* wd) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t pi = (uint32_t)__double2loint(tg[q]);
-            const bool valid = base + 64 * q + lane < len && (uint32_t)__double2hiint(tg[q]) == p.stamp && pi != kInvalidPix;
-            const bool live = valid && (((EMBA_ABL(p.ablate, 256) ? ~0u : wd[q]) >> (pi & 31u)) & 1u);     // model.cpp:396,409
-            const unsigned long long mk = __ballot(live);
-            if (live) list[n_live + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)(base + 64 * q + lane);
-            n_live += (int)__popcll(mk);
-        }
-    };
-    double tg[4]; uint32_t wd[4];
-    issue_tags(0, tg);
-    uint32_t P_act = 0;
-    if (GATHER) P_act = active_gather_prefix<kGramBlock>(aw, blockIdx.x, s_pre, s_ws);   // (its two barriers also publish the cleared combine table)
-    else __syncthreads();
-    GRAM_STAMP(1);
-    issue_words(0, tg, wd);
-    if (GATHER) active_gather_slice<kGramBlock>(aw, blockIdx.x, gridDim.x, P_act, s_pre);
-    GRAM_STAMP(2);
-    if (len > 0) {
-        finish_round(0, tg, wd);
-#pragma unroll 1
-        for (int base = 256; base < len; base += 256) { issue_tags(base, tg); issue_words(base, tg, wd); finish_round(base, tg, wd); }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // one wave: LDS operations complete in order
-    }
-    GRAM_STAMP(3);
-    if (n_live > 0) {
-        // ---- phase B
-        typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
-        const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)(p.slot_key + w_start);
-        const uint32_t k_a = key_s[0], k_b = key_s[len - 1];
-        const bool uniform = (k_a == k_b);                               // the whole chunk belongs to one control-pose pair
-        uint32_t cur_key = k_a;
-        bool dirty = false;
-        double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
-        auto flush = [&]() {
-            gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, p.dim, p.ablate, s_tag, s_tile);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
-        };
-        const double2* rec0 = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * w_start) + m;
-        const int n_st = (n_live + kStage - 1) / kStage;
-        auto load_stage = [&](int s, double2* x) {       // (unconditional: an entry past the end re-reads the first live record and is zeroed below)
-#pragma unroll
-            for (int u = 0; u < U; ++u) { const int e = kStage * s + 8 * u + R; x[u] = rec0[8 * (int)list[e < n_live ? e : 0]]; }
-        };
-        auto weight = [&](const double2& x) {
-            double w = 1.0;
-            if (p.irls) {
-                const double e = rec_elem14(x);
-                if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);          // cauchy, model.cpp:603
-                else { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }   // huber, :608-616
-            }
-            return w;
-        };
-        auto mfma3 = [&](bool use, double w, const double2& x) {
-            // selects, not multiplies: a lane past the end holds a copy of somebody else's record
-            const double ax = use ? w * x.x : 0.0, ay = use ? w * x.y : 0.0, bx = use ? x.x : 0.0, by = use ? x.y : 0.0;
-            if (!EMBA_ABL(p.ablate, 64)) {
-                acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
-                acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
-                acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
-            }
-        };
-        if (uniform) {
-            auto consume = [&](int s, const double2* x) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const bool ok = kStage * s + 8 * u + R < n_live;
-                    if (__ballot(ok)) { dirty = true; mfma3(ok, weight(x[u]), x[u]); }
-                }
-            };
-            double2 xA[U], xB[U];
-            load_stage(0, xA);
-            int s = 0;
-            for (; s + 2 < n_st; s += 2) {       // (both prefetches exist: no load sits under a branch inside the loop)
-                load_stage(s + 1, xB); consume(s, xA);
-                load_stage(s + 2, xA); consume(s + 1, xB);
-            }
-            // the last one or two stages, peeled: nothing is fetched that is not consumed — the wave's flush below is a real call, in front of
-            // which everything outstanding is waited for (a redundant prefetch of the last stage cost every wave one more round trip: 2.3 us)
-            if (s + 1 < n_st) { load_stage(s + 1, xB); consume(s, xA); consume(s + 1, xB); }
-            else consume(s, xA);
-        } else {
-            // the chunk holds a pair boundary (a few dozen waves per launch): 8 live records at a time, grouped by pair — a small rolled loop
-            // of its own, so that its registers and branches stay out of the pipelined loop above
-#pragma unroll 1
-            for (int e0 = 0; e0 < n_live; e0 += 8) {
-                const int e = e0 + R;
-                const bool in = e < n_live;
-                const int sl = list[in ? e : 0];
-                const double2 y = rec0[8 * sl];
-                const uint32_t key = in ? p.slot_key[w_start + sl] : 0xFFFFFFFFu;
-                const double w = weight(y);
-                unsigned long long remaining = __ballot(in);
-                while (remaining) {
-                    const int first = __ffsll((long long)remaining) - 1;
-                    const uint32_t k0 = (uint32_t)__shfl((int)key, first);
-                    if (k0 != cur_key) { if (dirty) flush(); cur_key = k0; dirty = false; }
-                    const bool mine = in && (key == k0);
-                    if (__ballot(mine)) { dirty = true; mfma3(mine, w, y); }
-                    remaining &= ~__ballot(mine);
-                }
-            }
-        }
-        GRAM_STAMP(4);
-        if (dirty) flush();
-    }
-    GRAM_STAMP(5);
-    __syncthreads();
-    GRAM_STAMP(6);
-    // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
-    for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
-        const uint32_t key = s_tag[i >> 8];
-        if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
-    }
-    GRAM_STAMP(7);
-#undef GRAM_STAMP
-}
+template <bool TAGS, bool GATHER>
+__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p, ActiveWriteParams aw) { gram_body<TAGS, kGramBlock, GATHER>(p, blockIdx.x, aw); }
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.

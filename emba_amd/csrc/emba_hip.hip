@@ -1323,6 +1323,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->thres = thres;
     c->eq_in_alt = false;   // new equations are being formed from the working set: the other set's are obsolete
     c->P_pending = true; c->active_done = false; c->accum_done = false;
+    c->finish_done = false;          // (the head of the pack has just been cleared: what a solve would read is no set of equations — found by the call-order pair test)
     c->x2_resident_P = (size_t)-1;   // (a solve of the PREVIOUS equations may have left its x2 on the device)
     c->lists_valid = false;          // (new active set)
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
@@ -1337,6 +1338,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->active_done && !c->P_pending) return fail(c, EMBA_ERR_STATE, "emba_form_active has not been called");
+    if (c->accum_done) return fail(c, EMBA_ERR_STATE, "these equations have been accumulated already: A11 | b1 are cleared by emba_form_active only (a second pass would add the sums again)");
     if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1953,6 +1955,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEq needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    if (c->eq_in_alt) return fail(c, EMBA_ERR_STATE, "an evaluation has been written since these equations were formed (its records are the working set): report the LM decision first — emba_map_reject / emba_trial_reject to go back to them, or form the new ones");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;
@@ -2018,6 +2021,7 @@ extern "C" emba_status emba_solve_shard_count(emba_ctx* c, int32_t n_ranks, size
 {
     if (!c || !counts_host || n_ranks < 1 || n_ranks > 1024) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_count: bad arguments") : EMBA_ERR_INVALID_ARG;
     if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "the sharded solve needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    if (c->eq_in_alt) return fail(c, EMBA_ERR_STATE, "an evaluation has been written since these equations were formed (its records are the working set): report the LM decision first — emba_map_reject / emba_trial_reject to go back to them, or form the new ones");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;
@@ -2061,6 +2065,7 @@ extern "C" emba_status emba_solve_shard_partial(emba_ctx* c, int32_t rank, int32
 {
     if (!c || !S_part_dev || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_partial: bad arguments") : EMBA_ERR_INVALID_ARG;
     if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "the sharded solve needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    if (c->eq_in_alt) return fail(c, EMBA_ERR_STATE, "an evaluation has been written since these equations were formed (its records are the working set): report the LM decision first — emba_map_reject / emba_trial_reject to go back to them, or form the new ones");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const int n = 3 * c->K, na = n + 1;
@@ -2124,6 +2129,7 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEqCG needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    if (c->eq_in_alt) return fail(c, EMBA_ERR_STATE, "an evaluation has been written since these equations were formed (its records are the working set): report the LM decision first — emba_map_reject / emba_trial_reject to go back to them, or form the new ones");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;

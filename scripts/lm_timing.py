@@ -29,6 +29,12 @@ def timed(name):
 for nm in ("set_events", "upload_map", "eval_launch", "eval_finish", "costs", "dataCost", "regCost", "form_active", "form_accumulate", "form_finish", "solveNormalEq", "updateMap",
            "acceptMap", "rejectMap"):
     if hasattr(m, nm): timed(nm)
+# the host's own part of an iteration: updateTraj (solver.cpp:226-234) + what Python spends between the model calls
+from emba_amd import io as emba_io
+_iu = emba_io.incremental_update
+def iu(*x, **k):
+    t = time.perf_counter(); r = _iu(*x, **k); T["host: updateTraj"] = T.get("host: updateTraj", 0.0) + time.perf_counter() - t; return r
+emba_io.incremental_update = iu
 t0 = time.perf_counter()
 r = solve_time_window(m, init, w.events, w.Gx, w.Gy, BASettings(), LMSettings(max_num_iter=max_iter), resident=True)
 wall = time.perf_counter() - t0
@@ -36,4 +42,7 @@ setup = T.get("set_events", 0) + T.get("upload_map", 0)
 print(f"N={n} K={K} pano {ph}x{2*ph}: {r.iterations} LM iterations, {sum(1 for e in r.log if e[4])} accepted; wall {wall*1e3:.1f} ms, of which set_events + first upload {setup*1e3:.1f} ms"
       f" -> {(wall-setup)/max(r.iterations,1)*1e3:.2f} ms per iteration")
 print("   ms inside the model calls: " + ", ".join(f"{k} {v*1e3:.2f}" for k, v in T.items()))
+inside = sum(v for k, v in T.items())
+print(f"   per iteration: " + ", ".join(f"{k} {v/max(r.iterations,1)*1e3:.3f}" for k, v in T.items() if k not in ("set_events", "upload_map")) +
+      f", everything else (Python between the calls) {(wall - inside)/max(r.iterations,1)*1e3:.3f} ms")
 m.close()

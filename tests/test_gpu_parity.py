@@ -863,3 +863,69 @@ def test_resident_step_sequences(gpu, oracle_mod, cfg, fast, gather, monkeypatch
     n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
     assert P == o["ne"]["P"]
     check("step after a re-form")
+
+
+def test_call_order_pairs_never_give_a_wrong_number(gpu, oracle_mod):
+    """the context carries ~20 phase flags; SURVEY §8b says the boundary is stateful across evaluateDataError -> formNormalEq.
+    Table-driven: every ordered PAIR (A, B) of the phase calls, on a fresh context (events + map registered, nothing evaluated) and on a formed
+    one, must each either succeed or fail with EMBA_ERR_STATE — and whatever a successful formNormalEq / solve returns must be the oracle's, as
+    must the canonical sequence run on the same context afterwards (no pair may leave it in a state that corrupts later valid use)."""
+    from emba_amd import EmbaError
+    from emba_amd._lib import ERR_STATE
+    w = small_workload(n_events=12000, pano_h=128, K=5, sensor=(32, 24), focal=30.0)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    lam = 1e-2
+    ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, True)
+
+    def check_solve(x1, x2):
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()) and np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+
+    ops = {
+        "eval_launch": lambda m: m.eval_launch(w.traj),
+        "eval_finish": lambda m: m.eval_finish(sync=False),
+        "form_active": lambda m: m.form_active(w.thres_valid_pixel),
+        "form_accumulate": lambda m: m.form_accumulate(),
+        "form_finish": lambda m: dict(ne=m.form_finish(w.alpha, download=True)),
+        "solve": lambda m: dict(x=m.solveNormalEq(lam, fix_first_pose=True)),
+        "update_map": lambda m: m.updateMap(None, 0.0),
+        "map_accept": lambda m: m.acceptMap(),
+        "map_reject": lambda m: m.rejectMap(),
+        "trial_reject": lambda m: m.rejectTrial(),
+        "step": lambda m: m.step(w.traj, w.thres_valid_pixel, w.alpha),
+    }
+    n_ok = n_state = 0
+    for start in ("fresh", "formed"):
+        for a in ops:
+            for b in ops:
+                m = make_legm(w)
+                m.set_events(w.events); m.upload_map(w.Gx, w.Gy)
+                if start == "formed":
+                    m.step(w.traj, w.thres_valid_pixel, w.alpha)
+                trial_map = False           # the device may hold a trial map (zero outside the active set): numbers are then not the oracle's at (Gx, Gy)
+                for name in (a, b):
+                    try:
+                        r = ops[name](m)
+                        n_ok += 1
+                    except EmbaError as e:
+                        assert e.status == ERR_STATE, f"{start}: {a} -> {b}: {name} failed with status {e.status} ({e})"
+                        n_state += 1
+                        continue
+                    if name == "update_map":
+                        trial_map = True
+                    if name in ("map_accept", "map_reject"):
+                        trial_map = trial_map and name == "map_accept"
+                    if isinstance(r, dict) and not trial_map:
+                        if "ne" in r:
+                            compare_normal_eq(r["ne"], o["ne"])
+                        else:
+                            check_solve(*r["x"])
+                # the canonical sequence on the same context afterwards
+                nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
+                ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, None, True, nem)
+                assert np.array_equal(nem, o["num_ev_map"]), f"{start}: {a} -> {b}: count map of the following evaluation"
+                assert_close(ep, o["ep"], "ep")
+                m.formNormalEq(None, w.K, None, w.thres_valid_pixel)
+                compare_normal_eq(m.applyL2Reg(w.alpha), o["ne"])
+                check_solve(*m.solveNormalEq(lam, fix_first_pose=True))
+                m.close()
+    assert n_ok > 100 and n_state > 50, (n_ok, n_state)

@@ -1,8 +1,18 @@
-# round-2 evidence: rocprofv3 kernel stats + counters of the three regimes (1 M: pixel order; 10 M / 100 M: tile order; scene events), sweep
+# round-4 evidence: rocprofv3 kernel stats + counters of every regime (1 M: pixel order; 3 M ... 100 M: tile order; scene events; the 8-GPU
+# configurations' per-rank shards), the size sweep, the LM-loop breakdown, the flip rate
 mkdir -p gpurun_out
-TAG=r02d_1M ARGS="" STEPS=50 bash scripts/profile.sh > gpurun_out/prof_1M.log 2>&1; echo "prof 1M rc=$?"
-TAG=r02d_10M ARGS="--events-per-gpu 10000000 --knots 97" STEPS=10 bash scripts/profile.sh > gpurun_out/prof_10M.log 2>&1; echo "prof 10M rc=$?"
-TAG=r02d_100M ARGS="--events-per-gpu 100000000 --knots 256 --pano-h 2048" STEPS=4 bash scripts/profile.sh > gpurun_out/prof_100M.log 2>&1; echo "prof 100M rc=$?"
-TAG=r02d_scene ARGS="--data scene" STEPS=50 bash scripts/profile.sh > gpurun_out/prof_scene.log 2>&1; echo "prof scene rc=$?"
-ORDERS="auto" bash scripts/scaling.sh > /dev/null 2>&1; cat gpurun_out/scaling.log
-timeout -k 10 300 python bench.py > gpurun_out/bench_default.json 2>/dev/null; tail -c 900 gpurun_out/bench_default.json
+P() { TAG=$1 ARGS="$2" STEPS=$3 bash scripts/profile.sh > gpurun_out/prof_$1.log 2>&1; echo "prof $1 rc=$?"; }
+P r04_1M "" 50
+P r04_3M "--events-per-gpu 3000000" 20
+P r04_10M "--events-per-gpu 10000000 --knots 97" 10
+P r04_10M_2048 "--events-per-gpu 10000000 --knots 256 --pano-h 2048" 10
+P r04_40M "--events-per-gpu 40000000 --knots 97 --pano-h 2048" 5
+P r04_100M "--events-per-gpu 100000000 --knots 256 --pano-h 2048" 4
+P r04_scene "--data scene" 50
+P r04_shard1M "--shard-of 8 --shard-rank 3" 50
+P r04_shard5M "--events-per-gpu 5000000 --knots 97 --sensor 640x480 --shard-of 8 --shard-rank 3 --yaw-rate 0.1" 10
+P r04_shard12M "--events-per-gpu 12500000 --knots 256 --pano-h 2048 --shard-of 8 --shard-rank 3" 6
+ORDERS="auto" bash scripts/scaling.sh > /dev/null 2>&1; cp gpurun_out/scaling.log gpurun_out/r04_scaling_sweep.txt; cat gpurun_out/scaling.log
+(python scripts/lm_timing.py; python scripts/lm_timing.py 1000000 1024 21 0.05 8; python scripts/lm_timing.py 10000000 1024 97 0.0104 6) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_lm_breakdown.txt; cat gpurun_out/r04_lm_breakdown.txt
+timeout -k 10 300 python bench.py > gpurun_out/bench_default.json 2>/dev/null; tail -c 1500 gpurun_out/bench_default.json
+timeout -k 10 900 python scripts/flip_rate.py --out gpurun_out/r04_flip_rate.txt > gpurun_out/flip.log 2>&1; echo "flip rate rc=$?"; tail -25 gpurun_out/r04_flip_rate.txt

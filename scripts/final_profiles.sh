@@ -16,3 +16,8 @@ ORDERS="auto" bash scripts/scaling.sh > /dev/null 2>&1; cp gpurun_out/scaling.lo
 (python scripts/lm_timing.py; python scripts/lm_timing.py 1000000 1024 21 0.05 8; python scripts/lm_timing.py 10000000 1024 97 0.0104 6) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_lm_breakdown.txt; cat gpurun_out/r04_lm_breakdown.txt
 timeout -k 10 300 python bench.py > gpurun_out/bench_default.json 2>/dev/null; tail -c 1500 gpurun_out/bench_default.json
 timeout -k 10 900 python scripts/flip_rate.py --out gpurun_out/r04_flip_rate.txt > gpurun_out/flip.log 2>&1; echo "flip rate rc=$?"; tail -25 gpurun_out/r04_flip_rate.txt
+# what comes back: the summaries (tracked under profiles/), not the raw rocprofv3 trees (gpurun merges at most 64 MiB of gpurun_out back)
+mkdir -p gpurun_out/profiles_r04 && cp profiles/r04_* gpurun_out/profiles_r04/ 2>/dev/null
+cp gpurun_out/r04_scaling_sweep.txt gpurun_out/r04_lm_breakdown.txt gpurun_out/r04_flip_rate.txt gpurun_out/bench_default.json gpurun_out/profiles_r04/ 2>/dev/null
+for d in gpurun_out/prof_r04_*; do rm -rf $d/trace $d/fetch $d/write $d/atomic; done
+du -sh gpurun_out

@@ -15,7 +15,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libemba_oracle.so")
+_LIB = os.environ.get("EMBA_ORACLE_LIB", os.path.join(_HERE, "libemba_oracle.so"))   # EMBA_ORACLE_LIB: another build of the same source (bench.py: -march=native on the GPU box's host)
 _REF = os.path.join(_HERE, "_ref", "libref_basalt.so")
 
 _dp = C.POINTER(C.c_double)
@@ -44,7 +44,7 @@ def lib():
     global _lib
     if _lib is None:
         srcs = [os.path.join(_HERE, f) for f in ("emba_oracle.c", "emba_oracle.h", "Makefile")]
-        if not os.path.exists(_LIB) or any(os.path.getmtime(f) > os.path.getmtime(_LIB) for f in srcs):
+        if "EMBA_ORACLE_LIB" not in os.environ and (not os.path.exists(_LIB) or any(os.path.getmtime(f) > os.path.getmtime(_LIB) for f in srcs)):
             build()
         L = C.CDLL(_LIB)
         L.emba_oracle_create.restype = C.c_void_p

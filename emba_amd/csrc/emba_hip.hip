@@ -103,6 +103,8 @@ struct emba_ctx {
     uint16_t* d_cp = nullptr; double* d_batch_u = nullptr;                                          // control-pose index (= spline segment) and spline parameter per batch
     double* d_ev_u = nullptr; uint16_t* d_ev_seg = nullptr;                                         // tile order: the same per entry of the device order
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
+    int segpose_mode = 0;      // EMBA_SEGPOSE=0|1 (A/B): pixel order evaluates the pose per event from segment records (default: yes)
+    bool segpose = false;      // ... in the current evaluation
     bool chunks_lpt = false;   // the chunk list is sorted longest first and walked in grid order (no XCD-contiguous remapping)
     bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
     size_t n_lead = 0;                             // lead-in copies the tile order added
@@ -682,6 +684,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
     if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
+    if (const char* sf = getenv("EMBA_SEGPOSE")) c->segpose_mode = 1 + atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_ONE_SET")) c->step_one_set = atoi(sf);
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
@@ -1169,8 +1172,15 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         q.count = c->d_count; q.npix = (long)c->npix; q.pixacc = c->d_pixacc; q.W = c->W; q.H = c->H; q.n_prep = n_prep_blk;
         q.batch_t_ns = c->d_batch_t; q.nb = nb; q.K = (int)K; q.t0_ns = t0_ns; q.dt_ns = dt_ns; q.pose = c->d_pose; q.err = c->d_err;
         q.err_next = c->d_err2 + ((c->eval_seq + 1u) & 1u);
-        q.n_pose = ((c->tile_order ? (int)K - 1 : nb) + 63) / 64;   // (tile order: K-1 segment records instead of nb batch poses)
-        q.seg = c->tile_order ? c->d_seg : nullptr;
+        // pixel order: per-event pose from the segment records too (warp_lane SEGPOSE; round 4, late) instead of one 112-B pose record per batch gathered by
+        // every event — 7 x 16-B gathers over 64 different lines per wave, and past ~7 M events a table that no longer fits the L2s.  Measured, same box,
+        // step time: 1 M events 101.2 -> 98.2 us, 1.5 M 150.8 -> 143.5, 10 M on 640x480 (city shape) 779 -> 714 (warp 0.60 -> 0.68 of the roofline),
+        // 10 M on 2048x4096 / K = 256 940 -> 861.  (Round 1 had measured the opposite at 1 M events, + 6 us, on a kernel that was then VALU-heavier in
+        // other places; EMBA_SEGPOSE=0 keeps the per-batch table for comparison.)
+        c->segpose = !c->tile_order && (c->segpose_mode ? c->segpose_mode == 2 : true);
+        const bool seg_records = c->tile_order || c->segpose;
+        q.n_pose = ((seg_records ? (int)K - 1 : nb) + 63) / 64;   // (K-1 segment records instead of nb batch poses)
+        q.seg = seg_records ? c->d_seg : nullptr;
         q.knots_dev = c->d_knots; q.knots_out = c->d_knots;
         q.inline_knots = (K <= kInlineKnots) ? 1 : 0;
         if (q.inline_knots) memcpy(kn.q, knots, (size_t)4 * K * sizeof(double));       // by value in the kernel arguments: no staging copy at all
@@ -1192,6 +1202,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)c->n_sorted;
         p.ev_u = c->tile_order ? c->d_ev_u : nullptr; p.ev_seg = c->tile_order ? c->d_ev_seg : nullptr;
+        p.batch_u = c->d_batch_u; p.batch_seg = c->d_cp;
         p.nblk = c->nblk; p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
@@ -1206,6 +1217,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.chunks = c->d_chunks; p.n_chunks = c->n_chunks; p.chunks_linear = c->chunks_lpt ? 1 : 0;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
         if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
+        else if (c->segpose) hipLaunchKernelGGL((emba_warp_residual_kernel<false, false, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; c->kt_valid[c->kt_slot][0] = true; }
         c->counts_raw = true;
@@ -1644,7 +1656,9 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
+    p.batch_u = c->d_batch_u; p.batch_seg = c->d_cp;
     if (c->tile_order) hipLaunchKernelGGL((emba_warp_residual_kernel<true, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
+    else if (c->segpose) hipLaunchKernelGGL((emba_warp_residual_kernel<true, false, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);   // (the last evaluation left segment records, not a pose table)
     else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     std::vector<double> h_pm(w_pm ? 2 * ns : 0), h_D(w_D ? 12 * ns : 0), h_dp(w_dp ? 2 * ns : 0), h_G(w_G ? 2 * ns : 0), h_t(w_t ? 2 * ns : 0);
     std::vector<uint16_t> h_cp(cp_idx ? c->n_batch : 0);

@@ -266,6 +266,7 @@ constexpr int kTileRecStage = 16;               // records staged per wave at a 
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; const uint32_t* ev_pm; long n_sorted; long nblk;   // ev_pm: entry -> pm-order index (nullptr: identity)
     const double* ev_u; const uint16_t* ev_seg;   // tile order: per entry the spline parameter u and the segment of its batch
+    const double* batch_u; const uint16_t* batch_seg;   // pixel order with per-event pose evaluation (SEGPOSE): the same per BATCH (two small, cache-resident tables)
     const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; pose: per-batch table (pixel order); seg: per-segment records (tile order)
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
@@ -328,7 +329,10 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // `prefetch` is called once, wave-uniformly, right after the texel gather has been waited for: the point of a group where nothing
 // the group still needs is loaded any more.  (Loads return in order: a prefetch issued earlier sits in front of the bearing-vector,
 // segment and texel gathers, and the waits for those L2 hits would pay the prefetch's HBM latency.)
-template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch, bool LATE_EP = false>
+// SEGPOSE (round 4; pixel order with a LARGE window): the pose is evaluated per event from its batch's spline parameter and segment record, as in the tile
+// order, instead of gathered from the per-batch table — at 10 M events that table is 11 MB of 112-B records, every event pulls one or two 128-B lines of it
+// past the L2 (counters: 1.37x the algorithmic bytes); the per-batch u / segment tables are 1 MB, the K-1 segment records a few KB.
+template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch, bool LATE_EP = false, bool SEGPOSE = false>
 __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o, PF prefetch = PF())
 {
     const bool valid = in.valid;
@@ -347,14 +351,16 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
         double b0, b1, b2;
         if (COMPACT) { b0 = bv[0]; b1 = bv[1]; b2 = bv[2]; }   // tile order: the bearing-vector gather is in flight while the pose is evaluated
         double R[9], J1[9];
-        if (COMPACT) {   // tile order: pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
+        if (COMPACT || SEGPOSE) {   // pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
             // (the K-1 segment records are cache-resident and fetched here, next to the bearing-vector gather whose latency is paid anyway:
             // prefetched with the event words they cost 24 VGPRs per pipeline stage)
-            const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * (EMBA_ABL(p.ablate, 16) ? (bi & 1u) : bi));
+            uint32_t sg = bi; double uu = in.u;
+            if (SEGPOSE) { uu = p.batch_u[bi]; sg = p.batch_seg[bi]; }
+            const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * (EMBA_ABL(p.ablate, 16) ? (sg & 1u) : sg));
             const double2 s0 = S2[0], s1 = S2[1], s2 = S2[2], s3 = S2[3], s4 = S2[4], s5 = S2[5];
             const double seg[kSegStride] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, s4.x, s4.y, s5.x, s5.y};
             double q[4];
-            spline2_event<!DUMP>(seg, in.u, q, J1);
+            spline2_event<!DUMP>(seg, uu, q, J1);
             quat_to_matrix(q, R);     // rot.matrix() per event, event_pano_warper.cpp:55
         } else {
             const double2* P2 = reinterpret_cast<const double2*>(p.pose + (size_t)kPoseStride * bi);
@@ -538,7 +544,7 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
 #ifndef WARP_OCC
 #define WARP_OCC
 #endif
-template <bool DUMP, bool COMPACT = false>
+template <bool DUMP, bool COMPACT = false, bool SEGPOSE = false>
 __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel(WarpParams p)
 {
     // One wave per workgroup, LDS operations complete in order: the record staging tile (first) and the run sums (afterwards) share
@@ -557,7 +563,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     LaneOut o;
     LaneIn in;
     load_event_words<COMPACT>(p, i, valid, in);
-    warp_lane<DUMP, COMPACT, NoPrefetch, (WARP_LATE_EP != 0) && !DUMP>(p, i, in, t, o);
+    warp_lane<DUMP, COMPACT, NoPrefetch, (WARP_LATE_EP != 0) && !DUMP, SEGPOSE>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;
     const uint32_t pi = o.pi;

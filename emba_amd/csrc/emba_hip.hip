@@ -382,6 +382,9 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     if (!tile) {
         c->d_ev_pix = c->d_pm_pix; c->d_ev_batch = c->d_pm_batch;
         c->n_sorted = ns;
+        // per entry the spline parameter and segment of its batch (the warp kernel's per-event pose: 10 B per entry, streamed with the event words)
+        if ((st = dev_alloc(c, &c->d_ev_u, std::max<size_t>(ns, 1))) || (st = dev_alloc(c, &c->d_ev_seg, std::max<size_t>(ns, 1)))) return st;
+        if (ns) hipLaunchKernelGGL(emba_entry_pose_args_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_batch, (long)ns, c->d_cp, c->d_batch_u, c->d_ev_seg, c->d_ev_u);
     } else {
         // expanded list: every event, plus a lead-in copy of its predecessor where its chain enters a tile -> stable sort by tile
         uint32_t* d_tot = d_err + 4;
@@ -1201,8 +1204,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     if (c->n_sorted) {
         WarpParams p{};
         p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)c->n_sorted;
-        p.ev_u = c->tile_order ? c->d_ev_u : nullptr; p.ev_seg = c->tile_order ? c->d_ev_seg : nullptr;
-        p.batch_u = c->d_batch_u; p.batch_seg = c->d_cp;
+        p.ev_u = c->d_ev_u; p.ev_seg = c->d_ev_seg;      // per entry, in both orders
         p.nblk = c->nblk; p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = c->use_texel ? c->d_texel : nullptr; p.W = c->W; p.H = c->H;
         p.rect_acc = (c->use_texel == 3) ? rect_cur : nullptr;
         p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
@@ -1651,12 +1653,11 @@ emba_status emba_dump_state(emba_ctx* c, double* pm, double* D, int32_t* cp_idx,
     if (w_pi) (void)hipMemsetAsync(d_pi, 0xFF, 2 * ns * 4, s);
     WarpParams p{};
     p.ev_pix = c->d_ev_pix; p.ev_batch = c->d_ev_batch; p.ev_slot = c->d_ev_slot; p.ev_pm = c->tile_order ? c->d_ev_pm : nullptr; p.n_sorted = (long)ns; p.nblk = c->nblk;
-    p.ev_u = c->tile_order ? c->d_ev_u : nullptr; p.ev_seg = c->tile_order ? c->d_ev_seg : nullptr;
+    p.ev_u = c->d_ev_u; p.ev_seg = c->d_ev_seg;
     p.pose = c->d_pose; p.seg = c->d_seg; p.lut = c->d_lut; p.texel = nullptr; p.rect_acc = nullptr; p.Gx = c->d_Gx; p.Gy = c->d_Gy; p.pixacc = c->d_pixacc;
     p.W = c->W; p.H = c->H; p.fx = c->fx; p.fy = c->fy; p.cx = c->cx;
     p.cy = c->cy; p.C_th = c->C_th; p.outlier_px = c->outlier_px; p.count = c->d_count; p.rec = c->d_rec; p.e_sorted = c->d_e_sorted;
     p.flag = c->d_flag; p.d_pm = d_pm; p.d_D = d_D; p.d_dp = d_dp; p.d_Gpm = d_G; p.d_temp = d_t; p.d_pm_int = d_pi;
-    p.batch_u = c->d_batch_u; p.batch_seg = c->d_cp;
     if (c->tile_order) hipLaunchKernelGGL((emba_warp_residual_kernel<true, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
     else if (c->segpose) hipLaunchKernelGGL((emba_warp_residual_kernel<true, false, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);   // (the last evaluation left segment records, not a pose table)
     else hipLaunchKernelGGL((emba_warp_residual_kernel<true, false>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);

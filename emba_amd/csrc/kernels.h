@@ -265,8 +265,7 @@ constexpr int kTileRecStage = 16;               // records staged per wave at a 
 
 struct WarpParams {
     const uint32_t* ev_pix; const uint32_t* ev_batch; const uint32_t* ev_slot; const uint32_t* ev_pm; long n_sorted; long nblk;   // ev_pm: entry -> pm-order index (nullptr: identity)
-    const double* ev_u; const uint16_t* ev_seg;   // tile order: per entry the spline parameter u and the segment of its batch
-    const double* batch_u; const uint16_t* batch_seg;   // pixel order with per-event pose evaluation (SEGPOSE): the same per BATCH (two small, cache-resident tables)
+    const double* ev_u; const uint16_t* ev_seg;   // per entry the spline parameter u and the segment of its batch (the pose is evaluated per event from them)
     const double* pose; const double* seg; const double* lut; const double* texel;  // texel == nullptr: Hessian on the fly from Gx, Gy; pose: per-batch table (pixel order); seg: per-segment records (tile order)
     const int* rect_acc;   // non-null: texels are valid only inside texel_rect(rect_acc); stencil fallback outside
     const double* Gx; const double* Gy;
@@ -314,7 +313,7 @@ struct LaneIn { uint32_t pw, bi, slot, pm; bool valid; double u; };   // pm: the
 // behind the lane's own stores in the in-order memory counter and every staging round would wait for the previous round's stores)
 // The loads are UNCONDITIONAL (index clamped into the arrays, `valid` applied by the consumer): a load under a lane mask is waited for
 // at the end of its branch, with everything issued before it — the tiled kernel's prefetch of the next group was waited for on the spot.
-template <bool COMPACT>
+template <bool COMPACT, bool SEGPOSE = false>
 __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bool valid, LaneIn& in)
 {
     const long last = p.n_sorted - 1;               // (n_sorted >= 1 whenever a warp kernel is launched)
@@ -322,6 +321,7 @@ __device__ __forceinline__ void load_event_words(const WarpParams& p, long i, bo
     in.valid = valid; in.u = 0.0;
     in.pw = stream_load(p.ev_pix + ic, COMPACT && EV_NT_LOAD); in.slot = stream_load(p.ev_slot + ic, COMPACT && EV_NT_LOAD);
     if (COMPACT) { in.pm = stream_load(p.ev_pm + ic, EV_NT_LOAD); in.u = stream_load(p.ev_u + ic, EV_NT_LOAD); in.bi = stream_load(p.ev_seg + ic, EV_NT_LOAD); }    // tile order: pm-order index, spline parameter and segment of the event's batch
+    else if (SEGPOSE) { in.pm = (uint32_t)ic; in.u = p.ev_u[ic]; in.bi = p.ev_seg[ic]; }   // pixel order, pose per event: spline parameter and SEGMENT of the entry's batch
     else { in.pm = (uint32_t)ic; in.bi = stream_load(p.ev_batch + ic, EV_NT_LOAD); }
 }
 
@@ -331,7 +331,7 @@ struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
 // segment and texel gathers, and the waits for those L2 hits would pay the prefetch's HBM latency.)
 // SEGPOSE (round 4; pixel order with a LARGE window): the pose is evaluated per event from its batch's spline parameter and segment record, as in the tile
 // order, instead of gathered from the per-batch table — at 10 M events that table is 11 MB of 112-B records, every event pulls one or two 128-B lines of it
-// past the L2 (counters: 1.37x the algorithmic bytes); the per-batch u / segment tables are 1 MB, the K-1 segment records a few KB.
+// past the L2 (counters: 1.37x the algorithmic bytes); u and the segment travel per entry with the event words (10 B, streamed), the K-1 segment records are a few KB.
 template <bool DUMP, bool COMPACT = false, class PF = NoPrefetch, bool LATE_EP = false, bool SEGPOSE = false>
 __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const LaneIn& in, int t, LaneOut& o, PF prefetch = PF())
 {
@@ -354,8 +354,7 @@ __device__ __forceinline__ void warp_lane(const WarpParams& p, long i, const Lan
         if (COMPACT || SEGPOSE) {   // pose per EVENT from its segment record and spline parameter (device_math.h: spline2_event)
             // (the K-1 segment records are cache-resident and fetched here, next to the bearing-vector gather whose latency is paid anyway:
             // prefetched with the event words they cost 24 VGPRs per pipeline stage)
-            uint32_t sg = bi; double uu = in.u;
-            if (SEGPOSE) { uu = p.batch_u[bi]; sg = p.batch_seg[bi]; }
+            const uint32_t sg = bi; const double uu = in.u;
             const double2* S2 = reinterpret_cast<const double2*>(p.seg + (size_t)kSegStride * (EMBA_ABL(p.ablate, 16) ? (sg & 1u) : sg));
             const double2 s0 = S2[0], s1 = S2[1], s2 = S2[2], s3 = S2[3], s4 = S2[4], s5 = S2[5];
             const double seg[kSegStride] = {s0.x, s0.y, s1.x, s1.y, s2.x, s2.y, s3.x, s3.y, s4.x, s4.y, s5.x, s5.y};
@@ -562,7 +561,7 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
     const bool valid = (i >= 0) && (i < p.n_sorted);
     LaneOut o;
     LaneIn in;
-    load_event_words<COMPACT>(p, i, valid, in);
+    load_event_words<COMPACT, SEGPOSE>(p, i, valid, in);
     warp_lane<DUMP, COMPACT, NoPrefetch, (WARP_LATE_EP != 0) && !DUMP, SEGPOSE>(p, i, in, t, o);
     if (DUMP) return;
     const bool inl = o.inl;

@@ -304,6 +304,17 @@ __global__ void emba_dev_gather_kernel(const uint32_t* __restrict__ keys, const 
     if (j == 0 || keys[j - 1] != keys[j]) bin_start[keys[j]] = (uint32_t)j;
 }
 
+// pixel order (the device order IS the pm-order): spline parameter and segment of every entry's batch, as two streams beside the event words — the warp
+// kernel then evaluates the pose per event (kernels.h: SEGPOSE) without a dependent lookup through the batch index
+__global__ void emba_entry_pose_args_kernel(const uint32_t* __restrict__ ev_batch, long nd, const uint16_t* __restrict__ cp, const double* __restrict__ batch_u,
+                                            uint16_t* __restrict__ ev_seg, double* __restrict__ ev_u)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nd) return;
+    const uint32_t b = ev_batch[j];
+    ev_seg[j] = cp[b]; ev_u[j] = batch_u[b];
+}
+
 // pair key of every measurement candidate of the device order, compacted: cand_pos = exclusive scan of cand_flag
 __global__ void emba_cand_keys_kernel(const uint32_t* __restrict__ ev_pix, const uint32_t* __restrict__ ev_batch, const uint16_t* __restrict__ cp, long nd,
                                       const uint32_t* __restrict__ cand_pos, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)

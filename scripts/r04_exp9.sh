@@ -1,5 +1,5 @@
 mkdir -p gpurun_out; L=gpurun_out/r04_exp9.log; rm -f $L
-EMBA_SEGPOSE=1 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "state_parity or baseline_size or normal_equations or irls or randomised or other_configurations or panorama_border or resident_step" > gpurun_out/r04_tests2.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "state_parity or baseline_size or normal_equations or irls or randomised or other_configurations or panorama_border or resident_step" > gpurun_out/r04_tests2.log 2>&1; rc=$?
 tail -3 gpurun_out/r04_tests2.log | tee -a $L
 [ $rc -ne 0 ] && { grep -E "Error|assert|FAILED|error" gpurun_out/r04_tests2.log | head -30; exit $rc; }
 run() { # label events pano_h K steps extra-args env...

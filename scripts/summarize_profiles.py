@@ -8,7 +8,9 @@ import collections, csv, glob, json, os, shutil, sys
 tag = sys.argv[1]
 src = os.path.join("gpurun_out", f"prof_{tag}")
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(glob.glob(f"{src}/trace/*/*_kernel_stats.csv")[0], f"profiles/{tag}_kernel_stats.csv")
+raw = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+if raw:
+    shutil.copy(raw[0], f"profiles/{tag}_kernel_stats.csv")
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("fetch", "write", "atomic"):
     fs = glob.glob(f"{src}/{name}/*/*_counter_collection.csv")
@@ -22,11 +24,13 @@ for k, d in vals.items():
     at = sum(d["TCC_EA0_ATOMIC_sum"]) / max(len(d["TCC_EA0_ATOMIC_sum"]), 1)
     rows.append((k, len(d["FETCH_SIZE"]), f, w, (2 * f + w) * 1024, at))
 rows.sort(key=lambda r: -r[4])
+if not rows:      # the raw rocprofv3 trees were pruned (scripts/final_profiles.sh): work from the per-kernel summary written before that
+    rows = [(r[0], int(r[1]), float(r[2]), float(r[3]), float(r[4]), float(r[5])) for r in list(csv.reader(open(f"profiles/{tag}_pmc_summary.csv")))[1:]]
 with open(f"profiles/{tag}_pmc_summary.csv", "w") as fo:
     fo.write("kernel,launches,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean,hbm_bytes_per_launch_corrected(2*FETCH+WRITE)*1024,TCC_EA0_ATOMIC_requests_mean\n")
     for r in rows:
         fo.write('"%s",%d,%.1f,%.1f,%.0f,%.0f\n' % r)
-cand = [r for r in rows if "emba_warp_tiled_kernel" in r[0]] or [r for r in rows if "emba_warp_residual_kernel" in r[0] and "true" not in r[0]]
+cand = [r for r in rows if "emba_warp_tiled_kernel" in r[0]] or [r for r in rows if "emba_warp_residual_kernel<false" in r[0]]
 dom = cand[0]
 bench = json.loads([l for l in open(f"{src}/bench_trace.log") if l.startswith("{")][-1])
 wkey = bench["config"]["workload"]

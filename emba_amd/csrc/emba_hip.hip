@@ -1920,6 +1920,17 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
             nks = std::max(1, std::min(nks_max, n_slices));
         }
         sp.direct = (nks == 1);
+        if (getenv("EMBA_SOLVE_DEBUG")) {      // diagnostic: how sparse is this chunk?  (products = (block pair, slice) pairs the SYRK forms)
+            hipStreamSynchronize(s);
+            std::vector<uint16_t> hr(p1 - p0); hipMemcpy(hr.data(), d_range, (p1 - p0) * 2, hipMemcpyDeviceToHost);
+            long w16 = 0, w64 = 0, hist[9] = {0};
+            for (uint16_t r : hr) { const int lo = r & 255, hi = r >> 8; if (lo > hi) continue; w16 += hi - lo + 1; const int b = (hi >> 2) - (lo >> 2) + 1; w64 += b; hist[b < 8 ? b : 8]++; }
+            long prod = 0, prod_diag = 0;
+            if (sparse) { std::vector<uint32_t> hc(nbp); hipMemcpy(hc.data(), d_cnt, nbp * 4, hipMemcpyDeviceToHost); for (int b = 0; b < nbp; ++b) { prod += hc[b]; int I, J; I = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5); while ((long)I * (I + 1) / 2 > b) --I; while ((long)(I + 1) * (I + 2) / 2 <= b) ++I; J = b - I * (I + 1) / 2; if (I == J) prod_diag += hc[b]; } }
+            fprintf(stderr, "[solve debug] pixels %ld slices %d nbp %d nks %d: mean 16-row groups per pixel %.2f, mean 64-row blocks written %.2f (hist 1..8+: %ld %ld %ld %ld %ld %ld %ld %ld), products %ld (diag %ld) = %.2f per slice; U written %.1f MB\n",
+                    (long)(p1 - p0), n_slices, nbp, nks, (double)w16 / (p1 - p0), (double)w64 / (p1 - p0), hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], prod, prod_diag,
+                    (double)prod / n_slices, w64 * 64.0 * 2 * 8 / 1e6);
+        }
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
         if (nks > 1)
             hipLaunchKernelGGL(emba_syrk_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256), (unsigned)((nks + kSyrkReduceGroup - 1) / kSyrkReduceGroup)),
@@ -1942,7 +1953,7 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
         const int nb = std::min(64, m - jb);
         hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
         const int below = m - jb - nb;                      // matrix rows under the panel; the rhs row (index m) comes on top of them
-        hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 255) / 256), dim3(256), 0, s, Sm, lds_, m + 1, jb, nb);
+        hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 4 * kTrsmRows - 1) / (4 * kTrsmRows)), dim3(256), 0, s, Sm, lds_, m + 1, jb, nb);
         if (below > 0) {
             const int tb = (below + 1 + 63) / 64;
             SyrkParams tp{};
@@ -1952,7 +1963,7 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
         }
     }
     hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);   // z = row n of the factor
-    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip, 1);
+    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }

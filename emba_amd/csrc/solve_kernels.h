@@ -47,6 +47,12 @@ __device__ __forceinline__ uint32_t rec_key(const RecView& v, uint32_t s)
     return v.packed ? (uint32_t)__double2hiint(v.rec[(size_t)kRecStride * s + 15]) : v.slot_key[s];
 }
 
+// compile-time loop: f(std::integral_constant<int, B>) ... f(std::integral_constant<int, E - 1>)
+template <int B, int E, class F> __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
@@ -134,41 +140,50 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const double* q = p.A22b2 + 5 * ic;
         h.q0 = q[0]; h.q1 = q[1]; h.q2 = q[2]; h.q3 = q[3]; h.q4 = q[4];
     };
-    Hdr h_cur, h_nxt;
+    // 16 records in flight at a time (lane l: element l&15 of record l>>4 of each group of four)
+    struct Grp { double x[4]; double2 dxy[4], et[4]; };
+    const int el = lane & 15, kk = lane >> 4;
+    auto load_grp = [&](uint32_t base, int m, int t0, Grp& g) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = t0 + 4 * u + kk;
+            const double* rp = p.view.rec + (size_t)kRecStride * (base + (uint32_t)(r < m ? r : 0));
+            g.x[u] = rp[el];
+            // dp, the residual and the tail word straight from the record's line (same address in the record's 16 lanes: one cached
+            // request) rather than broadcast from lanes 12-14 through the LDS crossbar, which this kernel's atomics already load
+            g.dxy[u] = reinterpret_cast<const double2*>(rp)[6];
+            g.et[u] = reinterpret_cast<const double2*>(rp)[7];
+        }
+    };
+    // (round 4) the FIRST record group of pixel i+1 is fetched while pixel i is worked on, its list bounds one pixel earlier still: a pixel used to
+    // cost one dependent round trip to its records with nothing else of the wave in flight (three waves per SIMD at K = 201: LDS)
+    Hdr h_cur, h_nxt, h_nn;
+    Grp g_cur, g_nxt;
     load_hdr(i_first, h_cur);
+    load_hdr(i_first + nwaves, h_nxt);
+    load_grp(h_cur.b0, (int)(h_cur.b1 - h_cur.b0), 0, g_cur);
     for (long i = i_first; i < p.p1; i += nwaves) {
-        load_hdr(i + nwaves, h_nxt);
+        load_hdr(i + 2 * nwaves, h_nn);
+        load_grp(h_nxt.b0, (int)(h_nxt.b1 - h_nxt.b0), 0, g_nxt);
         const double mxx = h_cur.q0 + p.lambda * h_cur.q0, mxy = h_cur.q1, myy = h_cur.q2 + p.lambda * h_cur.q2;   // model.cpp:748
         const double c00 = sqrt(mxx), c10 = mxy / c00, c11 = sqrt(myy - c10 * c10);
         if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
         const double y0 = h_cur.q3 / c00, y1 = (h_cur.q4 - c10 * y0) / c11;
         if (lane == 0) { p.yv[2 * i] = y0; p.yv[2 * i + 1] = y1; p.cfac[3 * i] = c00; p.cfac[3 * i + 1] = c10; p.cfac[3 * i + 2] = c11; }
         const uint32_t b0 = h_cur.b0, b1 = h_cur.b1;
-        const int el = lane & 15, kk = lane >> 4;
         unsigned long long rows_mask = 0ull;
         int rmin = 0x7FFFFFFF, rmax = -1;                               // first / last row of U the pixel's records touch
-        // 16 records in flight at a time (lane l: element l&15 of record l>>4 of each group of four).  The sums go to the LDS columns with
-        // fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
+        // The sums go to the LDS columns with fp64 LDS atomics: rows of different records, or of a record's c and p halves, may coincide.
         {
             const uint32_t base = b0; const int m = (int)(b1 - b0);
             for (int t0 = 0; t0 < m; t0 += 16) {
-                double x[4]; double2 dxy[4], et[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = t0 + 4 * u + kk;
-                    const double* rp = p.view.rec + (size_t)kRecStride * (base + (uint32_t)(r < m ? r : 0));
-                    x[u] = rp[el];
-                    // dp, the residual and the tail word straight from the record's line (same address in the record's 16 lanes: one cached
-                    // request) rather than broadcast from lanes 12-14 through the LDS crossbar, which this kernel's atomics already load
-                    dxy[u] = reinterpret_cast<const double2*>(rp)[6];
-                    et[u] = reinterpret_cast<const double2*>(rp)[7];
-                }
+                if (t0) load_grp(base, m, t0, g_cur);
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     if (t0 + 4 * u >= m) break;                             // (uniform)
                     const bool in = t0 + 4 * u + kk < m;
-                    const double dx = dxy[u].x, dy = dxy[u].y, e = et[u].x;
-                    const uint32_t keyu = (uint32_t)__double2hiint(et[u].y);      // (packed view: tail = {pixel, pair key})
+                    const double dx = g_cur.dxy[u].x, dy = g_cur.dxy[u].y, e = g_cur.et[u].x;
+                    const uint32_t keyu = (uint32_t)__double2hiint(g_cur.et[u].y);      // (packed view: tail = {pixel, pair key})
                     double w = 1.0;
                     if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
                     else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
@@ -177,7 +192,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
                         rows_mask |= (1ull << ((bc >> 6) & 63)) | (1ull << (((bc + 5) >> 6) & 63)) | (1ull << ((bp >> 6) & 63)) | (1ull << (((bp + 5) >> 6) & 63));
                         rmin = min(rmin, min(bc, bp)); rmax = max(rmax, max(bc, bp) + 5);
                     }
-                    const double wx = w * x[u];                                 // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
+                    const double wx = w * g_cur.x[u];                           // Yi_inv * dM_ddrot^T, model.cpp:483-487 / 679-683
                     if (in && el < 12) {
                         const int row = (el < 6) ? bc + el : bp + el - 6;
                         atomicAdd(&c0[row], wx * dx);
@@ -195,12 +210,13 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const int lo16 = (rmax >= 0) ? rmin >> 4 : 1, hi16 = (rmax >= 0) ? rmax >> 4 : 0;
         const int lo = (rmax >= 0) ? lo16 >> 2 : 1, hi = (rmax >= 0) ? hi16 >> 2 : 0;
         const int r0 = 64 * lo, r1 = (64 * (hi + 1) < p.n) ? 64 * (hi + 1) : p.n;
+        const double ic00 = 1.0 / c00, ic11 = 1.0 / c11;      // (reciprocals once per pixel: the band loop had two divisions per row)
         // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11 ;  and the block's share of U y (the right-hand side b1 - U y)
         double* u0 = p.U + (size_t)p.ldu * (2 * (i - p.p0));
         double* u1 = u0 + p.ldu;
         for (int r = r0 + lane; r < r1; r += 64) {
             const double a0 = c0[r], a1 = c1[r];
-            const double t0 = a0 / c00, t1 = (a1 - t0 * c10) / c11;
+            const double t0 = a0 * ic00, t1 = (a1 - t0 * c10) * ic11;
             u0[r] = t0;
             u1[r] = t1;
             c0[r] = 0.0; c1[r] = 0.0;
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
             if (p.slice_mask && rows_mask) atomicOr(p.slice_mask + (i - p.p0) / kSyrkSlicePix, rows_mask);
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        h_cur = h_nxt;
+        h_cur = h_nxt; h_nxt = h_nn; g_cur = g_nxt;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < p.n; r += 256) {
@@ -373,7 +389,9 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
         int m0, m1, m2;
         load(0, a0, b0, m0); load(1, a1, b1, m1);
         // (one loop body of three stages and nothing else: with early exits between the stages the register allocator kept the 128 accumulator
-        // registers in different places on different paths and copied them every trip; stages past the end run on zeros)
+        // registers in different places on different paths and copied them every trip; stages past the end run on zeros.  Round 4: a fourth
+        // buffer, three quads ahead, changed nothing — 1.73 vs 1.69 ms at config 2's shape: the kernel is not short of bytes in flight; at the
+        // MI355X's fp64 matrix rate, 64 cycles per 16x16x4, its 27 M MFMAs alone are 0.7 ms, its 6 GB of operand reads 0.75 ms)
         for (int it = 0; it < nq; it += 3) {
             load(it + 2, a2, b2, m2); mma(a0, b0, m0);
             load(it + 3, a0, b0, m0); mma(a1, b1, m1);
@@ -421,26 +439,34 @@ __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks
 }
 
 // ---- blocked Cholesky (lower, column-major), panels of 64 ---------------------------------------------------------------
-// (1) factor the diagonal block in LDS
-// ONE wave, left-looking, the whole block in registers: lane r owns row r (64 doubles); column j is
-//     L[r][j] = (A[r][j] - sum_{k<j} L[r][k] L[j][k]) / L[j][j],
-// where L[j][k] is lane j's register k, broadcast with v_readlane (j is uniform).  Both loops are fully unrolled so that every
-// register index is static; no LDS and no barrier on the 64-step critical path (the 256-thread right-looking version spent
-// ~1.2 us per column in barriers: 76 us per panel; the LDS left-looking one 56; this one ~12).
+// 1 / sqrt(d) for a positive, normal d: v_rsq_f64 (about 26 good bits) + two Newton steps.  The factorisation multiplies by it instead of
+// dividing by the square root: the pivot chain of a 64-column panel is 64 x (sqrt + divide) ~ 64 x 450 cycles otherwise, most of the kernel.
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h, y * y, 1.5);
+    y = y * fma(-h, y * y, 1.5);
+    return y;
+}
 
+// (1) factor the diagonal block.  ONE wave, the whole block in registers: lane r owns row r (64 doubles).  Right-looking: once column j is
+// final it goes to LDS and comes back as broadcast reads L[c][j] that update the lanes' columns c > j — 2016 independent fmas, every register
+// index static (both loops fully unrolled), no barrier (one wave).  The subtractions reach an entry in the same order k = 0, 1, ... as in the
+// left-looking form used until round 3; that one waited per column for a chain of j dependent fmas on v_readlane pairs (~40 cycles each) plus
+// a square root and a division: 35 us per panel.
 __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
 {
+    __shared__ __attribute__((aligned(16))) double s_col[2][64];
     const int r = threadIdx.x;
     double row[64];
 #pragma unroll
     for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
+    const double dg0 = (r < nb) ? A[(size_t)ld * (jb + r) + jb + r] : 1.0;      // the diagonal entry before elimination (the scale of the pivot test)
     bool bad = false, bad_sign = false;
-#pragma unroll
-    for (int j = 0; j < 64; ++j) {
-        double v = row[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v -= row[k] * readlane_f64(row[k], j);
-        const double d = readlane_f64(v, j);
+    // column j from the lanes' current row[j]: the pivot's square root and the scaled column
+    auto column = [&](int j, double rj) -> double {
+        const double d = readlane_f64(rj, j);
         // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
         // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
         // The case that occurs in practice is a control pose no event constrains: its rows and columns of S are exactly zero, so d == 0
@@ -450,110 +476,130 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
         // factors the former with a negative D entry and propagates the latter; a Cholesky factorisation can do neither, and a finite, partly
         // zeroed x1 with EMBA_OK would hide corrupted equations — info bit 2 (4), which the solve returns as EMBA_ERR_NUMERIC (the LM loop then
         // rejects the step, as it does for the NaN cost the reference would see).
-        const double d0 = readlane_f64(row[j], j);                 // lane j's column j is still the original diagonal entry here (left-looking)
-        const bool ok = d > 0.0;
-        const bool vanishing = !ok && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
+        const double d0 = readlane_f64(dg0, j);
+        const bool ok = d > 0.0 && d < 1.7e308;                                            // (inf / NaN: not ok, not vanishing)
+        const bool vanishing = !ok && (d <= 0.0) && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
         bad |= (j < nb) && !ok;
         bad_sign |= (j < nb) && !ok && !vanishing;
-        const double piv = ok ? sqrt(d) : 0.0;
-        row[j] = (r == j) ? piv : (ok ? v / piv : 0.0);     // rows above the diagonal hold garbage that is never read (k < j <= r below)
-    }
+        const double rs = ok ? rsqrt_nr(d) : 0.0;
+        double piv = d * rs;
+        piv = ok ? fma(0.5 * rs, fma(-piv, piv, d), piv) : 0.0;                             // sqrt(d), one correction step
+        return (r == j) ? piv : rj * rs;                     // rows above the diagonal hold garbage that is never read (only entries c > j are)
+    };
+    double lj = column(0, row[0]);
+    // (compile-time loops: every register index must be static, and the plain `#pragma unroll` form of this nest was left rolled, rows in scratch)
+    static_for<0, 64>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        row[j] = lj;
+        double* col = s_col[j & 1];
+        col[r] = lj;                                          // (one wave: its LDS operations execute in order — the reads below see this write)
+        double lnext = 0.0;
+        if constexpr (j + 1 < 64) {
+            row[j + 1] -= lj * col[j + 1];
+            __asm__ volatile("" : "+v"(row[j + 1]));
+            lnext = column(j + 1, row[j + 1]);                // the next pivot's chain (rsqrt_nr) runs under the updates of the other columns
+        }
+        // the other columns, 32 at a time: the broadcast reads of a group are issued together (the pins below are barriers for memory operations:
+        // a read placed between them would be waited for on the spot), then its fmas
+        static_for<0, 2>([&](auto gc) {
+            constexpr int g = 32 * decltype(gc)::value;
+            if constexpr (g + 32 > j + 2) {
+                double2 lc[16];
+                static_for<0, 16>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (g + 2 * q + 1 >= j + 2) lc[q] = reinterpret_cast<const double2*>(col)[(g >> 1) + q];
+                });
+                static_for<0, 16>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    constexpr int c0 = g + 2 * q, c1 = c0 + 1;
+                    // (pinned: left alone the compiler sinks every update to the step that reads the column — the left-looking form again — and
+                    // keeps the 2016 broadcast values alive until then)
+                    if constexpr (c0 >= j + 2) { row[c0] -= lj * lc[q].x; __asm__ volatile("" : "+v"(row[c0])); }
+                    if constexpr (c1 >= j + 2) { row[c1] -= lj * lc[q].y; __asm__ volatile("" : "+v"(row[c1])); }
+                });
+            }
+        });
+        lj = lnext;
+    });
     if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
     if (bad_sign && r == 0) atomicOr(info, 4);
 #pragma unroll
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
 
-// (2) panel below the diagonal block: row r of A[jb+nb.., jb..jb+nb) <- row * L_diag^-T   (one thread per row)
-// (35 us per panel, latency-bound on 2016 LDS broadcast reads per thread.  Tried, round 3: one wave per workgroup — 60 us, the four waves
-// of a workgroup were hiding each other's LDS latency; right-looking with the column of L contiguous in LDS — fully unrolled the compiler
-// hoists all 2016 reads and spills 15 KB per lane whatever barriers sit between the columns: 220 us; four partial sums: no change.)
+// (2) panel below the diagonal block: row * L_diag^-T for the rows A[jb+nb .. n) of the panel.  Lanes are the panel's 64 COLUMNS; lane c keeps
+// L_diag[c][0..c) in registers; a wave carries kTrsmRows rows at a time: x_k = a_k / L[k][k] leaves lane k by v_readlane and updates the lanes
+// c > k.  (Until round 3: one thread per row, 2016 dependent fmas on LDS broadcast reads — 35 us per panel whatever the number of rows.)
+constexpr int kTrsmRows = 4;
 __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict__ A, long ld, int n, int jb, int nb)
 {
-    __shared__ double s[64 * 65];
-    for (int i = threadIdx.x; i < nb * nb; i += 256) { const int r = i % nb, c = i / nb; s[c * 65 + r] = (r >= c) ? A[(size_t)ld * (jb + c) + jb + r] : 0.0; }
-    __syncthreads();
-    const int r = jb + nb + blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    double x[64];
+    const int c = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long r0 = (long)jb + nb + wave * kTrsmRows;
+    if (r0 >= n) return;                                                     // (wave-uniform)
+    double Lm[64];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) x[c] = (c < nb) ? A[(size_t)ld * (jb + c) + r] : 0.0;
+    for (int k = 0; k < 64; ++k) Lm[k] = (c < nb && k < c) ? A[(size_t)ld * (jb + k) + jb + c] : 0.0;      // L_diag[c][k], strictly below the diagonal
+    const double dg = (c < nb) ? A[(size_t)ld * (jb + c) + jb + c] : 0.0;
+    const double rd = (dg != 0.0) ? 1.0 / dg : 0.0;                           // zeroed column of a vanishing pivot (emba_chol_diag_kernel): x = 0
+    double a[kTrsmRows];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        if (c < nb) {
-            double v = x[c];
+    for (int i = 0; i < kTrsmRows; ++i) a[i] = (c < nb && r0 + i < n) ? A[(size_t)ld * (jb + c) + r0 + i] : 0.0;
 #pragma unroll
-            for (int k = 0; k < c; ++k) v -= x[k] * s[k * 65 + c];     // L_diag[c][k]
-            const double dg = s[c * 65 + c];
-            x[c] = (dg != 0.0) ? v / dg : 0.0;                        // zeroed column of a vanishing pivot (emba_chol_diag_kernel)
+    for (int k = 0; k < 64; ++k) {
+#pragma unroll
+        for (int i = 0; i < kTrsmRows; ++i) {
+            const double xk = readlane_f64(a[i] * rd, k);
+            a[i] = fma(-xk, Lm[k], a[i]);
         }
     }
 #pragma unroll
-    for (int c = 0; c < 64; ++c) if (c < nb) A[(size_t)ld * (jb + c) + r] = x[c];
+    for (int i = 0; i < kTrsmRows; ++i) if (c < nb && r0 + i < n) A[(size_t)ld * (jb + c) + r0 + i] = a[i] * rd;
 }
 
-// Solve L L^T x = b in place (one workgroup; 64-wide blocks: substitution inside a block by one wave in LDS, then the rest of the
-// right-hand side is updated by all threads).
-// backward_only: b already holds z = L^-1 rhs (the factorisation carried the right-hand side along as an extra row: schur_factor_solve)
-constexpr int kTrsvMaxN = 3072;   // right-hand sides up to this length stay in LDS during the backward sweep (K <= 1024)
-__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b, int backward_only)
+// Solve L^T x = z in place (one workgroup; b holds z = L^-1 rhs: the factorisation carried the right-hand side along as an extra row,
+// schur_factor_solve).  64-wide blocks from the bottom: one wave substitutes inside the block — lane t keeps column t of the block in registers,
+// x_j leaves lane j by v_readlane —, then every thread takes one row above the block and subtracts its 64-term dot product (the row's 64 factor
+// entries are contiguous: column r of L).
+constexpr int kTrsvMaxN = 3072;   // right-hand sides up to this length stay in LDS during the sweep (K <= 1024)
+__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b)
 {
     __shared__ double s_l[64 * 65];
     __shared__ double s_x[64];
     __shared__ double s_b[kTrsvMaxN];
     const int t = threadIdx.x;
-    // forward: L z = b
-    for (int jb = 0; jb < n && !backward_only; jb += 64) {
-        const int nb = (n - jb < 64) ? n - jb : 64;
-        for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
-        if (t < 64) s_x[t] = (t < nb) ? b[jb + t] : 0.0;
-        __syncthreads();
-        if (t < 64) {
-            double v = s_x[t];
-            for (int j = 0; j < nb; ++j) {
-                const double dg = s_l[j * 65 + j];
-                const double xj = (dg != 0.0) ? __shfl(v, j) / dg : 0.0;
-                if (t == j) v = xj; else if (t > j && t < nb) v -= s_l[j * 65 + t] * xj;
-            }
-            s_x[t] = v;
-            if (t < nb) b[jb + t] = v;
-        }
-        __syncthreads();
-        for (int r = jb + nb + t; r < n; r += 1024) {
-            double v = b[r];
-            for (int c = 0; c < nb; ++c) v -= L[(size_t)ld * (jb + c) + r] * s_x[c];
-            b[r] = v;
-        }
-        __syncthreads();
-    }
-    // backward: L^T x = z.  The right-hand side lives in LDS for the whole sweep (n <= kTrsvMaxN; beyond that in global memory as before).
     const bool in_lds = n <= kTrsvMaxN;
     if (in_lds) { for (int i = t; i < n; i += 1024) s_b[i] = b[i]; }
     __syncthreads();
     for (int jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {
         const int nb = (n - jb < 64) ? n - jb : 64;
-        for (int i = t; i < nb * nb; i += 1024) { const int r = i % nb, c = i / nb; s_l[c * 65 + r] = (r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
-        if (t < 64) s_x[t] = (t < nb) ? (in_lds ? s_b[jb + t] : b[jb + t]) : 0.0;
+        for (int i = t; i < 64 * 64; i += 1024) { const int r = i & 63, c = i >> 6; s_l[c * 65 + r] = (r < nb && c < nb && r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
         __syncthreads();
         if (t < 64) {
-            double v = s_x[t];
+            double v = (t < nb) ? (in_lds ? s_b[jb + t] : b[jb + t]) : 0.0;
             const double dgt = s_l[t * 65 + t];
-            const double rdt = (t < nb && dgt != 0.0) ? 1.0 / dgt : 0.0;            // pseudo-inverse: zero update where the pivot vanished
-            for (int j = nb - 1; j >= 0; --j) {
-                const double xj = __shfl(v * rdt, j);
-                if (t == j) v = xj; else if (t < j) v -= s_l[t * 65 + j] * xj;      // L^T[t][j] = L[j][t]
+            const double rdt = (dgt != 0.0) ? 1.0 / dgt : 0.0;                          // pseudo-inverse: zero update where the pivot vanished
+#pragma unroll
+            for (int j = 63; j >= 0; --j) {
+                const double xj = readlane_f64(v * rdt, j);
+                const double ltj = (j > t) ? s_l[t * 65 + j] : 0.0;                      // L[j][t] = L^T[t][j], strictly above the diagonal of L^T
+                v = fma(-xj, ltj, v);
             }
+            v *= rdt;
             s_x[t] = v;
             if (t < nb) { if (in_lds) s_b[jb + t] = v; else b[jb + t] = v; }
         }
         __syncthreads();
-        // rows above the block: one wave per row, lanes over the block's 64 columns (one coalesced 512-B load per row), xor-shuffle sum
-        for (int r = (t >> 6); r < jb; r += 16) {
-            const int c = t & 63;
-            double d = (c < nb) ? L[(size_t)ld * r + jb + c] * s_x[c] : 0.0;      // L^T[r][jb+c] = L[jb+c][r]
+        for (int r = t; r < jb; r += 1024) {
+            const double* lp = L + (size_t)ld * r + jb;
+            double d0 = 0.0, d1 = 0.0;
+            if (nb == 64) {
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-            if (c == 0) { if (in_lds) s_b[r] -= d; else b[r] -= d; }
+                for (int c = 0; c < 64; c += 2) { d0 = fma(lp[c], s_x[c], d0); d1 = fma(lp[c + 1], s_x[c + 1], d1); }
+            } else {
+                for (int c = 0; c < nb; ++c) d0 = fma(lp[c], s_x[c], d0);
+            }
+            if (in_lds) s_b[r] -= d0 + d1; else b[r] -= d0 + d1;
         }
         __syncthreads();
     }

@@ -1949,17 +1949,20 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
     hipStream_t s = c->stream;
     const int m = n - skip;
     double* Sm = d_S + (size_t)lds_ * skip + skip;
+    if (m + 1 <= 64 && skip <= 64) {                         // K <= 21: factor + both substitutions in one launch
+        hipLaunchKernelGGL(emba_chol_small_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, m, skip, d_rhs, d_info);
+        HIP_TRY(c, hipGetLastError());
+        return EMBA_OK;
+    }
+    // per panel: [diagonal factor — a launch of its own for the first panel only] / panel solve / trailing update + the next panel's diagonal factor
+    hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, 0, std::min(64, m), d_info);
     for (int jb = 0; jb < m; jb += 64) {
         const int nb = std::min(64, m - jb);
-        hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, jb, nb, d_info);
         const int below = m - jb - nb;                      // matrix rows under the panel; the rhs row (index m) comes on top of them
         hipLaunchKernelGGL(emba_chol_trsm_kernel, dim3((below + 1 + 4 * kTrsmRows - 1) / (4 * kTrsmRows)), dim3(256), 0, s, Sm, lds_, m + 1, jb, nb);
         if (below > 0) {
             const int tb = (below + 1 + 63) / 64;
-            SyrkParams tp{};
-            tp.A = Sm + (size_t)lds_ * jb + (jb + nb); tp.lda = lds_; tp.n = below + 1; tp.k = nb;
-            tp.C = Sm + (size_t)lds_ * (jb + nb) + (jb + nb); tp.ldc = lds_; tp.slab = nullptr; tp.nbp = tb * (tb + 1) / 2; tp.direct = 1;
-            hipLaunchKernelGGL(emba_syrk_kernel, dim3(tp.nbp, 1), dim3(256), 0, s, tp);
+            hipLaunchKernelGGL(emba_chol_trail_kernel, dim3(tb * (tb + 1) / 2), dim3(256), 0, s, Sm, lds_, jb, nb, below + 1, std::min(64, below), d_info);
         }
     }
     hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);   // z = row n of the factor

@@ -455,14 +455,10 @@ __device__ __forceinline__ double rsqrt_nr(double d)
 // index static (both loops fully unrolled), no barrier (one wave).  The subtractions reach an entry in the same order k = 0, 1, ... as in the
 // left-looking form used until round 3; that one waited per column for a chain of j dependent fmas on v_readlane pairs (~40 cycles each) plus
 // a square root and a division: 35 us per panel.
-__global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
+// the factorisation proper, one wave: row = lane r's row of the block (identity-padded beyond nb), dg0 = its diagonal entry before elimination;
+// s_col: 2 x 64 doubles of LDS.  On return row[c], c <= r < nb, is L[r][c].
+__device__ __forceinline__ void chol_diag_wave(double (&row)[64], double dg0, double (*s_col)[64], int r, int nb, int* __restrict__ info)      // nb: pivots j < nb are checked
 {
-    __shared__ __attribute__((aligned(16))) double s_col[2][64];
-    const int r = threadIdx.x;
-    double row[64];
-#pragma unroll
-    for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
-    const double dg0 = (r < nb) ? A[(size_t)ld * (jb + r) + jb + r] : 1.0;      // the diagonal entry before elimination (the scale of the pivot test)
     bool bad = false, bad_sign = false;
     // column j from the lanes' current row[j]: the pivot's square root and the scaled column
     auto column = [&](int j, double rj) -> double {
@@ -523,6 +519,17 @@ __global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__
     });
     if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
     if (bad_sign && r == 0) atomicOr(info, 4);
+}
+
+__global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double s_col[2][64];
+    const int r = threadIdx.x;
+    double row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
+    const double dg0 = (r < nb) ? A[(size_t)ld * (jb + r) + jb + r] : 1.0;      // the diagonal entry before elimination (the scale of the pivot test)
+    chol_diag_wave(row, dg0, s_col, r, nb, info);
 #pragma unroll
     for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
 }
@@ -555,6 +562,102 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < kTrsmRows; ++i) if (c < nb && r0 + i < n) A[(size_t)ld * (jb + c) + r0 + i] = a[i] * rd;
+}
+
+// Small systems, m + 1 <= 64 (K <= 21 with the first pose fixed): factor, forward and backward substitution in ONE wave and one launch.  The
+// right-hand side is row m of the augmented block (schur_factor_solve): factored along as one more row it becomes z = L^-1 rhs; L goes to LDS
+// and L^T x = z is solved as in emba_chol_trsv_kernel.  x (m entries) -> x_out[skip ..), zeros in front.  (Until round 4: diagonal factor, panel
+// solve of the one rhs row, rhs copy, triangular solve — four launches, 58 us on the device at K = 21.)
+__global__ __launch_bounds__(64) void emba_chol_small_kernel(const double* __restrict__ A, long ld, int m, int skip, double* __restrict__ x_out, int* __restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double s_col[2][64];
+    __shared__ double s_l[64 * 65];
+    __shared__ double s_z[64];
+    const int r = threadIdx.x;
+    double row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = (r <= m && c < m && r >= c) ? A[(size_t)ld * c + r] : ((r == c) ? 1.0 : 0.0);   // rows 0..m (m: the rhs), columns 0..m-1; identity elsewhere
+    const double dg0 = (r < m) ? A[(size_t)ld * r + r] : 1.0;
+    chol_diag_wave(row, dg0, s_col, r, m, info);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+        s_l[c * 65 + r] = (r < m && c <= r) ? row[c] : 0.0;                       // L[r][c]
+        if (r == m) s_z[c] = (c < m) ? row[c] : 0.0;                              // z
+    }
+    __syncthreads();
+    double v = (r < m) ? s_z[r] : 0.0;
+    const double dgt = s_l[r * 65 + r];
+    const double rdt = (r < m && dgt != 0.0) ? 1.0 / dgt : 0.0;                   // pseudo-inverse: zero update where the pivot vanished
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        const double xj = readlane_f64(v * rdt, j);
+        const double ltj = (j > r) ? s_l[r * 65 + j] : 0.0;                       // L[j][r] = L^T[r][j]
+        v = fma(-xj, ltj, v);
+    }
+    if (r < m) x_out[skip + r] = v * rdt;
+    if (r < skip) x_out[r] = 0.0;
+}
+
+// (3) trailing update after a panel, and the NEXT panel's diagonal factor in the same launch.  X = the panel's rows below the diagonal block
+// (after the panel solve; n_t of them, the right-hand-side row included), nb columns; the trailing matrix T (n_t x n_t, lower triangle) takes
+// T -= X X^T in 64 x 64 tiles, one workgroup per tile (I >= J): both 64 x nb slabs of X staged in LDS, wave w forms rows 16w..16w+15 of the tile
+// over the whole panel width (4 x 16 MFMAs).  The workgroup of tile (0, 0) then factors the next diagonal block from its updated tile (through
+// LDS: one wave, chol_diag_wave), which until round 4 was a launch of its own between this one and the next panel solve (28 + 27 us per panel in
+// sequence; together 30).  nb_next = size of the next diagonal block (0: none — the tile (0, 0) then only holds the right-hand side row).
+__global__ __launch_bounds__(256) void emba_chol_trail_kernel(double* __restrict__ A, long ld, int jb, int nb, int n_t, int nb_next, int* __restrict__ info)
+{
+    __shared__ __attribute__((aligned(16))) double s_i[64 * 64];
+    __shared__ __attribute__((aligned(16))) double s_j[64 * 65];           // (tile (0, 0): I == J, this slab is free and carries the updated tile to the factor)
+    __shared__ __attribute__((aligned(16))) double s_col[2][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, el = lane & 15, kk = lane >> 4;
+    int I, J;
+    syrk_block_pair(blockIdx.x, I, J);
+    const int I0 = 64 * I, J0 = 64 * J;
+    const double* X = A + (size_t)ld * jb + (jb + nb);                       // X[row][k] = X[ld * k + row]
+    double* T = A + (size_t)ld * (jb + nb) + (jb + nb);
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int row = i & 63, k = i >> 6;
+        s_i[i] = (k < nb && I0 + row < n_t) ? X[(size_t)ld * k + I0 + row] : 0.0;
+        if (I != J) s_j[i] = (k < nb && J0 + row < n_t) ? X[(size_t)ld * k + J0 + row] : 0.0;
+    }
+    __syncthreads();
+    const double* sb = (I != J) ? s_j : s_i;
+    double4_t acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int q = 0; q < 16; ++q) {
+        const int k = 4 * q + kk;
+        const double av = s_i[k * 64 + 16 * wv + el];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sb[k * 64 + 16 * b + el], acc[b], 0, 0, 0);
+    }
+    const bool first = (I == 0 && J == 0 && nb_next > 0);
+    if (first) __syncthreads();                                              // (s_j is about to be written: every wave is done reading s_i — the same slab here — no hazard, but keep the phases apart)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = 16 * wv + kk + 4 * r4, col = 16 * b + el;        // C/D layout of v_mfma_f64_16x16x4_f64
+            const int gr = I0 + row, gc = J0 + col;
+            if (gr < n_t && gc < n_t && gr >= gc) {
+                double* tp = T + (size_t)ld * gc + gr;
+                const double v = *tp - acc[b][r4];
+                if (first && gr < nb_next) s_j[col * 65 + row] = v;          // the next diagonal block: to the factor below, which writes it
+                else *tp = v;
+            }
+        }
+    if (!first) return;
+    __syncthreads();
+    if (wv != 0) return;
+    const int r = lane;
+    double row[64];
+#pragma unroll
+    for (int c = 0; c < 64; ++c) row[c] = (r < nb_next && c < nb_next && r >= c) ? s_j[c * 65 + r] : ((r == c) ? 1.0 : 0.0);   // (entries above the diagonal are never read)
+    const double dg0 = (r < nb_next) ? s_j[r * 65 + r] : 1.0;
+    chol_diag_wave(row, dg0, s_col, r, nb_next, info);
+#pragma unroll
+    for (int c = 0; c < 64; ++c) if (c < nb_next && r >= c && r < nb_next) T[(size_t)ld * c + r] = row[c];
 }
 
 // Solve L^T x = z in place (one workgroup; b holds z = L^-1 rhs: the factorisation carried the right-hand side along as an extra row,

@@ -13,7 +13,7 @@ P r04_shard1M "--shard-of 8 --shard-rank 3" 50
 P r04_shard5M "--events-per-gpu 5000000 --knots 97 --sensor 640x480 --shard-of 8 --shard-rank 3 --yaw-rate 0.1" 10
 P r04_shard12M "--events-per-gpu 12500000 --knots 256 --pano-h 2048 --shard-of 8 --shard-rank 3" 6
 ORDERS="auto" bash scripts/scaling.sh > /dev/null 2>&1; cp gpurun_out/scaling.log gpurun_out/r04_scaling_sweep.txt; cat gpurun_out/scaling.log
-(python scripts/lm_timing.py; python scripts/lm_timing.py 1000000 1024 21 0.05 8; python scripts/lm_timing.py 10000000 1024 97 0.0104 6) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_lm_breakdown.txt; cat gpurun_out/r04_lm_breakdown.txt
+(python scripts/lm_timing.py; python scripts/lm_timing.py 1000000 1024 21 0.05 8) 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_lm_breakdown.txt; cat gpurun_out/r04_lm_breakdown.txt
 timeout -k 10 300 python bench.py > gpurun_out/bench_default.json 2>/dev/null; tail -c 1500 gpurun_out/bench_default.json
 timeout -k 10 900 python scripts/flip_rate.py --out gpurun_out/r04_flip_rate.txt > gpurun_out/flip.log 2>&1; echo "flip rate rc=$?"; tail -25 gpurun_out/r04_flip_rate.txt
 # what comes back: the summaries (tracked under profiles/), not the raw rocprofv3 trees (gpurun merges at most 64 MiB of gpurun_out back)

@@ -470,6 +470,21 @@ def _unobserved_pose_workload(K=8, frac=0.55, **kw):
     return w
 
 
+@pytest.mark.parametrize("K,fix", [(22, True), (22, False), (23, True), (43, False), (44, True), (65, True), (65, False)])
+def test_schur_solve_at_the_panel_edges_of_the_factorisation(gpu, oracle_mod, K, fix):
+    """The blocked Cholesky's shapes around its 64-wide panels (round 4: single-launch form for m + 1 <= 64, trailing update + next diagonal block in
+    one launch): m = 3K - 3 or 3K unknown pose rows = 63 (the single-launch form, full), 66 (a panel and a 2-row one), 129 (two panels and a 1-row one),
+    192 (three full panels: the last trailing tile holds nothing but the right-hand-side row), 195."""
+    w = small_workload(n_events=40000, pano_h=128, K=K, sensor=(32, 24), focal=30.0, dt_knots=0.01, thres_valid_pixel=3)
+    g = gpu_run(w)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    for lam in (1e-2, 3.0):
+        x1, x2 = g["legm"].solveNormalEq(lam, fix_first_pose=fix)
+        ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max())
+        assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+
+
 @pytest.mark.parametrize("K,kw", [(8, {}), (90, dict(n_events=60000, pano_h=256, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3))])
 def test_schur_solve_with_an_unobserved_control_pose(gpu, oracle_mod, K, kw):
     """model.cpp:789 is Eigen's PIVOTED ldlt: for a semi-definite S (a control pose no event constrains) it returns, with a ZERO update in

@@ -715,6 +715,8 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view, const 
                                                             const double* __restrict__ yv, const double* __restrict__ cfac,
                                                             const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
 {
+    // (Round 4: prefetching the next pixel's first record group, as the U build does, made this kernel SLOWER — 374 -> 503 us at config 2's shape: at 56
+    // VGPRs it runs eight waves per SIMD, which already overlap the pixels' round trips; the extra stage costs occupancy.)
     // One wave per pixel; the pixel's records are consecutive (emba_csr_fill_sorted_kernel), 16 of them in flight (lane l: element l&15 of record
     // l>>4 of each group of four).  The 12-term dot product of a record and its weight stay inside the record's DPP row of 16 lanes — row shifts
     // on the VALU, no LDS crossbar: with xor-shuffles and broadcasts (14 ds_bpermute per group) the kernel ran at the LDS pipe's rate.

@@ -1293,11 +1293,15 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
         // list-driven gather: it rides in the head of the Gram kernel (as a kernel of its own it is no faster than the sweeping write: 109.6 vs
         // 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison, 0 the sweeping kernel)
-        // Where it pays (measured, same box, step time with the head vs with the sweeping kernel): 1 M events 101.2 vs 105.7 us, the 1 M-event shard of
-        // the 8 M-event stream 121.8 vs 127, scene-driven 1.17 M events 121 vs 135 — but 1.5 M events 161 vs 154, 3 M (tile order) 289 vs 281, 10 M 833
-        // vs 817: with more active pixels per block the head's dependent trips grow past what the launch saved.  Pixel order up to 1.3 M slots.
+        // Where it paid as a HEAD in front of the stream (same box, step time with the head vs with the sweeping kernel): 1 M events 101.2 vs 105.7 us,
+        // the 1 M-event shard of the 8 M-event stream 121.8 vs 127, scene-driven 1.17 M events 121 vs 135 — but 1.5 M events 161 vs 154, 3 M (tile order)
+        // 289 vs 281, 10 M 833 vs 817: with more active pixels per block the head's dependent trips grew past what the launch saved.
         const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count && c->n_cand &&
-                           (c->step_gather == 3 || (!c->tile_order && c->n_cand <= 1300000));    // (EMBA_STEP_GATHER=3: everywhere, for comparison)
+                           (c->step_gather == 3 || !c->tile_order || c->n_cand <= 3500000);      // (EMBA_STEP_GATHER=3: everywhere, for comparison)
+        // (round 4, late: the gather is now the work of 4 of a Gram block's 16 waves BESIDE the record stream, not a head in front of it: step time
+        // with it / with the sweeping launch — 1 M 92.6 / 96.4 us, 1.5 M 134.7 / 143.8, 2 M (tile order) 193.4 / 208.5, 3 M 274.4 / 280.9, 10 M on
+        // 640x480 (pixel order) 612.5 / 626.1, on 2048x4096 766.7 / 776.3; but 5 M (tile) 436.0 / 432.2, 40 M 3137 / 3014: a bandwidth-bound stream
+        // misses the four waves more than it gains from the launch — pixel order everywhere, tile order up to 3.5 M candidates)
         if (consume) { aw.clear_pixacc = c->d_pixacc; c->pixacc_clean = true; c->pixacc_consumed = true; }
         if (lists) { q.seg = c->d_seg_act; aw.seg = c->d_seg_act; if (consume) q.clear_inactive = c->d_pixacc; }
         // launch A: {active counts (+ markers -> counts, activity bits, cleared A11 | b1) || inlier-flag counts}; launch B: the active-set write,

@@ -87,6 +87,12 @@ template <class T> __device__ __forceinline__ T stream_load(const T* p, bool nt)
 constexpr int kGramPad = 256;     // record slots allocated past the last one: the Gram kernel's stages read whole 8-record groups
 constexpr int kGramChunkMin = 64; // smallest share of record slots a wave of the Gram kernel is given
 constexpr int kGramChunk = 1024;   // most record slots a wave of the Gram (A11/b1) kernel is given (multiple of 8)
+#ifndef GATHER_Q
+#define GATHER_Q 4
+#endif
+#ifndef GRAM_GATHER_WAVES
+#define GRAM_GATHER_WAVES 4      // waves of a Gram block that do its slice of the active-set gather while the other 12 stream records (GATHER form)
+#endif
 constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table).  Round 4, compact form at 1 M events: 8 waves
                                    // per CU 52 us, 4 waves 93 us, 24 waves (768 x 2, 80 VGPRs, 13 spilled) 39.6 us, 32 waves (64 VGPRs, 81 spilled) 52-66 us; 16: 37 us
 constexpr int kGramKeys = 4;       // control-pose pairs the block-level LDS table can hold before falling back to global atomics
@@ -1331,7 +1337,7 @@ __device__ __forceinline__ uint32_t active_gather_prefix(const ActiveWriteParams
 template <int NT>
 __device__ __forceinline__ void active_gather_slice(const ActiveWriteParams& a, long blk, long nblk, uint32_t P, const uint32_t* s_pre)
 {
-    constexpr int Q = 4, PIX = NT / 8;   // PIX pixels per pass of the block (8 lanes each), Q passes in flight
+    constexpr int Q = GATHER_Q, PIX = NT / 8;   // PIX pixels per pass of the block (8 lanes each), Q passes in flight
     const int tid = threadIdx.x;
     const long per = ((long)P + nblk - 1) / nblk;
     const long k0 = blk * per, k1 = (k0 + per < (long)P) ? k0 + per : (long)P;
@@ -1591,25 +1597,29 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     __shared__ uint32_t s_ws[kGramBlock / 64];
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
     if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
+    // GATHER: the block's slice of the gather is the work of its first kGW waves ONLY; the others go straight to the record stream, which depends on
+    // launch A's activity bits and on nothing the gather writes (round 4, late: with all 16 waves gathering first the head cost this kernel 9 us
+    // of dependent round trips in front of its stream; now they run beside it)
+    constexpr int kGW = GATHER ? GRAM_GATHER_WAVES : 0, kSW = kGramBlock / 64 - kGW;
     if (GATHER) {   // (its two barriers also publish the cleared combine table)
         const uint32_t P_act = active_gather_prefix<kGramBlock>(aw, gram_blk, s_pre, s_ws);
-        active_gather_slice<kGramBlock>(aw, gram_blk, gridDim.x, P_act, s_pre);
+        if (threadIdx.x < 64 * kGW) active_gather_slice<64 * (kGW ? kGW : 1)>(aw, gram_blk, gridDim.x, P_act, s_pre);
     } else {
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) - kGW;      // index among the streaming waves (< 0: a gather wave)
     // The block's 16 waves walk ONE contiguous range of 16 x chunk record slots together, stage by stage (wave w takes stages
     // w, w+16, ...): at any moment the block reads a compact window of the stream, as a grid-stride loop would, instead of 16
     // separate streams 128 KB apart (4096 concurrent streams chip-wide cost DRAM page locality once the records exceed the
     // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
     constexpr int U = TAGS ? GRAM_U : GRAM_U_NT;   // independent 1-KiB loads (8 records each) per wave and stage
-    constexpr int kStage = 8 * U, kStride = (kGramBlock / 64) * kStage;
+    constexpr int kStage = 8 * U, kStride = kSW * kStage;
     const long start = gram_blk * (kGramBlock / 64) * p.chunk;
     const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
     const int len = (int)(end - start);                              // <= 16 * kGramChunk: stage offsets are 32-bit
     const int off0 = wv * kStage;
-    const bool have_work = off0 < len;   // wave-uniform
+    const bool have_work = wv >= 0 && off0 < len;   // wave-uniform
     const int m = lane & 7, R = lane >> 3;
     if (have_work) {
 

@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
         // (one loop body of three stages and nothing else: with early exits between the stages the register allocator kept the 128 accumulator
         // registers in different places on different paths and copied them every trip; stages past the end run on zeros.  Round 4: a fourth
         // buffer, three quads ahead, changed nothing — 1.73 vs 1.69 ms at config 2's shape: the kernel is not short of bytes in flight; at the
-        // MI355X's fp64 matrix rate, 64 cycles per 16x16x4, its 27 M MFMAs alone are 0.7 ms, its 6 GB of operand reads 0.75 ms)
+        // MI355X's fp64 matrix rate, 64 cycles per 16x16x4, its 27 M MFMAs alone are 0.7 ms, its 6 GB of operand reads 0.75 ms.  Also measured: 16 B per lane
+        // — a lane fetches the row pair (32u + 2el, + 1) and the halves feed two row-permuted MFMA tiles, half the load instructions, 256-B runs —
+        // correct and no faster: 1.51 vs 1.50 ms, dense 1.23 vs 1.22)
         for (int it = 0; it < nq; it += 3) {
             load(it + 2, a2, b2, m2); mma(a0, b0, m0);
             load(it + 3, a0, b0, m0); mma(a1, b1, m1);

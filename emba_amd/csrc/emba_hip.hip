@@ -1408,6 +1408,12 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         constexpr long wpb = kGramBlock / 64;
         const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
         const ActiveWriteParams aw = c->aw_in_gram ? c->aw_saved : ActiveWriteParams{};
+        {   // gather waves per Gram block (EMBA_GATHER_WAVES=1|2|4 overrides)
+            static const int gw_env = getenv("EMBA_GATHER_WAVES") ? atoi(getenv("EMBA_GATHER_WAVES")) : 0;
+            // (measured, scripts/r04_exp15.sh: with ONE gather wave the gather outlasts the stream at every size — Gram kernel 57 vs 36 us at 1 M events,
+            // 1288 vs 1047 at 40 M —, two are within noise of four or of the sweeping launch from 5 M events up: four wherever the lists are used)
+            p.gather_waves = (gw_env == 1 || gw_env == 2 || gw_env == 4) ? gw_env : 4;
+        }
         if (p.tag) {
             if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_kernel<true, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
             else hipLaunchKernelGGL((emba_gram_kernel<true, false>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);

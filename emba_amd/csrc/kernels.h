@@ -1512,6 +1512,7 @@ struct GramParams {
     const double* tag;                                                    // per slot {pano pixel, stamp} (8 B), or nullptr: decide from the records themselves
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
+    int gather_waves;  // GATHER form: 1, 2 or 4 of the block's 16 waves do its slice of the active-set gather, the others stream (host: by size)
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
@@ -1600,10 +1601,15 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     // GATHER: the block's slice of the gather is the work of its first kGW waves ONLY; the others go straight to the record stream, which depends on
     // launch A's activity bits and on nothing the gather writes (round 4, late: with all 16 waves gathering first the head cost this kernel 9 us
     // of dependent round trips in front of its stream; now they run beside it)
-    constexpr int kGW = GATHER ? GRAM_GATHER_WAVES : 0, kSW = kGramBlock / 64 - kGW;
+    // How many: p.gather_waves (the host passes 4; 1 and 2 were measured, scripts/r04_exp15.sh: one wave's gather outlasts the stream at every size).
+    const int kGW = GATHER ? __builtin_amdgcn_readfirstlane(p.gather_waves) : 0, kSW = kGramBlock / 64 - kGW;
     if (GATHER) {   // (its two barriers also publish the cleared combine table)
         const uint32_t P_act = active_gather_prefix<kGramBlock>(aw, gram_blk, s_pre, s_ws);
-        if (threadIdx.x < 64 * kGW) active_gather_slice<64 * (kGW ? kGW : 1)>(aw, gram_blk, gridDim.x, P_act, s_pre);
+        if (threadIdx.x < 64 * kGW) {
+            if (kGW == 1) active_gather_slice<64>(aw, gram_blk, gridDim.x, P_act, s_pre);
+            else if (kGW == 2) active_gather_slice<128>(aw, gram_blk, gridDim.x, P_act, s_pre);
+            else active_gather_slice<256>(aw, gram_blk, gridDim.x, P_act, s_pre);
+        }
     } else {
         __syncthreads();
     }
@@ -1614,7 +1620,8 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     // separate streams 128 KB apart (4096 concurrent streams chip-wide cost DRAM page locality once the records exceed the
     // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
     constexpr int U = TAGS ? GRAM_U : GRAM_U_NT;   // independent 1-KiB loads (8 records each) per wave and stage
-    constexpr int kStage = 8 * U, kStride = kSW * kStage;
+    constexpr int kStage = 8 * U;
+    const int kStride = kSW * kStage;
     const long start = gram_blk * (kGramBlock / 64) * p.chunk;
     const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
     const int len = (int)(end - start);                              // <= 16 * kGramChunk: stage offsets are 32-bit

@@ -1937,6 +1937,17 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
             for (uint16_t r : hr) { const int lo = r & 255, hi = r >> 8; if (lo > hi) continue; w16 += hi - lo + 1; const int b = (hi >> 2) - (lo >> 2) + 1; w64 += b; hist[b < 8 ? b : 8]++; }
             long prod = 0, prod_diag = 0;
             if (sparse) { std::vector<uint32_t> hc(nbp); hipMemcpy(hc.data(), d_cnt, nbp * 4, hipMemcpyDeviceToHost); for (int b = 0; b < nbp; ++b) { prod += hc[b]; int I, J; I = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5); while ((long)I * (I + 1) / 2 > b) --I; while ((long)(I + 1) * (I + 2) / 2 <= b) ++I; J = b - I * (I + 1) / 2; if (I == J) prod_diag += hc[b]; } }
+            for (int R : {1, 2, 4, 8, 16}) {      // union band (16-row groups) of runs of R slices: what a band-resident product would have to hold
+                const size_t per = (size_t)R * kSyrkSlicePix; long ng = 0, fit12 = 0, fit16 = 0, wsum = 0; long fit16_pix = 0;
+                for (size_t g0 = 0; g0 < hr.size(); g0 += per) {
+                    int lo = 999, hi = -1;
+                    for (size_t i = g0; i < std::min(hr.size(), g0 + per); ++i) { const int l = hr[i] & 255, h = hr[i] >> 8; if (l > h) continue; lo = std::min(lo, l); hi = std::max(hi, h); }
+                    if (hi < 0) continue;
+                    ++ng; const int w = hi - lo + 1; wsum += w; if (w <= 12) ++fit12; if (w <= 16) { ++fit16; fit16_pix += (long)std::min(hr.size(), g0 + per) - (long)g0; }
+                }
+                fprintf(stderr, "[solve debug] runs of %2d slices: %ld runs, mean union band %.1f groups, <= 12 groups: %.1f %%, <= 16 groups: %.1f %% (%.1f %% of the pixels)\n", R, ng,
+                        (double)wsum / std::max(1L, ng), 100.0 * fit12 / std::max(1L, ng), 100.0 * fit16 / std::max(1L, ng), 100.0 * fit16_pix / std::max<size_t>(1, hr.size()));
+            }
             fprintf(stderr, "[solve debug] pixels %ld slices %d nbp %d nks %d: mean 16-row groups per pixel %.2f, mean 64-row blocks written %.2f (hist 1..8+: %ld %ld %ld %ld %ld %ld %ld %ld), products %ld (diag %ld) = %.2f per slice; U written %.1f MB\n",
                     (long)(p1 - p0), n_slices, nbp, nks, (double)w16 / (p1 - p0), (double)w64 / (p1 - p0), hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], prod, prod_diag,
                     (double)prod / n_slices, w64 * 64.0 * 2 * 8 / 1e6);

@@ -58,6 +58,8 @@ struct emba_ctx {
     // the per-pixel record lists + pixel-ordered records of the last LOCAL solve (workspaces 0, 33): a re-solve of the same equations with another
     // lambda (a rejected LM trial, solver.cpp:340-352) reuses them
     bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
+    bool perm_valid = false; uint32_t* d_perm = nullptr;   // column order of U for the local Schur solve (solve_perm), valid with the lists
+    int solve_perm_mode = -1;                               // EMBA_SOLVE_PERM=0|1 (A/B): -1 auto
     double* h_cost = nullptr;           // pinned: {data cost sum, reg cost sum} of emba_costs
     double* d_x2 = nullptr; size_t x2_cap = 0; size_t x2_resident_P = (size_t)-1;   // x2_resident_P: d_x2 holds the x2 of the last solve on this context (for that many pixels)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
@@ -688,6 +690,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
     if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
     if (const char* sf = getenv("EMBA_SEGPOSE")) c->segpose_mode = 1 + atoi(sf);
+    if (const char* sp = getenv("EMBA_SOLVE_PERM")) c->solve_perm_mode = atoi(sp) ? 1 : 0;
     if (const char* sf = getenv("EMBA_STEP_ONE_SET")) c->step_one_set = atoi(sf);
     if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
     if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
@@ -1343,7 +1346,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     c->P_pending = true; c->active_done = false; c->accum_done = false;
     c->finish_done = false;          // (the head of the pack has just been cleared: what a solve would read is no set of equations — found by the call-order pair test)
     c->x2_resident_P = (size_t)-1;   // (a solve of the PREVIOUS equations may have left its x2 on the device)
-    c->lists_valid = false;          // (new active set)
+    c->lists_valid = false; c->perm_valid = false;          // (new active set)
     if (!P && !pack_len) return EMBA_OK;   // asynchronous: P is read from device memory by the kernels that need it
     emba_status st = resolve_pending(c, true);   // counts only: a sharded host sizes exchange 2 from P while the gather still runs
     if (st) return st;
@@ -1862,7 +1865,7 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
         out->sorted.rec = (const double*)c->ws[33].p; out->sorted.packed = 1; out->sorted.pix_base = 0;
         return EMBA_OK;
     }
-    c->lists_valid = false;
+    c->lists_valid = false; c->perm_valid = false;
     if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
         (st = ws_get(c, 33, (n_rec + 1) * kRecStride * sizeof(double), (void**)&d_sorted)))
         return st;
@@ -1883,7 +1886,7 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
 // S_aug (lds x (n+1), zero or pre-initialised) -= U_aug U_aug^T over the pixels [0, n_pix) of the lists; A22b2 points at the first of
 // those pixels' {xx xy yy bx by}.  Also leaves y = C^-1 b2 (d_y) and the 2x2 Cholesky factors (d_cf).  Workspaces 8 (U), 12 (slabs).
 emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists& L, size_t n_pix, const double* A22b2, double lambda, int n,
-                             double* d_S, long lds_, double* d_y, double* d_cf, int* d_info)
+                             double* d_S, long lds_, double* d_y, double* d_cf, int* d_info, const uint32_t* perm = nullptr)
 {
     hipStream_t s = c->stream;
     // (the SYRK covers the n rows of S; row n of the augmented matrix, the right-hand side b1 - U y, is accumulated by the build kernel itself)
@@ -1896,7 +1899,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     SchurBuildParams bp{};
     bp.view = view; bp.off = L.off; bp.A22b2 = A22b2; bp.lambda = lambda;
     bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
-    bp.rhs_row = d_S + n; bp.lds = lds_;
+    bp.rhs_row = d_S + n; bp.lds = lds_; bp.perm = perm;
     const size_t lds_bytes = (size_t)9 * n * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", n / 3);
     if (lds_bytes > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1992,6 +1995,43 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
     return EMBA_OK;
 }
 
+// The column order of U for the local solve (emba_perm_keys_kernel): panorama columns first when the camera mostly pans (azimuth path of the optical axis
+// over the control poses >= its elevation path), the compact order (nullptr) otherwise.  Built once per list build; workspaces 34-36.
+emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
+{
+    *perm = nullptr;
+    // Measured (device time of one solve, with / without; the U build reads its pixels' records out of sequence and pays 5 % for it): config 2's shape (K = 201,
+    // 10 M events over 10 s) 3.96 / 4.16 ms — SYRK 1.25 / 1.52, 5.8 / 7.9 products per slice —; 10 M events at K = 97: 2.81 / 2.79; 1 M events over 1 s at
+    // K = 201 (every pixel sees the whole window: nothing to gain) 2.27 / 2.24.  From six row blocks (K >= 128) up, unless EMBA_SOLVE_PERM forces it.
+    if (c->solve_perm_mode == 0 || P < 4 * (size_t)kSyrkSlicePix || (c->solve_perm_mode < 0 && 3 * c->K < 384) || 3 * c->K < 256) return EMBA_OK;
+    if (c->perm_valid) { *perm = c->d_perm; return EMBA_OK; }
+    if (c->solve_perm_mode < 0) {
+        if (!c->h_knots || c->K < 2) return EMBA_OK;
+        double path_az = 0.0, path_el = 0.0, az0 = 0.0, el0 = 0.0;
+        for (int i = 0; i < c->K; ++i) {
+            const double x = c->h_knots[4 * i], y = c->h_knots[4 * i + 1], z = c->h_knots[4 * i + 2], w = c->h_knots[4 * i + 3];
+            const double ax = 2.0 * (x * z + w * y), ay = 2.0 * (y * z - w * x), az_ = 1.0 - 2.0 * (x * x + y * y);      // R (0, 0, 1)
+            const double az = atan2(ax, az_), el = asin(std::max(-1.0, std::min(1.0, ay)));
+            if (i) { double d = az - az0; while (d > M_PI) d -= 2.0 * M_PI; while (d < -M_PI) d += 2.0 * M_PI; path_az += fabs(d); path_el += fabs(el - el0); }
+            az0 = az; el0 = el;
+        }
+        if (path_az < path_el) return EMBA_OK;      // mostly tilting: a panorama row is the better slice already
+    }
+    hipStream_t s = c->stream;
+    uint32_t *d_cnt = nullptr, *d_tick = nullptr, *d_pm = nullptr;
+    emba_status st;
+    if ((st = ws_get(c, 34, ((size_t)c->W + 2) * 4, (void**)&d_cnt)) || (st = ws_get(c, 35, P * 4, (void**)&d_tick)) || (st = ws_get(c, 36, P * 4, (void**)&d_pm))) return st;
+    HIP_TRY(c, hipMemsetAsync(d_cnt, 0, ((size_t)c->W + 1) * 4, s));
+    hipLaunchKernelGGL(emba_perm_ticket_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active, (long)P, c->W, d_cnt, d_tick);
+    if ((st = dev_scan(c, d_cnt, d_cnt, (size_t)c->W, nullptr))) return st;
+    hipLaunchKernelGGL(emba_perm_place_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active, (long)P, c->W, d_cnt, d_tick, d_pm);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t* v0 = d_pm;
+    c->d_perm = v0; c->perm_valid = true;
+    *perm = v0;
+    return EMBA_OK;
+}
+
 RecView local_view(emba_ctx* c)
 {
     RecView v{};
@@ -2028,7 +2068,9 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     SolveLists L;
     if ((st = build_lists(c, view, M, P, &L))) return st;
     hipLaunchKernelGGL(emba_schur_init_kernel, dim3((unsigned)(((size_t)n * n + 255) / 256)), dim3(256), 0, s, pack_A11(c), pack_b1(c), n, lambda, d_S, lds_);
-    if ((st = schur_accumulate(c, L.sorted, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info))) return st;
+    const uint32_t* perm = nullptr;
+    if ((st = solve_perm(c, P, &perm))) return st;
+    if ((st = schur_accumulate(c, L.sorted, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info, perm))) return st;
     if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)

@@ -118,6 +118,7 @@ struct SchurBuildParams {
     uint16_t* range;                             // per pixel of the chunk: lo | hi << 8, the 16-ROW groups [lo, hi] its two columns of U are non-zero in (lo > hi: none);
                                                  // the columns are WRITTEN in the 64-row blocks [lo >> 2, hi >> 2]
     double* rhs_row; long lds;                   // rhs_row[lds * r] -= (U y)[r]: row n of the augmented S (the right-hand side b1 - U y), accumulated here
+    const uint32_t* perm;                        // column order of U: position j holds compact pixel perm[j] (nullptr: j).  off / A22b2 / yv / cfac stay indexed by the pixel
 };
 
 __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams p)
@@ -133,9 +134,11 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
     // Software pipeline over the wave's pixels: the list bounds and 2x2 block of pixel i+1 are fetched while pixel i is worked on; the pixel's
     // records are consecutive (emba_csr_fill_sorted_kernel), so a pixel costs ONE dependent round trip.
     const long i_first = p.p0 + (long)blockIdx.x * 4 + wv, i_last = p.p1 - 1;       // (loads of pixels past the end are clamped, never used)
-    struct Hdr { uint32_t b0, b1; double q0, q1, q2, q3, q4; };
+    struct Hdr { uint32_t b0, b1; long k; double q0, q1, q2, q3, q4; };
     auto load_hdr = [&](long i, Hdr& h) {
-        const long ic = i < i_last ? i : i_last;
+        const long ic0 = i < i_last ? i : i_last;
+        const long ic = p.perm ? (long)p.perm[ic0] : ic0;            // the compact pixel whose two columns sit at position i
+        h.k = ic;
         h.b0 = p.off[ic]; h.b1 = p.off[ic + 1];
         const double* q = p.A22b2 + 5 * ic;
         h.q0 = q[0]; h.q1 = q[1]; h.q2 = q[2]; h.q3 = q[3]; h.q4 = q[4];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const double c00 = sqrt(mxx), c10 = mxy / c00, c11 = sqrt(myy - c10 * c10);
         if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
         const double y0 = h_cur.q3 / c00, y1 = (h_cur.q4 - c10 * y0) / c11;
-        if (lane == 0) { p.yv[2 * i] = y0; p.yv[2 * i + 1] = y1; p.cfac[3 * i] = c00; p.cfac[3 * i + 1] = c10; p.cfac[3 * i + 2] = c11; }
+        if (lane == 0) { const long k = h_cur.k; p.yv[2 * k] = y0; p.yv[2 * k + 1] = y1; p.cfac[3 * k] = c00; p.cfac[3 * k + 1] = c10; p.cfac[3 * k + 2] = c11; }
         const uint32_t b0 = h_cur.b0, b1 = h_cur.b1;
         unsigned long long rows_mask = 0ull;
         int rmin = 0x7FFFFFFF, rmax = -1;                               // first / last row of U the pixel's records touch
@@ -235,6 +238,28 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         const double v = s_rhs[r];
         if (v != 0.0) atomicAdd(p.rhs_row + (size_t)p.lds * r, -v);
     }
+}
+
+// Column order of U (round 4, late).  The block-sparse SYRK forms a (row-block pair, slice) product wherever a slice of 128 consecutive columns' pixels has rows in
+// both blocks, so what it costs is set by the UNION band of a slice.  In ascending panorama index (the reference's column order) a slice is a piece of a panorama
+// row, 128+ pixels wide: under a panning camera its pixels are seen one after the other and the union band is 13 groups of 16 rows where a single pixel has 7.5
+// (config 2's shape).  Ordered by panorama COLUMN first a slice is a piece of a column (or of a few neighbouring ones), whose pixels are seen together:
+// 7.9 -> 5.8 products per slice there.
+// Any order gives the same S; x2, y and the 2x2 factors stay indexed by the compact pixel.
+// Built by counting, not sorting: every pixel takes a ticket in its panorama column (any order inside a column will do — its pixels have the same band),
+// the W column counts are scanned, the pixel goes to offset[column] + ticket.
+__global__ void emba_perm_ticket_kernel(const uint32_t* __restrict__ active_idx, long P, int W, uint32_t* __restrict__ col_cnt, uint32_t* __restrict__ ticket)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    ticket[k] = atomicAdd(col_cnt + active_idx[k] % (uint32_t)W, 1u);
+}
+__global__ void emba_perm_place_kernel(const uint32_t* __restrict__ active_idx, long P, int W, const uint32_t* __restrict__ col_off, const uint32_t* __restrict__ ticket,
+                                       uint32_t* __restrict__ perm)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= P) return;
+    perm[col_off[active_idx[k] % (uint32_t)W] + ticket[k]] = (uint32_t)k;
 }
 
 // Augmented system matrix (n+1) x (n+1), leading dimension lds: [A11 + lambda*diag(A11), . ; b1^T, 0] — the SYRK with the

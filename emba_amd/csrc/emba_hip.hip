@@ -1900,7 +1900,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     bp.view = view; bp.off = L.off; bp.A22b2 = A22b2; bp.lambda = lambda;
     bp.irls = c->irls; bp.eta = c->eta; bp.n = n; bp.U = d_U; bp.ldu = lds_; bp.yv = d_y; bp.cfac = d_cf; bp.info = d_info;
     bp.rhs_row = d_S + n; bp.lds = lds_; bp.perm = perm;
-    const size_t lds_bytes = (size_t)9 * n * sizeof(double);
+    const size_t lds_bytes = (size_t)(2 * kBuildWaves + 1) * n * sizeof(double);
     if (lds_bytes > 160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "K=%d too large for the per-wave column staging in LDS", n / 3);
     if (lds_bytes > 64 * 1024) HIP_TRY(c, hipFuncSetAttribute((const void*)emba_schur_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     // Block-sparse SYRK (>= 4 row blocks, i.e. K >= 64): the columns of a slice of kSyrkSlicePix consecutive active pixels — a piece of a
@@ -1923,7 +1923,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
             HIP_TRY(c, hipMemsetAsync(d_mask, 0, (size_t)n_slices * 8, s));
         }
         bp.slice_mask = d_mask;
-        hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + 3) / 4, 4096)), dim3(256), lds_bytes, s, bp);
+        hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + kBuildWaves - 1) / kBuildWaves, 4096)), dim3(64 * kBuildWaves), lds_bytes, s, bp);
         int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
         SyrkParams sp{};
         sp.A = d_U; sp.lda = lds_; sp.n = n; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.range = d_range;

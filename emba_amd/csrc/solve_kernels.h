@@ -121,19 +121,24 @@ struct SchurBuildParams {
     const uint32_t* perm;                        // column order of U: position j holds compact pixel perm[j] (nullptr: j).  off / A22b2 / yv / cfac stay indexed by the pixel
 };
 
-__global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams p)
+#ifndef SCHUR_BUILD_WAVES
+#define SCHUR_BUILD_WAVES 4
+#endif
+constexpr int kBuildWaves = SCHUR_BUILD_WAVES;     // waves per workgroup of the U build: (2 kBuildWaves + 1) n doubles of LDS.  Measured at config 2's shape: 3 waves 943 us,
+                                                   // 4: 906, 5: 1643, 6: 1439 (five would fit three workgroups = 15 waves per CU in LDS, and is slower all the same)
+__global__ __launch_bounds__(64 * kBuildWaves) void emba_schur_build_kernel(SchurBuildParams p)
 {
     extern __shared__ __attribute__((aligned(16))) double s_cols[];   // 4 waves x 2 columns x n, then the block's n partial sums of U y
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double* c0 = s_cols + (size_t)wv * 2 * p.n;
     double* c1 = c0 + p.n;
-    double* s_rhs = s_cols + (size_t)4 * 2 * p.n;
-    for (int r = threadIdx.x; r < 9 * p.n; r += 256) s_cols[r] = 0.0;   // (the columns are re-zeroed after every pixel, where they were touched)
+    double* s_rhs = s_cols + (size_t)kBuildWaves * 2 * p.n;
+    for (int r = threadIdx.x; r < (2 * kBuildWaves + 1) * p.n; r += 64 * kBuildWaves) s_cols[r] = 0.0;   // (the columns are re-zeroed after every pixel, where they were touched)
     __syncthreads();
-    const long nwaves = (long)gridDim.x * 4;
+    const long nwaves = (long)gridDim.x * kBuildWaves;
     // Software pipeline over the wave's pixels: the list bounds and 2x2 block of pixel i+1 are fetched while pixel i is worked on; the pixel's
     // records are consecutive (emba_csr_fill_sorted_kernel), so a pixel costs ONE dependent round trip.
-    const long i_first = p.p0 + (long)blockIdx.x * 4 + wv, i_last = p.p1 - 1;       // (loads of pixels past the end are clamped, never used)
+    const long i_first = p.p0 + (long)blockIdx.x * kBuildWaves + wv, i_last = p.p1 - 1;       // (loads of pixels past the end are clamped, never used)
     struct Hdr { uint32_t b0, b1; long k; double q0, q1, q2, q3, q4; };
     auto load_hdr = [&](long i, Hdr& h) {
         const long ic0 = i < i_last ? i : i_last;
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void emba_schur_build_kernel(SchurBuildParams 
         h_cur = h_nxt; h_nxt = h_nn; g_cur = g_nxt;
     }
     __syncthreads();
-    for (int r = threadIdx.x; r < p.n; r += 256) {
+    for (int r = threadIdx.x; r < p.n; r += 64 * kBuildWaves) {
         const double v = s_rhs[r];
         if (v != 0.0) atomicAdd(p.rhs_row + (size_t)p.lds * r, -v);
     }

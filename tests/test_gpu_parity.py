@@ -485,6 +485,23 @@ def test_schur_solve_at_the_panel_edges_of_the_factorisation(gpu, oracle_mod, K,
         assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
 
 
+@pytest.mark.parametrize("perm", ["0", "1"])
+def test_schur_solve_with_the_columns_of_U_in_panorama_column_order(gpu, oracle_mod, perm, monkeypatch):
+    """Round 4: the local Schur solve orders U's columns by panorama column when the camera pans (solve_perm: fewer (row-block pair, slice) products in the
+    block-sparse SYRK).  Any order gives the same S, x1, x2: forced on and off (EMBA_SOLVE_PERM) at K = 100 — five row blocks, block-sparse form — against the
+    oracle, then a re-solve with another lambda on the cached lists + order."""
+    monkeypatch.setenv("EMBA_SOLVE_PERM", perm)
+    w = small_workload(n_events=120000, pano_h=256, K=100, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3)
+    g = gpu_run(w)
+    assert g["ne"]["P"] >= 512              # (below four slices the order is not used)
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    for lam in (1e-2, 1.0):
+        x1, x2 = g["legm"].solveNormalEq(lam, fix_first_pose=True)
+        ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, True)
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max())
+        assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
+
+
 @pytest.mark.parametrize("K,kw", [(8, {}), (90, dict(n_events=60000, pano_h=256, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3))])
 def test_schur_solve_with_an_unobserved_control_pose(gpu, oracle_mod, K, kw):
     """model.cpp:789 is Eigen's PIVOTED ldlt: for a semi-definite S (a control pose no event constrains) it returns, with a ZERO update in

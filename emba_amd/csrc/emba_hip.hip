@@ -58,6 +58,7 @@ struct emba_ctx {
     // the per-pixel record lists + pixel-ordered records of the last LOCAL solve (workspaces 0, 33): a re-solve of the same equations with another
     // lambda (a rejected LM trial, solver.cpp:340-352) reuses them
     bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
+    uint32_t count_stamp = 0;   // record stamp (set_stamp) of the evaluation whose materialised, LOCAL counts d_count_own holds; 0: none (build_lists)
     bool perm_valid = false; uint32_t* d_perm = nullptr;   // column order of U for the local Schur solve (solve_perm), valid with the lists
     int solve_perm_mode = -1;                               // EMBA_SOLVE_PERM=0|1 (A/B): -1 auto
     double* h_cost = nullptr;           // pinned: {data cost sum, reg cost sum} of emba_costs
@@ -540,6 +541,7 @@ emba_status ensure_counts(emba_ctx* c)
 {
     if (!c->counts_raw) return EMBA_OK;
     c->counts_raw = false;
+    c->count_stamp = (c->d_count == c->d_count_own) ? c->set_stamp : 0u;
     hipLaunchKernelGGL(emba_count_materialise_kernel, dim3((unsigned)((c->npix + 2047) / 2048)), dim3(256), 0, c->stream, c->d_count, c->d_pixacc, (long)c->npix, c->count_mark);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
@@ -1081,6 +1083,7 @@ emba_status emba_bind_exchange_buffers(emba_ctx* c, int32_t* count_map_dev, doub
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     c->d_count = count_map_dev ? count_map_dev : c->d_count_own;
+    c->count_stamp = 0;
     c->pix_dirty_all = true;   // the new count buffer says nothing about which pixacc lines are dirty
     c->pixacc_clean = false;
     if (pack_dev) { c->d_pack = pack_dev; c->pack_cap = pack_cap; c->pack_bound = true; }
@@ -1102,6 +1105,7 @@ emba_status emba_count_expand(emba_ctx* c, const uint8_t* u8_dev)
 {
     if (!c || !u8_dev) return c ? fail(c, EMBA_ERR_INVALID_ARG, "count_expand: NULL") : EMBA_ERR_INVALID_ARG;
     if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    c->count_stamp = 0;      // (exchanged counts: no longer this context's own)
     hipLaunchKernelGGL(emba_count_expand_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, u8_dev, (long)c->npix, c->d_count);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
@@ -1153,6 +1157,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->eq_in_alt = true;
     }
     c->K = K;
+    c->count_stamp = 0;      // (the warp kernels are about to mark the count map for a new evaluation)
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
@@ -1292,7 +1297,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         q.err_dev = c->d_err; q.err_host = c->h_pinned_dev + 1;
         q.e_sorted = c->d_e_sorted; q.flag = c->d_flag; q.ep = c->d_ep; q.inl_idx = nullptr;   // (inlier numbers: on demand, ensure_inl_idx)
         q.seq = ++c->seq; q.seq_host = c->h_pinned_dev + 3; c->seq_armed = true;
-        if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; q.marker = c->count_mark; c->counts_raw = false; }   // launch A turns the markers into counts
+        if (c->counts_raw) { q.raw_count = c->d_count; q.pixacc = c->d_pixacc; q.marker = c->count_mark; c->counts_raw = false;      // launch A turns the markers into counts
+                             c->count_stamp = (c->d_count == c->d_count_own) ? c->set_stamp : 0u; }
         const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
         // list-driven gather: it rides in the head of the Gram kernel (as a kernel of its own it is no faster than the sweeping write: 109.6 vs
         // 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison, 0 the sweeping kernel)
@@ -1869,8 +1875,28 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
     if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
         (st = ws_get(c, 33, (n_rec + 1) * kRecStride * sizeof(double), (void**)&d_sorted)))
         return st;
-    HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
-    if (n_rec) hipLaunchKernelGGL(emba_csr_count_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_cursor);
+    // list lengths: from the context's own count map while it still belongs to the evaluation that wrote these records (count_stamp), else counted
+    // from the records (all-reduced / saturated / externally bound counts, a trial evaluation since, the sharded solve's received records)
+    static const int cmap_env = getenv("EMBA_SOLVE_COUNTS") ? atoi(getenv("EMBA_SOLVE_COUNTS")) : -1;      // 0: always from the records; 2: both, compared (diagnostic)
+    const bool from_map = cmap_env != 0 && !view.packed && c->count_stamp != 0 && c->count_stamp == view.stamp && c->d_count == c->d_count_own && n_pix == c->P && n_pix;
+    if (from_map && cmap_env != 2) {
+        hipLaunchKernelGGL(emba_csr_count_from_map_kernel, dim3(nblocks(n_pix)), dim3(256), 0, s, c->d_active, c->d_count, (long)n_pix, d_cursor);
+    } else {
+        HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
+        if (n_rec) hipLaunchKernelGGL(emba_csr_count_kernel, dim3(nblocks(n_rec)), dim3(256), 0, s, view, (long)n_rec, d_cursor);
+        if (from_map) {      // diagnostic: the two must agree
+            std::vector<uint32_t> a(n_pix), b(n_pix);
+            uint32_t* d_tmp = nullptr;
+            if ((st = ws_get(c, 38, n_pix * 4, (void**)&d_tmp))) return st;
+            hipLaunchKernelGGL(emba_csr_count_from_map_kernel, dim3(nblocks(n_pix)), dim3(256), 0, s, c->d_active, c->d_count, (long)n_pix, d_tmp);
+            HIP_TRY(c, hipMemcpyAsync(a.data(), d_cursor, n_pix * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(b.data(), d_tmp, n_pix * 4, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            size_t bad = 0; for (size_t i = 0; i < n_pix; ++i) bad += a[i] != b[i];
+            fprintf(stderr, "[solve counts] P %zu: %zu pixels where the count map and the records disagree\n", n_pix, bad);
+            if (bad) return fail(c, EMBA_ERR_STATE, "count map and record counts disagree on %zu pixels", bad);
+        }
+    }
     if ((st = dev_scan(c, d_cursor, d_off, n_pix, d_off + n_pix))) return st;
     HIP_TRY(c, hipMemsetAsync(d_cursor, 0, (n_pix + 1) * 4, s));
     // the participating records, copied into pixel order (the passes over them — U build, x2, every CG iteration — then stream)

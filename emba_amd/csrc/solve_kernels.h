@@ -72,6 +72,16 @@ __global__ void emba_csr_count_kernel(RecView v, long n_rec, uint32_t* __restric
     if (rec_pixel(v, s, k)) atomicAdd(cnt + k, 1u);
 }
 
+// The same counts without a pass over the records: a valid record with pixel p <=> an inlier measurement counted at p by the evaluation that wrote it
+// (the warp kernels write the record and count the measurement together), so while the context's OWN count map still holds the materialised counts of that
+// evaluation (emba_ctx::count_stamp) the list length of active pixel k is count[active_idx[k]].  (csr_count: 250 us at config 2's shape — it fetches every
+// record's line for its tail word.)
+__global__ void emba_csr_count_from_map_kernel(const uint32_t* __restrict__ active_idx, const int32_t* __restrict__ count, long P, uint32_t* __restrict__ cnt)
+{
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < P) { const int32_t v = count[active_idx[k]]; cnt[k] = v > 0 ? (uint32_t)v : 0u; }
+}
+
 // Sorted fill: every participating record takes a ticket in its pixel's list and is COPIED there (eight lanes per 128-B record: coalesced
 // reads in slot order, one full line written per record), with the tail rewritten to the packed form {pixel of the list, pair key}.  The
 // U build, the x2 kernel and every iteration of the CG solver then stream a pixel's records from consecutive lines instead of gathering
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256) void emba_csr_fill_sorted_kernel(RecView v, lo
         bool ok;
         if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(val.y) - v.pix_base); ok = true; }
         else { uint32_t pi; ok = record_valid(val.y, v.stamp, pi); if (ok) { k = v.compact[pi]; ok = k >= 0; } }
-        if (ok) { pos = off[k] + atomicAdd(cursor + k, 1u); key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s]; }
+        if (ok) { pos = off[k] + atomicAdd(cursor + k, 1u); key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s]; if (pos >= (uint32_t)n_rec) k = -1; }   // (never, with true counts: no write past the buffer whatever the counts)
         else k = -1;
     }
     k = __shfl(k, lane | 7); pos = (uint32_t)__shfl((int)pos, lane | 7); key = (uint32_t)__shfl((int)key, lane | 7);

@@ -7,7 +7,7 @@ names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("emba::", "
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 solves, i = [], 0
 while i < len(rows):
-    if names[i] == "csr_count":
+    if names[i].startswith("csr_count"):
         j, agg = i, collections.OrderedDict()
         while j < len(rows):
             agg[names[j]] = agg.get(names[j], 0) + dur[j]

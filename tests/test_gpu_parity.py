@@ -787,7 +787,7 @@ def test_randomised_small_configurations(gpu, oracle_mod):
 @pytest.mark.skipif(not os.environ.get("EMBA_SOAK"), reason="opt-in soak: EMBA_SOAK=<cases> (a one-off sweep after kernel changes, minutes)")
 def test_randomised_soak(gpu, oracle_mod):
     """EMBA_SOAK=N: N more seeded random configurations than test_randomised_small_configurations, with wider ranges (K up to 45: the multi-panel
-    factorisation; up to 150 k events), through evaluation, normal equations, solve, and a second evaluation + formation on the same context."""
+    factorisation; up to 150 k events), through evaluation, normal equations, solve, a second evaluation + formation and two resident single-call steps on the same context."""
     n_cases = int(os.environ["EMBA_SOAK"])
     rng = np.random.default_rng(777)
     bad = []
@@ -834,6 +834,11 @@ def test_randomised_soak(gpu, oracle_mod):
             if w.alpha:
                 ne2 = m.applyL2Reg(w.alpha)
             compare_normal_eq(ne2, o2["ne"])
+            # the resident single-call step (what bench.py times) twice on the same context, at the second trajectory
+            for _ in range(2):
+                n_inl, P = m.step(w.traj, thres, w.alpha, cost[0], cost[1])
+                assert n_inl == o2["ep"].size and P == o2["ne"]["P"], "step counts"
+                compare_normal_eq(m._finish(w.alpha, False), o2["ne"])
             m.close()
         except AssertionError as e:
             bad.append(f"{tag}: {e}")

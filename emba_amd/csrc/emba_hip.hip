@@ -2000,12 +2000,12 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
     const int m = n - skip;
     double* Sm = d_S + (size_t)lds_ * skip + skip;
     if (m + 1 <= 64 && skip <= 64) {                         // K <= 21: factor + both substitutions in one launch
-        hipLaunchKernelGGL(emba_chol_small_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, m, skip, d_rhs, d_info);
+        hipLaunchKernelGGL(emba_chol_small_kernel, dim3(1), dim3(256), 0, s, Sm, lds_, m, skip, d_rhs, d_info);
         HIP_TRY(c, hipGetLastError());
         return EMBA_OK;
     }
     // per panel: [diagonal factor — a launch of its own for the first panel only] / panel solve / trailing update + the next panel's diagonal factor
-    hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(64), 0, s, Sm, lds_, 0, std::min(64, m), d_info);
+    hipLaunchKernelGGL(emba_chol_diag_kernel, dim3(1), dim3(256), 0, s, Sm, lds_, 0, std::min(64, m), d_info);
     for (int jb = 0; jb < m; jb += 64) {
         const int nb = std::min(64, m - jb);
         const int below = m - jb - nb;                      // matrix rows under the panel; the rhs row (index m) comes on top of them

@@ -563,17 +563,78 @@ __device__ __forceinline__ void chol_diag_wave(double (&row)[64], double dg0, do
     if (bad_sign && r == 0) atomicOr(info, 4);
 }
 
-__global__ __launch_bounds__(64) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
+// The same factorisation by FOUR waves (round 4, late): every wave holds all 64 rows (lane r = row r) of 16 of the block's columns — wave w the columns
+// 16w .. 16w+15 —, the owner of column j scales it and puts it in LDS, one barrier, then every wave with columns right of j updates them.  A single wave
+// spent its 28 us issuing ~15 k instructions; four waves issue a quarter each and the 64 barriers cost less than that.  rw[cc] = the lane's row, column
+// 16w + cc; on return rw[cc] = L[r][16w + cc] for 16w + cc <= r < nb.  All 256 threads of the block must call it.
+__device__ __forceinline__ void chol_diag_block4(double (&rw)[16], double dg0, double (*s_col)[64], int r, int w, int nb, int* __restrict__ info)
+{
+    bool bad = false, bad_sign = false;
+    // column j from the lanes' current row[j]: the pivot's square root and the scaled column
+    auto column = [&](int j, double rj) -> double {
+        const double d = readlane_f64(rj, j);
+        // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
+        // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
+        // The case that occurs in practice is a control pose no event constrains: its rows and columns of S are exactly zero, so d == 0
+        // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
+        // (round 4) Only a VANISHING pivot is that case: d == 0, or a non-positive value within rounding of it — 64 ulp of the
+        // diagonal entry it was eliminated from.  A pivot that is clearly negative, or not finite, means S is indefinite or carries a NaN: Eigen
+        // factors the former with a negative D entry and propagates the latter; a Cholesky factorisation can do neither, and a finite, partly
+        // zeroed x1 with EMBA_OK would hide corrupted equations — info bit 2 (4), which the solve returns as EMBA_ERR_NUMERIC (the LM loop then
+        // rejects the step, as it does for the NaN cost the reference would see).
+        const double d0 = readlane_f64(dg0, j);
+        const bool ok = d > 0.0 && d < 1.7e308;                                            // (inf / NaN: not ok, not vanishing)
+        const bool vanishing = !ok && (d <= 0.0) && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
+        bad |= (j < nb) && !ok;
+        bad_sign |= (j < nb) && !ok && !vanishing;
+        const double rs = ok ? rsqrt_nr(d) : 0.0;
+        double piv = d * rs;
+        piv = ok ? fma(0.5 * rs, fma(-piv, piv, d), piv) : 0.0;                             // sqrt(d), one correction step
+        return (r == j) ? piv : rj * rs;                     // rows above the diagonal hold garbage that is never read (only entries c > j are)
+    };
+    static_for<0, 64>([&](auto jc) {
+        constexpr int j = decltype(jc)::value, owner = j >> 4, jj = j & 15;
+        double* col = s_col[j & 1];
+        double lj = 0.0;
+        if (w == owner) { lj = column(j, rw[jj]); rw[jj] = lj; col[r] = lj; }
+        __syncthreads();
+        if (w == owner) {
+            if constexpr (jj < 15) {
+                double2 lc[8];
+                static_for<0, 8>([&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (2 * q + 1 > jj) lc[q] = reinterpret_cast<const double2*>(col + 16 * owner)[q]; });
+                static_for<0, 8>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    // (pinned where they are written: see chol_diag_wave)
+                    if constexpr (2 * q > jj) { rw[2 * q] -= lj * lc[q].x; __asm__ volatile("" : "+v"(rw[2 * q])); }
+                    if constexpr (2 * q + 1 > jj) { rw[2 * q + 1] -= lj * lc[q].y; __asm__ volatile("" : "+v"(rw[2 * q + 1])); }
+                });
+            }
+        } else if (w > owner) {
+            const double lr = col[r];
+            double2 lc[8];
+            static_for<0, 8>([&](auto qc) { constexpr int q = decltype(qc)::value; lc[q] = reinterpret_cast<const double2*>(col + 16 * w)[q]; });
+            static_for<0, 8>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                rw[2 * q] -= lr * lc[q].x; __asm__ volatile("" : "+v"(rw[2 * q]));
+                rw[2 * q + 1] -= lr * lc[q].y; __asm__ volatile("" : "+v"(rw[2 * q + 1]));
+            });
+        }
+    });
+    if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
+    if (bad_sign && r == 0) atomicOr(info, 4);
+}
+
+__global__ __launch_bounds__(256) void emba_chol_diag_kernel(double* __restrict__ A, long ld, int jb, int nb, int* __restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double s_col[2][64];
-    const int r = threadIdx.x;
-    double row[64];
+    const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double rw[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) row[c] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0);   // identity padding
+    for (int cc = 0; cc < 16; ++cc) { const int c = 16 * w + cc; rw[cc] = (r < nb && c < nb) ? A[(size_t)ld * (jb + c) + jb + r] : ((r == c) ? 1.0 : 0.0); }   // identity padding
     const double dg0 = (r < nb) ? A[(size_t)ld * (jb + r) + jb + r] : 1.0;      // the diagonal entry before elimination (the scale of the pivot test)
-    chol_diag_wave(row, dg0, s_col, r, nb, info);
+    chol_diag_block4(rw, dg0, s_col, r, w, nb, info);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = row[c];
+    for (int cc = 0; cc < 16; ++cc) { const int c = 16 * w + cc; if (c < nb && r >= c && r < nb) A[(size_t)ld * (jb + c) + jb + r] = rw[cc]; }
 }
 
 // (2) panel below the diagonal block: row * L_diag^-T for the rows A[jb+nb .. n) of the panel.  Lanes are the panel's 64 COLUMNS; lane c keeps
@@ -610,23 +671,25 @@ __global__ __launch_bounds__(256) void emba_chol_trsm_kernel(double* __restrict_
 // right-hand side is row m of the augmented block (schur_factor_solve): factored along as one more row it becomes z = L^-1 rhs; L goes to LDS
 // and L^T x = z is solved as in emba_chol_trsv_kernel.  x (m entries) -> x_out[skip ..), zeros in front.  (Until round 4: diagonal factor, panel
 // solve of the one rhs row, rhs copy, triangular solve — four launches, 58 us on the device at K = 21.)
-__global__ __launch_bounds__(64) void emba_chol_small_kernel(const double* __restrict__ A, long ld, int m, int skip, double* __restrict__ x_out, int* __restrict__ info)
+__global__ __launch_bounds__(256) void emba_chol_small_kernel(const double* __restrict__ A, long ld, int m, int skip, double* __restrict__ x_out, int* __restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double s_col[2][64];
     __shared__ double s_l[64 * 65];
     __shared__ double s_z[64];
-    const int r = threadIdx.x;
-    double row[64];
+    const int r = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double rw[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) row[c] = (r <= m && c < m && r >= c) ? A[(size_t)ld * c + r] : ((r == c) ? 1.0 : 0.0);   // rows 0..m (m: the rhs), columns 0..m-1; identity elsewhere
+    for (int cc = 0; cc < 16; ++cc) { const int c = 16 * w + cc; rw[cc] = (r <= m && c < m && r >= c) ? A[(size_t)ld * c + r] : ((r == c) ? 1.0 : 0.0); }   // rows 0..m (m: the rhs), columns 0..m-1; identity elsewhere
     const double dg0 = (r < m) ? A[(size_t)ld * r + r] : 1.0;
-    chol_diag_wave(row, dg0, s_col, r, m, info);
+    chol_diag_block4(rw, dg0, s_col, r, w, m, info);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) {
-        s_l[c * 65 + r] = (r < m && c <= r) ? row[c] : 0.0;                       // L[r][c]
-        if (r == m) s_z[c] = (c < m) ? row[c] : 0.0;                              // z
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = 16 * w + cc;
+        s_l[c * 65 + r] = (r < m && c <= r) ? rw[cc] : 0.0;                       // L[r][c]
+        if (r == m) s_z[c] = (c < m) ? rw[cc] : 0.0;                              // z
     }
     __syncthreads();
+    if (w != 0) return;
     double v = (r < m) ? s_z[r] : 0.0;
     const double dgt = s_l[r * 65 + r];
     const double rdt = (r < m && dgt != 0.0) ? 1.0 / dgt : 0.0;                   // pseudo-inverse: zero update where the pivot vanished
@@ -691,15 +754,16 @@ __global__ __launch_bounds__(256) void emba_chol_trail_kernel(double* __restrict
         }
     if (!first) return;
     __syncthreads();
-    if (wv != 0) return;
-    const int r = lane;
-    double row[64];
+    {
+        const int r = lane, w = __builtin_amdgcn_readfirstlane(wv);
+        double rw[16];
 #pragma unroll
-    for (int c = 0; c < 64; ++c) row[c] = (r < nb_next && c < nb_next && r >= c) ? s_j[c * 65 + r] : ((r == c) ? 1.0 : 0.0);   // (entries above the diagonal are never read)
-    const double dg0 = (r < nb_next) ? s_j[r * 65 + r] : 1.0;
-    chol_diag_wave(row, dg0, s_col, r, nb_next, info);
+        for (int cc = 0; cc < 16; ++cc) { const int c = 16 * w + cc; rw[cc] = (r < nb_next && c < nb_next && r >= c) ? s_j[c * 65 + r] : ((r == c) ? 1.0 : 0.0); }   // (entries above the diagonal are never read)
+        const double dg0 = (r < nb_next) ? s_j[r * 65 + r] : 1.0;
+        chol_diag_block4(rw, dg0, s_col, r, w, nb_next, info);
 #pragma unroll
-    for (int c = 0; c < 64; ++c) if (c < nb_next && r >= c && r < nb_next) T[(size_t)ld * c + r] = row[c];
+        for (int cc = 0; cc < 16; ++cc) { const int c = 16 * w + cc; if (c < nb_next && r >= c && r < nb_next) T[(size_t)ld * c + r] = rw[cc]; }
+    }
 }
 
 // Solve L^T x = z in place (one workgroup; b holds z = L^-1 rhs: the factorisation carried the right-hand side along as an extra row,

@@ -492,80 +492,13 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return y;
 }
 
-// (1) factor the diagonal block.  ONE wave, the whole block in registers: lane r owns row r (64 doubles).  Right-looking: once column j is
-// final it goes to LDS and comes back as broadcast reads L[c][j] that update the lanes' columns c > j — 2016 independent fmas, every register
-// index static (both loops fully unrolled), no barrier (one wave).  The subtractions reach an entry in the same order k = 0, 1, ... as in the
-// left-looking form used until round 3; that one waited per column for a chain of j dependent fmas on v_readlane pairs (~40 cycles each) plus
-// a square root and a division: 35 us per panel.
-// the factorisation proper, one wave: row = lane r's row of the block (identity-padded beyond nb), dg0 = its diagonal entry before elimination;
-// s_col: 2 x 64 doubles of LDS.  On return row[c], c <= r < nb, is L[r][c].
-__device__ __forceinline__ void chol_diag_wave(double (&row)[64], double dg0, double (*s_col)[64], int r, int nb, int* __restrict__ info)      // nb: pivots j < nb are checked
-{
-    bool bad = false, bad_sign = false;
-    // column j from the lanes' current row[j]: the pivot's square root and the scaled column
-    auto column = [&](int j, double rj) -> double {
-        const double d = readlane_f64(rj, j);
-        // A vanishing pivot does not stop the reference: Eigen's ldlt (model.cpp:789) leaves such a column as it is and its solve takes
-        // the PSEUDO-inverse of D — a zero update in that component (LDLT.h:362-381, 583-589; pinned: tests/golden/eigen_solvers.npz).
-        // The case that occurs in practice is a control pose no event constrains: its rows and columns of S are exactly zero, so d == 0
-        // here whatever the pivot order.  Same behaviour: the column is zeroed, L[j][j] = 0 marks it, the substitutions return 0 there.
-        // (round 4) Only a VANISHING pivot is that case: d == 0, or a non-positive value within rounding of it — 64 ulp of the
-        // diagonal entry it was eliminated from.  A pivot that is clearly negative, or not finite, means S is indefinite or carries a NaN: Eigen
-        // factors the former with a negative D entry and propagates the latter; a Cholesky factorisation can do neither, and a finite, partly
-        // zeroed x1 with EMBA_OK would hide corrupted equations — info bit 2 (4), which the solve returns as EMBA_ERR_NUMERIC (the LM loop then
-        // rejects the step, as it does for the NaN cost the reference would see).
-        const double d0 = readlane_f64(dg0, j);
-        const bool ok = d > 0.0 && d < 1.7e308;                                            // (inf / NaN: not ok, not vanishing)
-        const bool vanishing = !ok && (d <= 0.0) && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
-        bad |= (j < nb) && !ok;
-        bad_sign |= (j < nb) && !ok && !vanishing;
-        const double rs = ok ? rsqrt_nr(d) : 0.0;
-        double piv = d * rs;
-        piv = ok ? fma(0.5 * rs, fma(-piv, piv, d), piv) : 0.0;                             // sqrt(d), one correction step
-        return (r == j) ? piv : rj * rs;                     // rows above the diagonal hold garbage that is never read (only entries c > j are)
-    };
-    double lj = column(0, row[0]);
-    // (compile-time loops: every register index must be static, and the plain `#pragma unroll` form of this nest was left rolled, rows in scratch)
-    static_for<0, 64>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        row[j] = lj;
-        double* col = s_col[j & 1];
-        col[r] = lj;                                          // (one wave: its LDS operations execute in order — the reads below see this write)
-        double lnext = 0.0;
-        if constexpr (j + 1 < 64) {
-            row[j + 1] -= lj * col[j + 1];
-            __asm__ volatile("" : "+v"(row[j + 1]));
-            lnext = column(j + 1, row[j + 1]);                // the next pivot's chain (rsqrt_nr) runs under the updates of the other columns
-        }
-        // the other columns, 32 at a time: the broadcast reads of a group are issued together (the pins below are barriers for memory operations:
-        // a read placed between them would be waited for on the spot), then its fmas
-        static_for<0, 2>([&](auto gc) {
-            constexpr int g = 32 * decltype(gc)::value;
-            if constexpr (g + 32 > j + 2) {
-                double2 lc[16];
-                static_for<0, 16>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    if constexpr (g + 2 * q + 1 >= j + 2) lc[q] = reinterpret_cast<const double2*>(col)[(g >> 1) + q];
-                });
-                static_for<0, 16>([&](auto qc) {
-                    constexpr int q = decltype(qc)::value;
-                    constexpr int c0 = g + 2 * q, c1 = c0 + 1;
-                    // (pinned: left alone the compiler sinks every update to the step that reads the column — the left-looking form again — and
-                    // keeps the 2016 broadcast values alive until then)
-                    if constexpr (c0 >= j + 2) { row[c0] -= lj * lc[q].x; __asm__ volatile("" : "+v"(row[c0])); }
-                    if constexpr (c1 >= j + 2) { row[c1] -= lj * lc[q].y; __asm__ volatile("" : "+v"(row[c1])); }
-                });
-            }
-        });
-        lj = lnext;
-    });
-    if (bad && r == 0) atomicOr(info, 2);     // diagnostic only (what ldlt.info() == NumericalIssue is to the reference: never read)
-    if (bad_sign && r == 0) atomicOr(info, 4);
-}
-
-// The same factorisation by FOUR waves (round 4, late): every wave holds all 64 rows (lane r = row r) of 16 of the block's columns — wave w the columns
-// 16w .. 16w+15 —, the owner of column j scales it and puts it in LDS, one barrier, then every wave with columns right of j updates them.  A single wave
-// spent its 28 us issuing ~15 k instructions; four waves issue a quarter each and the 64 barriers cost less than that.  rw[cc] = the lane's row, column
+// (1) factor the diagonal block.
+// The factorisation proper, by FOUR waves: every wave holds all 64 rows (lane r = row r) of 16 of the block's columns — wave w the columns 16w .. 16w+15 —,
+// the owner of column j scales it (pivot as rsqrt_nr) and puts it in LDS, one barrier, then every wave with columns right of j updates them from broadcast
+// reads.  Right-looking, every update pinned where it is written (an empty asm with the register as in/out operand: left alone the compiler sinks the updates
+// to the step that reads the column — the left-looking form — and keeps all the broadcast values alive until then), compile-time loops (every register index
+// static).  History: one wave, left-looking on v_readlane pairs, sqrt + division per column: 35 us per panel; one wave, right-looking through LDS: 28 (it
+// issued ~15 k instructions); four waves issue a quarter each and the 64 barriers cost less than that: 18.  rw[cc] = the lane's row, column
 // 16w + cc; on return rw[cc] = L[r][16w + cc] for 16w + cc <= r < nb.  All 256 threads of the block must call it.
 __device__ __forceinline__ void chol_diag_block4(double (&rw)[16], double dg0, double (*s_col)[64], int r, int w, int nb, int* __restrict__ info)
 {
@@ -604,7 +537,6 @@ __device__ __forceinline__ void chol_diag_block4(double (&rw)[16], double dg0, d
                 static_for<0, 8>([&](auto qc) { constexpr int q = decltype(qc)::value; if constexpr (2 * q + 1 > jj) lc[q] = reinterpret_cast<const double2*>(col + 16 * owner)[q]; });
                 static_for<0, 8>([&](auto qc) {
                     constexpr int q = decltype(qc)::value;
-                    // (pinned where they are written: see chol_diag_wave)
                     if constexpr (2 * q > jj) { rw[2 * q] -= lj * lc[q].x; __asm__ volatile("" : "+v"(rw[2 * q])); }
                     if constexpr (2 * q + 1 > jj) { rw[2 * q + 1] -= lj * lc[q].y; __asm__ volatile("" : "+v"(rw[2 * q + 1])); }
                 });
@@ -707,8 +639,8 @@ __global__ __launch_bounds__(256) void emba_chol_small_kernel(const double* __re
 // (after the panel solve; n_t of them, the right-hand-side row included), nb columns; the trailing matrix T (n_t x n_t, lower triangle) takes
 // T -= X X^T in 64 x 64 tiles, one workgroup per tile (I >= J): both 64 x nb slabs of X staged in LDS, wave w forms rows 16w..16w+15 of the tile
 // over the whole panel width (4 x 16 MFMAs).  The workgroup of tile (0, 0) then factors the next diagonal block from its updated tile (through
-// LDS: one wave, chol_diag_wave), which until round 4 was a launch of its own between this one and the next panel solve (28 + 27 us per panel in
-// sequence; together 30).  nb_next = size of the next diagonal block (0: none — the tile (0, 0) then only holds the right-hand side row).
+// LDS: its four waves, chol_diag_block4), which until round 4 was a launch of its own between this one and the next panel solve (28 + 27 us per panel in
+// sequence; together 34).  nb_next = size of the next diagonal block (0: none — the tile (0, 0) then only holds the right-hand side row).
 __global__ __launch_bounds__(256) void emba_chol_trail_kernel(double* __restrict__ A, long ld, int jb, int nb, int n_t, int nb_next, int* __restrict__ info)
 {
     __shared__ __attribute__((aligned(16))) double s_i[64 * 64];

@@ -257,8 +257,16 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
 // ------------------------------------------------------------------------------------------------
 struct ChunkDesc { uint32_t begin, end; int32_t x0, y0; };   // entries [begin, end) of the device order; LDS tile origin (panorama px)
 
-constexpr int kTileW = 48, kTileH = 24;         // LDS accumulator tile: a 32 x 8 bin plus a margin of 8 px on every side
-constexpr int kTileMargin = 8;
+#ifndef TILE_W
+#define TILE_W 48
+#define TILE_H 24
+#define TILE_MARGIN 8
+#endif
+constexpr int kTileW = TILE_W, kTileH = TILE_H;         // LDS accumulator tile: a 32 x 8 bin plus a margin of 8 px on every side.  Other shapes of the same 1152-px budget
+                                                        // (round 4, profiles/r04_tile_shape_sweep.txt): bins of 64x8, 48x12, 32x20 with a 4-px margin cut the lead-in copies at
+                                                        // 3 M events from 23 % to 21 / 16 / 14 % (the chains cross ROWS of bins more than columns) and change the warp kernel's
+                                                        // time by less than its run-to-run spread (153-158 us; 10 M: 459-502; 40 M: 1655-1717)
+constexpr int kTileMargin = TILE_MARGIN;
 constexpr int kTilePx = kTileW * kTileH;
 #ifndef TILE_WAVES
 #define TILE_WAVES 8

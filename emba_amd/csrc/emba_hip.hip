@@ -1960,12 +1960,12 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         }
         sp.direct = (nks == 1);
         if (getenv("EMBA_SOLVE_DEBUG")) {      // diagnostic: how sparse is this chunk?  (products = (block pair, slice) pairs the SYRK forms)
-            hipStreamSynchronize(s);
-            std::vector<uint16_t> hr(p1 - p0); hipMemcpy(hr.data(), d_range, (p1 - p0) * 2, hipMemcpyDeviceToHost);
+            (void)hipStreamSynchronize(s);
+            std::vector<uint16_t> hr(p1 - p0); (void)hipMemcpy(hr.data(), d_range, (p1 - p0) * 2, hipMemcpyDeviceToHost);
             long w16 = 0, w64 = 0, hist[9] = {0};
             for (uint16_t r : hr) { const int lo = r & 255, hi = r >> 8; if (lo > hi) continue; w16 += hi - lo + 1; const int b = (hi >> 2) - (lo >> 2) + 1; w64 += b; hist[b < 8 ? b : 8]++; }
             long prod = 0, prod_diag = 0;
-            if (sparse) { std::vector<uint32_t> hc(nbp); hipMemcpy(hc.data(), d_cnt, nbp * 4, hipMemcpyDeviceToHost); for (int b = 0; b < nbp; ++b) { prod += hc[b]; int I, J; I = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5); while ((long)I * (I + 1) / 2 > b) --I; while ((long)(I + 1) * (I + 2) / 2 <= b) ++I; J = b - I * (I + 1) / 2; if (I == J) prod_diag += hc[b]; } }
+            if (sparse) { std::vector<uint32_t> hc(nbp); (void)hipMemcpy(hc.data(), d_cnt, nbp * 4, hipMemcpyDeviceToHost); for (int b = 0; b < nbp; ++b) { prod += hc[b]; int I, J; I = (int)((sqrt(8.0 * b + 1.0) - 1.0) * 0.5); while ((long)I * (I + 1) / 2 > b) --I; while ((long)(I + 1) * (I + 2) / 2 <= b) ++I; J = b - I * (I + 1) / 2; if (I == J) prod_diag += hc[b]; } }
             for (int R : {1, 2, 4, 8, 16}) {      // union band (16-row groups) of runs of R slices: what a band-resident product would have to hold
                 const size_t per = (size_t)R * kSyrkSlicePix; long ng = 0, fit12 = 0, fit16 = 0, wsum = 0; long fit16_pix = 0;
                 for (size_t g0 = 0; g0 < hr.size(); g0 += per) {

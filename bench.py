@@ -45,6 +45,49 @@ def pmc_traffic(workload_desc):
     return best
 
 
+def _read(path):
+    try:
+        return open(path).read().strip()
+    except Exception:
+        return None
+
+
+def device_power_state(pci_id=None):
+    """What the card itself reports through sysfs while the bench runs (VERDICT r4 #1c): current sclk / mclk / fclk level of pp_dpm_*, power cap
+    and power draw.  pci_id (hipDeviceGetPCIBusId of the context's device) names the card; without it every card of the host is listed."""
+    import glob
+    import re
+    dirs = [f"/sys/bus/pci/devices/{pci_id.lower()}"] if pci_id else sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))[:8]
+    out = {}
+    for d in dirs:
+        ent = {}
+        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk"), ("fclk_mhz", "pp_dpm_fclk")):
+            t = _read(os.path.join(d, fn))
+            if t:
+                cur = [ln for ln in t.splitlines() if ln.rstrip().endswith("*")] or t.splitlines()[-1:]
+                mm = re.search(r"(\d+)\s*Mhz", cur[0], re.I)
+                ent[key] = int(mm.group(1)) if mm else cur[0]
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            for key, fn in (("power_cap_w", "power1_cap"), ("power_avg_w", "power1_average"), ("power_w", "power1_input")):
+                t = _read(os.path.join(hw, fn))
+                if t and t.lstrip("-").isdigit():
+                    ent[key] = round(int(t) * 1e-6, 1)
+        if ent:
+            out[os.path.basename(d) if pci_id else os.path.basename(os.path.dirname(d))] = ent
+    if pci_id and out:
+        return next(iter(out.values()))
+    if not out:
+        import shutil
+        import subprocess
+        smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        try:
+            r = subprocess.run([smi, "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=30)
+            out = {"rocm_smi": json.loads(r.stdout)} if r.returncode == 0 and r.stdout.strip().startswith("{") else {"rocm_smi_error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:   # noqa: BLE001
+            out = {"error": repr(e)[:200]}
+    return out
+
+
 def host_cores():
     """Cores this process may use on the GPU box: CPU affinity, capped by the cgroup CPU quota when one is set."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -89,6 +132,7 @@ def cpu_baseline(w, budget_s=10.0):
         O.set_threads(1)
     native = cpu_baseline_native(budget_s / 2)
     return {"value": ev.size() / med1, "unit": "events/s", "cores": 1, "kind": "port", "march_native": native,
+            "all_cores_value": ev.size() / medn, "all_cores": cores, "march_native_value": (native or {}).get("value"),
             "sample": f"full workload ({ev.size()} events), {n1} passes, median pass {med1 * 1e3:.1f} ms, "
                       f"host nproc={os.cpu_count()}, usable cores={host_cores()}",
             "all_cores": {"value": ev.size() / medn, "unit": "events/s", "cores": cores, "kind": "port (OpenMP mode of the oracle)",
@@ -149,9 +193,12 @@ def main():
                     help="uniform: SURVEY §8d's i.i.d. events (the BASELINE workload).  scene: events an ideal event camera fires while "
                          "rotating in front of an analytic scene (edge-clustered, polarity-consistent; emba_amd.synth.simulate_events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-ep", action="store_true",
-                    help="(always on since round 4) the step WITH the compaction of the residuals into the reference-order ep vector (what the one-shot "
-                         "drop-in entry point emba_eval_data_error always produces) is timed in an extra block; reported as config.with_ep_ms_per_step, never as value")
+    ap.add_argument("--no-with-ep", action="store_true",
+                    help="skip the extra (untimed w.r.t. value) block that times the step WITH the compaction of the residuals into the reference-order ep "
+                         "vector (config.with_ep_ms_per_step)")
+    ap.add_argument("--long-steps", type=int, default=300,
+                    help="steps of the second, longer timed block behind the K contractual ones (ms_per_step_long; every 16th of its steps is sampled with HIP "
+                         "events around ALL of its launches); 0 skips it")
     ap.add_argument("--shard-of", type=int, default=1,
                     help="time ONE rank's shard of a window sharded over this many GPUs, on one GPU and without collectives: the global stream has "
                          "shard-of x events-per-gpu events, the rank holds its time range + per-pixel halo (what each GPU of configs 4 / 5 computes)")
@@ -272,8 +319,13 @@ def main():
     # the stream (and for ~1.2 ms at step 460-462); nothing like it in the following 3000 steps.  A 20-step timed region that happens to contain
     # it reads 3 ms per step instead of 0.1.  Blocks of steps are timed between barriers until two consecutive blocks agree within 3 % AND the
     # thousand is complete; the block time is all-reduced (MAX), so every rank runs the same count.
+    # (the thousand-step floor is for SHORT steps — the stall sits at a launch count, and a 20-step region of 0.1-ms steps is what it ruins; at
+    # >= 1 ms per step the floor is what 1 s of stepping gives (a 100 M-event step is 7 ms: the stall is < 1 % of a 4-step region's time per step there,
+    # and under rocprofv3 --pmc a thousand serialised steps would not fit the profile scripts' timeouts).  All of it is reported: config.settle.)
     n_blk = int(min(max(np.ceil(0.02 / max(t_w, 1e-6)), 8), 400))
-    prev, done = None, args.warmup + 3 + n_extra
+    floor_steps = 1000 if t_w < 1e-3 else int(min(1000, max(3 * n_blk, np.ceil(1.0 / t_w))))
+    prev, done, slowest_blk = None, args.warmup + 3 + n_extra, 0.0
+    t_settle = time.perf_counter()
     for _ in range(200):
         t_b = time.perf_counter()
         for _ in range(n_blk):
@@ -285,9 +337,12 @@ def main():
             tt = torch.tensor([t_b], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_b = float(tt.item())
-        if prev is not None and abs(t_b - prev) <= 0.03 * prev and done >= 1000:
+        slowest_blk = max(slowest_blk, t_b)
+        if prev is not None and abs(t_b - prev) <= 0.03 * prev and done >= floor_steps:
             break
         prev = t_b
+    settle = {"untimed_steps": int(done), "floor_steps": int(floor_steps), "block": int(n_blk), "wall_s": round(time.perf_counter() - t_settle, 3),
+              "slowest_block_ms_per_step": slowest_blk * 1e3, "last_block_ms_per_step": t_b * 1e3}
     # Kernel durations by HIP events on the kernels' stream, sampled on every 8th step of the timed region (at most 16 samples), each sample in
     # its own set of events that is read AFTER the loop: an event record opens a bubble of a few us in front of the next kernel, and reading one
     # back inside the loop would make the host wait for the Gram kernel — timing every step would distort the very throughput being measured.
@@ -319,7 +374,7 @@ def main():
     # the step WITH the residuals compacted into the reference-order ep vector, as one more untimed block of steps (like the exchanges below):
     # reported as config.with_ep_ms_per_step in every line, never as `value`
     with_ep_ms = None
-    if True:
+    if not args.no_with_ep:
         barrier()
         t_e = time.perf_counter()
         for _ in range(args.steps):
@@ -327,6 +382,54 @@ def main():
             m.compact_ep()
         barrier()
         with_ep_ms = (time.perf_counter() - t_e) / args.steps * 1e3
+
+    # a second, LONGER block of the same step (ms_per_step_long), in which every 16th step is sampled with HIP events around ALL of
+    # its launches — consecutive events, so the four intervals tile the sampled step's device time — plus what an event bracket reads around
+    # an EMPTY kernel on this box (bracket_overhead_us), the shader clock a probe kernel measures right behind the block, and the card's own
+    # report of its clocks and power cap.  None of it touches `value`.
+    long_ms, kern_all, bracket_us, clocks, power_state = None, None, None, None, None
+    if args.long_steps > 0:
+        n_long = int(min(args.long_steps, max(32, np.ceil(3.0 / max(t_b, 1e-6)))))        # at most ~3 s of stepping
+        try:
+            pci = m.pci_bus_id()
+        except Exception:   # noqa: BLE001
+            pci = None
+        m.kernel_timing_all(True)
+        lslots, psamples = [], []
+        barrier()
+        t_l = time.perf_counter()
+        for i in range(n_long):
+            timed = (i % 16 == 8) and len(lslots) < 16
+            if timed:
+                lslots.append(len(lslots))
+            m.enable_kernel_timing(timed, lslots[-1] if timed else 0)
+            step()
+            if rank == 0 and pci and i % 32 == 24 and len(psamples) < 8:      # the card's own report WHILE the block runs (a few file reads; the
+                psamples.append(device_power_state(pci))                       # launches queued ahead keep the GPU busy meanwhile)
+        barrier()
+        long_ms = (time.perf_counter() - t_l) / n_long * 1e3
+        if world > 1:
+            tt = torch.tensor([long_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            long_ms = float(tt.item())
+        psamples = [q for q in psamples if isinstance(q, dict) and isinstance(q.get("sclk_mhz"), int)]
+        if psamples:
+            power_state = {"pci_bus_id": pci, "samples_during_long_block": len(psamples),
+                           "sclk_mhz": {"min": min(q["sclk_mhz"] for q in psamples), "mean": float(np.mean([q["sclk_mhz"] for q in psamples])), "max": max(q["sclk_mhz"] for q in psamples)},
+                           "mclk_mhz": psamples[-1].get("mclk_mhz"), "fclk_mhz": psamples[-1].get("fclk_mhz"), "power_cap_w": psamples[-1].get("power_cap_w"),
+                           "power_w": {"mean": float(np.mean([q.get("power_w") or q.get("power_avg_w") or 0.0 for q in psamples])),
+                                       "max": max(q.get("power_w") or q.get("power_avg_w") or 0.0 for q in psamples)}}
+        else:
+            power_state = {"pci_bus_id": pci, "all_cards_after_block": device_power_state()}
+        m.enable_kernel_timing(False)
+        m.kernel_timing_all(False)
+        rows = [m.kernel_ms_all(sl) for sl in lslots]
+        rows = [r for r in rows if min(r) >= 0]
+        clocks = m.clock_probe()
+        bracket_us = m.bracket_overhead_us(50)
+        if rows:
+            mean = [float(np.mean([r[k] for r in rows])) for k in range(4)]
+            kern_all = {"prep_pose_texel": mean[0], "warp": mean[1], "post_warp_a": mean[2], "gram": mean[3], "samples": len(rows), "n_long": n_long}
 
     # the exchanges alone (same buffers, same sizes, same stream), untimed w.r.t. `value`: what a step spends in collectives
     coll_ms = None
@@ -343,8 +446,22 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total / (elapsed / args.steps)
-        wk = float(np.mean(warp_ms))
+        wk_raw = float(np.mean(warp_ms))
+        # The bracket's own cost, calibrated in this run, two ways.  (i) empty_kernel_bracket_us: an EMPTY kernel between two events, queued behind work —
+        # an upper bound (it contains the empty kernel's own dispatch-to-completion time, which a profiler also counts as that kernel's duration).
+        # (ii) bracket_overhead_us: the steps sampled with consecutive events around all four launches are slower than their unsampled neighbours of the
+        # same block by exactly what the event records add — (sum of the four intervals - ms_per_step_long) / 4 per interval.  The dominant kernel's
+        # time is reported NET of (ii) (the figure rocprofv3's kernel trace agrees with), the raw reading beside it.
+        bracket_cost_us = None
+        if kern_all and long_ms:
+            bracket_cost_us = max(0.0, (kern_all["prep_pose_texel"] + kern_all["warp"] + kern_all["post_warp_a"] + kern_all["gram"] - long_ms) * 1e3 / 4.0)
+        wk = max(wk_raw - (bracket_cost_us if bracket_cost_us is not None else 0.0) * 1e-3, 1e-6)
         n_launch = local.size()
+        n_cand = m.event_counts()[1]
+        inl_frac = float(n_inl) / max(n_launch, 1)
+        # inlier-weighted byte model (VERDICT r4 #4c): event + link + predecessor are read for every event (36 B); the map gathers, ep, the count
+        # and A22 | b2 read-modify-writes and the 112-B A12 factor happen per INLIER (208 B)
+        wbytes = 36.0 + 208.0 * inl_frac
         # (a shard-of-N run times one rank's part of the stream: its traffic summary is keyed by the shard, not by the whole window's description)
         wkey = w.describe() if args.shard_of == 1 else f"{w.describe()} shard {args.shard_rank} of {args.shard_of}"
         tr = pmc_traffic(wkey) if world == 1 else None
@@ -355,6 +472,7 @@ def main():
             "value": value, "unit": "events/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic" if args.data == "uniform" else "synthetic (simulated scene)",
+            "ms_per_step_long": long_ms,
             "config": {"workload": w.describe(), "events_per_gpu": args.events_per_gpu, "total_events": n_total,
                        "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
                        "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
@@ -362,17 +480,33 @@ def main():
                        "parallelism": f"time-sharded x{world}" if world > 1 else (f"shard {args.shard_rank} of {args.shard_of} of the window, one GPU, no collectives" if args.shard_of > 1 else "single GPU"),
                        "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms, "with_ep_ms_per_step": with_ep_ms,
                        "backend": ("gloo, all ranks on device 0 (rehearsal)" if args.one_device else "rccl") if use_dist else None,
-                       "inliers_rank0": int(n_inl), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
-                       "setup": m.setup_info()},
+                       "inliers_rank0": int(n_inl), "inlier_frac": inl_frac, "candidates_rank0": int(n_cand), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
+                       "settle": settle, "setup": m.setup_info()},
             "roofline": {"bound": "hbm", "kernel": "emba_warp_tiled_kernel" if m.setup_info()["tile_order"] else "emba_warp_residual_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": (tr["hbm_bytes_per_launch"] if tr else None), "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/)",
                          "counter_GBs": counter, "counter_frac": (counter / HBM_PEAK_GBS if counter else None),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_EVENT * n_launch,
-                         "bytes_per_event": ALGO_BYTES_PER_EVENT, "events_per_launch": n_launch, "kernel_ms": wk,
+                         "bytes_per_event": ALGO_BYTES_PER_EVENT, "events_per_launch": n_launch, "kernel_ms": wk, "kernel_ms_raw": wk_raw,
+                         "bracket_overhead_us": bracket_cost_us, "empty_kernel_bracket_us": bracket_us,
                          "accumulate_kernel_ms": float(np.mean(accum_ms)),
-                         "path_frac": ALGO_BYTES_PER_EVENT * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         "path_frac": ALGO_BYTES_PER_EVENT * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "inlier_weighted": {"bytes_per_event": wbytes, "model": "36 + 208 x inlier_frac", "inlier_frac": inl_frac,
+                                             "frac": wbytes * n_launch / (wk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "path_frac": wbytes * n_launch / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         }
+        if kern_all:
+            ksum = kern_all["prep_pose_texel"] + kern_all["warp"] + kern_all["post_warp_a"] + kern_all["gram"]
+            # consecutive events: the four intervals tile a sampled step from its first launch to the end of its last kernel (each includes the
+            # record of the event that ends it, ~bracket_overhead_us less what queuing hides); gap_ms = what a step of the SAME block costs on
+            # the host's clock beyond that — negative when the sampled steps' event records make them slower than the unsampled ones
+            out["kernels_ms"] = dict(kern_all, sum=ksum, gap_ms=(long_ms - ksum) if long_ms else None,
+                                     gap_vs_timed_region_ms=ms_per_step - ksum,
+                                     note="HIP events around all launches of every 16th step of the long block; intervals, not net of the bracket overhead")
+        out["device"] = {"clock_probe": clocks, "sysfs": power_state,
+                         "note": "sysfs: the card's own report sampled WHILE the long block ran (the clock the kernels had; at the power cap it sits below the "
+                                 "attribute's peak).  clock_probe: shader cycles (s_memtime) per second of the constant-rate clock around a light fp32 chain on every "
+                                 "SIMD, right behind the block — the clock the chip returns to when the load is light"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
         print(json.dumps(out))

@@ -91,6 +91,11 @@ SIGNATURES = {
     "emba_enable_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "emba_last_kernel_ms": (C.c_int, [C.c_void_p, _fp, _fp]),
     "emba_kernel_ms_slot": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp]),
+    "emba_kernel_timing_all": (C.c_int, [C.c_void_p, C.c_int32]),
+    "emba_kernel_ms_all": (C.c_int, [C.c_void_p, C.c_int32, _fp]),
+    "emba_bracket_overhead_us": (C.c_int, [C.c_void_p, C.c_int32, _fp]),
+    "emba_clock_probe": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _i32p, _i32p, _i32p]),
+    "emba_device_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     # single-process multi-GPU host
     "emba_group_create": (C.c_int, [C.POINTER(EmbaCfg), _i32p, C.c_int32, C.POINTER(C.c_void_p)]),
     "emba_group_destroy": (None, [C.c_void_p]),

@@ -157,8 +157,11 @@ struct emba_ctx {
     // timing
     hipEvent_t ev_start[8]{}, ev_stop[8]{};
     bool kernel_timing = false;
-    hipEvent_t kt_sets[16][4]{}; hipEvent_t* kt = kt_sets[0]; int kt_slot = 0;  // per slot: warp start/stop, accum start/stop (emba_enable_kernel_timing)
-    bool kt_valid[16][2]{};
+    hipEvent_t kt_sets[16][5]{}; hipEvent_t* kt = kt_sets[0]; int kt_slot = 0;  // per slot: warp start/stop, accum start/stop (emba_enable_kernel_timing), [4]: in front of the step's first launch
+    bool kt_valid[16][3]{};
+    bool kt_all = false;        // emba_kernel_timing_all: also record [4], so that the four intervals [4]->[0]->[1]->[2]->[3] tile the whole step (prep | warp | post-warp | Gram)
+    hipEvent_t cal_ev[2]{};     // emba_bracket_overhead_us / emba_clock_probe
+    unsigned long long* d_probe = nullptr;
     bool kt_warp_valid = false, kt_accum_valid = false;
     int n_cu = 256;  // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     int ablate = 0;  // diagnostics builds only (-DEMBA_DIAG): EMBA_ABLATE bit mask; always 0 in the shipped library
@@ -738,7 +741,9 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     for (int i = 0; i < 8; ++i) { CREATE_TRY(hipEventCreate(&c->ev_start[i])); CREATE_TRY(hipEventCreate(&c->ev_stop[i])); }
     // every slot of the kernel-timing events up front: creating one later can stall the calling thread for tens of milliseconds (round 4: a 38-51 ms
     // pause inside bench.py's timed loop, once per process, at the first use of a new slot — the runtime growing its signal pool)
-    for (int k = 0; k < 16; ++k) for (int i = 0; i < 4; ++i) CREATE_TRY(hipEventCreate(&c->kt_sets[k][i]));
+    for (int k = 0; k < 16; ++k) for (int i = 0; i < 5; ++i) CREATE_TRY(hipEventCreate(&c->kt_sets[k][i]));
+    for (int i = 0; i < 2; ++i) CREATE_TRY(hipEventCreate(&c->cal_ev[i]));
+    CREATE_TRY(hipMalloc((void**)&c->d_probe, 8 * sizeof(unsigned long long))); c->caps[reinterpret_cast<void**>(&c->d_probe)] = 8 * sizeof(unsigned long long);
     CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
 #undef CREATE_TRY
     *out = c;
@@ -757,7 +762,8 @@ void emba_destroy(emba_ctx* c)
     if (c->h_knots) (void)hipHostFree(c->h_knots);
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
-    for (int k = 0; k < 16; ++k) for (int i = 0; i < 4; ++i) if (c->kt_sets[k][i]) (void)hipEventDestroy(c->kt_sets[k][i]);
+    for (int k = 0; k < 16; ++k) for (int i = 0; i < 5; ++i) if (c->kt_sets[k][i]) (void)hipEventDestroy(c->kt_sets[k][i]);
+    for (int i = 0; i < 2; ++i) if (c->cal_ev[i]) (void)hipEventDestroy(c->cal_ev[i]);
     for (auto& w : c->ws) if (w.p) (void)hipFree(w.p);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1065,6 +1071,8 @@ emba_status emba_get_map_active(emba_ctx* c, double* gxy_host, size_t cap_P)
     if (!c || !gxy_host) return c ? fail(c, EMBA_ERR_INVALID_ARG, "gxy_host NULL") : EMBA_ERR_INVALID_ARG;
     if (!c->have_map) return fail(c, EMBA_ERR_STATE, "no map resident");
     if (!c->active_done && !c->P_pending) return fail(c, EMBA_ERR_STATE, "no active set (formNormalEq) yet");
+    // (only a trial map — emba_update_map's output — is zero outside the active set it was built from; an uploaded or accepted map is not)
+    if (!c->map_is_trial) return fail(c, EMBA_ERR_STATE, "emba_get_map_active returns the trial map emba_update_map built; no trial map is resident");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st = resolve_pending(c);
     if (st) return st;
@@ -1169,7 +1177,9 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     int* rect_cur = c->d_rect;
     // the clearing pass over count map + accumulator lines is only needed when the previous evaluation's sums are still in their lines (it was
     // never formed by the resident step, whose gather clears them behind itself); the count map's entries are stamped and need no clearing
-    const int n_prep_blk = c->pixacc_clean ? 0 : (int)((c->npix + 1023) / 1024);
+    // (... and only when a warp kernel follows to re-mark it — an EMPTY window launches none, so its count map and active set would be the
+    // previous window's; the reference clears, model.cpp:85, and finds P = 0)
+    const int n_prep_blk = (c->pixacc_clean && c->n_sorted) ? 0 : (int)((c->npix + 1023) / 1024);
     // Hessian source: with several events per panorama pixel (measured break-even: ~4) the full texel pack (one 48-B gather per
     // measurement instead of an 18-load stencil) pays for itself; otherwise texels are packed only inside the bounding box of the pixels an
     // earlier evaluation touched, and the warp kernel falls back to the stencil outside it.
@@ -1204,6 +1214,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         q.n_tex = (c->use_texel == 3) ? 1024 : 0;
         q.Gx = c->d_Gx; q.Gy = c->d_Gy; q.rect = rect_cur; q.texel = c->d_texel;
         if (q.n_pose + q.n_tex + q.n_prep == 0) q.n_prep = 1;   // (an empty window on clean lines: block 0 still clears the next status word)
+        if (c->kernel_timing && c->kt_all) { HIP_TRY(c, hipEventRecord(c->kt[4], s)); c->kt_valid[c->kt_slot][2] = true; }
         hipLaunchKernelGGL(emba_prep_pose_texel_kernel, dim3((unsigned)(q.n_pose + q.n_tex + q.n_prep)), dim3(256), 0, s, q, kn);
     }
     if (c->use_texel == 1)
@@ -1822,9 +1833,9 @@ emba_status emba_enable_kernel_timing(emba_ctx* c, int32_t on)
     c->kernel_timing = on != 0;
     if (on) {       // on = 1 + slot: the next evaluation / form record their events in that slot, to be read later (emba_kernel_ms_slot)
         const int slot = on - 1;
-        for (int i = 0; i < 4; ++i) if (!c->kt_sets[slot][i]) HIP_TRY(c, hipEventCreate(&c->kt_sets[slot][i]));
+        for (int i = 0; i < 5; ++i) if (!c->kt_sets[slot][i]) HIP_TRY(c, hipEventCreate(&c->kt_sets[slot][i]));
         c->kt = c->kt_sets[slot]; c->kt_slot = slot;
-        c->kt_valid[slot][0] = c->kt_valid[slot][1] = false;
+        c->kt_valid[slot][0] = c->kt_valid[slot][1] = c->kt_valid[slot][2] = false;
     }
     c->kt_warp_valid = c->kt_accum_valid = false;
     return EMBA_OK;
@@ -1849,6 +1860,90 @@ emba_status emba_last_kernel_ms(emba_ctx* c, float* warp_ms, float* accum_ms)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
     return emba_kernel_ms_slot(c, c->kt_slot, warp_ms, accum_ms);
+}
+
+emba_status emba_kernel_timing_all(emba_ctx* c, int32_t on)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    c->kt_all = on != 0;
+    return EMBA_OK;
+}
+
+emba_status emba_kernel_ms_all(emba_ctx* c, int32_t slot, float* ms4)
+{
+    if (!c || !ms4 || slot < 0 || slot >= 16) return EMBA_ERR_INVALID_ARG;
+    hipEvent_t* k = c->kt_sets[slot];
+    for (int i = 0; i < 4; ++i) ms4[i] = -1.f;
+    if (!(c->kt_valid[slot][0] && c->kt_valid[slot][1] && c->kt_valid[slot][2])) return EMBA_OK;
+    HIP_TRY(c, hipEventSynchronize(k[3]));
+    HIP_TRY(c, hipEventElapsedTime(ms4 + 0, k[4], k[0]));     // prep || pose || texel (+ the full texel pack where it is used)
+    HIP_TRY(c, hipEventElapsedTime(ms4 + 1, k[0], k[1]));     // warp kernel
+    HIP_TRY(c, hipEventElapsedTime(ms4 + 2, k[1], k[2]));     // launch A (+ the sweeping active write where it is a launch of its own)
+    HIP_TRY(c, hipEventElapsedTime(ms4 + 3, k[2], k[3]));     // Gram kernel (with the gather inside)
+    return EMBA_OK;
+}
+
+emba_status emba_bracket_overhead_us(emba_ctx* c, int32_t reps, float* us)
+{
+    if (!c || !us || reps < 1 || reps > 1000) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    double sum = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        // the bracket sits BEHIND queued work, like the brackets of a step: a busy kernel first, then event | empty kernel | event
+        hipLaunchKernelGGL(emba_clock_probe_kernel, dim3(1), dim3(64), 0, s, c->d_probe + 4, 256);
+        HIP_TRY(c, hipEventRecord(c->cal_ev[0], s));
+        hipLaunchKernelGGL(emba_empty_kernel, dim3(1), dim3(64), 0, s);
+        HIP_TRY(c, hipEventRecord(c->cal_ev[1], s));
+        HIP_TRY(c, hipEventSynchronize(c->cal_ev[1]));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->cal_ev[0], c->cal_ev[1]));
+        sum += ms;
+    }
+    HIP_TRY(c, hipGetLastError());
+    *us = (float)(sum / reps * 1e3);
+    return EMBA_OK;
+}
+
+emba_status emba_clock_probe(emba_ctx* c, double* sclk_mhz_est, double* probe_us, double* memtime_per_realtime, int32_t* clock_rate_khz,
+                             int32_t* mem_clock_rate_khz, int32_t* wall_clock_rate_khz)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int v = 0;
+    if (clock_rate_khz) { *clock_rate_khz = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, c->device) == hipSuccess) *clock_rate_khz = v; }
+    if (mem_clock_rate_khz) { *mem_clock_rate_khz = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, c->device) == hipSuccess) *mem_clock_rate_khz = v; }
+    int wall_khz = 100000;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, c->device) == hipSuccess && v > 0) wall_khz = v;
+    if (wall_clock_rate_khz) *wall_clock_rate_khz = wall_khz;
+    // every SIMD of the chip busy with one wave's dependent chain of kClockProbeOps fp32 adds (4 cycles each on a 16-lane SIMD, issued back to back)
+    const int loops = 1024;
+    HIP_TRY(c, hipEventRecord(c->cal_ev[0], s));
+    hipLaunchKernelGGL(emba_clock_probe_kernel, dim3((unsigned)c->n_cu), dim3(256), 0, s, c->d_probe, loops);
+    HIP_TRY(c, hipEventRecord(c->cal_ev[1], s));
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_probe, sizeof h, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->spun = false;
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->cal_ev[0], c->cal_ev[1]));
+    const double wall_s = (double)h[1] / ((double)wall_khz * 1e3);      // the wave's own constant-rate clock around its chain
+    if (probe_us) *probe_us = wall_s * 1e6;
+    // s_memtime counts shader cycles (measured, round 5: 8.08 ticks per dependent v_add_f32 of the chain, the pipeline's 8-cycle dependent-issue
+    // cadence; its ratio to the 100-MHz counter moves with the power state), so ticks(s_memtime) / seconds(s_memrealtime) IS the shader clock
+    if (sclk_mhz_est) *sclk_mhz_est = wall_s > 0 ? (double)h[0] / wall_s * 1e-6 : 0.0;
+    if (memtime_per_realtime) *memtime_per_realtime = h[1] ? (double)h[0] / ((double)kClockProbeUnroll * loops) : 0.0;
+    (void)ms;
+    return EMBA_OK;
+}
+
+emba_status emba_device_pci_bus_id(emba_ctx* c, char* buf, size_t len)
+{
+    if (!c || !buf || len < 16) return EMBA_ERR_INVALID_ARG;
+    HIP_TRY(c, hipDeviceGetPCIBusId(buf, (int)len, c->device));
+    return EMBA_OK;
 }
 
 }  // extern "C"

@@ -2063,4 +2063,28 @@ __global__ __launch_bounds__(256) void emba_reg_cost_kernel(const double* __rest
     if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Measurement aids of bench.py: what an event bracket around NOTHING reads on this box, and the shader clock the chip
+// really runs at while it is busy.  Neither touches the product's data.
+// ------------------------------------------------------------------------------------------------
+__global__ void emba_empty_kernel() {}
+
+constexpr int kClockProbeUnroll = 256;
+// One wave per SIMD: a dependent chain of loops x kClockProbeUnroll v_add_f32 (a 16-lane SIMD issues a wave64 fp32 add in 4 cycles and dependent
+// adds go back to back), bracketed by the constant-rate clock (s_memrealtime) and the shader's own counter (s_memtime).
+// out[0] = s_memtime ticks, out[1] = s_memrealtime ticks (block 0, lane 0), out[2] = the chain's value (keeps it alive).
+__global__ __launch_bounds__(256) void emba_clock_probe_kernel(unsigned long long* __restrict__ out, int loops)
+{
+    float x = (float)threadIdx.x, y = 1.0f;
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < loops; ++i) {
+#pragma unroll
+        for (int u = 0; u < kClockProbeUnroll; ++u) __asm__ volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+    }
+    __asm__ volatile("s_nop 0" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = t1 - t0; out[1] = r1 - r0; }
+    if (x == -1.0f) out[2] = (unsigned long long)x;
+}
+
 }  // namespace emba

@@ -517,8 +517,10 @@ __device__ __forceinline__ void chol_diag_block4(double (&rw)[16], double dg0, d
         // zeroed x1 with EMBA_OK would hide corrupted equations — info bit 2 (4), which the solve returns as EMBA_ERR_NUMERIC (the LM loop then
         // rejects the step, as it does for the NaN cost the reference would see).
         const double d0 = readlane_f64(dg0, j);
-        const bool ok = d > 0.0 && d < 1.7e308;                                            // (inf / NaN: not ok, not vanishing)
-        const bool vanishing = !ok && (d <= 0.0) && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
+        // (a positive SUBNORMAL pivot is not usable either — rsqrt_nr's y * y overflows on it and the column would turn into inf / NaN
+        // with no info bit set; Eigen's own tolerance for "D_j is zero" is DBL_MIN, LDLT.h:583-589 — it is a vanishing pivot)
+        const bool ok = d >= 2.2250738585072014e-308 && d < 1.7e308;                       // (inf / NaN: not ok, not vanishing)
+        const bool vanishing = !ok && (d < 2.2250738585072014e-308) && (d >= -64.0 * 2.220446049250313e-16 * fabs(d0));      // false for NaN
         bad |= (j < nb) && !ok;
         bad_sign |= (j < nb) && !ok && !vanishing;
         const double rs = ok ? rsqrt_nr(d) : 0.0;

@@ -323,8 +323,17 @@ void LEGM::updateMap(cv::Mat& Gx_new, cv::Mat& Gy_new, const VecXd& x2, const do
     const size_t npix = (size_t)Gx_new.rows * Gx_new.cols;
     // zero the planes: everything (two memsets of H x W doubles), or — when the clones are known to be the map an accepted trial of this
     // object produced — just that trial's active pixels, the only places where they are not zero already
-    if (st.cur_nonzero_valid) for (uint32_t p : st.cur_nonzero) { gx[p] = 0.0; gy[p] = 0.0; }
-    else { std::memset(gx, 0, npix * sizeof(double)); std::memset(gy, 0, npix * sizeof(double)); }
+    bool zeroed = false;
+    if (st.cur_nonzero_valid) {
+        for (uint32_t p : st.cur_nonzero) { gx[p] = 0.0; gy[p] = 0.0; }
+        //  ... which holds for solver.cpp's call order (Gx.clone() of the accepted map, :237-238) but is an assumption about the caller:
+        // a strided sample of both planes must now read zero, else these are other Mats and everything is cleared as the reference does (model.cpp:892-901)
+        std::vector<double> smp;
+        legm_hip_detail::sample_plane(gx, npix, smp); legm_hip_detail::sample_plane(gy, npix, smp);
+        zeroed = true;
+        for (double v : smp) if (v != 0.0 || v != v) { zeroed = false; break; }
+    }
+    if (!zeroed) { std::memset(gx, 0, npix * sizeof(double)); std::memset(gy, 0, npix * sizeof(double)); }
     if (st.numeric_failure) {
         // x2 is NaN (see solveNormalEq): the reference's loop writes Gx + damping * NaN into the active pixels and zero elsewhere
         // (model.cpp:863-903); the device is not touched, the trial evaluation that follows is short-circuited

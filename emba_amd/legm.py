@@ -456,3 +456,32 @@ class LEGM:
         a, b = C.c_float(0), C.c_float(0)
         self._check(self._L.emba_last_kernel_ms(self._ctx, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def kernel_timing_all(self, on=True):
+        """Sampled steps also record an event in front of their first launch: kernel_ms_all(slot) then returns the four intervals that tile the
+        step's device time (prep || pose || texel, warp, post-warp launch A, Gram)."""
+        self._check(self._L.emba_kernel_timing_all(self._ctx, 1 if on else 0))
+
+    def kernel_ms_all(self, slot):
+        v = (C.c_float * 4)()
+        self._check(self._L.emba_kernel_ms_all(self._ctx, int(slot), v))
+        return [float(x) for x in v]
+
+    def bracket_overhead_us(self, reps=50):
+        """Mean HIP-event interval around an EMPTY kernel queued behind running work: what a bracket reads for a kernel of zero length."""
+        us = C.c_float(0)
+        self._check(self._L.emba_bracket_overhead_us(self._ctx, int(reps), C.byref(us)))
+        return us.value
+
+    def clock_probe(self):
+        """Device clock attributes and the shader clock measured by a probe kernel while the whole chip is busy (emba_clock_probe)."""
+        sclk, us, ratio = C.c_double(0), C.c_double(0), C.c_double(0)
+        cr, mr, wr = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._L.emba_clock_probe(self._ctx, C.byref(sclk), C.byref(us), C.byref(ratio), C.byref(cr), C.byref(mr), C.byref(wr)))
+        return {"sclk_mhz_measured": sclk.value, "probe_us": us.value, "cycles_per_dependent_add": ratio.value,
+                "attr_clock_rate_khz": cr.value, "attr_mem_clock_rate_khz": mr.value, "attr_wall_clock_rate_khz": wr.value}
+
+    def pci_bus_id(self):
+        buf = C.create_string_buffer(32)
+        self._check(self._L.emba_device_pci_bus_id(self._ctx, buf, 32))
+        return buf.value.decode()

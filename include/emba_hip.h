@@ -338,6 +338,21 @@ emba_status emba_enable_kernel_timing(emba_ctx* ctx, int32_t on);      /* on = 0
 emba_status emba_last_kernel_ms(emba_ctx* ctx, float* warp_ms, float* accum_ms);
 /* ... read LATER, after the timed loop: sampled steps then cost their event records only, not a host wait each (bench.py) */
 emba_status emba_kernel_ms_slot(emba_ctx* ctx, int32_t slot, float* warp_ms, float* accum_ms);
+/* All launches of a sampled step (VERDICT r4 #1a).  emba_kernel_timing_all(ctx, 1): sampled steps also record an event in front of their first
+ * launch, so that four consecutive intervals tile the step's device time; emba_kernel_ms_all returns them for a slot:
+ * ms4[0] prep || pose || texel, [1] the warp kernel, [2] post-warp launch A (+ the sweeping active write where it is a launch of its own),
+ * [3] the Gram kernel (with the active-set gather where it rides inside); -1 where a sampled step did not record them. */
+emba_status emba_kernel_timing_all(emba_ctx* ctx, int32_t on);
+emba_status emba_kernel_ms_all(emba_ctx* ctx, int32_t slot, float* ms4);
+/* What an event bracket costs by itself: the mean HIP-event interval around an EMPTY kernel queued behind running work (reps brackets). */
+emba_status emba_bracket_overhead_us(emba_ctx* ctx, int32_t reps, float* us);
+/* The clocks this run had: the device attributes (kHz), and a probe kernel — one wave per SIMD running a dependent chain of fp32 adds
+ * between two reads each of the constant-rate clock (s_memrealtime) and the shader-cycle counter (s_memtime): *probe_us its duration,
+ * *sclk_mhz = shader cycles / duration, *cycles_per_add the chain's cadence (8 on gfx950: a sanity check of the counter).  Any pointer may be NULL. */
+emba_status emba_clock_probe(emba_ctx* ctx, double* sclk_mhz, double* probe_us, double* cycles_per_add, int32_t* clock_rate_khz,
+                             int32_t* mem_clock_rate_khz, int32_t* wall_clock_rate_khz);
+/* "0000:xx:00.0" of the context's device (hipDeviceGetPCIBusId): /sys/bus/pci/devices/<id>/ holds the card's own clock and power report. */
+emba_status emba_device_pci_bus_id(emba_ctx* ctx, char* buf, size_t len);
 
 /* ---- Several GPUs behind ONE host thread ------------------------------------------------------------------------
  * The reference front-end is one process that owns one LEGM (src/emba/emba.cpp:378; solver.cpp:63-353 calls it).  An emba_group is

@@ -971,6 +971,34 @@ def test_resident_step_sequences(gpu, oracle_mod, cfg, fast, gather, monkeypatch
     check("step after a re-form")
 
 
+def test_empty_window_after_a_resident_step(gpu, oracle_mod):
+    """the count map is stamped, not cleared, between evaluations — which needs a warp kernel to re-mark it.  A window of
+    fewer than 100 events (quirk Q1: no whole batch, nothing is warped) after a resident step launches none: the reference clears num_ev_map
+    (model.cpp:85) and finds no inlier and no active pixel; so must the device, instead of the previous window's materialised counts."""
+    from emba_amd import EventPacket
+    w = small_workload(n_events=20000)
+    m = make_legm(w)
+    m.set_events(w.events)
+    m.upload_map(w.Gx, w.Gy)
+    o = oracle_run(oracle_mod, w)
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert n_inl == o["ep"].size and P == o["ne"]["P"] and P > 0
+    ev = w.events
+    short = EventPacket(ev.x[:60].copy(), ev.y[:60].copy(), ev.polarity[:60].copy(), ev.t_ns[:60].copy())
+    m.set_events(short)
+    nem = np.full((w.pano_h, w.pano_w), -7, dtype=np.int32)
+    ep = m.evaluateDataError(w.traj, None, None, None, True, nem)
+    assert ep.size == 0 and not nem.any()
+    ne = m.formNormalEq(None, w.K, nem, w.thres_valid_pixel)
+    assert ne["P"] == 0 and ne["active"].size == 0 and not np.any(ne["A11"]) and not np.any(ne["b1"])
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)        # and as a resident step
+    assert n_inl == 0 and P == 0
+    m.set_events(w.events)                                        # the next window is the first one again
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert n_inl == o["ep"].size and P == o["ne"]["P"]
+    compare_normal_eq(m._finish(w.alpha, False), o["ne"])
+
+
 def test_call_order_pairs_never_give_a_wrong_number(gpu, oracle_mod):
     """the context carries ~20 phase flags; SURVEY §8b says the boundary is stateful across evaluateDataError -> formNormalEq.
     Table-driven: every ordered PAIR (A, B) of the phase calls, on a fresh context (events + map registered, nothing evaluated) and on a formed

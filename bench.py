@@ -194,11 +194,13 @@ def main():
                          "rotating in front of an analytic scene (edge-clustered, polarity-consistent; emba_amd.synth.simulate_events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-with-ep", action="store_true",
-                    help="skip the extra (untimed w.r.t. value) block that times the step WITH the compaction of the residuals into the reference-order ep "
-                         "vector (config.with_ep_ms_per_step)")
+                    help="skip the extra (untimed w.r.t. value) blocks that time the step with / without the compaction of the residuals into the "
+                         "reference-order ep vector (config.with_ep_ms_per_step, config.no_ep_ms_per_step)")
     ap.add_argument("--long-steps", type=int, default=300,
                     help="steps of the second, longer timed block behind the K contractual ones (ms_per_step_long; every 16th of its steps is sampled with HIP "
                          "events around ALL of its launches); 0 skips it")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="emba_set_option on the context (A/B comparisons: order=1, step_gather=0, step_ep=0 ...); results do not depend on any of them")
     ap.add_argument("--shard-of", type=int, default=1,
                     help="time ONE rank's shard of a window sharded over this many GPUs, on one GPU and without collectives: the global stream has "
                          "shard-of x events-per-gpu events, the rank holds its time range + per-pixel halo (what each GPU of configs 4 / 5 computes)")
@@ -257,6 +259,9 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=local_rank, stream=stream)
+    for kv in args.opt:
+        name, _, val = kv.partition("=")
+        m.set_option(name.strip(), int(val))
     count_t = torch.zeros(npix, dtype=torch.int32, device=dev)
     pack_t = torch.zeros(9 * w.K * w.K + 3 * w.K + 5 * npix, dtype=torch.float64, device=dev)
 
@@ -371,17 +376,32 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # the step WITH the residuals compacted into the reference-order ep vector, as one more untimed block of steps (like the exchanges below):
-    # reported as config.with_ep_ms_per_step in every line, never as `value`
-    with_ep_ms = None
+    # Round 5: on one GPU the step PRODUCES the reference-order ep vector (what evaluateDataError returns, model.cpp:256) — compacted by tail blocks
+    # of its Gram launch (option step_ep) — so `value` is the step with ep.  Two more untimed blocks say what that costs: the same step with the option
+    # off (config.no_ep_ms_per_step: what rounds 1-4 reported as `value`), and, where the step does not produce ep itself (several ranks; windows too
+    # long for the tail form), the step followed by the stand-alone compaction (config.with_ep_ms_per_step).
+    with_ep_ms, no_ep_ms = None, None
+    ep_in_step = (world == 1 and not args.force_collectives and m.get_option("step_ep") == 1)
     if not args.no_with_ep:
         barrier()
         t_e = time.perf_counter()
         for _ in range(args.steps):
             step()
-            m.compact_ep()
+            m.compact_ep()          # (a no-op where the step has produced ep already)
         barrier()
         with_ep_ms = (time.perf_counter() - t_e) / args.steps * 1e3
+        if ep_in_step:
+            m.set_option("step_ep", 0)
+            for _ in range(3):
+                step()
+            barrier()
+            t_e = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            no_ep_ms = (time.perf_counter() - t_e) / args.steps * 1e3
+            m.set_option("step_ep", 1)
+            step()
 
     # a second, LONGER block of the same step (ms_per_step_long), in which every 16th step is sampled with HIP events around ALL of
     # its launches — consecutive events, so the four intervals tile the sampled step's device time — plus what an event bracket reads around
@@ -404,24 +424,30 @@ def main():
                 lslots.append(len(lslots))
             m.enable_kernel_timing(timed, lslots[-1] if timed else 0)
             step()
-            if rank == 0 and pci and i % 32 == 24 and len(psamples) < 8:      # the card's own report WHILE the block runs (a few file reads; the
-                psamples.append(device_power_state(pci))                       # launches queued ahead keep the GPU busy meanwhile)
         barrier()
         long_ms = (time.perf_counter() - t_l) / n_long * 1e3
         if world > 1:
             tt = torch.tensor([long_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             long_ms = float(tt.item())
+        m.enable_kernel_timing(False)
+        # the card's own report WHILE it steps: a short block of its own behind the long one (a sample is a handful of sysfs reads, ~0.1 ms of host time —
+        # inside the long block eight of them cost it 3 us per step)
+        n_clk = int(min(96, max(16, np.ceil(0.5 / max(t_b, 1e-6)))))
+        for i in range(n_clk):
+            step()
+            if rank == 0 and pci and i % max(n_clk // 8, 1) == max(n_clk // 8, 1) - 1 and len(psamples) < 8:
+                psamples.append(device_power_state(pci))
+        barrier()
         psamples = [q for q in psamples if isinstance(q, dict) and isinstance(q.get("sclk_mhz"), int)]
         if psamples:
-            power_state = {"pci_bus_id": pci, "samples_during_long_block": len(psamples),
+            power_state = {"pci_bus_id": pci, "samples_while_stepping": len(psamples),
                            "sclk_mhz": {"min": min(q["sclk_mhz"] for q in psamples), "mean": float(np.mean([q["sclk_mhz"] for q in psamples])), "max": max(q["sclk_mhz"] for q in psamples)},
                            "mclk_mhz": psamples[-1].get("mclk_mhz"), "fclk_mhz": psamples[-1].get("fclk_mhz"), "power_cap_w": psamples[-1].get("power_cap_w"),
                            "power_w": {"mean": float(np.mean([q.get("power_w") or q.get("power_avg_w") or 0.0 for q in psamples])),
                                        "max": max(q.get("power_w") or q.get("power_avg_w") or 0.0 for q in psamples)}}
         else:
             power_state = {"pci_bus_id": pci, "all_cards_after_block": device_power_state()}
-        m.enable_kernel_timing(False)
         m.kernel_timing_all(False)
         rows = [m.kernel_ms_all(sl) for sl in lslots]
         rows = [r for r in rows if min(r) >= 0]
@@ -475,10 +501,11 @@ def main():
             "ms_per_step_long": long_ms,
             "config": {"workload": w.describe(), "events_per_gpu": args.events_per_gpu, "total_events": n_total,
                        "thres_valid_pixel": w.thres_valid_pixel, "alpha": w.alpha, "cost": "quadratic",
-                       "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; residuals stay per event in HBM "
-                               "(the host API's compacted ep vector is produced when it is asked for)",
+                       "step": "evaluateDataError(eval_deriv)+formNormalEq+applyL2Reg, inputs resident in HBM; " +
+                               ("the reference-order residual vector ep is produced in every step" if ep_in_step else
+                                "residuals stay per event in HBM (the compacted ep vector is produced when it is asked for: with_ep_ms_per_step)"),
                        "parallelism": f"time-sharded x{world}" if world > 1 else (f"shard {args.shard_rank} of {args.shard_of} of the window, one GPU, no collectives" if args.shard_of > 1 else "single GPU"),
-                       "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms, "with_ep_ms_per_step": with_ep_ms,
+                       "events_per_rank": int(local.size()), "collectives_ms_per_step": coll_ms, "with_ep_ms_per_step": with_ep_ms, "no_ep_ms_per_step": no_ep_ms, "ep_in_step": ep_in_step,
                        "backend": ("gloo, all ranks on device 0 (rehearsal)" if args.one_device else "rccl") if use_dist else None,
                        "inliers_rank0": int(n_inl), "inlier_frac": inl_frac, "candidates_rank0": int(n_cand), "active_pixels": int(sh.P), "set_events_s": round(t_set, 3),
                        "settle": settle, "setup": m.setup_info()},
@@ -504,7 +531,7 @@ def main():
                                      gap_vs_timed_region_ms=ms_per_step - ksum,
                                      note="HIP events around all launches of every 16th step of the long block; intervals, not net of the bracket overhead")
         out["device"] = {"clock_probe": clocks, "sysfs": power_state,
-                         "note": "sysfs: the card's own report sampled WHILE the long block ran (the clock the kernels had; at the power cap it sits below the "
+                         "note": "sysfs: the card's own report sampled WHILE a block of steps ran, right behind the long block (the clock the kernels had; at the power cap it sits below the "
                                  "attribute's peak).  clock_probe: shader cycles (s_memtime) per second of the constant-rate clock around a light fp32 chain on every "
                                  "SIMD, right behind the block — the clock the chip returns to when the load is light"}
         if world == 1 and not args.no_cpu_baseline:

@@ -47,6 +47,7 @@ SIGNATURES = {
                                       C.c_size_t, _dp, _dp, _dp]),
     "emba_get_A12_sparse": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _dp, _dp, _dp, _dp]),
     "emba_compact_ep": (C.c_int, [C.c_void_p]),
+    "emba_get_ep": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _szp]),
     "emba_get_inlier_pixels": (C.c_int, [C.c_void_p, _u32p]),
     "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
     "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),
@@ -84,6 +85,8 @@ SIGNATURES = {
     "emba_form_finish": (C.c_int, [C.c_void_p, C.c_double, _dp, _dp, _u32p, C.c_size_t, _dp, _dp, _dp]),
     "emba_step": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
     "emba_last_counts": (C.c_int, [C.c_void_p, _szp, _szp]),
+    "emba_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
+    "emba_get_option": (C.c_int, [C.c_void_p, C.c_char_p, _i32p]),
     "emba_sync": (C.c_int, [C.c_void_p]),
     "emba_timer_start": (C.c_int, [C.c_void_p, C.c_int32]),
     "emba_timer_stop": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -98,6 +101,8 @@ SIGNATURES = {
     "emba_device_pci_bus_id": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     # single-process multi-GPU host
     "emba_group_create": (C.c_int, [C.POINTER(EmbaCfg), _i32p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "emba_group_create_flags": (C.c_int, [C.POINTER(EmbaCfg), _i32p, C.c_int32, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "emba_group_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32]),
     "emba_group_destroy": (None, [C.c_void_p]),
     "emba_group_last_error": (C.c_char_p, [C.c_void_p]),
     "emba_group_size": (C.c_int32, [C.c_void_p]),

@@ -60,7 +60,7 @@ struct emba_ctx {
     bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
     uint32_t count_stamp = 0;   // record stamp (set_stamp) of the evaluation whose materialised, LOCAL counts d_count_own holds; 0: none (build_lists)
     bool perm_valid = false; uint32_t* d_perm = nullptr;   // column order of U for the local Schur solve (solve_perm), valid with the lists
-    int solve_perm_mode = -1;                               // EMBA_SOLVE_PERM=0|1 (A/B): -1 auto
+    int solve_perm_mode = -1;                               // option solve_perm (A/B): -1 auto, 0 off, 1 on
     double* h_cost = nullptr;           // pinned: {data cost sum, reg cost sum} of emba_costs
     double* d_x2 = nullptr; size_t x2_cap = 0; size_t x2_resident_P = (size_t)-1;   // x2_resident_P: d_x2 holds the x2 of the last solve on this context (for that many pixels)
     int32_t* d_count_own = nullptr; int32_t* d_count = nullptr;
@@ -71,7 +71,7 @@ struct emba_ctx {
     bool step_consume = false;     // set by emba_step around its emba_form_active: this gather is the sums' only reader
     bool force_generic_a22 = false;
     int32_t count_mark = 0;        // count_marker(stamp) of the last evaluation: what its touched pixels hold in a raw count map
-    int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (EMBA_TEXEL=auto|pack|fly|rect)
+    int texel_mode = 0;   // 0 auto, 1 pack every texel, 2 always on-the-fly stencil, 3 texel rectangle (option texel)
     int use_texel = 0;    // what the current evaluation uses: 0 fly, 1 full pack, 3 rectangle
     int* d_rect = nullptr;       // {xmin,ymin,xmax,ymax} of the pixels the previous evaluation touched
     int* d_blk_rect = nullptr;   // per prep-block boxes
@@ -106,22 +106,22 @@ struct emba_ctx {
     uint16_t* d_cp = nullptr; double* d_batch_u = nullptr;                                          // control-pose index (= spline segment) and spline parameter per batch
     double* d_ev_u = nullptr; uint16_t* d_ev_seg = nullptr;                                         // tile order: the same per entry of the device order
     ChunkDesc* d_chunks = nullptr; long n_chunks = 0;                                               // tile order: one per workgroup of the tiled warp kernel
-    int segpose_mode = 0;      // EMBA_SEGPOSE=0|1 (A/B): pixel order evaluates the pose per event from segment records (default: yes)
+    int segpose_mode = 0;      // option segpose (A/B; 0 auto = yes, 1 no, 2 yes): pixel order evaluates the pose per event from segment records (default: yes)
     bool segpose = false;      // ... in the current evaluation
     bool chunks_lpt = false;   // the chunk list is sorted longest first and walked in grid order (no XCD-contiguous remapping)
-    bool tile_order = false; int order_mode = 0;   // EMBA_ORDER=auto|pixel|tile (0 auto, 1 pixel, 2 tile)
+    bool tile_order = false; int order_mode = 0;   // option order: 0 auto, 1 pixel, 2 tile
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
     double* d_seg = nullptr; int seg_cap = 0;                 // tile order: per-segment constants the tiled kernel evaluates each event's pose from (12 doubles per segment)
-    int step_gather = 2;    // EMBA_STEP_GATHER: how emba_step writes its active set + A22 | b2 rows — 0 the sweeping kernel (emba_active_write_kernel), 1 the list-driven
+    int step_gather = 2;    // option step_gather: how emba_step writes its active set + A22 | b2 rows — 0 the sweeping kernel (emba_active_write_kernel), 1 the list-driven
                             // gather as a kernel of its own, 2 (default) the list-driven gather as the head of the compact Gram kernel
     uint16_t* d_seg_act = nullptr;   // launch A's per-unit active lists (offsets inside the unit), n_ablk * kActivePix entries
     bool aw_in_gram = false; ActiveWriteParams aw_saved{};   // the gather of the running step, to be issued with its Gram launch (emba_form_accumulate)
-    int step_one_set = 1;      // EMBA_STEP_ONE_SET=0: emba_step alternates between two record sets like an LM loop's evaluations (A/B)
+    int step_one_set = 1;      // option step_one_set = 0: emba_step alternates between two record sets like an LM loop's evaluations (A/B)
     bool no_alt_set = false;   // set by emba_step around its evaluation: the step re-forms the equations itself, nothing of the previous ones can be gone back to —
                                // no second record set (+12.8 GB at 100 M events for callers that can never reject)
-    int step_fast = 1;   // EMBA_STEP_FAST=0: emba_step keeps the clearing pass in front of every evaluation (A/B)
-    double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (EMBA_GRAM_TAGS=0 disables)
+    int step_fast = 1;   // option step_fast = 0: emba_step keeps the clearing pass in front of every evaluation (A/B)
+    double* d_tag = nullptr; int use_tags = 1;   // per-slot {pano pixel, stamp}: lets the Gram kernel skip dead slots without fetching them (option gram_tags = 0 disables)
     double* d_rec = nullptr; uint32_t* d_slot_key = nullptr; uint32_t rec_stamp = 0;   // evaluation number stamped into the records (record_valid)
     // Two record sets (a rejected LM trial must not cost a re-evaluation).  d_rec / d_tag / set_stamp are the WORKING set: what
     // the last evaluation wrote and what formNormalEq and the solvers read.  An evaluation that would overwrite records the current normal
@@ -135,6 +135,11 @@ struct emba_ctx {
     double* d_e_sorted = nullptr; uint8_t* d_flag = nullptr; int32_t* d_inl_idx = nullptr;
     size_t n_outside_tile = 0; int n_rebin = 0; uint32_t last_rebin_stamp = 0;   // tile order: inliers found outside their tile in the last evaluation; how often the window was re-binned
     bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
+    bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
+    bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
+    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
+    int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
+    bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
     double* d_ep = nullptr;
     // order / key cache
@@ -443,8 +448,8 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         }
         // Chunk sizes differ (every bin is cut on its own) and the grid is a few rounds of the chip's workgroup slots: with the longest chunks FIRST the
         // last round is made of the short ones (longest-processing-time order; workgroups are dispatched in grid order as slots free up).
-        // EMBA_CHUNK_ORDER=bin keeps the bins' order (neighbouring chunks on one XCD).
-        c->chunks_lpt = !(getenv("EMBA_CHUNK_ORDER") && !strcmp(getenv("EMBA_CHUNK_ORDER"), "bin"));
+        // Option chunk_order_bin keeps the bins' order (neighbouring chunks on one XCD).
+        c->chunks_lpt = !c->opt_chunk_order_bin;
         if (c->chunks_lpt) std::stable_sort(h_chunks.begin(), h_chunks.end(), [](const ChunkDesc& a, const ChunkDesc& b) { return a.end - a.begin > b.end - b.begin; });
         c->n_chunks = (long)h_chunks.size();
         if ((st = dev_alloc(c, &c->d_chunks, h_chunks.size()))) return st;
@@ -564,7 +569,7 @@ emba_status launch_ep_compaction(emba_ctx* c)
                            c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
         hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, perm, c->d_fblk_off,
                            (long)c->n_pm, c->d_ep, c->d_inl_idx);
-        c->inl_idx_valid = true;
+        c->inl_idx_valid = true; c->ep_valid = true;
         HIP_TRY(c, hipGetLastError());
     } else {
         HIP_TRY(c, hipMemsetAsync(c->d_total, 0, sizeof(uint32_t), s));
@@ -586,7 +591,7 @@ emba_status ensure_inl_idx(emba_ctx* c)
     hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, c->stream, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off,
                        (long)c->n_pm, c->d_ep, c->d_inl_idx);   // (ep is rewritten with the same values)
     HIP_TRY(c, hipGetLastError());
-    c->inl_idx_valid = true;
+    c->inl_idx_valid = true; c->ep_valid = true;
     return EMBA_OK;
 }
 
@@ -691,14 +696,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     if (const char* ab = getenv("EMBA_ABLATE")) { c->ablate = atoi(ab); if (c->ablate) fprintf(stderr, "emba_hip: DIAGNOSTICS build, EMBA_ABLATE=%d: results are WRONG\n", c->ablate); }
 #endif
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && ncu > 0) c->n_cu = ncu; }
-    if (const char* gt = getenv("EMBA_GRAM_TAGS")) c->use_tags = atoi(gt);
-    if (const char* sf = getenv("EMBA_STEP_FAST")) c->step_fast = atoi(sf);
-    if (const char* sf = getenv("EMBA_STEP_GATHER")) c->step_gather = atoi(sf);
-    if (const char* sf = getenv("EMBA_SEGPOSE")) c->segpose_mode = 1 + atoi(sf);
-    if (const char* sp = getenv("EMBA_SOLVE_PERM")) c->solve_perm_mode = atoi(sp) ? 1 : 0;
-    if (const char* sf = getenv("EMBA_STEP_ONE_SET")) c->step_one_set = atoi(sf);
-    if (const char* om = getenv("EMBA_ORDER")) c->order_mode = !strcmp(om, "pixel") ? 1 : !strcmp(om, "tile") ? 2 : 0;
-    if (const char* tm = getenv("EMBA_TEXEL")) c->texel_mode = !strcmp(tm, "pack") ? 1 : !strcmp(tm, "fly") ? 2 : !strcmp(tm, "rect") ? 3 : 0;
+    // (the A/B switches of rounds 1-4 — EMBA_ORDER, EMBA_STEP_FAST, EMBA_STEP_GATHER, EMBA_SEGPOSE, EMBA_GRAM_TAGS, ... — are options now: emba_set_option)
 
 #define CREATE_TRY(call)                                                                                  \
     do {                                                                                                  \
@@ -1043,6 +1041,7 @@ emba_status emba_trial_reject(emba_ctx* c)
     c->K = c->eq_saved.K; c->thres = c->eq_saved.thres; c->irls = c->eq_saved.irls; c->eta = c->eq_saved.eta;
     // the per-event residuals, the count map and the per-pixel sums are the rejected trial's: formNormalEq needs a new evaluation
     c->eval_launched = c->eval_done = false; c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
+    c->ep_valid = false; c->ep_in_gram = false;
     return EMBA_OK;
 }
 
@@ -1168,6 +1167,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->count_stamp = 0;      // (the warp kernels are about to mark the count map for a new evaluation)
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
+    c->ep_valid = false; c->ep_in_gram = false;
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
@@ -1197,7 +1197,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         // every event — 7 x 16-B gathers over 64 different lines per wave, and past ~7 M events a table that no longer fits the L2s.  Measured, same box,
         // step time: 1 M events 101.2 -> 98.2 us, 1.5 M 150.8 -> 143.5, 10 M on 640x480 (city shape) 779 -> 714 (warp 0.60 -> 0.68 of the roofline),
         // 10 M on 2048x4096 / K = 256 940 -> 861.  (Round 1 had measured the opposite at 1 M events, + 6 us, on a kernel that was then VALU-heavier in
-        // other places; EMBA_SEGPOSE=0 keeps the per-batch table for comparison.)
+        // other places; option segpose = 1 keeps the per-batch table for comparison.)
         c->segpose = !c->tile_order && (c->segpose_mode ? c->segpose_mode == 2 : true);
         const bool seg_records = c->tile_order || c->segpose;
         q.n_pose = ((seg_records ? (int)K - 1 : nb) + 63) / 64;   // (K-1 segment records instead of nb batch poses)
@@ -1312,12 +1312,12 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
                              c->count_stamp = (c->d_count == c->d_count_own) ? c->set_stamp : 0u; }
         const bool consume = c->step_consume && c->step_fast && !c->force_generic_a22;    // this gather is the per-pixel sums' only reader: lines are zeroed behind it
         // list-driven gather: it rides in the head of the Gram kernel (as a kernel of its own it is no faster than the sweeping write: 109.6 vs
-        // 108.5 us per step at 1 M events; EMBA_STEP_GATHER=1 forces that form for comparison, 0 the sweeping kernel)
+        // 108.5 us per step at 1 M events; option step_gather = 1 forces that form for comparison, 0 the sweeping kernel)
         // Where it paid as a HEAD in front of the stream (same box, step time with the head vs with the sweeping kernel): 1 M events 101.2 vs 105.7 us,
         // the 1 M-event shard of the 8 M-event stream 121.8 vs 127, scene-driven 1.17 M events 121 vs 135 — but 1.5 M events 161 vs 154, 3 M (tile order)
         // 289 vs 281, 10 M 833 vs 817: with more active pixels per block the head's dependent trips grew past what the launch saved.
         const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count && c->n_cand &&
-                           (c->step_gather == 3 || !c->tile_order || c->n_cand <= 3500000);      // (EMBA_STEP_GATHER=3: everywhere, for comparison)
+                           (c->step_gather == 3 || !c->tile_order || c->n_cand <= 3500000);      // (step_gather = 3: everywhere, for comparison)
         // (round 4, late: the gather is now the work of 4 of a Gram block's 16 waves BESIDE the record stream, not a head in front of it: step time
         // with it / with the sweeping launch — 1 M 92.6 / 96.4 us, 1.5 M 134.7 / 143.8, 2 M (tile order) 193.4 / 208.5, 3 M 274.4 / 280.9, 10 M on
         // 640x480 (pixel order) 612.5 / 626.1, on 2048x4096 766.7 / 776.3; but 5 M (tile) 436.0 / 432.2, 40 M 3137 / 3014: a bandwidth-bound stream
@@ -1340,8 +1340,11 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // (round 4, measured and dropped: this write on a side stream beside the Gram kernel — both only depend on launch A — costs more than it
         // hides: each cross-stream event edge opens a 7-12 us bubble on this stack, 114.5 vs 107.6 us per step)
         // The resident one-GPU step (lists): the write is list-driven and balanced (active_gather_block) and rides in the head of the compact Gram
-        // kernel — emba_form_accumulate issues it — or runs as a kernel of its own (EMBA_STEP_GATHER=1, or where the Gram kernel is another form)
+        // kernel — emba_form_accumulate issues it — or runs as a kernel of its own (step_gather = 1, or where the Gram kernel is another form)
         c->aw_in_gram = false;
+        // the residual vector ep of this evaluation: compacted by tail blocks of the Gram launch that follows (kernels.h: ep_tail_block) — launch A has just
+        // left the per-block inlier-flag counts they need
+        c->ep_in_gram = c->step_wants_ep && c->n_cand && c->n_fblk <= kEpTailMaxFblk;
         if (lists && c->step_gather >= 2) { c->aw_saved = aw; c->aw_in_gram = true; }
         else if (lists) hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, aw);
         else hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
@@ -1426,10 +1429,17 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         const long waves = ((long)c->n_cand + chunk - 1) / chunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
         constexpr long wpb = kGramBlock / 64;
-        const unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+        unsigned grid = (unsigned)((waves + wpb - 1) / wpb);
+        p.n_gram_blocks = (int)grid;
+        const bool ep_tail = c->ep_in_gram && !ep_host && c->n_pm;
+        if (ep_tail) {
+            p.ep_flag = c->d_flag; p.ep_e = c->d_e_sorted; p.ep_out = c->d_ep; p.ep_fblk_cnt = c->d_fblk_cnt; p.ep_n_pm = (long)c->n_pm; p.ep_n_fblk = c->n_fblk;
+            grid += (unsigned)((c->n_pm + kEpTailBlk - 1) / kEpTailBlk);
+        }
+        c->ep_in_gram = false;
         const ActiveWriteParams aw = c->aw_in_gram ? c->aw_saved : ActiveWriteParams{};
-        {   // gather waves per Gram block (EMBA_GATHER_WAVES=1|2|4 overrides)
-            static const int gw_env = getenv("EMBA_GATHER_WAVES") ? atoi(getenv("EMBA_GATHER_WAVES")) : 0;
+        {   // gather waves per Gram block (option gather_waves = 1|2|4 overrides)
+            const int gw_env = c->opt_gather_waves;
             // (measured, scripts/r04_exp15.sh: with ONE gather wave the gather outlasts the stream at every size — Gram kernel 57 vs 36 us at 1 M events,
             // 1288 vs 1047 at 40 M —, two are within noise of four or of the sweeping launch from 5 M events up: four wherever the lists are used)
             p.gather_waves = (gw_env == 1 || gw_env == 2 || gw_env == 4) ? gw_env : 4;
@@ -1442,6 +1452,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
             else hipLaunchKernelGGL((emba_gram_kernel<false, false>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
         }
         c->aw_in_gram = false;
+        if (ep_tail) c->ep_valid = true;
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
     HIP_TRY(c, hipGetLastError());
@@ -1549,8 +1560,24 @@ emba_status emba_compact_ep(emba_ctx* c)
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->ep_valid) return EMBA_OK;      // (the resident step's Gram launch has produced it already)
     c->inl_idx_valid = false;      // (asked for explicitly: produce it for THIS call)
     return ensure_inl_idx(c);
+}
+
+emba_status emba_get_ep(emba_ctx* c, double* ep_host, size_t cap, size_t* n_inliers)
+{
+    if (!c || (!ep_host && cap)) return c ? fail(c, EMBA_ERR_INVALID_ARG, "ep_host NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st;
+    if ((st = resolve_pending(c))) return st;
+    if (!c->ep_valid && (st = ensure_inl_idx(c))) return st;      // (not produced by a resident step: the stand-alone compaction)
+    if (n_inliers) *n_inliers = c->n_inliers;
+    if (cap < c->n_inliers) return fail(c, EMBA_ERR_CAPACITY, "cap=%zu < inliers=%zu", cap, c->n_inliers);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->n_inliers) HIP_TRY(c, hipMemcpy(ep_host, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
+    return EMBA_OK;
 }
 
 emba_status emba_get_inlier_pixels(emba_ctx* c, uint32_t* pix_host)
@@ -1758,8 +1785,9 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
     c->fused_alpha = alpha;   // A22/b2 come from the accumulator, so applyL2Reg rides along with the gather
     c->step_consume = (c->step_fast != 0);   // ... which is their only reader: it zeroes the lines behind itself and the next evaluation needs no clearing pass
+    c->step_wants_ep = (c->step_ep != 0);    // the step returns what evaluateDataError returns: ep, compacted in the tail of its Gram launch
     st = emba_form_active(c, thres, nullptr, nullptr);
-    c->step_consume = false;
+    c->step_consume = false; c->step_wants_ep = false;
     if (st) return st;
     if ((st = emba_form_accumulate(c, nullptr, irls, eta))) return st;
     if ((st = emba_form_finish(c, alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr))) return st;
@@ -1781,6 +1809,50 @@ emba_status emba_set_cost(emba_ctx* c, int32_t irls, double eta)
     if (irls < 0 || irls > 2) return fail(c, EMBA_ERR_INVALID_ARG, "irls must be 0 (quadratic), 1 (huber) or 2 (cauchy)");
     c->cost_irls = irls; c->cost_eta = irls ? eta : 0.0;
     return EMBA_OK;
+}
+
+// ---- tuning and A/B switches (documented, versioned by EMBA_ABI_VERSION; not environment variables) ----------------------------
+namespace {
+struct OptionRef { const char* name; int emba_ctx::*field; int lo, hi; };
+const OptionRef kOptions[] = {
+    {"step_ep", &emba_ctx::step_ep, 0, 1},
+    {"step_fast", &emba_ctx::step_fast, 0, 1},
+    {"step_gather", &emba_ctx::step_gather, 0, 3},
+    {"step_one_set", &emba_ctx::step_one_set, 0, 1},
+    {"gram_tags", &emba_ctx::use_tags, 0, 1},
+    {"segpose", &emba_ctx::segpose_mode, 0, 2},
+    {"order", &emba_ctx::order_mode, 0, 2},
+    {"texel", &emba_ctx::texel_mode, 0, 3},
+    {"solve_perm", &emba_ctx::solve_perm_mode, -1, 1},
+    {"gather_waves", &emba_ctx::opt_gather_waves, 0, 4},
+    {"chunk_order_bin", &emba_ctx::opt_chunk_order_bin, 0, 1},
+    {"solve_counts", &emba_ctx::opt_solve_counts, -1, 2},
+    {"syrk_dense", &emba_ctx::opt_syrk_dense, 0, 1},
+    {"solve_debug", &emba_ctx::opt_solve_debug, 0, 1},
+    {"poisson", &emba_ctx::opt_poisson, 0, 2},
+    {"gemm64", &emba_ctx::opt_gemm64, 0, 1},
+};
+}  // namespace
+
+emba_status emba_set_option(emba_ctx* c, const char* name, int32_t value)
+{
+    if (!c || !name) return EMBA_ERR_INVALID_ARG;
+    for (const OptionRef& o : kOptions)
+        if (!strcmp(o.name, name)) {
+            if (value < o.lo || value > o.hi) return fail(c, EMBA_ERR_INVALID_ARG, "option %s: %d outside [%d, %d]", name, (int)value, o.lo, o.hi);
+            c->*(o.field) = (int)value;
+            if (!strcmp(name, "order") || !strcmp(name, "chunk_order_bin")) c->keys_ready = false;      // the device order is rebuilt at the next evaluation
+            return EMBA_OK;
+        }
+    return fail(c, EMBA_ERR_INVALID_ARG, "unknown option '%s'", name);
+}
+
+emba_status emba_get_option(emba_ctx* c, const char* name, int32_t* value)
+{
+    if (!c || !name || !value) return EMBA_ERR_INVALID_ARG;
+    for (const OptionRef& o : kOptions)
+        if (!strcmp(o.name, name)) { *value = c->*(o.field); return EMBA_OK; }
+    return fail(c, EMBA_ERR_INVALID_ARG, "unknown option '%s'", name);
 }
 
 emba_status emba_last_counts(emba_ctx* c, size_t* n_inliers, size_t* P)
@@ -1972,7 +2044,7 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
         return st;
     // list lengths: from the context's own count map while it still belongs to the evaluation that wrote these records (count_stamp), else counted
     // from the records (all-reduced / saturated / externally bound counts, a trial evaluation since, the sharded solve's received records)
-    static const int cmap_env = getenv("EMBA_SOLVE_COUNTS") ? atoi(getenv("EMBA_SOLVE_COUNTS")) : -1;      // 0: always from the records; 2: both, compared (diagnostic)
+    const int cmap_env = c->opt_solve_counts;      // option solve_counts — 0: always from the records; 2: both, compared (diagnostic)
     const bool from_map = cmap_env != 0 && !view.packed && c->count_stamp != 0 && c->count_stamp == view.stamp && c->d_count == c->d_count_own && n_pix == c->P && n_pix;
     if (from_map && cmap_env != 2) {
         hipLaunchKernelGGL(emba_csr_count_from_map_kernel, dim3(nblocks(n_pix)), dim3(256), 0, s, c->d_active, c->d_count, (long)n_pix, d_cursor);
@@ -2027,8 +2099,8 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
     // Block-sparse SYRK (>= 4 row blocks, i.e. K >= 64): the columns of a slice of kSyrkSlicePix consecutive active pixels — a piece of a
     // panorama row — are non-zero only in the rows of the control poses in view while the camera looked there; over a long window
     // (config 2: 10 s, K = 201) that is a band, and only the (row-block pair, slice) products with both blocks populated are formed.
-    // EMBA_SYRK=dense switches it off (comparison).
-    const bool sparse = nb64 >= 4 && nb64 <= 64 && !(getenv("EMBA_SYRK") && !strcmp(getenv("EMBA_SYRK"), "dense"));
+    // Option syrk_dense switches it off (comparison).
+    const bool sparse = nb64 >= 4 && nb64 <= 64 && !c->opt_syrk_dense;
     for (size_t p0 = 0; p0 < n_pix; p0 += chunk) {
         const size_t p1 = std::min(n_pix, p0 + chunk);
         bp.p0 = (long)p0; bp.p1 = (long)p1;
@@ -2054,7 +2126,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
             nks = std::max(1, std::min(nks_max, n_slices));
         }
         sp.direct = (nks == 1);
-        if (getenv("EMBA_SOLVE_DEBUG")) {      // diagnostic: how sparse is this chunk?  (products = (block pair, slice) pairs the SYRK forms)
+        if (c->opt_solve_debug) {      // diagnostic: how sparse is this chunk?  (products = (block pair, slice) pairs the SYRK forms)
             (void)hipStreamSynchronize(s);
             std::vector<uint16_t> hr(p1 - p0); (void)hipMemcpy(hr.data(), d_range, (p1 - p0) * 2, hipMemcpyDeviceToHost);
             long w16 = 0, w64 = 0, hist[9] = {0};
@@ -2123,7 +2195,7 @@ emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
     *perm = nullptr;
     // Measured (device time of one solve, with / without; the U build reads its pixels' records out of sequence and pays 5 % for it): config 2's shape (K = 201,
     // 10 M events over 10 s) 3.96 / 4.16 ms — SYRK 1.25 / 1.52, 5.8 / 7.9 products per slice —; 10 M events at K = 97: 2.81 / 2.79; 1 M events over 1 s at
-    // K = 201 (every pixel sees the whole window: nothing to gain) 2.27 / 2.24.  From six row blocks (K >= 128) up, unless EMBA_SOLVE_PERM forces it.
+    // K = 201 (every pixel sees the whole window: nothing to gain) 2.27 / 2.24.  From six row blocks (K >= 128) up, unless option solve_perm forces it.
     if (c->solve_perm_mode == 0 || P < 4 * (size_t)kSyrkSlicePix || (c->solve_perm_mode < 0 && 3 * c->K < 384) || 3 * c->K < 256) return EMBA_OK;
     if (c->perm_valid) { *perm = c->d_perm; return EMBA_OK; }
     if (c->solve_perm_mode < 0) {
@@ -2431,9 +2503,9 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
     const int H = c->H, W = c->W;
     const size_t npix = c->npix;
     emba_status st;
-    // EMBA_POISSON=dense: both axes by sine-matrix products (four GEMMs: the round-1/2 form, kept for comparison); default: Fourier analysis
+    // option poisson = 1 (dense): both axes by sine-matrix products (four GEMMs: the round-1/2 form, kept for comparison); default: Fourier analysis
     // along H only + tridiagonal solves along W (poisson_kernels.h) — a third of the arithmetic, same solution to rounding.
-    const bool dense = getenv("EMBA_POISSON") && !strcmp(getenv("EMBA_POISSON"), "dense");
+    const bool dense = c->opt_poisson == 1;      // option poisson: 1 dense sine transforms, 2 no folding (comparison forms)
     if (!c->d_SH) {   // first use: S_H, its eigenvalues, two scratch planes
         if ((st = dev_alloc(c, &c->d_SH, (size_t)H * H)) || (st = dev_alloc(c, &c->d_lamH, (size_t)H)) || (st = dev_alloc(c, &c->d_pF, npix)) || (st = dev_alloc(c, &c->d_pT, npix))) {
             dev_free(c, c->d_SH); dev_free(c, c->d_lamH); dev_free(c, c->d_pF); dev_free(c, c->d_pT);
@@ -2451,7 +2523,7 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         if ((st = dev_alloc(c, &c->d_thomas, npix))) return st;
         hipLaunchKernelGGL(emba_thomas_coef_kernel, dim3((H + 63) / 64), dim3(64), 0, s, c->d_lamH, H, W, c->d_thomas);
     }
-    const bool fold = !dense && (H % 2 == 0) && H >= 64 && !(getenv("EMBA_POISSON") && !strcmp(getenv("EMBA_POISSON"), "nofold"));
+    const bool fold = !dense && (H % 2 == 0) && H >= 64 && c->opt_poisson != 2;
     if (fold && !c->d_Sfold) {
         if ((st = dev_alloc(c, &c->d_Sfold, (size_t)H * H / 2))) return st;
         hipLaunchKernelGGL(emba_sine_folded_kernel, dim3((unsigned)(((size_t)H * H / 2 + 255) / 256)), dim3(256), 0, s, H, c->d_Sfold);
@@ -2473,7 +2545,7 @@ extern "C" emba_status emba_reconstruct_intensity(emba_ctx* c, const double* Gx_
         p.vec = ((K & 1) == 0 && (N & 1) == 0) ? 1 : 0;
         const long tm = (M + kGemmBM - 1) / kGemmBM, wide = tm * ((N + 127) / 128), narrow = tm * ((N + 63) / 64);
         const long big = ((M + kGemmBM2 - 1) / kGemmBM2) * ((N + kGemmBN2 - 1) / kGemmBN2);
-        const bool use_big = big >= (long)c->n_cu && !(getenv("EMBA_GEMM") && !strcmp(getenv("EMBA_GEMM"), "64"));
+        const bool use_big = big >= (long)c->n_cu && !c->opt_gemm64;
         if (use_big) hipLaunchKernelGGL(emba_dgemm128_kernel, dim3((unsigned)grid8(big)), dim3(512), 0, s, p);
         else if (wide >= 2L * c->n_cu) hipLaunchKernelGGL(emba_dgemm_kernel<128>, dim3((unsigned)grid8(wide)), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(emba_dgemm_kernel<64>, dim3((unsigned)grid8(narrow)), dim3(256), 0, s, p);

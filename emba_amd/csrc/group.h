@@ -149,6 +149,7 @@ struct RankPool {
 
 struct emba_group {
     int n = 0;
+    int opt_x2_split = -1;      // -1 auto (from 3 M events per rank), 0 one piece, 1 split
     std::vector<emba_ctx*> ctx;
     std::vector<int> dev;
     bool use_rccl = false;
@@ -324,6 +325,11 @@ extern "C" {
 
 emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, emba_group** out)
 {
+    return emba_group_create_flags(cfg, devices, n_ranks, 0, out);
+}
+
+emba_status emba_group_create_flags(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, uint32_t flags, emba_group** out)
+{
     if (!out) return EMBA_ERR_INVALID_ARG;
     *out = nullptr;
     if (!cfg || !devices || n_ranks < 1 || n_ranks > 64) return fail(nullptr, EMBA_ERR_INVALID_ARG, "emba_group_create: bad arguments");
@@ -351,9 +357,9 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
         hipEventCreateWithFlags(&g->ev_side0[n_ranks], hipEventDisableTiming) != hipSuccess)
         return bail(EMBA_ERR_HIP, "hipEventCreate failed");
     const std::set<int> distinct(g->dev.begin(), g->dev.end());
-    // EMBA_GROUP_FORCE_RCCL=1: a one-rank group goes through RCCL as well (what a one-GPU box can rehearse of the RCCL path: the run-time
+    // EMBA_GROUP_FORCE_RCCL: a one-rank group goes through RCCL as well (what a one-GPU box can rehearse of the RCCL path: the run-time
     // binding, communicator set-up and every collective call, with world size 1)
-    const bool force = n_ranks == 1 && getenv("EMBA_GROUP_FORCE_RCCL") && atoi(getenv("EMBA_GROUP_FORCE_RCCL"));
+    const bool force = n_ranks == 1 && (flags & EMBA_GROUP_FORCE_RCCL);
     if ((n_ranks > 1 && (int)distinct.size() == n_ranks) || force) {
         std::string e;
         if (!g_rccl.load(&e)) return bail(EMBA_ERR_HIP, e);
@@ -364,8 +370,8 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
         return bail(EMBA_ERR_INVALID_ARG, "a group's ranks must sit on distinct devices (RCCL) or all on one device (in-library exchange)");
     }
     g->pool.n = n_ranks;
-    // EMBA_GROUP_THREADS=0: the caller's thread drives every rank itself (debugging)
-    if (n_ranks > 1 && !(getenv("EMBA_GROUP_THREADS") && !atoi(getenv("EMBA_GROUP_THREADS")))) g->pool.start(n_ranks, g->dev);
+    // EMBA_GROUP_NO_THREADS: the caller's thread drives every rank itself (debugging)
+    if (n_ranks > 1 && !(flags & EMBA_GROUP_NO_THREADS)) g->pool.start(n_ranks, g->dev);
     *out = g;
     return EMBA_OK;
 }
@@ -560,7 +566,7 @@ emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double e
     // written — when the cost was declared before the evaluation, form_accumulate only adds the A11 | b1 head — and their all-reduce runs
     // on the ranks' SIDE streams while the Gram kernels form the head on the ranks' own streams; the small head follows.
     // (worth it once the Gram kernel is long enough to hide a collective behind — the head then costs one more collective's latency: from a
-    // few million events per rank; EMBA_X2_SPLIT=0/1 overrides)
+    // few million events per rank; option x2_split overrides)
     size_t n_max = 0;
     for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
     // "final" is decided from the cost the LAST EVALUATION weighted its per-pixel sums with (acc_irls / acc_eta, recorded by emba_eval_launch),
@@ -569,7 +575,7 @@ emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double e
     bool rows_final = true;
     for (int r = 0; r < g->n; ++r) rows_final = rows_final && (irls == g->ctx[r]->acc_irls) && (irls == 0 || eta == g->ctx[r]->acc_eta);
     bool split = n_max >= 3000000;
-    if (const char* v = getenv("EMBA_X2_SPLIT")) split = atoi(v) != 0;
+    if (g->opt_x2_split >= 0) split = g->opt_x2_split != 0;      // emba_group_set_option("x2_split")
     split = split && rows_final;
     if (!split) {
         { emba_status st = gpool(g, [&](int r) { return emba_form_accumulate(g->ctx[r], nullptr, irls, eta); }); if (st) return st; }      // F2
@@ -748,6 +754,18 @@ emba_status emba_group_trial_reject(emba_group* g)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
     for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_trial_reject(g->ctx[r]));
+    return EMBA_OK;
+}
+
+emba_status emba_group_set_option(emba_group* g, const char* name, int32_t value)
+{
+    if (!g || !name) return EMBA_ERR_INVALID_ARG;
+    if (!strcmp(name, "x2_split")) {
+        if (value < -1 || value > 1) return EMBA_ERR_INVALID_ARG;
+        g->opt_x2_split = value;
+        return EMBA_OK;
+    }
+    for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_set_option(g->ctx[r], name, value));
     return EMBA_OK;
 }
 

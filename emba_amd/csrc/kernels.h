@@ -1521,6 +1521,9 @@ struct GramParams {
     double* A11; double* b1; int dim;  // dim = 3K
     int ablate;  // diagnostics only: 32 no flush atomics, 64 no MFMA
     int gather_waves;  // GATHER form: 1, 2 or 4 of the block's 16 waves do its slice of the active-set gather, the others stream (host: by size)
+    int n_gram_blocks; // blocks [0, n_gram_blocks) of the grid form the Gram sums; the blocks behind them (the resident step, ep_out != nullptr) compact the
+                       // residuals into the reference-order ep vector (ep_tail_block): no launch and no scan launch of their own
+    const uint8_t* ep_flag; const double* ep_e; double* ep_out; const uint32_t* ep_fblk_cnt; long ep_n_pm, ep_n_fblk;
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
@@ -1614,9 +1617,9 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     if (GATHER) {   // (its two barriers also publish the cleared combine table)
         const uint32_t P_act = active_gather_prefix<kGramBlock>(aw, gram_blk, s_pre, s_ws);
         if (threadIdx.x < 64 * kGW) {
-            if (kGW == 1) active_gather_slice<64>(aw, gram_blk, gridDim.x, P_act, s_pre);
-            else if (kGW == 2) active_gather_slice<128>(aw, gram_blk, gridDim.x, P_act, s_pre);
-            else active_gather_slice<256>(aw, gram_blk, gridDim.x, P_act, s_pre);
+            if (kGW == 1) active_gather_slice<64>(aw, gram_blk, p.n_gram_blocks, P_act, s_pre);
+            else if (kGW == 2) active_gather_slice<128>(aw, gram_blk, p.n_gram_blocks, P_act, s_pre);
+            else active_gather_slice<256>(aw, gram_blk, p.n_gram_blocks, P_act, s_pre);
         }
     } else {
         __syncthreads();
@@ -1886,8 +1889,58 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     }
 }
 
+// ep = the inliers' residuals in the reference's order (model.cpp:221,256: sensor pixel major, then time = pm-order) — what evaluateDataError RETURNS.
+// Round 5: in the resident step the compaction rides at the END of the Gram launch instead of being a scan + a compaction launch of
+// its own (+ 10 us per step at 1 M events).  Launch A has left the inlier-flag count of every kFlagBlk pm entries; a tail block takes kEpTailBlk entries
+// (four of those), sums the counts in front of it itself (a few thousand L2-resident words: the host uses this form up to kEpTailMaxFblk of them) and
+// writes its inliers' residuals at their ranks.  The tail blocks start as Gram blocks retire (one 16-wave block per CU either way).
+constexpr int kEpTailBlk = 4 * kFlagBlk;
+constexpr long kEpTailMaxFblk = 8192;       // <= 8.4 M pm entries: every tail block sums at most that many per-block counts
+__device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
+{
+    __shared__ uint32_t s_x[kGramBlock / 64], s_b[kGramBlock / 64];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const long nfront = cb * (kEpTailBlk / kFlagBlk);
+    uint32_t part = 0;
+    for (long j0 = 0; j0 < nfront; j0 += kGramBlock) {
+        const long j = j0 + t;
+        const uint32_t v = p.ep_fblk_cnt[j < p.ep_n_fblk ? j : p.ep_n_fblk - 1];
+        if (j < nfront) part += v;
+    }
+    const long i0 = cb * kEpTailBlk + 4L * t;
+    uint32_t fl = 0;
+    double e[4] = {0.0, 0.0, 0.0, 0.0};
+    if (i0 + 4 <= p.ep_n_pm) {
+        fl = *reinterpret_cast<const uint32_t*>(p.ep_flag + i0);
+        const double2 a = *reinterpret_cast<const double2*>(p.ep_e + i0), b = *reinterpret_cast<const double2*>(p.ep_e + i0 + 2);
+        e[0] = a.x; e[1] = a.y; e[2] = b.x; e[3] = b.y;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (i0 + k < p.ep_n_pm) { fl |= (uint32_t)p.ep_flag[i0 + k] << (8 * k); e[k] = p.ep_e[i0 + k]; }
+    }
+    const uint32_t m = ((fl & 0xFFu) ? 1u : 0u) | ((fl & 0xFF00u) ? 2u : 0u) | ((fl & 0xFF0000u) ? 4u : 0u) | ((fl & 0xFF000000u) ? 8u : 0u);
+    const uint32_t mine = __popc(m);
+    uint32_t x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (lane >= o) x += y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if (lane == 63) s_x[wv] = x;
+    if (lane == 0) s_b[wv] = part;
+    __syncthreads();
+    uint32_t k = x - mine;
+#pragma unroll
+    for (int w = 0; w < kGramBlock / 64; ++w) { k += s_b[w]; if (w < wv) k += s_x[w]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) if (m & (1u << q)) p.ep_out[k++] = e[q];
+}
+
 template <bool TAGS, bool GATHER>
-__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p, ActiveWriteParams aw) { gram_body<TAGS, kGramBlock, GATHER>(p, blockIdx.x, aw); }
+__global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p, ActiveWriteParams aw)
+{
+    if ((int)blockIdx.x >= p.n_gram_blocks) { ep_tail_block((long)blockIdx.x - p.n_gram_blocks, p); return; }      // (block-uniform)
+    gram_body<TAGS, kGramBlock, GATHER>(p, blockIdx.x, aw);
+}
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic
 // case takes them from pixacc instead.  One thread per record, five fp64 atomics into the compact pack.

@@ -81,6 +81,22 @@ inline std::vector<int> devices_from_env()
     return dev;
 }
 
+// EMBA_HIP_OPTIONS="name=value,name=value": tuning switches of the device library (emba_group_set_option) for a node the launch file configures —
+// like EMBA_HIP_DEVICES, the adapter's own deployment settings: the reference's constructor signature has no room for them
+inline void options_from_env(emba_host::ShardedLEGM& impl)
+{
+    const char* e = std::getenv("EMBA_HIP_OPTIONS");
+    if (!e) return;
+    std::string s(e), tok;
+    for (size_t i = 0; i <= s.size(); ++i) {
+        if (i == s.size() || s[i] == ',') {
+            const size_t eq = tok.find('=');
+            if (eq != std::string::npos) impl.setOption(tok.substr(0, eq), std::atoi(tok.c_str() + eq + 1));
+            tok.clear();
+        } else tok.push_back(s[i]);
+    }
+}
+
 // allocation + size + a hash over 4096 events spread through the packet (all four fields) + the last one: see ShardedLEGM::packetKey
 inline uint64_t packet_key(const EventPacket& ev)
 {
@@ -154,6 +170,7 @@ LEGM::LEGM(const sensor_msgs::CameraInfo& camera_info_msg, double C_th, int pano
         g_state[this] = LegmHipState();
         g_state[this].impl.reset(new emba_host::ShardedLEGM(camera_info_msg.width, camera_info_msg.height, lut.data(), C_th, pano_width, pano_height,
                                                             legm_hip_detail::devices_from_env()));
+        legm_hip_detail::options_from_env(*g_state[this].impl);
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
 }
 

@@ -18,16 +18,20 @@ namespace emba_host {
 class ShardedLEGM {
 public:
     // devices: one entry per rank.  Distinct devices: RCCL over xGMI.  All equal (e.g. {0, 0}): ranks share a GPU (tests).
-    ShardedLEGM(int sensor_w, int sensor_h, const double* bearing_lut, double C_th, int pano_width, int pano_height, const std::vector<int>& devices)
+    // flags: EMBA_GROUP_FORCE_RCCL / EMBA_GROUP_NO_THREADS (include/emba_hip.h)
+    ShardedLEGM(int sensor_w, int sensor_h, const double* bearing_lut, double C_th, int pano_width, int pano_height, const std::vector<int>& devices,
+                uint32_t flags = 0)
         : W_(pano_width), H_(pano_height)
     {
         emba_cfg cfg{};
         cfg.sensor_w = sensor_w; cfg.sensor_h = sensor_h; cfg.pano_w = pano_width; cfg.pano_h = pano_height;
         cfg.bearing_lut = bearing_lut; cfg.C_th = C_th; cfg.event_batch = 100; cfg.outlier_px = 10.0;
         std::vector<int32_t> dev(devices.begin(), devices.end());
-        const emba_status st = emba_group_create(&cfg, dev.data(), (int32_t)dev.size(), &g_);
+        const emba_status st = emba_group_create_flags(&cfg, dev.data(), (int32_t)dev.size(), flags, &g_);
         if (st != EMBA_OK) throw StatusError(st, std::string("emba_group_create: ") + emba_last_error(nullptr));
     }
+    // tuning / A-B switches by name (emba_group_set_option: every rank's emba_set_option + the group's own x2_split); results do not depend on them
+    void setOption(const std::string& name, int value) { check(emba_group_set_option(g_, name.c_str(), (int32_t)value)); }
     ~ShardedLEGM() { emba_group_destroy(g_); }
     ShardedLEGM(const ShardedLEGM&) = delete;
     ShardedLEGM& operator=(const ShardedLEGM&) = delete;

@@ -424,6 +424,22 @@ class LEGM:
         self._P = b_.value
         return a_.value, b_.value
 
+    def get_ep(self):
+        """The last evaluation's residual vector in the reference's order, as the resident step left it on the device (or compacted now)."""
+        n = C.c_size_t(0)
+        ep = np.empty(max(int(self.n_events), 1), dtype=np.float64)
+        self._check(self._L.emba_get_ep(self._ctx, _p(ep, _dp), ep.size, C.byref(n)))
+        return ep[: n.value].copy()
+
+    def set_option(self, name, value):
+        """Tuning / A-B switch by name (include/emba_hip.h: emba_set_option); results do not depend on any of them."""
+        self._check(self._L.emba_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int32(0)
+        self._check(self._L.emba_get_option(self._ctx, name.encode(), C.byref(v)))
+        return v.value
+
     def compact_ep(self):
         """Enqueue the residual compaction into the reference-order `ep` vector on the device (emba_compact_ep)."""
         self._check(self._L.emba_compact_ep(self._ctx))

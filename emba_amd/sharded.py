@@ -306,6 +306,8 @@ class ShardedModel:
 class HipEngine:
     """Adapter: emba_amd.LEGM phase calls + torch CUDA tensors as the exchange buffers (product path)."""
 
+    x2_split = None      # None: auto (from 3 M events per rank); 0 / 1: exchange 2 in one piece / split (x2_split_pays)
+
     def __init__(self, legm, check_stream=True):
         """check_stream: the collectives of torch.distributed run on torch's CURRENT stream, the kernels on the LEGM's stream; unless
         the two are the same stream nothing orders a kernel against the all-reduce that follows it.  Pass False only with a `dist`
@@ -341,12 +343,11 @@ class HipEngine:
 
     def x2_split_pays(self, n_max):
         """Splitting exchange 2 hides the bulk of it behind the Gram kernel but adds one small collective: worth it from a few million
-        events per rank (Gram kernel >= ~100 us against a collective's tens of microseconds of latency); EMBA_X2_SPLIT=0/1 overrides.
+        events per rank (Gram kernel >= ~100 us against a collective's tens of microseconds of latency); HipEngine.x2_split = 0 / 1 overrides
+        (the same on every rank: it changes the sequence of collectives).
         n_max: events of the LARGEST shard — the same number on every rank (ShardedLEGM.set_events)."""
-        import os
-        v = os.environ.get("EMBA_X2_SPLIT")
-        if v is not None:
-            return v != "0"
+        if self.x2_split is not None:
+            return bool(self.x2_split)
         return n_max >= 3_000_000
 
     def eval_launch(self, traj):

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define EMBA_ABI_VERSION 1
+#define EMBA_ABI_VERSION 2
 
 typedef enum {
     EMBA_OK = 0,
@@ -104,7 +104,7 @@ emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint
 
 /* Diagnostics of the once-per-window work: wall time of the last emba_set_events[_dev] and of the order preparation done by
  * the first evaluation (control-pose pairs, record slots, optional tile order), whether the tile order is in use (events binned
- * by the panorama tile the first trajectory sends them to: EMBA_ORDER=auto|pixel|tile), entries of the device order (events +
+ * by the panorama tile the first trajectory sends them to: option "order"), entries of the device order (events +
  * halo / lead-in copies) and workgroup chunks of the tiled kernel.  Any pointer may be NULL. */
 emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
                                size_t* n_entries, size_t* n_chunks);
@@ -156,9 +156,13 @@ emba_status emba_get_A12_sparse(emba_ctx* ctx, int32_t* cp_c, int32_t* cp_p, int
                                 double* jc /*n*6*/, double* jp /*n*6*/, double* dp /*n*2*/);
 
 /* Enqueue the compaction of the last evaluation's residuals into the reference-order vector `ep` (model.cpp:221,256) and the per-event inlier
- * numbers, on the device.  The resident step leaves this to whoever asks for `ep` (nothing on the device reads it); the one-shot
- * emba_eval_data_error always pays for it.  bench.py --with-ep times a step with it. */
+ * numbers, on the device.  Nothing on the device reads `ep`.  The resident step (emba_step, option step_ep) produces it in the tail blocks of its
+ * Gram launch (round 5) — this call is then a no-op; the phase-level calls of an LM loop leave it to whoever asks; the one-shot
+ * emba_eval_data_error always pays for it. */
 emba_status emba_compact_ep(emba_ctx* ctx);
+/* The last evaluation's `ep` (what LEGM::evaluateDataError returns, model.cpp:256) to the host: as the resident step left it, or compacted now.
+ * ep_host: capacity `cap` doubles (EMBA_ERR_CAPACITY below the inlier count); *n_inliers (may be NULL) its length.  Synchronizes. */
+emba_status emba_get_ep(emba_ctx* ctx, double* ep_host, size_t cap, size_t* n_inliers);
 
 /* Sensor pixel (y * sensor_w + x) of every inlier measurement of the last evaluation, in the order of ep (sensor pixel major, then time;
  * model.cpp:179-186): pix_host has capacity n_inliers.  What a multi-GPU host merges the ranks' residual vectors by (emba_group_eval). */
@@ -321,6 +325,26 @@ emba_status emba_step(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, i
  * with any declaration (a mismatch falls back to the records).  emba_step declares its own cost for its own evaluation. */
 emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
 
+/* Tuning and A/B switches: options by name, integer values, part of the ABI (EMBA_ABI_VERSION 2); an unknown name or a value out
+ * of range is EMBA_ERR_INVALID_ARG.  Every option changes SPEED or the internal form only — results are the same under all of them (tests/test_gpu_parity.py
+ * runs the parity cases under the non-default values).  Defaults are what the measurements under profiles/ chose.
+ *   order          0 auto | 1 pixel order | 2 tile order of the device's event stream (takes effect at the next evaluation: the order is rebuilt)
+ *   texel          0 auto | 1 pack every texel | 2 3x3 stencil on the fly | 3 pack inside the previous footprint's rectangle
+ *   segpose        0 auto (= 2) | 1 per-batch pose table in pixel order | 2 per-event pose from the K-1 segment records
+ *   gram_tags      1 the pixel order's 8-B tag stream lets the Gram kernel skip dead slots | 0 decide from the records
+ *   step_ep        1 emba_step compacts the residuals into ep (what evaluateDataError returns) in the tail of its Gram launch | 0 on demand only
+ *   step_fast      1 emba_step zeroes the per-pixel sums behind their reader (no clearing pass) | 0 keeps the clearing pass
+ *   step_gather    0 sweeping active-set write | 1 list-driven gather as a launch | 2 (default) inside the Gram kernel | 3 inside it at every size
+ *   step_one_set   1 emba_step keeps one record set | 0 alternates between two like an LM loop
+ *   gather_waves   0 auto (4) | 1 | 2 | 4 waves of a Gram workgroup do its slice of the gather
+ *   chunk_order_bin 0 tile-order chunks longest first | 1 in bin order
+ *   solve_perm     -1 auto | 0 | 1 U's columns ordered by panorama column in the Schur solve
+ *   solve_counts   -1 auto | 0 list lengths counted from the records | 2 both, compared
+ *   syrk_dense     1 dense instead of block-sparse SYRK;  solve_debug 1 prints the band statistics of a solve
+ *   poisson        0 folded Fourier form | 1 dense sine transforms | 2 no folding;  gemm64 1 forces the 64-wide GEMM tiles */
+emba_status emba_set_option(emba_ctx* ctx, const char* name, int32_t value);
+emba_status emba_get_option(emba_ctx* ctx, const char* name, int32_t* value);
+
 /* Inlier count of the last evaluation and active-pixel count of the last emba_form_active, once resolved
  * (after any synchronizing call, e.g. emba_form_finish or emba_sync). */
 emba_status emba_last_counts(emba_ctx* ctx, size_t* n_inliers, size_t* P);
@@ -365,9 +389,17 @@ emba_status emba_device_pci_bus_id(emba_ctx* ctx, char* buf, size_t len);
  * anything else (diagnostics, dumps).  emba_group_eval + emba_group_form are the two halves of emba_group_step with the reference's
  * call shape (solver.cpp:75,251 evaluateDataError; :114-130 formNormalEq[IRLS] + applyL2Reg), so the EMBA::LEGM adapter
  * (emba_amd/host/legm_adapter.hpp) sits on a group of any size — one rank included — without a change to solver.cpp.
- * With more than one rank every rank's launches are issued from a host thread of its own (EMBA_GROUP_THREADS=0: from the caller's). */
+ * With more than one rank every rank's launches are issued from a host thread of its own (EMBA_GROUP_NO_THREADS: from the caller's). */
 typedef struct emba_group emba_group;
 emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, emba_group** out);   /* cfg->device, cfg->stream are ignored */
+/* ... with flags: EMBA_GROUP_FORCE_RCCL — a ONE-rank group goes through RCCL too (what a one-GPU box can rehearse of that path: run-time binding of
+ * librccl, communicator set-up, every collective call, world size 1); EMBA_GROUP_NO_THREADS — the caller's thread drives every rank itself. */
+#define EMBA_GROUP_FORCE_RCCL 1u
+#define EMBA_GROUP_NO_THREADS 2u
+emba_status emba_group_create_flags(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, uint32_t flags, emba_group** out);
+/* emba_set_option on every rank's context, plus the group's own: x2_split — -1 auto (from 3 M events per rank) | 0 exchange 2 in one piece | 1 its
+ * A22 | b2 rows on the side streams under the Gram kernel. */
+emba_status emba_group_set_option(emba_group* g, const char* name, int32_t value);
 void        emba_group_destroy(emba_group* g);
 const char* emba_group_last_error(const emba_group* g);
 int32_t     emba_group_size(const emba_group* g);

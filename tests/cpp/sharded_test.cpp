@@ -27,6 +27,8 @@ int main(int argc, char** argv)
     if (!f) return 2;
     std::vector<int> devices;
     for (char* tok = strtok(argv[2], ","); tok; tok = strtok(nullptr, ",")) devices.push_back(atoi(tok));
+    const int x2_split = argc > 3 ? atoi(argv[3]) : -1;                       // option x2_split: -1 auto, 0 one piece, 1 split
+    const uint32_t flags = argc > 4 ? (uint32_t)atoi(argv[4]) : 0u;           // EMBA_GROUP_FORCE_RCCL = 1
     const int sw = rd1<int32_t>(f), sh = rd1<int32_t>(f), W = rd1<int32_t>(f), H = rd1<int32_t>(f), K = rd1<int32_t>(f), thres = rd1<int32_t>(f);
     const int64_t t0 = rd1<int64_t>(f), dt = rd1<int64_t>(f), n = rd1<int64_t>(f);
     const double C_th = rd1<double>(f), alpha = rd1<double>(f);
@@ -46,7 +48,8 @@ int main(int argc, char** argv)
     emba_host::EventPacket ev(n);
     for (int64_t k = 0; k < n; ++k) ev[k] = {x[k], y[k], t[k], pol[k] != 0};
     try {
-        emba_host::ShardedLEGM model(sw, sh, lut.data(), C_th, W, H, devices);
+        emba_host::ShardedLEGM model(sw, sh, lut.data(), C_th, W, H, devices, flags);
+        model.setOption("x2_split", x2_split);
         emba_host::TrajectoryView traj{knots.data(), K, t0, dt};
         model.setEvents(ev);
         model.uploadMap(Gx.data(), Gy.data());

@@ -23,7 +23,7 @@ def test_header_symbols_all_exported_and_bound(hip_lib):
     for s in syms:
         assert hasattr(hip_lib, s), f"{s} declared in include/emba_hip.h but not exported by libemba_hip.so"
     assert sorted(_lib.SIGNATURES) == syms, "ctypes binding table and header disagree"
-    assert hip_lib.emba_abi_version() == 1
+    assert hip_lib.emba_abi_version() == 2
     assert b"gfx950" in hip_lib.emba_build_info()
 
 

@@ -73,11 +73,9 @@ def test_cpp_sharded_host_matches_oracle(tmp_path, hip_lib, oracle_mod, devices,
     x1, x2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
     p = tmp_path / "in.bin"
     _write_case(p, w, o, (lam, fix, x1, x2))
-    env = dict(os.environ)
-    env["EMBA_X2_SPLIT"] = "0" if devices == "0,0,0" else "1"     # exchange 2 split (rows on the side streams, under the Gram kernel) or in one piece
-    if force_rccl:      # one rank through RCCL itself: run-time binding of librccl, ncclCommInitAll, grouped all-reduce / send / recv calls
-        env["EMBA_GROUP_FORCE_RCCL"] = "1"
-    r = subprocess.run([exe, str(p), devices], capture_output=True, text=True, timeout=180, env=env)
+    x2_split = "0" if devices == "0,0,0" else "1"     # option x2_split: exchange 2 split (rows on the side streams, under the Gram kernel) or in one piece
+    # force_rccl (EMBA_GROUP_FORCE_RCCL): one rank through RCCL itself — run-time binding of librccl, ncclCommInitAll, grouped all-reduce / send / recv calls
+    r = subprocess.run([exe, str(p), devices, x2_split, "1" if force_rccl else "0"], capture_output=True, text=True, timeout=180)
     print(r.stdout, r.stderr)
     last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""      # (RCCL prints a version banner first)
     assert r.returncode == 0 and last.startswith("OK"), r.stdout + r.stderr
@@ -123,7 +121,7 @@ def test_adapter_runs_the_reference_call_order(tmp_path, hip_lib, oracle_mod, de
         # formNormalEqIRLS declares its cost AFTER the first evaluation — the gathered (quadratic) A22 | b2 rows are then NOT final and
         # must not travel through the split exchange 2 while emba_form_accumulate rebuilds them from the records: forced on here (it only switches
         # itself on from 3 M events per rank)
-        env["EMBA_X2_SPLIT"] = "1"
+        env["EMBA_HIP_OPTIONS"] = "x2_split=1"
     r = subprocess.run([ADAPTER_EXE, str(p), str(max_iter), "1" if use_irls else "0", "1" if use_cg else "0"], capture_output=True, text=True, timeout=300, env=env)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout + r.stderr

@@ -23,9 +23,15 @@ def gpu():
     return True
 
 
+OPTIONS = {}      # emba_set_option values every context of a test gets (monkeypatch.setitem): the library's A/B switches are options, not env variables
+
+
 def make_legm(w):
     from emba_amd import LEGM
-    return LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    for k, v in OPTIONS.items():
+        m.set_option(k, v)
+    return m
 
 
 def gpu_run(w, thres=None, cost_type="quadratic", a=0.0, alpha=None, dense_A12=False, dump=False):
@@ -179,7 +185,7 @@ def test_tile_order_rebins_after_trajectory_drift(gpu, oracle_mod, monkeypatch):
     tile (+ 8-px margin) must still give the oracle's results (those events go to HBM one by one), is reported by
     emba_last_tile_drift, and makes the NEXT evaluation rebuild the order — after which (same poses) nothing is outside any more."""
     from emba_amd.synth import so3_exp_xyzw
-    monkeypatch.setenv("EMBA_ORDER", "tile")
+    monkeypatch.setitem(OPTIONS, "order", 2)
     w = small_workload(n_events=60000, pano_h=256, K=11, sensor=(48, 36), focal=40.0)
     m = make_legm(w)
     m.set_events(w.events)
@@ -368,7 +374,7 @@ def test_other_configurations_against_oracle(gpu, oracle_mod, cfg):
 def test_hessian_sources_agree(gpu, oracle_mod, mode, monkeypatch):
     """The three ways the warp kernel can obtain the Hessian (3x3 stencil on the planes, full texel pack, texel rectangle of the
     previous footprint) must give identical results; run two evaluations so that the rectangle is populated."""
-    monkeypatch.setenv("EMBA_TEXEL", mode)
+    monkeypatch.setitem(OPTIONS, "texel", {"pack": 1, "fly": 2, "rect": 3}[mode])
     w = small_workload(n_events=30000)
     m = make_legm(w)
     m.set_events(w.events)
@@ -489,9 +495,9 @@ def test_schur_solve_at_the_panel_edges_of_the_factorisation(gpu, oracle_mod, K,
 @pytest.mark.parametrize("perm", ["0", "1"])
 def test_schur_solve_with_the_columns_of_U_in_panorama_column_order(gpu, oracle_mod, perm, monkeypatch):
     """Round 4: the local Schur solve orders U's columns by panorama column when the camera pans (solve_perm: fewer (row-block pair, slice) products in the
-    block-sparse SYRK).  Any order gives the same S, x1, x2: forced on and off (EMBA_SOLVE_PERM) at K = 100 — five row blocks, block-sparse form — against the
+    block-sparse SYRK).  Any order gives the same S, x1, x2: forced on and off (option solve_perm) at K = 100 — five row blocks, block-sparse form — against the
     oracle, then a re-solve with another lambda on the cached lists + order."""
-    monkeypatch.setenv("EMBA_SOLVE_PERM", perm)
+    monkeypatch.setitem(OPTIONS, "solve_perm", int(perm))
     w = small_workload(n_events=120000, pano_h=256, K=100, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3)
     g = gpu_run(w)
     assert g["ne"]["P"] >= 512              # (below four slices the order is not used)
@@ -665,7 +671,7 @@ def test_poisson_reconstruction_matches_oracle(gpu, pano_h, monkeypatch):
     """reconstructFromGradient (poisson_reconstruction.cpp:9-50, laplace.cpp:587-797) against the numpy restatement: Fourier
     analysis along H (sine-matrix products on the fp64 matrix cores, folded by the matrix's symmetry for even H) + tridiagonal solves along W;
     75 x 150 exercises the ragged tiles, the unaligned loads and the unfolded odd length, 1024 x 2048 is the BASELINE panorama, 2048 x 4096
-    config 5's.  The round-1/2 form (both axes by sine-matrix products, EMBA_POISSON=dense) must give the same panorama."""
+    config 5's.  The round-1/2 form (both axes by sine-matrix products, option poisson = 1) must give the same panorama."""
     from oracle import poisson as OP
     w = small_workload(n_events=2000, pano_h=pano_h)
     m = make_legm(w)
@@ -682,7 +688,7 @@ def test_poisson_reconstruction_matches_oracle(gpu, pano_h, monkeypatch):
     m.upload_map(Gx, Gy)
     assert np.array_equal(m.reconstructIntensity(), M)
     if pano_h <= 256:
-        monkeypatch.setenv("EMBA_POISSON", "dense")
+        m.set_option("poisson", 1)
         assert_close(m.reconstructIntensity(), Mo, "intensity panorama (dense form)", tight=1e-10)
 
 
@@ -789,6 +795,8 @@ def test_randomised_soak(gpu, oracle_mod):
     """EMBA_SOAK=N: N more seeded random configurations than test_randomised_small_configurations, with wider ranges (K up to 45: the multi-panel
     factorisation; up to 150 k events), through evaluation, normal equations, solve, a second evaluation + formation and two resident single-call steps on the same context."""
     n_cases = int(os.environ["EMBA_SOAK"])
+    if os.environ.get("EMBA_SOAK_ORDER"):      # "tile": the second sweep, with the tile order forced (option order = 2)
+        OPTIONS["order"] = {"pixel": 1, "tile": 2}[os.environ["EMBA_SOAK_ORDER"]]
     rng = np.random.default_rng(777)
     bad = []
     for case in range(n_cases):
@@ -927,12 +935,12 @@ def test_costs_in_one_call(gpu, oracle_mod, cost):
 @pytest.mark.parametrize("fast,gather", [("1", "2"), ("1", "1"), ("1", "0"), ("0", "2"), ("0", "0")])
 def test_resident_step_sequences(gpu, oracle_mod, cfg, fast, gather, monkeypatch):
     """The resident one-GPU step (emba_step) in the sequences a host produces.  Round 4: its active-set write + A22 | b2 gather is list-driven and rides in the head
-    of the Gram kernel (EMBA_STEP_GATHER=2; 1: a kernel of its own; 0: the sweeping kernel of the other paths), the accumulator lines are zeroed
-    behind their readers so that the next evaluation has no clearing pass (EMBA_STEP_FAST=0 keeps the pass), and the count map's entries are stamped instead of cleared — each of which could leak one evaluation's state into the
+    of the Gram kernel (option step_gather = 2; 1: a kernel of its own; 0: the sweeping kernel of the other paths), the accumulator lines are zeroed
+    behind their readers so that the next evaluation has no clearing pass (option step_fast = 0 keeps the pass), and the count map's entries are stamped instead of cleared — each of which could leak one evaluation's state into the
     next.  Checked against the oracle after: two steps in a row; an evaluation that is never formed (a rejected trial) in between; a second
     formNormalEq, with another threshold, on the evaluation a step has consumed (A22 | b2 then come from the records)."""
     from emba_amd.synth import make_workload
-    monkeypatch.setenv("EMBA_STEP_FAST", fast); monkeypatch.setenv("EMBA_STEP_GATHER", gather)
+    monkeypatch.setitem(OPTIONS, "step_fast", int(fast)); monkeypatch.setitem(OPTIONS, "step_gather", int(gather))
     w = make_workload() if cfg == "baseline" else small_workload(**cfg)
     m = make_legm(w)
     m.set_events(w.events)
@@ -969,6 +977,45 @@ def test_resident_step_sequences(gpu, oracle_mod, cfg, fast, gather, monkeypatch
     n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
     assert P == o["ne"]["P"]
     check("step after a re-form")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n_events=30000),                                                         # 30 000 pm entries: 8 tail blocks, the last one ragged
+    dict(n_events=4100, pano_h=75, sensor=(48, 36), focal=45.0),                  # just past one tail block
+    dict(n_events=20300, pano_h=128, K=5, sensor=(32, 24), focal=30.0, thres_valid_pixel=2),
+    dict(n_events=20000, order=2),                                                # tile order: flags / residuals are indexed in pm-order there too
+    "baseline",
+])
+def test_resident_step_returns_ep_in_reference_order(gpu, oracle_mod, cfg, monkeypatch):
+    """Round 5: the resident step produces what evaluateDataError RETURNS — the inliers' residuals in the reference's order
+    (model.cpp:221,256: sensor pixel major, then time) — in tail blocks of its Gram launch, without a scan or compaction launch.  The vector the
+    step left on the device must be the oracle's ep element for element, step after step, with and without unformed evaluations in between; with
+    the option off (step_ep = 0) the stand-alone compaction gives the same vector."""
+    from emba_amd.synth import make_workload
+    if cfg != "baseline" and "order" in cfg:
+        cfg = dict(cfg); monkeypatch.setitem(OPTIONS, "order", cfg.pop("order"))
+    w = make_workload() if cfg == "baseline" else small_workload(**cfg)
+    m = make_legm(w)
+    m.set_events(w.events)
+    m.upload_map(w.Gx, w.Gy)
+    o = oracle_run(oracle_mod, w)
+    assert o["ep"].size > 100
+    for it in range(2):
+        n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+        assert n_inl == o["ep"].size and P == o["ne"]["P"]
+        ep = m.get_ep()
+        assert ep.shape == o["ep"].shape
+        assert_close(ep, o["ep"], f"ep of step {it}")
+    m.eval_launch(w.traj); m.eval_finish(sync=False)              # an evaluation nobody forms, then a step again
+    n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert_close(m.get_ep(), o["ep"], "ep after an unformed evaluation")
+    compare_normal_eq(m._finish(w.alpha, False), o["ne"])
+    m.set_option("step_ep", 0)
+    m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert_close(m.get_ep(), o["ep"], "ep on demand")
+    m.set_option("step_ep", 1)
+    m.step(w.traj, w.thres_valid_pixel, w.alpha, "huber", 0.1)   # IRLS step: same residual vector (the weights are formNormalEq's)
+    assert_close(m.get_ep(), o["ep"], "ep of an IRLS step")
 
 
 def test_empty_window_after_a_resident_step(gpu, oracle_mod):

@@ -109,7 +109,7 @@ def _rank_main(shared, rank, w, results, compressed=False, solve=None):
                                             (dict(n_events=20000), True)])
 def test_two_rank_threads_on_one_gpu(oracle_mod, cfg, compressed, monkeypatch):
     # exchange 2 in one piece (what these sizes get by default) and split (A22 | b2 rows reduced while the Gram kernel runs)
-    monkeypatch.setenv("EMBA_X2_SPLIT", "1" if compressed or cfg["n_events"] > 25000 else "0")
+    monkeypatch.setattr("emba_amd.sharded.HipEngine.x2_split", 1 if compressed or cfg["n_events"] > 25000 else 0)
     import torch
     assert torch.cuda.is_available()
     from emba_amd.sharded import merge_ep

@@ -2336,7 +2336,7 @@ extern "C" emba_status emba_solve_shard_pack(emba_ctx* c, int32_t n_ranks, doubl
     unsigned long long* d_cnt = (unsigned long long*)c->ws[14].p;
     HIP_TRY(c, hipMemsetAsync(d_cnt + 2 * n_ranks, 0, (size_t)n_ranks * 8, s));
     if (c->n_cand && send_dev)
-        hipLaunchKernelGGL(emba_shard_pack_kernel, dim3(nblocks(c->n_cand)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt + n_ranks,
+        hipLaunchKernelGGL(emba_shard_pack_kernel, dim3(nblocks(c->n_cand, 32)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt + n_ranks,
                            d_cnt + 2 * n_ranks, send_dev);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;

@@ -506,6 +506,8 @@ emba_status emba_group_eval(emba_group* g, const double* knots, int32_t K, int64
         G_HIP(g, hipStreamSynchronize(g->ctx[0]->stream));
         G_HIP(g, hipMemcpy(num_ev_map_out, g->count[0], g->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
     }
+    if (!ep_out && !n_inliers)      // nothing asked for: E2 is enqueued only (the costs / formNormalEq that follow find an evaluation to work on)
+        for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr));
     if (ep_out || n_inliers) {
         // per rank: residuals in the rank's own reference order + the sensor pixel of each; merged by (pixel, rank)
         std::vector<std::vector<double>> ep(g->n); std::vector<std::vector<uint32_t>> px(g->n);
@@ -667,8 +669,16 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
     if (!g) return EMBA_ERR_INVALID_ARG;
     if (g->n == 1 && !g->use_rccl) { G_TRY(g, 0, emba_solve_normal_eq(g->ctx[0], lambda, fix_first_pose, x1_host, x2_host)); return EMBA_OK; }
     const int n = g->n;
+    const auto t_dbg0 = std::chrono::steady_clock::now(); auto t_dbg = t_dbg0;
+    auto stage = [&](const char* what) {      // option solve_debug on rank 0: host time per stage of the sharded solve (stderr)
+        if (!g->ctx[0]->opt_solve_debug) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[group solve] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_dbg).count());
+        t_dbg = now;
+    };
     std::vector<std::vector<size_t>> cnt(n, std::vector<size_t>(n, 0));
     { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_count(g->ctx[r], n, cnt[r].data()); }); if (st) return st; }
+    stage("shard_count");
     std::vector<size_t> n_recv(n, 0), n_send(n, 0);
     std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
     for (int r = 0; r < n; ++r) for (int d = 0; d < n; ++d) { n_send[r] += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
@@ -681,21 +691,28 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
             (st = grow(g, r, &g->sv_S[r], &g->cap_S[r], s_doubles)) || (st = grow(g, r, &g->sv_x2[r], &g->cap_x2[r], std::max<size_t>(2 * g->P, 2))))
             return st;
     }
+    stage("grow");
     { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_pack(g->ctx[r], n, g->sv_send[r]); }); if (st) return st; }
+    stage("shard_pack");
     { emba_status st = group_alltoall(g, g->sv_send.data(), g->sv_recv.data(), cnt16); if (st) return st; }
+    stage("alltoall (enqueue)");
     { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_partial(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, g->sv_S[r]); }); if (st) return st; }
+    stage("shard_partial");
     { emba_status st = group_allreduce(g, (void* const*)g->sv_S.data(), s_doubles, XType::F64); if (st) return st; }
+    stage("allreduce S (enqueue)");
     // a 2x2 block that is not positive definite shows up on its pixel's owner only: every rank finishes (x2 exchange included) and the
     // failure is reported once, for the group
     std::vector<emba_status> fin(n, EMBA_OK);
     (void)g->pool.run([&](int r) {
         fin[r] = emba_solve_shard_finish(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, fix_first_pose, g->sv_S[r], r == 0 ? x1_host : nullptr, g->sv_x2[r]);
         return EMBA_OK; });
+    stage("shard_finish");
     for (int r = 0; r < n; ++r) if (fin[r] && fin[r] != EMBA_ERR_NUMERIC) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
     { emba_status st = group_allreduce(g, (void* const*)g->sv_x2.data(), 2 * g->P, XType::F64); if (st) return st; }
     G_HIP(g, hipSetDevice(g->dev[0]));
     if (x2_host && g->P) G_HIP(g, hipMemcpyAsync(x2_host, g->sv_x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
     for (int r = 0; r < n; ++r) { G_HIP(g, hipSetDevice(g->dev[r])); G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream)); }
+    stage("x2 allreduce + sync");
     for (int r = 0; r < n; ++r) if (fin[r]) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
     g->x2_on_ranks = true;
     return EMBA_OK;

@@ -962,29 +962,61 @@ __device__ __forceinline__ int pixel_owner(long k, long P, int n_ranks)
     return r;
 }
 
+// Wave-aggregated tickets: the lanes of a wave that want a slot in the same owner's list take them with ONE atomic (the leader adds the group's size and
+// hands out consecutive positions).  Round 5: with one atomic per record the ~1 M records of the BASELINE window queued on n_ranks addresses — 5.9 ms for the
+// count kernel and as much again for the pack kernel on two ranks (11.6 of a 12-ms LM iteration), against 0.3 ms for the whole single-rank solve.
+__device__ __forceinline__ unsigned long long wave_owner_ticket(bool active, int owner, unsigned long long* __restrict__ cursor)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long pos = 0, remaining = __ballot(active);
+    while (remaining) {                                                    // (wave-uniform: at most n_ranks trips)
+        const int leader = __ffsll((long long)remaining) - 1;
+        const int o = __shfl(owner, leader);
+        const bool mine = active && owner == o;
+        const unsigned long long same = __ballot(mine);
+        unsigned long long base = 0;
+        if (lane == leader) base = atomicAdd(cursor + o, (unsigned long long)__popcll(same));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader) << 32) | (uint32_t)__shfl((int)(base & 0xFFFFFFFFull), leader);
+        if (mine) pos = base + (unsigned long long)__popcll(same & ((1ull << lane) - 1ull));
+        remaining &= ~same;
+    }
+    return pos;
+}
+
 __global__ void emba_shard_count_kernel(RecView v, long n_rec, long P, int n_ranks, unsigned long long* __restrict__ cnt)
 {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_rec) return;
-    int32_t k;
-    if (rec_pixel(v, s, k)) atomicAdd(cnt + pixel_owner(k, P, n_ranks), 1ull);
+    int32_t k = 0;
+    const bool ok = s < n_rec && rec_pixel(v, s, k);
+    (void)wave_owner_ticket(ok, ok ? pixel_owner(k, P, n_ranks) : 0, cnt);
 }
 
-// packed record = the record with its tail word rewritten to {compact pixel index, control-pose pair key}
-__global__ void emba_shard_pack_kernel(RecView v, long n_rec, long P, int n_ranks, const unsigned long long* __restrict__ off,
-                                       unsigned long long* __restrict__ cursor, double* __restrict__ out)
+// packed record = the record with its tail word rewritten to {compact pixel index, control-pose pair key}.  Eight lanes per 128-B record (coalesced reads in
+// slot order, one full line written per record), like emba_csr_fill_sorted_kernel; launch with 32 records per 256-thread block.
+__global__ __launch_bounds__(256) void emba_shard_pack_kernel(RecView v, long n_rec, long P, int n_ranks, const unsigned long long* __restrict__ off,
+                                                              unsigned long long* __restrict__ cursor, double* __restrict__ out)
 {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_rec) return;
-    int32_t k;
-    if (!rec_pixel(v, s, k)) return;
-    const int r = pixel_owner(k, P, n_ranks);
-    const unsigned long long pos = off[r] + atomicAdd(cursor + r, 1ull);
-    const double2* src = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * s);
-    double2* dst = reinterpret_cast<double2*>(out + (size_t)kRecStride * pos);
-#pragma unroll
-    for (int q = 0; q < 7; ++q) dst[q] = src[q];
-    dst[7] = make_double2(src[7].x, __hiloint2double((int)rec_key(v, (uint32_t)s), (int)k));
+    const long s = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
+    const int lane = threadIdx.x & 63, c8 = threadIdx.x & 7;
+    const long sc = s < n_rec ? s : n_rec - 1;                       // (n_rec >= 1 whenever this is launched; every lane stays for the shuffles)
+    const double2 val = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * sc)[c8];
+    int32_t k = -1; int owner = 0; uint32_t key = 0;
+    bool ok = false;
+    if (c8 == 7 && s < n_rec) {                                      // the lane that holds the tail word
+        if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(val.y) - v.pix_base); ok = true; }
+        else { uint32_t pi; ok = record_valid(val.y, v.stamp, pi); if (ok) { k = v.compact[pi]; ok = k >= 0; } }
+        if (ok) { owner = pixel_owner(k, P, n_ranks); key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s]; }
+    }
+    unsigned long long pos = wave_owner_ticket(ok, owner, cursor);
+    if (ok) pos += off[owner];
+    const int src = lane | 7;
+    const int okb = __shfl(ok ? 1 : 0, src);
+    k = __shfl(k, src); key = (uint32_t)__shfl((int)key, src);
+    pos = ((unsigned long long)(uint32_t)__shfl((int)(pos >> 32), src) << 32) | (uint32_t)__shfl((int)(pos & 0xFFFFFFFFull), src);
+    if (!okb) return;
+    double2 o = val;
+    if (c8 == 7) o.y = __hiloint2double((int)key, (int)k);
+    reinterpret_cast<double2*>(out + (size_t)kRecStride * pos)[c8] = o;
 }
 
 // S_aug += [A11m, . ; b1^T, 0] (the replicated part, added once after the all-reduce of the partial Schur sums)

@@ -42,11 +42,11 @@ public:
     // the EventPacket argument of evaluateDataError (model.h:83-84), once per window
     void setEvents(const EventPacket& ev)
     {
-        std::vector<uint16_t> x(ev.size()), y(ev.size());
-        std::vector<uint8_t> pol(ev.size());
-        std::vector<int64_t> t(ev.size());
-        for (size_t k = 0; k < ev.size(); ++k) { x[k] = ev[k].x; y[k] = ev[k].y; pol[k] = ev[k].polarity ? 1 : 0; t[k] = ev[k].t_ns; }
-        check(emba_group_set_events(g_, x.data(), y.data(), pol.data(), t.data(), ev.size()));
+        // struct of arrays for the C ABI; the staging vectors are kept (a sliding-window run registers a window of about the same size again and
+        // again: 13 B per event of freshly mapped pages each time cost more than the conversion itself — 10 M events: ~25 ms)
+        sx_.resize(ev.size()); sy_.resize(ev.size()); sp_.resize(ev.size()); st_.resize(ev.size());
+        for (size_t k = 0; k < ev.size(); ++k) { sx_[k] = ev[k].x; sy_[k] = ev[k].y; sp_[k] = ev[k].polarity ? 1 : 0; st_[k] = ev[k].t_ns; }
+        check(emba_group_set_events(g_, sx_.data(), sy_.data(), sp_.data(), st_.data(), ev.size()));
     }
     void uploadMap(const double* Gx, const double* Gy) { check(emba_group_upload_map(g_, Gx, Gy)); }
 
@@ -87,6 +87,34 @@ public:
         return {it, err};
     }
     void rejectTrial() { check(emba_group_trial_reject(g_)); }
+
+    // ---- the same phases with NOTHING returned to the host (the resident loop of solve_time_window.hpp) ----
+    // evaluateDataError on the resident (current or trial) map: residuals, count map and per-event state stay on the device(s); enqueue only
+    void evaluateResident(const TrajectoryView& traj)
+    {
+        K_ = traj.num_ctrl_poses;
+        check(emba_group_eval(g_, traj.knots_xyzw, traj.num_ctrl_poses, traj.t0_ns, traj.dt_ns, nullptr, nullptr, nullptr, nullptr, nullptr));
+    }
+    // formNormalEq[IRLS] + applyL2Reg on that state; the blocks stay in the ranks' packs.  Returns the number of inlier measurements.
+    size_t formResident(int thres_valid_pixel, const std::string& cost_type, double a, double alpha)
+    {
+        size_t n_inl = 0;
+        check(emba_group_form(g_, thres_valid_pixel, irls_code(cost_type), a, alpha, &n_inl, &P_));
+        n_inliers_ = n_inl;
+        return n_inl;
+    }
+    // solveNormalEq with x1 to the host and x2 left on every rank's device (for updateMapResident)
+    void solveNormalEqResident(double lambda, bool fix_first_pose, std::vector<double>& x1)
+    {
+        x1.assign(3 * (size_t)K_, 0.0);
+        check(emba_group_solve(g_, lambda, fix_first_pose ? 1 : 0, x1.data(), nullptr));
+    }
+    // both cost terms of the last evaluation, one host synchronisation (solver.cpp:88-91, 257-268)
+    void costs(const std::string& cost_type, double a, double alpha, double& data_cost, double& reg_cost)
+    {
+        check(emba_group_costs(g_, irls_code(cost_type), a, alpha, &data_cost, &reg_cost));
+    }
+    void sync() { for (int r = 0; r < world(); ++r) if (emba_sync(emba_group_ctx(g_, r)) != EMBA_OK) throw StatusError(EMBA_ERR_HIP, emba_last_error(emba_group_ctx(g_, r))); }
     size_t numInliers() const { return n_inliers_; }
 
     // evaluateDataError (model.cpp:72-258) + formNormalEq[IRLS] (:316-687) + applyL2Reg (:689-719) on the resident map, over all ranks.
@@ -170,6 +198,7 @@ private:
     int W_, H_, K_ = 0;
     size_t P_ = 0, n_inliers_ = 0;
     bool have_ev_ = false; const Event* ev_ptr_ = nullptr; size_t ev_n_ = 0; uint64_t ev_key_ = 0;
+    std::vector<uint16_t> sx_, sy_; std::vector<uint8_t> sp_; std::vector<int64_t> st_;      // setEvents' staging (grow-only)
 };
 
 }  // namespace emba_host

@@ -147,3 +147,77 @@ def test_adapter_runs_the_reference_call_order(tmp_path, hip_lib, oracle_mod, de
     sx = float((Gx_o.ravel() * ((np.arange(n) % 7) + 1)).sum()); sy = float((Gy_o.ravel() * ((np.arange(n) % 5) + 1)).sum())
     mp_ = [l.split() for l in lines if l.startswith("MAP ")][0]
     assert float(mp_[1]) == pytest.approx(sx, rel=5e-2 if use_cg else 1e-7, abs=1e-9) and float(mp_[2]) == pytest.approx(sy, rel=5e-2 if use_cg else 1e-7, abs=1e-9)
+
+
+def test_cpp_resident_host_compiles_and_links(tmp_path, hip_lib):
+    exe = _build(tmp_path, hip_lib, "resident_test")
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0", False, False), ("0,0,0", True, False)])
+def test_cpp_resident_solve_time_window(tmp_path, hip_lib, oracle_mod, devices, use_irls, use_cg):
+    """EMBA::solveTimeWindow (solver.cpp:11-368) as a C++ host with everything of an iteration resident in HBM
+    (emba_amd/host/solve_time_window.hpp on emba_host::ShardedLEGM; 1, 2 and 3 ranks on one GPU; Schur, Huber IRLS, CG) — against the same loop in
+    emba_amd/solver.py on the device path (the log must agree decision for decision and cost for cost) and against the loop on the CPU oracle;
+    the run-time records are written in the reference's line formats."""
+    from emba_amd import LEGM, synth
+    from emba_amd.solver import BASettings, LMSettings, solve_time_window
+    from helpers import OracleModel
+    from test_lm_solver_cpu import perturbed
+    exe = _build(tmp_path, hip_lib, "resident_test")
+    w = synth.make_scene_workload(n_steps=1000)
+    init = perturbed(w)
+    wi = synth.Workload(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th, w.Gx, w.Gy, init, w.events, w.thres_valid_pixel, 5.0)
+    p = tmp_path / "in.bin"
+    o = dict(ep=np.zeros(0), num_ev_map=np.zeros((w.pano_h, w.pano_w), np.int32),
+             ne=dict(P=0, A11=np.zeros((3 * w.K, 3 * w.K)), b1=np.zeros(3 * w.K), A22=np.zeros((0, 2, 2)), b2=np.zeros(0), active=np.zeros(0, np.uint32)))
+    _write_case(p, wi, o)           # (only the inputs are read)
+    max_iter = 8
+    out_dir = tmp_path / "results"
+    r = subprocess.run([exe, str(p), devices, str(max_iter), "1" if use_irls else "0", "1" if use_cg else "0", str(out_dir)], capture_output=True, text=True, timeout=300)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.strip().splitlines()
+    lm = [l.split() for l in lines if l.startswith("LM ")]
+    end = [l.split() for l in lines if l.startswith("END ")][0]
+    knots = np.array([[float(v) for v in l.split()[1:]] for l in lines if l.startswith("KNOT ")])
+    ba = BASettings(use_IRLS=use_irls, cost_type="huber", eta=0.1, alpha=5.0, use_CG=use_cg)
+    # (1) the Python resident loop on the device path, one rank: same decisions, same costs
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    rp = solve_time_window(m, init, w.events, w.Gx, w.Gy, ba, LMSettings(max_num_iter=max_iter), resident=True)
+    m.close()
+    assert len(lm) == len(rp.log) and int(end[1]) == rp.iterations and bool(int(end[2])) == rp.converged
+    assert [int(l[5]) for l in lm] == [int(e[4]) for e in rp.log], "accept / reject sequence differs from solver.py's"
+    ranks = len(devices.split(","))
+    tol_py = 1e-2 if use_cg else (1e-12 if ranks == 1 else 1e-9)      # (several ranks: other summation order of the per-rank sums; CG: see below)
+    for l, e in zip(lm, rp.log):
+        assert float(l[3]) == pytest.approx(e[2], rel=tol_py) and float(l[4]) == pytest.approx(e[3], rel=tol_py)
+    # (2) the loop on the CPU oracle
+    om = OracleModel(oracle_mod, w, use_cg=use_cg)
+    ro = solve_time_window(om, init, w.events, w.Gx, w.Gy, ba, LMSettings(max_num_iter=max_iter))
+    assert len(lm) == len(ro.log) and int(end[1]) == ro.iterations and bool(int(end[2])) == ro.converged
+    assert [int(l[5]) for l in lm] == [int(e[4]) for e in ro.log], "accept / reject sequence differs from the oracle loop"
+    assert any(int(l[5]) for l in lm) and not all(int(l[5]) for l in lm), "the case is meant to contain accepted AND rejected steps"
+    tol = 1e-2 if use_cg else 1e-7      # (CG stops at a relative residual of 1e-6, model.cpp:823-824: each LM step's iterate is only that well defined)
+    for l, e in zip(lm, ro.log):
+        assert float(l[3]) == pytest.approx(e[2], rel=tol) and float(l[4]) == pytest.approx(e[3], rel=tol)
+    assert np.abs(knots - ro.traj.knots_xyzw).max() < (1e-3 if use_cg else 1e-7)
+    Gx_o, Gy_o = om.downloadMap()
+    n = Gx_o.size
+    sx = float((Gx_o.ravel() * ((np.arange(n) % 7) + 1)).sum()); sy = float((Gy_o.ravel() * ((np.arange(n) % 5) + 1)).sum())
+    mp_ = [l.split() for l in lines if l.startswith("MAP ")][0]
+    assert float(mp_[1]) == pytest.approx(sx, rel=5e-2 if use_cg else 1e-7, abs=1e-9) and float(mp_[2]) == pytest.approx(sy, rel=5e-2 if use_cg else 1e-7, abs=1e-9)
+    # (3) the reference's run-time records (solver.cpp:105-151, 170-178, 205-223, 271-291)
+    fr = out_dir / "final_results"
+    it_lines = (fr / "iterations.txt").read_text().splitlines()
+    assert it_lines[0] == "window #1" and sum(l.startswith("iter #") for l in it_lines) == len(lm)
+    n_acc = sum(int(l[5]) for l in lm)
+    form = (fr / "runtime_formEqs.txt").read_text().splitlines()
+    assert len(form) == 1 + n_acc - (1 if int(lm[-1][5]) and (int(end[2]) or len(lm) > max_iter) else 0) or len(form) in (n_acc, n_acc + 1)
+    assert all(l.startswith("iter #") and "count_formEqs" in l and "sec_average_formEqs" in l for l in form)
+    assert len((fr / "runtime_solveEqs.txt").read_text().splitlines()) == len(lm)
+    obj = (fr / "runtime_objFuncs.txt").read_text().splitlines()
+    assert len(obj) == len(lm) and all(" Np = " in l for l in obj)
+    if use_cg:
+        assert len((fr / "CG_iterations.txt").read_text().splitlines()) == len(lm)

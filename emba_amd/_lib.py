@@ -78,6 +78,7 @@ SIGNATURES = {
     "emba_count_map_ready": (C.c_int, [C.c_void_p]),
     "emba_count_compress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "emba_count_expand": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "emba_step_form_active": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "emba_eval_launch": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64]),
     "emba_eval_finish": (C.c_int, [C.c_void_p, _dp, _szp, _i32p]),
     "emba_form_active": (C.c_int, [C.c_void_p, C.c_int32, _szp, _szp]),

@@ -140,6 +140,7 @@ struct emba_ctx {
     int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
+    const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
     double* d_ep = nullptr;
     // order / key cache
@@ -1102,8 +1103,14 @@ emba_status emba_count_compress(emba_ctx* c, uint8_t* u8_dev, int32_t cap)
 {
     if (!c || !u8_dev || cap < 1 || cap > 255) return c ? fail(c, EMBA_ERR_INVALID_ARG, "count_compress: bad arguments") : EMBA_ERR_INVALID_ARG;
     if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
-    { emba_status st0 = ensure_counts(c); if (st0) return st0; }
-    hipLaunchKernelGGL(emba_count_compress_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, c->d_count, (long)c->npix, (int)cap, u8_dev);
+    if (c->counts_raw) {      // markers -> this rank's counts AND their saturated bytes in one sweep (ensure_counts + the compression below)
+        c->counts_raw = false;
+        c->count_stamp = (c->d_count == c->d_count_own) ? c->set_stamp : 0u;
+        hipLaunchKernelGGL(emba_count_materialise_compress_kernel, dim3((unsigned)((c->npix + 2047) / 2048)), dim3(256), 0, c->stream, c->d_count, c->d_pixacc, (long)c->npix,
+                           c->count_mark, (int)cap, u8_dev);
+    } else {
+        hipLaunchKernelGGL(emba_count_compress_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, c->stream, c->d_count, (long)c->npix, (int)cap, u8_dev);
+    }
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }
@@ -1298,6 +1305,16 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
     // from the records (the generic path of emba_form_accumulate), and its L2 term from emba_form_finish
     c->force_generic_a22 = c->pixacc_consumed;
     if (c->force_generic_a22) { aw.A22b2 = nullptr; aw.alpha = 0.0; c->fused_alpha = 0.0; }
+    // a sharded window's rank in resident-step mode (emba_step_form_active): activity from the exchanged byte counts, which launch A reads beside this rank's
+    // own counts — where the list-driven gather cannot be used the bytes are expanded into the count map first and the sweeping forms below see global counts
+    const bool lists_ok = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && c->n_cand &&
+                          (c->step_gather == 3 || !c->tile_order || c->n_cand <= 3500000);
+    if (c->global_u8 && !(lists_ok && c->ep_deferred && c->n_sorted && !c->counts_raw)) {
+        { emba_status st0 = ensure_counts(c); if (st0) return st0; }
+        c->count_stamp = 0;
+        hipLaunchKernelGGL(emba_count_expand_kernel, dim3((unsigned)((c->npix + 1023) / 1024)), dim3(256), 0, s, c->global_u8, npix, c->d_count);
+        c->global_u8 = nullptr;
+    }
     if (c->ep_deferred && c->n_sorted) {
         c->ep_deferred = false;
         PostWarpParams q{};
@@ -1316,8 +1333,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // Where it paid as a HEAD in front of the stream (same box, step time with the head vs with the sweeping kernel): 1 M events 101.2 vs 105.7 us,
         // the 1 M-event shard of the 8 M-event stream 121.8 vs 127, scene-driven 1.17 M events 121 vs 135 — but 1.5 M events 161 vs 154, 3 M (tile order)
         // 289 vs 281, 10 M 833 vs 817: with more active pixels per block the head's dependent trips grew past what the launch saved.
-        const bool lists = c->step_consume && c->step_gather && !c->force_generic_a22 && (long)c->n_ablk <= kGatherMaxUnits && q.raw_count && c->n_cand &&
-                           (c->step_gather == 3 || !c->tile_order || c->n_cand <= 3500000);      // (step_gather = 3: everywhere, for comparison)
+        q.global_u8 = c->global_u8;
+        const bool lists = lists_ok && (q.raw_count || q.global_u8);      // (step_gather = 3: everywhere, for comparison)
         // (round 4, late: the gather is now the work of 4 of a Gram block's 16 waves BESIDE the record stream, not a head in front of it: step time
         // with it / with the sweeping launch — 1 M 92.6 / 96.4 us, 1.5 M 134.7 / 143.8, 2 M (tile order) 193.4 / 208.5, 3 M 274.4 / 280.9, 10 M on
         // 640x480 (pixel order) 612.5 / 626.1, on 2048x4096 766.7 / 776.3; but 5 M (tile) 436.0 / 432.2, 40 M 3137 / 3014: a bandwidth-bound stream
@@ -1794,6 +1811,19 @@ emba_status emba_step(emba_ctx* c, const double* knots, int32_t K, int64_t t0_ns
     if (n_inliers) *n_inliers = c->n_inliers;
     if (P) *P = c->P;
     return EMBA_OK;
+}
+
+emba_status emba_step_form_active(emba_ctx* c, int32_t thres, const uint8_t* global_counts_u8_dev)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched) return fail(c, EMBA_ERR_STATE, "emba_eval_launch has not been called");
+    emba_status st;
+    if ((st = emba_eval_finish(c, nullptr, nullptr, nullptr))) return st;
+    c->step_consume = (c->step_fast != 0);
+    c->global_u8 = global_counts_u8_dev;
+    st = emba_form_active(c, thres, nullptr, nullptr);
+    c->step_consume = false; c->global_u8 = nullptr;
+    return st;
 }
 
 emba_status emba_count_map_ready(emba_ctx* c)

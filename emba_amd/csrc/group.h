@@ -150,6 +150,7 @@ struct RankPool {
 struct emba_group {
     int n = 0;
     int opt_x2_split = -1;      // -1 auto (from 3 M events per rank), 0 one piece, 1 split
+    int opt_step_fast = 1;      // the ranks' forms run as resident steps where they can (emba_step_form_active); option group_step_fast = 0: the sweeping forms (A/B)
     std::vector<emba_ctx*> ctx;
     std::vector<int> dev;
     bool use_rccl = false;
@@ -553,6 +554,42 @@ emba_status emba_group_form(emba_group* g, int32_t thres, int32_t irls, double e
         if (P) *P = g->P;
         return EMBA_OK;
     }
+    // Round 5: a rank's step = the one-GPU step.  Where exchange 1 travels as saturated bytes, the per-pixel sums carry this cost's weights and the
+    // shards are small enough for the list-driven gather (below the size from which exchange 2 is split: the two do not combine — the rows are written inside the
+    // Gram launch), every rank runs emba_step_form_active on the exchanged bytes: launch A with lists + zeroing, gather inside the Gram kernel, no clearing pass
+    // in the next evaluation, no expansion of the bytes into the int32 map.  The sequence of collectives is the same as below: all-reduce(u8), all-reduce(pack).
+    {
+        size_t n_max = 0;
+        for (int r = 0; r < g->n; ++r) n_max = std::max(n_max, g->n_local[r]);
+        bool fast = !g->x1_done && thres >= 1 && thres <= 255 / g->n && n_max < 3000000 && g->opt_x2_split <= 0 && g->opt_step_fast != 0;
+        for (int r = 0; r < g->n; ++r) fast = fast && (irls == g->ctx[r]->acc_irls) && (irls == 0 || eta == g->ctx[r]->acc_eta) && g->ctx[r]->eval_launched;
+        if (fast) {
+            const int cap = 255 / g->n;
+            { emba_status st = gpool(g, [&](int r) { return emba_count_compress(g->ctx[r], g->count_u8[r], cap); }); if (st) return st; }
+            { emba_status st = group_allreduce(g, (void* const*)g->count_u8.data(), g->npix, XType::U8); if (st) return st; }                      // X1
+            { emba_status st = gpool(g, [&](int r) {                                                                                              // E2, F1, F2
+                  emba_status s1 = emba_step_form_active(g->ctx[r], thres, g->count_u8[r]);
+                  return s1 ? s1 : emba_form_accumulate(g->ctx[r], nullptr, irls, eta); });
+              if (st) return st; }
+            size_t ni0 = 0;
+            G_TRY(g, 0, emba_last_counts(g->ctx[0], &ni0, &g->P));          // the gather's first block publishes P: polled, the Gram kernels still run
+            const size_t pl = g->ctx[0]->pack_len;
+            { emba_status st = group_allreduce(g, (void* const*)g->pack.data(), pl, XType::F64); if (st) return st; }                             // X2
+            std::vector<size_t> ni(g->n, 0), pp(g->n, 0);
+            { emba_status st = gpool(g, [&](int r) {                                                                                              // F3
+                  emba_status s1 = emba_form_finish(g->ctx[r], alpha, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);
+                  return s1 ? s1 : emba_last_counts(g->ctx[r], &ni[r], &pp[r]); });
+              if (st) return st; }
+            g->n_inliers = 0;
+            for (int r = 0; r < g->n; ++r) {
+                g->n_inliers += ni[r];
+                if (pp[r] != g->P) return gfail(g, EMBA_ERR_STATE, "ranks disagree on the active set (%zu vs %zu pixels)", pp[r], g->P);
+            }
+            if (n_inliers) *n_inliers = g->n_inliers;
+            if (P) *P = g->P;
+            return EMBA_OK;
+        }
+    }
     {   // X1, then E2 and F1 (enqueue only) in the fork-join that expands the exchanged counts
         const std::function<emba_status(int)> e2f1 = [&](int r) {
             emba_status s1 = emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr);
@@ -780,6 +817,11 @@ emba_status emba_group_set_option(emba_group* g, const char* name, int32_t value
     if (!strcmp(name, "x2_split")) {
         if (value < -1 || value > 1) return EMBA_ERR_INVALID_ARG;
         g->opt_x2_split = value;
+        return EMBA_OK;
+    }
+    if (!strcmp(name, "group_step_fast")) {
+        if (value < 0 || value > 1) return EMBA_ERR_INVALID_ARG;
+        g->opt_step_fast = value;
         return EMBA_OK;
     }
     for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_set_option(g->ctx[r], name, value));

@@ -932,7 +932,7 @@ __device__ __forceinline__ uint32_t active_mask8(const int32_t* __restrict__ cou
 // The same over a RAW count map (markers left by the warp kernel): a touched pixel's count is the sixth double of its accumulator
 // line; the counts are written back, which turns the map into the num_ev_map of model.cpp:227 for everyone downstream.
 __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ count, const double* __restrict__ pixacc, long p0, long npix, int thres,
-                                                      int32_t marker, uint32_t* touched = nullptr)
+                                                      int32_t marker, uint32_t* touched = nullptr, int* c_out = nullptr)
 {
     // entry == marker: touched by THIS evaluation -> its count from the accumulator line; anything else that is not zero is what an earlier
     // evaluation left behind (counts, or markers nobody asked about) -> zero.  The map needs no clearing pass between evaluations.
@@ -968,6 +968,10 @@ __device__ __forceinline__ uint32_t materialise_mask8(int32_t* __restrict__ coun
 #pragma unroll
     for (int k = 0; k < 8; ++k) { m |= (uint32_t)(c[k] >= thres) << k; tm |= (uint32_t)(c[k] != 0) << k; }
     if (touched) *touched = tm;
+    if (c_out) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) c_out[k] = c[k];
+    }
     return m;
 }
 
@@ -979,8 +983,12 @@ __global__ __launch_bounds__(256) void emba_count_materialise_kernel(int32_t* __
 __device__ __forceinline__ void active_count_block(long blk, const int32_t* __restrict__ count, long npix, int thres,
                                                    uint32_t* __restrict__ blk_cnt, int32_t* raw_count = nullptr, const double* pixacc = nullptr,
                                                    uint8_t* __restrict__ active_bits = nullptr, int* __restrict__ blk_rect = nullptr, int W = 1, int32_t marker = 0,
-                                                   uint16_t* __restrict__ seg = nullptr, double* __restrict__ clear_inactive = nullptr)
+                                                   uint16_t* __restrict__ seg = nullptr, double* __restrict__ clear_inactive = nullptr,
+                                                   const uint8_t* __restrict__ global_u8 = nullptr)
 {
+    // global_u8 (a rank of a sharded window, round 5): activity — count >= thres, model.cpp:333,409 — is a property of the GLOBAL counts, which the host has
+    // all-reduced as saturated bytes (exchange 1); `count` then holds THIS rank's materialised counts and only says which pixels the rank touched (the lines
+    // to clear, the texel rectangle).  A pixel can be active without a local measurement: its line is zero and its row of A22 | b2 comes from the others.
     // seg (the resident one-GPU step): the unit's active pixels, ascending, as offsets inside the unit at seg[blk * kActivePix + rank] — the
     // gather that follows (active_gather_block) then works from lists, balanced over the whole grid, instead of sweeping the count map again.
     // clear_inactive (same step): the accumulator lines of touched pixels that did NOT become active are zeroed here (their count has just been
@@ -988,7 +996,17 @@ __device__ __forceinline__ void active_count_block(long blk, const int32_t* __re
     __shared__ uint32_t s_w[4];
     const long p0 = blk * kActivePix + 8 * threadIdx.x;
     uint32_t tm = 0;
-    const uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres, marker, &tm) : active_mask8(count, p0, npix, thres, &tm);
+    uint32_t m8 = raw_count ? materialise_mask8(raw_count, pixacc, p0, npix, thres, marker, &tm) : active_mask8(count, p0, npix, thres, &tm);
+    if (global_u8) {
+        m8 = 0;
+        if (p0 + 8 <= npix) {
+            const uint2 g = *reinterpret_cast<const uint2*>(global_u8 + p0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { m8 |= (uint32_t)((int)((g.x >> (8 * k)) & 255u) >= thres) << k; m8 |= (uint32_t)((int)((g.y >> (8 * k)) & 255u) >= thres) << (4 + k); }
+        } else {
+            for (int k = 0; k < 8; ++k) if (p0 + k < npix && (int)global_u8[p0 + k] >= thres) m8 |= 1u << k;
+        }
+    }
     if (active_bits && p0 < npix) active_bits[p0 >> 3] = (uint8_t)m8;
     if (blk_rect) {   // bounding box of the pixels THIS evaluation touched, per block; the active-write kernel's last block reduces them
         __shared__ int s_box[4][4];     // into the rectangle the next evaluation packs its texels in
@@ -1065,6 +1083,7 @@ struct PostWarpParams {
                                                               // depends on launch A only)
     int* blk_rect; int W;                                     // non-null: per-block bounding boxes of the touched pixels (-> the next evaluation's texel rectangle)
     uint16_t* seg; double* clear_inactive;                    // the resident one-GPU step (active_count_block): per-unit active lists; zero the lines of touched, inactive pixels
+    const uint8_t* global_u8;                                 // a sharded window's rank: activity from the all-reduced saturated byte counts (active_count_block)
 };
 
 struct ActiveWriteParams {
@@ -1087,7 +1106,7 @@ __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
 {
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack
     if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
-    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W, p.marker, p.seg, p.clear_inactive);
+    if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W, p.marker, p.seg, p.clear_inactive, p.global_u8);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
 }
 
@@ -1402,6 +1421,25 @@ __global__ __launch_bounds__(256) void emba_active_gather_kernel(ActiveWritePara
 }
 
 
+
+// Exchange-1 compression straight from the warp kernel's markers (round 5): the rank's counts are materialised (markers -> the count in the sixth double of the
+// pixel's accumulator line; whatever an earlier evaluation left -> 0) and their saturated bytes written in the same pass — one sweep of the map instead of two.
+__global__ __launch_bounds__(256) void emba_count_materialise_compress_kernel(int32_t* __restrict__ count, const double* __restrict__ pixacc, long npix, int32_t marker,
+                                                                              int cap, uint8_t* __restrict__ out)
+{
+    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (p0 >= npix) return;
+    int c[8];
+    (void)materialise_mask8(count, pixacc, p0, npix, 1, marker, nullptr, c);
+    if (p0 + 8 <= npix) {
+        uint2 o;
+        o.x = (uint32_t)min(c[0], cap) | ((uint32_t)min(c[1], cap) << 8) | ((uint32_t)min(c[2], cap) << 16) | ((uint32_t)min(c[3], cap) << 24);
+        o.y = (uint32_t)min(c[4], cap) | ((uint32_t)min(c[5], cap) << 8) | ((uint32_t)min(c[6], cap) << 16) | ((uint32_t)min(c[7], cap) << 24);
+        *reinterpret_cast<uint2*>(out + p0) = o;
+    } else {
+        for (int k = 0; k < 8; ++k) if (p0 + k < npix) out[p0 + k] = (uint8_t)min(c[k], cap);
+    }
+}
 
 // Exchange-1 compression: int32 counts <-> saturated bytes (4 pixels per thread)
 __global__ void emba_count_compress_kernel(const int32_t* __restrict__ count, long npix, int cap, uint8_t* __restrict__ out)

@@ -395,6 +395,10 @@ class LEGM:
         self._P = P.value
         return P.value, pl.value
 
+    def step_form_active(self, thres, global_u8_ptr=None):
+        """F1 of a resident step on a rank of a sharded window (emba_step_form_active): activity from the all-reduced saturated byte counts."""
+        self._check(self._L.emba_step_form_active(self._ctx, int(thres), C.c_void_p(global_u8_ptr) if global_u8_ptr else None))
+
     def form_accumulate(self, cost_type="quadratic", a=0.0):
         self._check(self._L.emba_form_accumulate(self._ctx, None, COST_TYPES[cost_type], float(a)))
 

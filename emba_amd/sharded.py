@@ -141,8 +141,26 @@ class ShardedLEGM:
         multi = self.world > 1 or self.force_collectives
         # ... the split of exchange 2 pays once the Gram kernel is long enough to hide a collective behind (the head then costs a third collective's latency)
         split_x2 = getattr(self, "_declared", False) and (not hasattr(e, "x2_split_pays") or e.x2_split_pays(getattr(self, "n_max", 0)))
+        cap = 255 // max(self.world, 1)
+        # Round 5: a rank's step = the one-GPU step.  Where exchange 1 travels as saturated bytes, the per-pixel sums carry this cost's weights
+        # (declared before the evaluation) and exchange 2 is not split (small shards: the rows are written inside the Gram launch), the engine forms in the
+        # resident step's way on the exchanged BYTES (emba_step_form_active): launch A with active lists + zeroing, gather inside the Gram kernel, no clearing
+        # pass in the next evaluation, no expansion into the int32 map.  Every condition is rank-invariant; the collectives are the same two as below.
+        if (multi and getattr(self, "_declared", False) and not split_x2 and self.count_u8 is not None and 1 <= thres_valid_pixel <= cap
+                and hasattr(e, "step_form_active") and getattr(e, "step_fast", True) and getattr(self, "n_max", 0) < 3_000_000):
+            self.last_form_resident = True
+            e.count_compress(self.count_u8, cap)                  # markers -> this rank's counts and their saturated bytes, one sweep
+            dist.all_reduce(self.count_u8)                        # X1
+            e.step_form_active(thres_valid_pixel, self.count_u8)  # E2, F1 (enqueue only)
+            e.form_accumulate(cost_type, a)                       # F2: Gram with the active-set write + A22 | b2 gather inside
+            n_inl, self.P = e.last_counts()                       # (polled: the gather's first block publishes P)
+            self.pack_len = 9 * int(e.K) ** 2 + 3 * int(e.K) + 5 * self.P
+            dist.all_reduce(self.pack[: self.pack_len])           # X2
+            out = e.form_finish(alpha, download)                  # F3: applyL2Reg once, after the reduce
+            n_inl, self.P = e.last_counts()
+            return n_inl, out
+        self.last_form_resident = False
         if multi:
-            cap = 255 // max(self.world, 1)
             if self.count_u8 is not None and thres_valid_pixel <= cap and hasattr(e, "count_compress"):
                 e.count_compress(self.count_u8, cap)          # int32 -> min(count, cap) bytes
                 dist.all_reduce(self.count_u8)                # X1 (SUM) on a quarter of the bytes; cannot overflow: world * cap <= 255
@@ -306,6 +324,7 @@ class ShardedModel:
 class HipEngine:
     """Adapter: emba_amd.LEGM phase calls + torch CUDA tensors as the exchange buffers (product path)."""
 
+    step_fast = True     # the ranks' forms run as resident steps where they can (emba_step_form_active); False: the sweeping forms (A/B)
     x2_split = None      # None: auto (from 3 M events per rank); 0 / 1: exchange 2 in one piece / split (x2_split_pays)
 
     def __init__(self, legm, check_stream=True):
@@ -373,6 +392,9 @@ class HipEngine:
 
     def count_expand(self, u8_tensor):
         self.m.count_expand(u8_tensor.data_ptr())
+
+    def step_form_active(self, thres, u8_tensor):
+        self.m.step_form_active(thres, u8_tensor.data_ptr())
 
     def form_accumulate(self, cost_type, a):
         self.m.form_accumulate(cost_type, a)

@@ -290,6 +290,15 @@ emba_status emba_count_map_ready(emba_ctx* ctx);
 emba_status emba_count_compress(emba_ctx* ctx, uint8_t* u8_dev, int32_t cap);
 emba_status emba_count_expand(emba_ctx* ctx, const uint8_t* u8_dev);
 
+/* Phase F1 of a RESIDENT step on a rank of a sharded window (round 5: what emba_step does on one GPU, between the two exchanges): emba_eval_finish +
+ * emba_form_active in the step's form — launch A leaves per-unit active lists and zeroes the touched-but-inactive accumulator lines, the active-set write +
+ * A22 | b2 gather ride inside the Gram launch of the emba_form_accumulate that follows and zero the lines they read, so the next evaluation needs no clearing
+ * pass.  global_counts_u8_dev: the all-reduced saturated byte counts of exchange 1 (emba_count_compress on every rank, then the caller's all-reduce) — activity is
+ * decided from THEM (model.cpp:333,409 on the global counts) while the context's own count map keeps this rank's counts; NULL: from the count map.  Asynchronous;
+ * P comes from emba_last_counts once the Gram launch is enqueued.  No applyL2Reg here: emba_form_finish(alpha) after exchange 2.  This evaluation's per-pixel
+ * sums are consumed: a second formNormalEq on it rebuilds A22 | b2 from the records. */
+emba_status emba_step_form_active(emba_ctx* ctx, int32_t thres_valid_pixel, const uint8_t* global_counts_u8_dev);
+
 /* Phase E1: pose table, Hessian/texel pack, warp + residual + count + factor records.  Asynchronous
  * on the context's stream.  After it the count map holds THIS rank's counts. */
 emba_status emba_eval_launch(emba_ctx* ctx, const double* knots_xyzw_host, int32_t K, int64_t t0_ns,
@@ -398,7 +407,8 @@ emba_status emba_group_create(const emba_cfg* cfg, const int32_t* devices, int32
 #define EMBA_GROUP_NO_THREADS 2u
 emba_status emba_group_create_flags(const emba_cfg* cfg, const int32_t* devices, int32_t n_ranks, uint32_t flags, emba_group** out);
 /* emba_set_option on every rank's context, plus the group's own: x2_split — -1 auto (from 3 M events per rank) | 0 exchange 2 in one piece | 1 its
- * A22 | b2 rows on the side streams under the Gram kernel. */
+ * A22 | b2 rows on the side streams under the Gram kernel; group_step_fast — 1 the ranks form as resident steps where they can (emba_step_form_active) |
+ * 0 the sweeping forms. */
 emba_status emba_group_set_option(emba_group* g, const char* name, int32_t value);
 void        emba_group_destroy(emba_group* g);
 const char* emba_group_last_error(const emba_group* g);

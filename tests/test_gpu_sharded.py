@@ -98,18 +98,22 @@ def _rank_main(shared, rank, w, results, compressed=False, solve=None):
         ep_pix = np.zeros(ep.size, dtype=np.int64)
         sel = d["inlier_idx"] >= 0
         ep_pix[d["inlier_idx"][sel]] = pix[sel]
-        results[rank] = dict(ne=out, count=count.cpu().numpy(), ep=ep.copy(), ep_pix=ep_pix, n_inl=n_inl, sol=sol)
+        resident = bool(getattr(sh, "last_form_resident", False))       # (round 5: the global saturated counts then stay in the byte buffer of exchange 1)
+        results[rank] = dict(ne=out, count=(cu8 if resident else count).cpu().numpy().astype(np.int32), ep=ep.copy(), ep_pix=ep_pix, n_inl=n_inl, sol=sol,
+                             resident=resident)
     except Exception as e:  # noqa: BLE001
         shared.errors.append((rank, repr(e)))
         shared.barrier.abort()
         raise
 
 
-@pytest.mark.parametrize("cfg,compressed", [(dict(n_events=20000), False), (dict(n_events=30050, pano_h=256, K=11, sensor=(64, 48), focal=60.0), False),
-                                            (dict(n_events=20000), True)])
-def test_two_rank_threads_on_one_gpu(oracle_mod, cfg, compressed, monkeypatch):
-    # exchange 2 in one piece (what these sizes get by default) and split (A22 | b2 rows reduced while the Gram kernel runs)
-    monkeypatch.setattr("emba_amd.sharded.HipEngine.x2_split", 1 if compressed or cfg["n_events"] > 25000 else 0)
+@pytest.mark.parametrize("cfg,compressed,split", [(dict(n_events=20000), False, 0), (dict(n_events=30050, pano_h=256, K=11, sensor=(64, 48), focal=60.0), False, 1),
+                                                  (dict(n_events=20000), True, 1), (dict(n_events=20000), True, 0),
+                                                  (dict(n_events=30050, pano_h=75, K=11, sensor=(48, 36), focal=45.0), True, None)])
+def test_two_rank_threads_on_one_gpu(oracle_mod, cfg, compressed, split, monkeypatch):
+    # exchange 2 in one piece (what these sizes get by default) and split (A22 | b2 rows reduced while the Gram kernel runs); compressed exchange 1 WITHOUT the
+    # split: the ranks form as resident steps (round 5: emba_step_form_active on the exchanged bytes — lists, gather inside the Gram launch, no clearing pass)
+    monkeypatch.setattr("emba_amd.sharded.HipEngine.x2_split", split)
     import torch
     assert torch.cuda.is_available()
     from emba_amd.sharded import merge_ep
@@ -122,6 +126,7 @@ def test_two_rank_threads_on_one_gpu(oracle_mod, cfg, compressed, monkeypatch):
     assert not shared.errors, shared.errors
     o = oracle_run(oracle_mod, w)
     for r in range(world):
+        assert results[r]["resident"] == (compressed and not split)
         got = results[r]["count"].reshape(w.pano_h, w.pano_w)
         if compressed:   # saturated bytes: exact below the per-rank cap, same activity everywhere
             assert np.array_equal(got >= w.thres_valid_pixel, o["num_ev_map"] >= w.thres_valid_pixel)
@@ -236,7 +241,9 @@ def _rank8_main(shared, rank, w, init, lam, damping, results):
         model.set_events(w.events)
         model.upload_map(w.Gx, w.Gy)
         n_inl, ne = sh.iteration(init, w.thres_valid_pixel, w.alpha, download=True)
-        count_h = count.cpu().numpy()          # (the trial evaluation below starts a new count map)
+        # (the trial evaluation below starts a new count map)  Round 5: where the ranks form as resident steps the GLOBAL saturated counts stay in the byte
+        # buffer of exchange 1 — the int32 map keeps the rank's own counts
+        count_h = (cu8 if getattr(sh, "last_form_resident", False) else count).cpu().numpy().astype(np.int32)
         cost0 = model.dataCost() + model.regCost(w.alpha)
         x1, x2 = sh.solveNormalEq(lam, True)
         traj_new = emba_io.incremental_update(init, x1, True)

@@ -2213,7 +2213,7 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
         }
     }
     hipLaunchKernelGGL(emba_schur_rhs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_S, lds_, n, skip, d_rhs);   // z = row n of the factor
-    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(1024), 0, s, Sm, lds_, m, d_rhs + skip);
+    hipLaunchKernelGGL(emba_chol_trsv_kernel, dim3(1), dim3(kTrsvThreads), 0, s, Sm, lds_, m, d_rhs + skip);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
 }

@@ -91,6 +91,9 @@ constexpr int kGramChunk = 1024;   // most record slots a wave of the Gram (A11/
 #define GATHER_Q 4
 #endif
 #ifndef GRAM_GATHER_WAVES
+#ifndef GRAM_WAVE_TILE
+#define GRAM_WAVE_TILE 1         // a wave's last flush goes to its own LDS tile by plain stores (gram_wave_tile) instead of fp64 LDS atomics into the block's table
+#endif
 #define GRAM_GATHER_WAVES 4      // waves of a Gram block that do its slice of the active-set gather while the other 12 stream records (GATHER form)
 #endif
 constexpr int kGramBlock = 1024;   // threads per block of the Gram kernel (16 waves share one LDS combine table).  Round 4, compact form at 1 M events: 8 waves
@@ -1619,6 +1622,32 @@ __device__ __attribute__((noinline)) void gram_flush(double4_t ee, double4_t oe,
     }
 }
 
+// The wave's LAST flush (round 5): its symmetric 16 x 16 sum as 256 plain LDS stores into the wave's own tile instead of ~16 fp64 LDS atomics per lane into the
+// block's shared table, where the sixteen waves of a block queued on the same 156 addresses (s_memtime stamps, round 4: 3.2 us per wave in the flush and 2.8 in the
+// barrier behind it, of a 17.8-us wave).  The two same-record quadrants of an accumulator (lanes j < 8 with rows i < 8: the even records; lanes j >= 8 with rows
+// i >= 8: the odd ones) are first added by a DPP row shift — lane (q, j) takes lane (q, j + 8) — then the 32 lanes j < 8 store ee -> (2i, 2j), oe -> (2i+1, 2j) and
+// its transpose, oo -> (2i+1, 2j+1): every entry of the tile exactly once.  The block sums the waves' tiles per control-pose pair after its final barrier.
+__device__ __forceinline__ double dpp_row_shl8(double v)      // lane l <- lane l + 8 of its row of 16 (0 where there is none)
+{
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x108, 0xf, 0xf, true),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x108, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void gram_wave_tile(double4_t ee, double4_t oe, double4_t oo, double* __restrict__ tile)
+{
+    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const double e = ee[r] + dpp_row_shl8(ee[r + 2]), x = oe[r] + dpp_row_shl8(oe[r + 2]), o = oo[r] + dpp_row_shl8(oo[r + 2]);
+        if (j < 8) {
+            const int i = q + 4 * r;
+            tile[(2 * i) * 16 + 2 * j] = e;
+            tile[(2 * i + 1) * 16 + 2 * j] = x;
+            tile[(2 * j) * 16 + 2 * i + 1] = x;
+            tile[(2 * i + 1) * 16 + 2 * j + 1] = o;
+        }
+    }
+}
+
 // elements 14 (residual) and 15 ({pano_idx, aux}) of the record whose 8 lanes this lane belongs to: they sit in lane 8R+7
 // (ds_swizzle bit-mask mode inside 32 lanes: lane' = (lane & 0x18) | 7; no address VGPR, no memory request)
 __device__ __forceinline__ double rec_elem14(double2 v)
@@ -1645,8 +1674,11 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     __shared__ double s_tile[kGramKeys * 256];
     __shared__ uint32_t s_pre[GATHER ? kGatherMaxUnits + 1 : 1];
     __shared__ uint32_t s_ws[kGramBlock / 64];
+    __shared__ double s_wtile[(kGramBlock / 64) * 256];      // every wave's own 16 x 16 sum of its last pair (gram_wave_tile)
+    __shared__ uint32_t s_wkey[kGramBlock / 64];
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) s_tile[i] = 0.0;
     if (threadIdx.x < kGramKeys) s_tag[threadIdx.x] = 0xFFFFFFFFu;
+    if (threadIdx.x < kGramBlock / 64) s_wkey[threadIdx.x] = 0xFFFFFFFFu;
     // GATHER: the block's slice of the gather is the work of its first kGW waves ONLY; the others go straight to the record stream, which depends on
     // launch A's activity bits and on nothing the gather writes (round 4, late: with all 16 waves gathering first the head cost this kernel 9 us
     // of dependent round trips in front of its stream; now they run beside it)
@@ -1917,13 +1949,48 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
         iterate(off, xD, xA, xC, actB, kfB, klB, actA, kfA, klA); off += kStride;
     }
     }
+#if !GRAM_WAVE_TILE
     if (dirty) flush();
+#else
+    if (dirty) {      // the wave's last pair: plain stores into its own tile (a pair change in mid-stream — a few dozen waves per launch — went through flush())
+        const int wabs = threadIdx.x >> 6;
+        gram_wave_tile(acc_ee, acc_oe, acc_oo, s_wtile + wabs * 256);
+        if (lane == 0) s_wkey[wabs] = cur_key;
+    }
+#endif
     }  // have_work
     __syncthreads();
     // block-level flush of the combine table: entry (k, row, col) by thread k*256 + row*16 + col
     for (int i = threadIdx.x; i < kGramKeys * 256; i += kGramBlock) {
         const uint32_t key = s_tag[i >> 8];
         if (key != 0xFFFFFFFFu) gram_atomic_out(s_tile[i], (i >> 4) & 15, i & 15, key, p.A11, p.b1, p.dim, p.ablate);
+    }
+    // ... and of the waves' own tiles: thread e < 256 owns entry e; the waves that ended on the same pair are summed first (the first of them leads).
+    // The sixteen keys come to registers in one go and every tile read is independent of the others (block-uniform predicates): two LDS round trips, not a
+    // chain of a hundred (which cost this kernel 5 us when it was written as loops over LDS-resident keys).
+    if (threadIdx.x < 256) {
+        const int e = threadIdx.x, row = e >> 4, col = e & 15;
+        constexpr int NW = kGramBlock / 64;
+        uint32_t kw[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) kw[w] = s_wkey[w];
+        double tv[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) tv[w] = (kw[w] != 0xFFFFFFFFu) ? s_wtile[w * 256 + e] : 0.0;
+        if (row < 12 && (col < 12 || col == 14)) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                if (kw[w] == 0xFFFFFFFFu) continue;
+                bool leader = true;
+#pragma unroll
+                for (int w2 = 0; w2 < w; ++w2) leader = leader && (kw[w2] != kw[w]);
+                if (!leader) continue;
+                double sum = 0.0;
+#pragma unroll
+                for (int w2 = w; w2 < NW; ++w2) sum += (kw[w2] == kw[w]) ? tv[w2] : 0.0;
+                gram_atomic_out(sum, row, col, kw[w], p.A11, p.b1, p.dim, p.ablate);
+            }
+        }
     }
 }
 

@@ -705,19 +705,20 @@ __global__ __launch_bounds__(256) void emba_chol_trail_kernel(double* __restrict
 // schur_factor_solve).  64-wide blocks from the bottom: one wave substitutes inside the block — lane t keeps column t of the block in registers,
 // x_j leaves lane j by v_readlane —, then every thread takes one row above the block and subtracts its 64-term dot product (the row's 64 factor
 // entries are contiguous: column r of L).
+constexpr int kTrsvThreads = 512;  // (round 5: 1024 threads capped the kernel at 128 VGPRs and the single wave's 64 preloaded factor entries spilled: 120 B of scratch per lane)
 constexpr int kTrsvMaxN = 3072;   // right-hand sides up to this length stay in LDS during the sweep (K <= 1024)
-__global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b)
+__global__ __launch_bounds__(kTrsvThreads) void emba_chol_trsv_kernel(const double* __restrict__ L, long ld, int n, double* __restrict__ b)
 {
     __shared__ double s_l[64 * 65];
     __shared__ double s_x[64];
     __shared__ double s_b[kTrsvMaxN];
     const int t = threadIdx.x;
     const bool in_lds = n <= kTrsvMaxN;
-    if (in_lds) { for (int i = t; i < n; i += 1024) s_b[i] = b[i]; }
+    if (in_lds) { for (int i = t; i < n; i += kTrsvThreads) s_b[i] = b[i]; }
     __syncthreads();
     for (int jb = ((n - 1) / 64) * 64; jb >= 0; jb -= 64) {
         const int nb = (n - jb < 64) ? n - jb : 64;
-        for (int i = t; i < 64 * 64; i += 1024) { const int r = i & 63, c = i >> 6; s_l[c * 65 + r] = (r < nb && c < nb && r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
+        for (int i = t; i < 64 * 64; i += kTrsvThreads) { const int r = i & 63, c = i >> 6; s_l[c * 65 + r] = (r < nb && c < nb && r >= c) ? L[(size_t)ld * (jb + c) + jb + r] : 0.0; }
         __syncthreads();
         if (t < 64) {
             double v = (t < nb) ? (in_lds ? s_b[jb + t] : b[jb + t]) : 0.0;
@@ -734,10 +735,14 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
             if (t < nb) { if (in_lds) s_b[jb + t] = v; else b[jb + t] = v; }
         }
         __syncthreads();
-        for (int r = t; r < jb; r += 1024) {
+        for (int r = t; r < jb; r += kTrsvThreads) {
             const double* lp = L + (size_t)ld * r + jb;
             double d0 = 0.0, d1 = 0.0;
-            if (nb == 64) {
+            if (nb == 64 && ((reinterpret_cast<uintptr_t>(lp) & 15) == 0)) {      // the row's 64 factor entries as 32 16-B loads
+                const double2* lp2 = reinterpret_cast<const double2*>(lp);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) { const double2 l2 = lp2[c]; d0 = fma(l2.x, s_x[2 * c], d0); d1 = fma(l2.y, s_x[2 * c + 1], d1); }
+            } else if (nb == 64) {
 #pragma unroll
                 for (int c = 0; c < 64; c += 2) { d0 = fma(lp[c], s_x[c], d0); d1 = fma(lp[c + 1], s_x[c + 1], d1); }
             } else {
@@ -747,7 +752,7 @@ __global__ __launch_bounds__(1024) void emba_chol_trsv_kernel(const double* __re
         }
         __syncthreads();
     }
-    if (in_lds) { for (int i = t; i < n; i += 1024) b[i] = s_b[i]; }
+    if (in_lds) { for (int i = t; i < n; i += kTrsvThreads) b[i] = s_b[i]; }
 }
 
 // x2_i = C_i^-T (y_i - z_i), z_i = A12_i^T x1 C^-T... computed from the records of pixel i:  A12_i^T x1 = sum_m w_m (v_m . x1) dp_m,

@@ -37,6 +37,8 @@ class LMResult:
     iterations: int
     converged: bool
     log: list = field(default_factory=list)      # (iter, log10(lambda), cost_min, cost_new, accepted)
+    reason: str = ""            # which of the reference's stopping rules ended the loop: "tolerance" (solver.cpp:319-339), or the while condition of :63-64 —
+                                # "lambda" (left [1e-300, 1e3]: no damping finds a better point), "cost" (below 1e-16), "max_iter"
 
 
 class RuntimeLog:
@@ -206,7 +208,7 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
             if abs(1 - cost_min / (cost_min_old + 1e-10)) < lm.tol_fun:
                 count_tol += 1
                 if count_tol >= lm.num_times_tol_fun_sat:
-                    return LMResult(traj, cost_min, it, True, log)
+                    return LMResult(traj, cost_min, it, True, log, "tolerance")
         else:                                                                        # :340-352
             decreased = False
             # the reference reuses its host copies of A, b after a rejection (formNormalEq is skipped, solver.cpp:66-131).  On the device the
@@ -220,4 +222,5 @@ def solve_time_window(model, traj, events, Gx, Gy, ba=BASettings(), lm=LMSetting
                 ph.form(traj.size())
             lam *= 10
             count_tol = 0
-    return LMResult(traj, cost_min, it, False, log)
+    reason = "max_iter" if it > lm.max_num_iter else ("cost" if cost_min <= 1e-16 else "lambda")
+    return LMResult(traj, cost_min, it, False, log, reason)

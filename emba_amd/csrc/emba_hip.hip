@@ -47,6 +47,7 @@ struct emba_ctx {
     int sw = 0, sh = 0, W = 0, H = 0;
     size_t S = 0, npix = 0;
     double fx = 0, fy = 0, cx = 0, cy = 0, C_th = 0, outlier_px = 10.0;
+    double fov_x = M_PI, fov_y = M_PI;    // the sensor's field of view (rad), from the bearing LUT
 
     // persistent device buffers
     double* d_lut = nullptr;
@@ -137,7 +138,7 @@ struct emba_ctx {
     bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
-    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
+    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
@@ -714,6 +715,16 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     else { CREATE_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
     CREATE_TRY(hipMalloc((void**)&c->d_lut, c->S * 3 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_lut)] = c->S * 3 * sizeof(double);
     CREATE_TRY(hipMemcpy(c->d_lut, cfg->bearing_lut, c->S * 3 * sizeof(double), hipMemcpyHostToDevice));
+    {   // the sensor's field of view from the bearing vectors (x / z, y / z extents): what schur_accumulate estimates the band of U with
+        double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+        for (size_t i = 0; i < c->S; ++i) {
+            const double z = cfg->bearing_lut[3 * i + 2];
+            if (!(z > 0.0)) continue;
+            const double ax = atan(cfg->bearing_lut[3 * i] / z), ay = atan(cfg->bearing_lut[3 * i + 1] / z);
+            x0 = std::min(x0, ax); x1 = std::max(x1, ax); y0 = std::min(y0, ay); y1 = std::max(y1, ay);
+        }
+        c->fov_x = x1 > x0 ? x1 - x0 : M_PI; c->fov_y = y1 > y0 ? y1 - y0 : M_PI;
+    }
     c->cfg.bearing_lut = nullptr;  // not retained
     CREATE_TRY(hipMalloc((void**)&c->d_texel, c->npix * kTexelStride * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_texel)] = c->npix * kTexelStride * sizeof(double);
     CREATE_TRY(hipMalloc((void**)&c->d_count_own, c->npix * sizeof(int32_t))); c->caps[reinterpret_cast<void**>(&c->d_count_own)] = c->npix * sizeof(int32_t);
@@ -1858,6 +1869,7 @@ const OptionRef kOptions[] = {
     {"chunk_order_bin", &emba_ctx::opt_chunk_order_bin, 0, 1},
     {"solve_counts", &emba_ctx::opt_solve_counts, -1, 2},
     {"syrk_dense", &emba_ctx::opt_syrk_dense, 0, 1},
+    {"syrk_lists", &emba_ctx::opt_syrk_lists, 0, 2},
     {"solve_debug", &emba_ctx::opt_solve_debug, 0, 1},
     {"poisson", &emba_ctx::opt_poisson, 0, 2},
     {"gemm64", &emba_ctx::opt_gemm64, 0, 1},
@@ -2108,6 +2120,8 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
 
 // S_aug (lds x (n+1), zero or pre-initialised) -= U_aug U_aug^T over the pixels [0, n_pix) of the lists; A22b2 points at the first of
 // those pixels' {xx xy yy bx by}.  Also leaves y = C^-1 b2 (d_y) and the 2x2 Cholesky factors (d_cf).  Workspaces 8 (U), 12 (slabs).
+bool axis_path(const emba_ctx* c, double* path_az_out, double* path_el_out);
+
 emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists& L, size_t n_pix, const double* A22b2, double lambda, int n,
                              double* d_S, long lds_, double* d_y, double* d_cf, int* d_info, const uint32_t* perm = nullptr)
 {
@@ -2150,10 +2164,34 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
         SyrkParams sp{};
         sp.A = d_U; sp.lda = lds_; sp.n = n; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.range = d_range;
+        // Where it pays: a BANDED U — a pixel is in view for the fraction fov / (path of the optical axis over the window) of the control poses, and an operand block
+        // is read once per pair of its band.  With a dense band (every pixel sees the whole window: 1 s at any K) there is nothing to re-use that the lists form does
+        // not get from its longer runs (measured: 10 M events / K = 97 over 1 s 3.14 vs 3.38 ms per solve, 1 M / K = 201 over 1 s 2.5 vs 2.75; config 2's shape, 10 s:
+        // 4.15 vs 3.93).  Option syrk_lists: 0 auto, 1 the lists form always, 2 the item form always.
+        double paz = 0.0, pel = 0.0, in_view = 1.0;
+        if (axis_path(c, &paz, &pel)) in_view = std::min(1.0, (paz >= pel ? c->fov_x : c->fov_y) / std::max(std::max(paz, pel), 1e-9));
+        const int band_blocks = std::min(nb64, (int)std::ceil(in_view * nb64) + 1);
+        const bool items_form = sparse && (c->opt_syrk_lists == 2 || (c->opt_syrk_lists == 0 && 2 * band_blocks <= nb64));
         if (sparse) {
-            hipLaunchKernelGGL(emba_syrk_lists_kernel, dim3((unsigned)nbp), dim3(64), 0, s, d_mask, n_slices, nbp, d_list, d_cnt);
+            if (!items_form || c->opt_solve_debug) hipLaunchKernelGGL(emba_syrk_lists_kernel, dim3((unsigned)nbp), dim3(64), 0, s, d_mask, n_slices, nbp, d_list, d_cnt);
             sp.list = d_list; sp.count = d_cnt; sp.n_slices = n_slices;
             nks = std::max(1, std::min(nks_max, n_slices));
+        }
+        // ITEM form of the block-sparse product (round 5, SyrkParams::items): workgroups = (block pair, chunk of slices) in chunk-major order.  Option syrk_lists = 1
+        // keeps the round-3/4 form (a workgroup per (pair, part) walking every nks-th slice of the pair's list).
+        int item_chunk = 0, n_item_chunks = 0;
+        uint32_t* d_pair_items = nullptr; uint32_t* d_items = nullptr;
+        const uint32_t item_cap = 4096;
+        if (items_form) {
+            const long pairs_est = (long)band_blocks * (band_blocks + 1) / 2;
+            item_chunk = (int)std::min<long>(64, std::max<long>(4, ((long)n_slices * pairs_est * 3 / 2 + 2999) / 3000));
+            n_item_chunks = (n_slices + item_chunk - 1) / item_chunk;
+            if (n_item_chunks > 65535 || nbp > 65535) return fail(c, EMBA_ERR_CAPACITY, "too many slice chunks for the item form of the block-sparse product");
+            double* d_slab2 = nullptr;
+            if ((st = ws_get(c, 12, std::max<size_t>((size_t)nks_max * nbp, item_cap) * 4096 * 8, (void**)&d_slab2)) ||
+                (st = ws_get(c, 37, (size_t)nbp * n_item_chunks * 4, (void**)&d_pair_items)) || (st = ws_get(c, 39, ((size_t)nbp * n_item_chunks + 2) * 4, (void**)&d_items)))
+                return st;
+            sp.slab = d_slab2;
         }
         sp.direct = (nks == 1);
         if (c->opt_solve_debug) {      // diagnostic: how sparse is this chunk?  (products = (block pair, slice) pairs the SYRK forms)
@@ -2177,6 +2215,19 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
             fprintf(stderr, "[solve debug] pixels %ld slices %d nbp %d nks %d: mean 16-row groups per pixel %.2f, mean 64-row blocks written %.2f (hist 1..8+: %ld %ld %ld %ld %ld %ld %ld %ld), products %ld (diag %ld) = %.2f per slice; U written %.1f MB\n",
                     (long)(p1 - p0), n_slices, nbp, nks, (double)w16 / (p1 - p0), (double)w64 / (p1 - p0), hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8], prod, prod_diag,
                     (double)prod / n_slices, w64 * 64.0 * 2 * 8 / 1e6);
+        }
+        if (items_form) {
+            int32_t* d_ord = reinterpret_cast<int32_t*>(d_list);                  // (nbp * n_slices words >= nbp * n_item_chunks)
+            uint32_t* d_n_items = d_items + (size_t)nbp * n_item_chunks;
+            hipLaunchKernelGGL(emba_syrk_item_flag_kernel, dim3((unsigned)n_item_chunks), dim3(256), 0, s, d_mask, n_slices, nbp, item_chunk, d_ord);
+            hipLaunchKernelGGL(emba_syrk_item_ord_kernel, dim3((unsigned)((nbp + 63) / 64)), dim3(64), 0, s, nbp, n_item_chunks, d_ord, d_cnt);
+            hipLaunchKernelGGL(emba_syrk_item_list_kernel, dim3(1), dim3(1024), 0, s, d_ord, nbp, n_item_chunks, d_items, d_pair_items, d_n_items);
+            sp.list = nullptr; sp.count = nullptr; sp.n_slices = n_slices; sp.direct = 0;
+            sp.items = d_items; sp.n_items = d_n_items; sp.slice_mask = d_mask; sp.item_chunk = item_chunk; sp.item_cap = item_cap;
+            hipLaunchKernelGGL(emba_syrk_kernel, dim3((unsigned)((size_t)nbp * n_item_chunks)), dim3(256), 0, s, sp);
+            hipLaunchKernelGGL(emba_syrk_item_reduce_kernel, dim3((unsigned)(((size_t)nbp * 4096 + 255) / 256)), dim3(256), 0, s, sp.slab, d_pair_items, d_cnt, n_item_chunks, item_cap,
+                               nbp, n, d_S, lds_);
+            continue;
         }
         hipLaunchKernelGGL(emba_syrk_kernel, dim3(nbp, nks), dim3(256), 0, s, sp);
         if (nks > 1)
@@ -2220,6 +2271,22 @@ emba_status schur_factor_solve(emba_ctx* c, double* d_S, long lds_, int n, int s
 
 // The column order of U for the local solve (emba_perm_keys_kernel): panorama columns first when the camera mostly pans (azimuth path of the optical axis
 // over the control poses >= its elevation path), the compact order (nullptr) otherwise.  Built once per list build; workspaces 34-36.
+// azimuth / elevation path length (rad) of the optical axis over the control poses of the last evaluation (the host's pinned copy)
+bool axis_path(const emba_ctx* c, double* path_az_out, double* path_el_out)
+{
+    if (!c->h_knots || c->K < 2) return false;
+    double path_az = 0.0, path_el = 0.0, az0 = 0.0, el0 = 0.0;
+    for (int i = 0; i < c->K; ++i) {
+        const double x = c->h_knots[4 * i], y = c->h_knots[4 * i + 1], z = c->h_knots[4 * i + 2], w = c->h_knots[4 * i + 3];
+        const double ax = 2.0 * (x * z + w * y), ay = 2.0 * (y * z - w * x), az_ = 1.0 - 2.0 * (x * x + y * y);      // R (0, 0, 1)
+        const double az = atan2(ax, az_), el = asin(std::max(-1.0, std::min(1.0, ay)));
+        if (i) { double d = az - az0; while (d > M_PI) d -= 2.0 * M_PI; while (d < -M_PI) d += 2.0 * M_PI; path_az += fabs(d); path_el += fabs(el - el0); }
+        az0 = az; el0 = el;
+    }
+    *path_az_out = path_az; *path_el_out = path_el;
+    return true;
+}
+
 emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
 {
     *perm = nullptr;
@@ -2229,15 +2296,8 @@ emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
     if (c->solve_perm_mode == 0 || P < 4 * (size_t)kSyrkSlicePix || (c->solve_perm_mode < 0 && 3 * c->K < 384) || 3 * c->K < 256) return EMBA_OK;
     if (c->perm_valid) { *perm = c->d_perm; return EMBA_OK; }
     if (c->solve_perm_mode < 0) {
-        if (!c->h_knots || c->K < 2) return EMBA_OK;
-        double path_az = 0.0, path_el = 0.0, az0 = 0.0, el0 = 0.0;
-        for (int i = 0; i < c->K; ++i) {
-            const double x = c->h_knots[4 * i], y = c->h_knots[4 * i + 1], z = c->h_knots[4 * i + 2], w = c->h_knots[4 * i + 3];
-            const double ax = 2.0 * (x * z + w * y), ay = 2.0 * (y * z - w * x), az_ = 1.0 - 2.0 * (x * x + y * y);      // R (0, 0, 1)
-            const double az = atan2(ax, az_), el = asin(std::max(-1.0, std::min(1.0, ay)));
-            if (i) { double d = az - az0; while (d > M_PI) d -= 2.0 * M_PI; while (d < -M_PI) d += 2.0 * M_PI; path_az += fabs(d); path_el += fabs(el - el0); }
-            az0 = az; el0 = el;
-        }
+        double path_az = 0.0, path_el = 0.0;
+        if (!axis_path(c, &path_az, &path_el)) return EMBA_OK;
         if (path_az < path_el) return EMBA_OK;      // mostly tilting: a panorama row is the better slice already
     }
     hipStream_t s = c->stream;

@@ -312,6 +312,13 @@ struct SyrkParams {
     // the column slices (2 * kSyrkSlicePix columns each) in which BOTH of its 64-row blocks have non-zeros
     const uint32_t* list; const uint32_t* count; int n_slices;
     const uint16_t* range;   // per PAIR of columns (one pixel): the 16-row groups [lo, hi] = (r & 255, r >> 8) that hold data; everything else of those columns reads as zero.  nullptr: all rows
+    // ITEM form (round 5; items != nullptr, 1-D grid): one workgroup per (block pair, CHUNK of item_chunk consecutive slices) that holds at least one product, the
+    // items in CHUNK-MAJOR order — the workgroups in flight at any time work on neighbouring slices, so the operand blocks the pairs of a slice share (each is read by
+    // every pair of its band: B^2 block reads per slice for B blocks of data) are re-read while they are still in the Infinity Cache instead of from HBM at random
+    // times of the launch.  Every item writes its 64 x 64 partial to slab[item]; emba_syrk_item_reduce_kernel sums a pair's items.
+    // (Measured and dropped on the way: contiguous slice ranges per part with all pairs of a part on one XCD — with U's columns in panorama-column order a range of
+    // slices is a time window, only the ~10 pairs of its band have work and the other 45 workgroups of the part idle: SYRK 1.22 -> 4.65 ms at config 2's shape.)
+    const uint32_t* items; const uint32_t* n_items; const unsigned long long* slice_mask; int item_chunk; uint32_t item_cap;
 };
 
 // per block pair (I >= J) the slices whose columns touch both row blocks: one wave per pair, ballot-compacted
@@ -350,7 +357,24 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int el = lane & 15, kk = lane >> 4;
     int I, J;
-    syrk_block_pair(blockIdx.x, I, J);
+    __shared__ uint8_t s_vs[64];             // item form: the chunk's slices that hold a product of this pair, in order
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    uint32_t item_chunk_idx = 0; int item_ns = 0;
+    if (p.items) {
+        if (blockIdx.x >= p.n_items[0]) return;                               // (block-uniform; the grid is an upper bound)
+        const uint32_t it = p.items[blockIdx.x];
+        bx = it & 0xFFFFu; item_chunk_idx = it >> 16; by = 0;
+    }
+    syrk_block_pair((int)bx, I, J);
+    if (p.items) {
+        const unsigned long long need = (1ull << (I & 63)) | (1ull << (J & 63));
+        const long sl = (long)item_chunk_idx * p.item_chunk + lane;
+        const bool v = lane < p.item_chunk && sl < p.n_slices && (p.slice_mask[sl] & need) == need;
+        const unsigned long long vm = __ballot(v);
+        if (wv == 0 && v) s_vs[__popcll(vm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+        item_ns = (int)__popcll(vm);
+        __syncthreads();
+    }
     const int I0 = 64 * I, J0 = 64 * J;
     double4_t acc[4][4];
 #pragma unroll
@@ -362,19 +386,22 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     // (all of it scalar: wave-uniform).
     constexpr int kQuadsPerSlice = 2 * kSyrkSlicePix / 16;
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    const uint32_t cnt = p.list ? p.count[blockIdx.x] : 0u;
-    const uint32_t* lst = p.list ? p.list + (size_t)blockIdx.x * p.n_slices : nullptr;
+    const uint32_t cnt = p.list ? p.count[bx] : 0u;
+    const uint32_t* lst = p.list ? p.list + (size_t)bx * p.n_slices : nullptr;
     const long kslice = ((p.k + gridDim.y - 1) / gridDim.y + 3) / 4 * 4;
-    const long dkb = (long)blockIdx.y * kslice, dke = (dkb + kslice < p.k) ? dkb + kslice : p.k;
+    const long dkb = (long)by * kslice, dke = (dkb + kslice < p.k) ? dkb + kslice : p.k;
+    uint32_t l0 = by, lstep = gridDim.y;       // block-sparse: the block's entries of its pair's list are l0, l0 + lstep, ... (strided parts), or a contiguous piece of it
     int nq;
-    if (p.list) nq = (cnt > blockIdx.y) ? (int)((cnt - blockIdx.y + gridDim.y - 1) / gridDim.y) * kQuadsPerSlice : 0;
+    if (p.items) nq = item_ns * kQuadsPerSlice;
+    else if (p.list) nq = (cnt > by) ? (int)((cnt - by + gridDim.y - 1) / gridDim.y) * kQuadsPerSlice : 0;
     else { const long span = dke - dkb - 4 * wvs; nq = span > 0 ? (int)((span + 15) / 16) : 0; }
     auto quad = [&](int it) -> long {
         if (it >= nq) return -1;
-        if (p.list) return (long)lst[blockIdx.y + (uint32_t)(it / kQuadsPerSlice) * gridDim.y] * (2 * kSyrkSlicePix) + 16 * (it % kQuadsPerSlice) + 4 * wvs;
+        if (p.items) return ((long)item_chunk_idx * p.item_chunk + s_vs[it / kQuadsPerSlice]) * (2 * kSyrkSlicePix) + 16 * (it % kQuadsPerSlice) + 4 * wvs;
+        if (p.list) return (long)lst[l0 + (uint32_t)(it / kQuadsPerSlice) * lstep] * (2 * kSyrkSlicePix) + 16 * (it % kQuadsPerSlice) + 4 * wvs;
         return dkb + 16L * it + 4 * wvs;
     };
-    const long kend = p.list ? p.k : dke;
+    const long kend = (p.list || p.items) ? p.k : dke;
     // Operand loads are UNCONDITIONAL (clamped addresses, zeros selected afterwards) and run TWO quads ahead of the MFMAs through three
     // register buffers used round-robin: a wave's 16 MFMAs per quad are 1024 matrix-pipe cycles, two waves share a SIMD, so two quads in
     // flight cover ~2 us of load latency.  (Before: load, wait, 16 MFMAs, next load — 26 TFLOP/s dense, 9 block-sparse.)
@@ -456,9 +483,101 @@ __global__ __launch_bounds__(256) void emba_syrk_kernel(SyrkParams p)
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int row = I0 + (i & 63), colg = J0 + (i >> 6);
-        if (p.direct) { if (row < p.n && colg < p.n && row >= colg) p.C[(size_t)p.ldc * colg + row] -= s_tile[i]; }
-        else p.slab[((size_t)blockIdx.y * p.nbp + blockIdx.x) * 4096 + i] = s_tile[i];
+        if (p.items) {
+            if (blockIdx.x < p.item_cap) p.slab[(size_t)blockIdx.x * 4096 + i] = s_tile[i];
+            else if (row < p.n && colg < p.n && row >= colg && s_tile[i] != 0.0) atomicAdd(&p.C[(size_t)p.ldc * colg + row], -s_tile[i]);      // (more items than slabs: never at the sizes measured)
+        }
+        else if (p.direct) { if (row < p.n && colg < p.n && row >= colg) p.C[(size_t)p.ldc * colg + row] -= s_tile[i]; }
+        else p.slab[((size_t)by * p.nbp + bx) * 4096 + i] = s_tile[i];
     }
+}
+
+// ---- the ITEM form's lists ----------------------------------------------------------------------------------------------------------------
+// (1) flags: one workgroup per chunk, its threads over the block pairs — does chunk c hold a product of pair bp?  Then one thread per pair turns its flags
+// into ordinals: ord[c * nbp + bp] = the pair's k-th item (k = 0, 1, ...), -1 elsewhere.  (As ONE kernel — a thread per pair walking chunks x slices — this
+// took 418 us at config 2's shape.)
+__global__ __launch_bounds__(256) void emba_syrk_item_flag_kernel(const unsigned long long* __restrict__ slice_mask, int n_slices, int nbp, int chunk, int32_t* __restrict__ ord)
+{
+    __shared__ unsigned long long s_m[64];
+    const int c = blockIdx.x;
+    const int s0 = c * chunk, ns = min(chunk, n_slices - s0);
+    if ((int)threadIdx.x < ns) s_m[threadIdx.x] = slice_mask[s0 + threadIdx.x];
+    __syncthreads();
+    for (int bp = threadIdx.x; bp < nbp; bp += blockDim.x) {
+        int I, J;
+        syrk_block_pair(bp, I, J);
+        const unsigned long long need = (1ull << (I & 63)) | (1ull << (J & 63));
+        bool any = false;
+        for (int k = 0; k < ns; ++k) any = any || ((s_m[k] & need) == need);
+        ord[(size_t)c * nbp + bp] = any ? 1 : -1;
+    }
+}
+__global__ void emba_syrk_item_ord_kernel(int nbp, int n_chunks, int32_t* __restrict__ ord, uint32_t* __restrict__ pair_cnt)
+{
+    const int bp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bp >= nbp) return;
+    int k = 0;
+    for (int c = 0; c < n_chunks; ++c) {
+        const size_t f = (size_t)c * nbp + bp;
+        const bool any = ord[f] > 0;
+        ord[f] = any ? k : -1;
+        k += any ? 1 : 0;
+    }
+    pair_cnt[bp] = (uint32_t)k;
+}
+// (2) ordered compaction in chunk-major order (one workgroup): items[j] = pair | chunk << 16, pair_items[bp * n_chunks + k] = j, n_items
+__global__ __launch_bounds__(1024) void emba_syrk_item_list_kernel(const int32_t* __restrict__ ord, int nbp, int n_chunks, uint32_t* __restrict__ items, uint32_t* __restrict__ pair_items,
+                                                                   uint32_t* __restrict__ n_items)
+{
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_base;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    const long total = (long)nbp * n_chunks;
+    for (long f0 = 0; f0 < total; f0 += 1024) {
+        const long f = f0 + t;
+        const int32_t k = f < total ? ord[f] : -1;
+        const bool v = k >= 0;
+        const unsigned long long m = __ballot(v);
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_w[w];
+        if (v) {
+            const uint32_t j = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t bp = (uint32_t)(f % nbp), c = (uint32_t)(f / nbp);
+            items[j] = bp | (c << 16);
+            pair_items[(size_t)bp * n_chunks + k] = j;
+        }
+        __syncthreads();
+        if (t == 0) { uint32_t tot = 0; for (int w = 0; w < 16; ++w) tot += s_w[w]; s_base += tot; }
+        __syncthreads();
+    }
+    if (t == 0) n_items[0] = s_base;
+}
+// (3) C -= the sum of a pair's item slabs
+__global__ void emba_syrk_item_reduce_kernel(const double* __restrict__ slab, const uint32_t* __restrict__ pair_items, const uint32_t* __restrict__ pair_cnt, int n_chunks,
+                                             uint32_t item_cap, int nbp, int n, double* __restrict__ C, long ldc)
+{
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)nbp * 4096) return;
+    const int bp = (int)(idx >> 12), i = (int)(idx & 4095);
+    int I, J;
+    syrk_block_pair(bp, I, J);
+    const int row = 64 * I + (i & 63), col = 64 * J + (i >> 6);
+    if (row >= n || col >= n || row < col) return;
+    const uint32_t cnt = pair_cnt[bp];
+    const uint32_t* lst = pair_items + (size_t)bp * n_chunks;
+    double a0 = 0.0, a1 = 0.0;
+    uint32_t k = 0;
+    for (; k + 1 < cnt; k += 2) {
+        const uint32_t j0 = lst[k], j1 = lst[k + 1];
+        if (j0 < item_cap) a0 += slab[(size_t)j0 * 4096 + i];
+        if (j1 < item_cap) a1 += slab[(size_t)j1 * 4096 + i];
+    }
+    if (k < cnt) { const uint32_t j0 = lst[k]; if (j0 < item_cap) a0 += slab[(size_t)j0 * 4096 + i]; }
+    C[(size_t)ldc * col + row] -= a0 + a1;
 }
 
 // C -= sum over the split-K slabs.  blockIdx.y takes a group of kSyrkReduceGroup slabs, so the reduction of a small matrix

@@ -12,6 +12,9 @@ if os.environ.get("SOLVE_CONFIGS"):
 for n, ph, K, dt in CONFIGS:
     w = make_workload(n_events=n, pano_h=ph, K=K, dt_knots=dt)
     m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h)
+    for kv in os.environ.get("SOLVE_OPTS", "").split(","):      # e.g. SOLVE_OPTS=syrk_xcd=1 (emba_set_option)
+        if "=" in kv:
+            m.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     m.set_events(w.events); m.upload_map(w.Gx, w.Gy)
     ts, tv = [], []
     for it in range(6):

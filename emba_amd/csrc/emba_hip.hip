@@ -110,6 +110,7 @@ struct emba_ctx {
     int segpose_mode = 0;      // option segpose (A/B; 0 auto = yes, 1 no, 2 yes): pixel order evaluates the pose per event from segment records (default: yes)
     bool segpose = false;      // ... in the current evaluation
     bool chunks_lpt = false;   // the chunk list is sorted longest first and walked in grid order (no XCD-contiguous remapping)
+    double order_per_px = 0.0, order_lead_frac = 0.0;   // what the last order decision saw (diagnostics: emba_last_order_stats)
     bool tile_order = false; int order_mode = 0;   // option order: 0 auto, 1 pixel, 2 tile
     size_t n_lead = 0;                             // lead-in copies the tile order added
     int64_t* d_batch_t = nullptr; double* d_pose = nullptr;   // pose table: 112 B per batch (pixel order; the tile order only uses it to predict the bins)
@@ -389,7 +390,11 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // — every entry of the tile order is a warp, lead-ins included, and a workgroup's LDS tile is zeroed and flushed for a handful of groups).
         // (round 3, with at least 5 groups per wave and chunk: 2 M events 220 vs 246 us per step, 1.5 M 188 vs 155 — the pixel order falls off a cliff
         // between 1.5 M and 2 M events, where its 128-B records stop fitting the 256-MB Infinity Cache)
-        tile = (c->order_mode == 2) || (c->n_used >= 2000000 && per_px >= 8.0 && lead_frac <= 0.35);
+        // (round 5: a slow pan over a big sensor — the city shape at 0.1 rad/s: 10 M events on 640x480, 50 events per panorama pixel, 40 % lead-ins — is
+        // atomic-request bound in pixel order (7.3 M requests on 155 k lines); the tile order's LDS sums win there in spite of the extra entries: step 867 vs
+        // 946-995 us.  Hence the second clause: very dense tiles tolerate more lead-ins.)
+        tile = (c->order_mode == 2) || (c->n_used >= 2000000 && per_px >= 8.0 && (lead_frac <= 0.35 || (per_px >= 24.0 && lead_frac <= 0.5)));
+        c->order_per_px = per_px; c->order_lead_frac = lead_frac;
     }
 
     if (!tile) {
@@ -930,6 +935,14 @@ emba_status emba_last_setup_ms(const emba_ctx* c, double* set_events_ms, double*
     if (tile_order) *tile_order = c->tile_order ? 1 : 0;
     if (n_entries) *n_entries = c->n_sorted;
     if (n_chunks) *n_chunks = (size_t)c->n_chunks;
+    return EMBA_OK;
+}
+
+emba_status emba_last_order_stats(const emba_ctx* c, double* events_per_pano_px, double* lead_in_frac)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    if (events_per_pano_px) *events_per_pano_px = c->order_per_px;
+    if (lead_in_frac) *lead_in_frac = c->order_lead_frac;
     return EMBA_OK;
 }
 

@@ -132,7 +132,10 @@ class LEGM:
         t = C.c_int32(0)
         ne, nc = C.c_size_t(0), C.c_size_t(0)
         self._check(self._L.emba_last_setup_ms(self._ctx, C.byref(a), C.byref(b), C.byref(t), C.byref(ne), C.byref(nc)))
-        return dict(set_events_ms=a.value, prepare_ms=b.value, tile_order=bool(t.value), entries=ne.value, chunks=nc.value)
+        pp, lf = C.c_double(0), C.c_double(0)
+        self._check(self._L.emba_last_order_stats(self._ctx, C.byref(pp), C.byref(lf)))
+        return dict(set_events_ms=a.value, prepare_ms=b.value, tile_order=bool(t.value), entries=ne.value, chunks=nc.value,
+                    events_per_pano_px=round(pp.value, 2), lead_in_frac=round(lf.value, 3))
 
     def tile_drift(self):
         """(inliers of the last resolved evaluation outside their tile, times the window was re-binned): emba_last_tile_drift."""

@@ -109,6 +109,10 @@ emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint
 emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
                                size_t* n_entries, size_t* n_chunks);
 
+/* What the last pixel / tile order decision of a window saw (at its first evaluation): events per panorama pixel of the occupied 32 x 8-px tiles under the
+ * first trajectory, and the fraction of lead-in copies the tile order would add.  Diagnostics; either pointer may be NULL. */
+emba_status emba_last_order_stats(const emba_ctx* ctx, double* events_per_pano_px, double* lead_in_frac);
+
 /* Tile order only: inliers of the last resolved evaluation that the tiled kernel found outside their tile (+ margin) — the
  * trajectory has moved them since the order was built; they are handled correctly, one HBM atomic each — and how many times this
  * context has rebuilt the order of a window for that reason (done at the next evaluation once a fifth of the inliers are outside).

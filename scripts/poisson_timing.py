@@ -1,5 +1,5 @@
 """f3 timing: emba_reconstruct_intensity on the resident map (no host copies in the timed region), default path (Fourier analysis along H + tridiagonal
-solves along W) and EMBA_POISSON=dense (four sine-matrix GEMMs), with the error against the numpy/scipy oracle."""
+solves along W) and, with `dense` as argument, option poisson = 1 (four sine-matrix GEMMs), with the error against the numpy/scipy oracle."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,10 +7,11 @@ from emba_amd import LEGM
 from emba_amd.synth import pinhole_bearing_lut
 from oracle import poisson as OP
 
-mode = os.environ.get("EMBA_POISSON", "default")
+mode = sys.argv[1] if len(sys.argv) > 1 else "default"
 for H in (75, 512, 1024, 2048):
     W = 2 * H
     m = LEGM(64, 48, pinhole_bearing_lut(64, 48, 60., 60., 32., 24.), 0.2, W, H)
+    m.set_option("poisson", {"default": 0, "dense": 1, "nofold": 2}[mode])
     rng = np.random.default_rng(0)
     Gx, Gy = rng.normal(size=(H, W)), rng.normal(size=(H, W))
     m.upload_map(Gx, Gy)

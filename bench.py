@@ -381,7 +381,7 @@ def main():
     # off (config.no_ep_ms_per_step: what rounds 1-4 reported as `value`), and, where the step does not produce ep itself (several ranks; windows too
     # long for the tail form), the step followed by the stand-alone compaction (config.with_ep_ms_per_step).
     with_ep_ms, no_ep_ms = None, None
-    ep_in_step = (world == 1 and not args.force_collectives and m.get_option("step_ep") == 1)
+    ep_in_step = (world == 1 and not args.force_collectives and m.get_option("step_ep") == 1 and m.get_option("ep_valid") == 1)
     if not args.no_with_ep:
         barrier()
         t_e = time.perf_counter()

@@ -139,6 +139,7 @@ struct emba_ctx {
     bool inl_idx_valid = false;   // the per-event inlier numbers are produced on demand (dumps, caller-supplied ep): 4 B/event the step does not write
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
+    bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
     int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
@@ -748,7 +749,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     CREATE_TRY(hipMalloc((void**)&c->d_rect, 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_rect)] = 4 * sizeof(int);
     { const int init[4] = {0x7FFFFFFF, 0x7FFFFFFF, -1, -1}; CREATE_TRY(hipMemcpy(c->d_rect, init, sizeof init, hipMemcpyHostToDevice)); }
     CREATE_TRY(hipMalloc((void**)&c->d_blk_rect, c->n_ablk * 4 * sizeof(int))); c->caps[reinterpret_cast<void**>(&c->d_blk_rect)] = c->n_ablk * 4 * sizeof(int);   // per active-count block: box of the touched pixels
-    CREATE_TRY(hipMalloc((void**)&c->d_total, 2 * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_total)] = 2 * sizeof(uint32_t);
+    CREATE_TRY(hipMalloc((void**)&c->d_total, 4 * sizeof(uint32_t))); c->caps[reinterpret_cast<void**>(&c->d_total)] = 4 * sizeof(uint32_t);   // [0] inliers [1] P [2] scratch total
     CREATE_TRY(hipMalloc((void**)&c->d_scalar, 2 * sizeof(double))); c->caps[reinterpret_cast<void**>(&c->d_scalar)] = 2 * sizeof(double);
     CREATE_TRY(hipHostMalloc((void**)&c->h_pinned, 64, hipHostMallocMapped));
     memset(c->h_pinned, 0, 64);
@@ -1198,7 +1199,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
     c->count_stamp = 0;      // (the warp kernels are about to mark the count map for a new evaluation)
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
     c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->inl_idx_valid = false;
-    c->ep_valid = false; c->ep_in_gram = false;
+    c->ep_valid = false; c->ep_in_gram = false; c->ep_after_gram = false;
     if (c->pix_dirty_all) {   // first use of these buffers: num_ev_map.setTo(0), model.cpp:85 (+ every per-pixel accumulator line)
         HIP_TRY(c, hipMemsetAsync(c->d_count, 0, c->npix * sizeof(int32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->d_pixacc, 0, c->npix * kPixAccStride * sizeof(double), s));
@@ -1385,7 +1386,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         c->aw_in_gram = false;
         // the residual vector ep of this evaluation: compacted by tail blocks of the Gram launch that follows (kernels.h: ep_tail_block) — launch A has just
         // left the per-block inlier-flag counts they need
-        c->ep_in_gram = c->step_wants_ep && c->n_cand && c->n_fblk <= kEpTailMaxFblk;
+        c->ep_in_gram = c->step_wants_ep && c->step_ep != 2 && c->n_cand && c->n_fblk <= kEpTailMaxFblk;
+        c->ep_after_gram = c->step_wants_ep && !c->ep_in_gram;
         if (lists && c->step_gather >= 2) { c->aw_saved = aw; c->aw_in_gram = true; }
         else if (lists) hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, aw);
         else hipLaunchKernelGGL(emba_active_write_kernel, dim3((unsigned)c->n_ablk), dim3(256), 0, s, aw);
@@ -1496,6 +1498,13 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         if (ep_tail) c->ep_valid = true;
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
+    if (c->ep_after_gram && !ep_host && c->n_pm) {      // the step's ep for a window too long for the tail form: launch A's per-block flag counts -> offsets -> compaction
+        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total + 2, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
+        hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off, (long)c->n_pm,
+                           c->d_ep, (int32_t*)nullptr);
+        c->ep_valid = true;
+    }
+    c->ep_after_gram = false;
     HIP_TRY(c, hipGetLastError());
     c->accum_done = true; c->finish_done = false;
     return EMBA_OK;
@@ -1869,7 +1878,7 @@ emba_status emba_set_cost(emba_ctx* c, int32_t irls, double eta)
 namespace {
 struct OptionRef { const char* name; int emba_ctx::*field; int lo, hi; };
 const OptionRef kOptions[] = {
-    {"step_ep", &emba_ctx::step_ep, 0, 1},
+    {"step_ep", &emba_ctx::step_ep, 0, 2},
     {"step_fast", &emba_ctx::step_fast, 0, 1},
     {"step_gather", &emba_ctx::step_gather, 0, 3},
     {"step_one_set", &emba_ctx::step_one_set, 0, 1},
@@ -1905,6 +1914,7 @@ emba_status emba_set_option(emba_ctx* c, const char* name, int32_t value)
 emba_status emba_get_option(emba_ctx* c, const char* name, int32_t* value)
 {
     if (!c || !name || !value) return EMBA_ERR_INVALID_ARG;
+    if (!strcmp(name, "ep_valid")) { *value = c->ep_valid ? 1 : 0; return EMBA_OK; }      // read-only: the device holds the last evaluation's ep (a step produced it, or a compaction)
     for (const OptionRef& o : kOptions)
         if (!strcmp(o.name, name)) { *value = c->*(o.field); return EMBA_OK; }
     return fail(c, EMBA_ERR_INVALID_ARG, "unknown option '%s'", name);

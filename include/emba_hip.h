@@ -345,7 +345,8 @@ emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
  *   texel          0 auto | 1 pack every texel | 2 3x3 stencil on the fly | 3 pack inside the previous footprint's rectangle
  *   segpose        0 auto (= 2) | 1 per-batch pose table in pixel order | 2 per-event pose from the K-1 segment records
  *   gram_tags      1 the pixel order's 8-B tag stream lets the Gram kernel skip dead slots | 0 decide from the records
- *   step_ep        1 emba_step compacts the residuals into ep (what evaluateDataError returns) in the tail of its Gram launch | 0 on demand only
+ *   step_ep        1 emba_step compacts the residuals into ep (what evaluateDataError returns): in the tail of its Gram launch, or for windows of more than
+ *                  8.4 M entries by a scan + a compaction launch behind it (2: that form always) | 0 on demand only.  (emba_get_option "ep_valid", read-only: the device holds ep)
  *   step_fast      1 emba_step zeroes the per-pixel sums behind their reader (no clearing pass) | 0 keeps the clearing pass
  *   step_gather    0 sweeping active-set write | 1 list-driven gather as a launch | 2 (default) inside the Gram kernel | 3 inside it at every size
  *   step_one_set   1 emba_step keeps one record set | 0 alternates between two like an LM loop

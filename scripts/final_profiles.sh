@@ -14,6 +14,7 @@ TAG=r05 timeout -k 10 500 bash scripts/solve_trace.sh > gpurun_out/solve_trace_r
 (timeout -k 10 400 python scripts/resident_host_timing.py; timeout -k 10 200 python scripts/resident_host_timing.py 1000000 1024 21 0.05 8) 2>&1 | grep -v amdgpu.ids > gpurun_out/profiles_r05/r05_resident_host_timing.txt; cat gpurun_out/profiles_r05/r05_resident_host_timing.txt
 fi
 if [ "${PART:-1}" = 2 ]; then
+P r05_city "--events-per-gpu 10000000 --knots 97 --sensor 640x480 --yaw-rate 0.1" 10
 P r05_3M "--events-per-gpu 3000000" 20
 P r05_5M "--events-per-gpu 5000000 --knots 97" 20
 P r05_shard5M "--events-per-gpu 5000000 --knots 97 --sensor 640x480 --shard-of 8 --shard-rank 3 --yaw-rate 0.1" 10

@@ -1012,7 +1012,12 @@ def test_resident_step_returns_ep_in_reference_order(gpu, oracle_mod, cfg, monke
     compare_normal_eq(m._finish(w.alpha, False), o["ne"])
     m.set_option("step_ep", 0)
     m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert m.get_option("ep_valid") == 0
     assert_close(m.get_ep(), o["ep"], "ep on demand")
+    m.set_option("step_ep", 2)                                    # the form windows of more than 8.4 M entries get: scan + compaction launches behind the Gram launch
+    m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert m.get_option("ep_valid") == 1
+    assert_close(m.get_ep(), o["ep"], "ep by the launches behind the Gram kernel")
     m.set_option("step_ep", 1)
     m.step(w.traj, w.thres_valid_pixel, w.alpha, "huber", 0.1)   # IRLS step: same residual vector (the weights are formNormalEq's)
     assert_close(m.get_ep(), o["ep"], "ep of an IRLS step")

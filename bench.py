@@ -223,6 +223,12 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
+    # ONE JSON line on stdout, whatever the libraries underneath print: RCCL writes a five-line version banner to STDOUT when its first communicator comes up
+    # (seen with --force-collectives, round 5).  From here on file descriptor 1 is the process's stderr; the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -536,7 +542,7 @@ def main():
                                  "SIMD, right behind the block — the clock the chip returns to when the load is light"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -2380,8 +2380,8 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)
-        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), 0, s, L.sorted, L.off, d_y,
-                           d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2);
+        hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), (size_t)n * sizeof(double), s, L.sorted, L.off, d_y,
+                           d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2, n);
     HIP_TRY(c, hipGetLastError());
     int info = 0;
     HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2507,8 +2507,8 @@ extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_
         RecView view{};       // the received records in pixel order, as emba_solve_shard_partial's build_lists left them
         view.rec = (const double*)c->ws[33].p; view.packed = 1; view.pix_base = 0;
         if (n_pix)
-            hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((n_pix + 3) / 4, 8192)), dim3(256), 0, s, view, (const uint32_t*)c->ws[0].p,
-                               d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo);
+            hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((n_pix + 3) / 4, 8192)), dim3(256), (size_t)n * sizeof(double), s, view, (const uint32_t*)c->ws[0].p,
+                               d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo, n);
     }
     HIP_TRY(c, hipGetLastError());
     int info = 0;

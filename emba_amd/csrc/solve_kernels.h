@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void emba_csr_fill_sorted_kernel(RecView v, lo
     reinterpret_cast<double2*>(out + (size_t)kRecStride * pos)[c8] = o;
 }
 
+// 1 / sqrt(d) for a positive, normal d: v_rsq_f64 (about 26 good bits) + two Newton steps.  The factorisation multiplies by it instead of
+// dividing by the square root: the pivot chain of a 64-column panel is 64 x (sqrt + divide) ~ 64 x 450 cycles otherwise, most of the kernel.
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h, y * y, 1.5);
+    y = y * fma(-h, y * y, 1.5);
+    return y;
+}
+
 // ---- U chunk: one wave per active pixel ---------------------------------------------------------------------------------
 // Column slices of the block-sparse SYRK: kSyrkSlicePix consecutive active pixels (ascending panorama index = a piece of a panorama row).
 // The control poses a pixel's measurements involve are those in view while the camera looks at it, so over a long window (config 2:
@@ -185,9 +196,14 @@ __global__ __launch_bounds__(64 * kBuildWaves) void emba_schur_build_kernel(Schu
         load_hdr(i + 2 * nwaves, h_nn);
         load_grp(h_nxt.b0, (int)(h_nxt.b1 - h_nxt.b0), 0, g_nxt);
         const double mxx = h_cur.q0 + p.lambda * h_cur.q0, mxy = h_cur.q1, myy = h_cur.q2 + p.lambda * h_cur.q2;   // model.cpp:748
-        const double c00 = sqrt(mxx), c10 = mxy / c00, c11 = sqrt(myy - c10 * c10);
-        if (!(mxx > 0.0) || !(myy - c10 * c10 > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
-        const double y0 = h_cur.q3 / c00, y1 = (h_cur.q4 - c10 * y0) / c11;
+        // 2x2 Cholesky by reciprocal square roots (v_rsq_f64 + two Newton steps, rsqrt_nr): two square roots, three divisions and two reciprocals per pixel were
+        // ~150 fp64 VALU instructions that every lane of the wave executed (round 5); the factor agrees with sqrt / divide to an ulp or two (x2 is compared at 1e-7)
+        const double rs0 = rsqrt_nr(mxx);
+        const double c00 = mxx * rs0, c10 = mxy * rs0, dd = myy - c10 * c10;
+        const double rs1 = rsqrt_nr(dd);
+        const double c11 = dd * rs1;
+        if (!(mxx > 0.0) || !(dd > 0.0)) { if (lane == 0) atomicOr(p.info, 1); }
+        const double y0 = h_cur.q3 * rs0, y1 = (h_cur.q4 - c10 * y0) * rs1;
         if (lane == 0) { const long k = h_cur.k; p.yv[2 * k] = y0; p.yv[2 * k + 1] = y1; p.cfac[3 * k] = c00; p.cfac[3 * k + 1] = c10; p.cfac[3 * k + 2] = c11; }
         const uint32_t b0 = h_cur.b0, b1 = h_cur.b1;
         unsigned long long rows_mask = 0ull;
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(64 * kBuildWaves) void emba_schur_build_kernel(Schu
         const int lo16 = (rmax >= 0) ? rmin >> 4 : 1, hi16 = (rmax >= 0) ? rmax >> 4 : 0;
         const int lo = (rmax >= 0) ? lo16 >> 2 : 1, hi = (rmax >= 0) ? hi16 >> 2 : 0;
         const int r0 = 64 * lo, r1 = (64 * (hi + 1) < p.n) ? 64 * (hi + 1) : p.n;
-        const double ic00 = 1.0 / c00, ic11 = 1.0 / c11;      // (reciprocals once per pixel: the band loop had two divisions per row)
+        const double ic00 = rs0, ic11 = rs1;      // (the reciprocals of the factor's diagonal: the band loop had two divisions per row)
         // U = A12 * C^-T :  u0 = a0/c00 ;  u1 = (a1 - a0*c10/c00)/c11 ;  and the block's share of U y (the right-hand side b1 - U y)
         double* u0 = p.U + (size_t)p.ldu * (2 * (i - p.p0));
         double* u1 = u0 + p.ldu;
@@ -601,17 +617,6 @@ __global__ void emba_syrk_reduce_kernel(const double* __restrict__ slab, int nks
 }
 
 // ---- blocked Cholesky (lower, column-major), panels of 64 ---------------------------------------------------------------
-// 1 / sqrt(d) for a positive, normal d: v_rsq_f64 (about 26 good bits) + two Newton steps.  The factorisation multiplies by it instead of
-// dividing by the square root: the pivot chain of a 64-column panel is 64 x (sqrt + divide) ~ 64 x 450 cycles otherwise, most of the kernel.
-__device__ __forceinline__ double rsqrt_nr(double d)
-{
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    y = y * fma(-h, y * y, 1.5);
-    y = y * fma(-h, y * y, 1.5);
-    return y;
-}
-
 // (1) factor the diagonal block.
 // The factorisation proper, by FOUR waves: every wave holds all 64 rows (lane r = row r) of 16 of the block's columns — wave w the columns 16w .. 16w+15 —,
 // the owner of column j scales it (pivot as rsqrt_nr) and puts it in LDS, one barrier, then every wave with columns right of j updates them from broadcast
@@ -878,8 +883,13 @@ __global__ __launch_bounds__(kTrsvThreads) void emba_chol_trsv_kernel(const doub
 // then z = C^-1 (A12_i^T x1)  (since U^T x1 = C^-1 A12^T x1)                                                       model.cpp:791
 __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view, const uint32_t* __restrict__ off,
                                                             const double* __restrict__ yv, const double* __restrict__ cfac,
-                                                            const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2)
+                                                            const double* __restrict__ x1, int irls, double eta, long P, double* __restrict__ x2, int n)
 {
+    // (round 5) x1 — 3K doubles — sits in LDS: a record's 12 products needed x1[row] by a gather that could only be issued once the record's pair key had
+    // arrived, a second dependent round trip per group of records
+    extern __shared__ double s_x1[];
+    for (int r = threadIdx.x; r < n; r += 256) s_x1[r] = x1[r];
+    __syncthreads();
     // (Round 4: prefetching the next pixel's first record group, as the U build does, made this kernel SLOWER — 374 -> 503 us at config 2's shape: at 56
     // VGPRs it runs eight waves per SIMD, which already overlap the pixels' round trips; the extra stage costs occupancy.)
     // One wave per pixel; the pixel's records are consecutive (emba_csr_fill_sorted_kernel), 16 of them in flight (lane l: element l&15 of record
@@ -911,7 +921,7 @@ __global__ __launch_bounds__(256) void emba_schur_x2_kernel(RecView view, const 
                 const bool in = base + 4 * u + kk < b1;
                 const double x = xv[u];
                 const int row = (el < 6) ? 3 * (int)(key[u] >> 16) + el : 3 * (int)(key[u] & 0xFFFFu) + el - 6;
-                double d = (in && el < 12) ? x * x1[row] : 0.0;
+                double d = (in && el < 12) ? x * s_x1[row] : 0.0;
                 // rotations inside the row: every lane ends with the whole dot product.  (NOT a shift-scan with the total handed to lanes 12 / 13 by
                 // two different shifts behind a select: the compiler turns that select into two branches with one DPP move in each, and a DPP
                 // move reads zero from lanes its branch has masked off)

@@ -140,7 +140,7 @@ struct emba_ctx {
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
     bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
-    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
+    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
@@ -154,6 +154,7 @@ struct emba_ctx {
     int K = 0;
     bool eval_launched = false, eval_done = false, active_done = false, accum_done = false;
     size_t n_inliers = 0, P = 0, pack_len = 0;
+    size_t P_prev = 0;                                      // active pixels of the last equations whose count the host has seen (this window): the Gram kernel's form is chosen by it
     bool compact_valid = false;   // d_compact matches the current active set (built on demand)
     int cost_irls = 0; double cost_eta = 0.0;   // robust cost declared with emba_set_cost: what the NEXT evaluation weights its per-pixel sums with
     int acc_irls = 0; double acc_eta = 0.0;     // ... and what the per-pixel sums of the LAST evaluation were weighted with
@@ -236,7 +237,7 @@ void dev_free(emba_ctx* c, T*& p)
 void free_window(emba_ctx* c)
 {   // (the buffers stay: the next window reuses them, see dev_alloc)
     c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
-    c->have_events = false; c->keys_ready = false; c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0;
+    c->have_events = false; c->keys_ready = false; c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0; c->P_prev = 0;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
 }
 
@@ -647,6 +648,7 @@ emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
     if (c->P_pending) {
         c->P_pending = false;
         c->P = (size_t)(uint32_t)c->h_pinned[2];
+        c->P_prev = c->P;
         c->pack_len = (size_t)9 * c->K * c->K + (size_t)3 * c->K + 5 * c->P;
         if (c->pack_len > c->pack_cap)
             return fail(c, EMBA_ERR_CAPACITY, "pack buffer too small: need %zu doubles, have %zu", c->pack_len, c->pack_cap);
@@ -1463,11 +1465,17 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         p.ablate = c->ablate;
         // slots per wave: whole rounds of one 16-wave block per CU with equal shares (1 M events: one round of 236 slots per wave),
         // between kGramChunkMin and kGramChunk slots
+        // Sparse slot streams (pixel order on a large panorama: most inliers fall on pixels that stay inactive): stages of 128 tags, only the live records fetched (180 -> 78 us at 10 M events on 2048 x 4096, K = 256).
+        // Which form: option gram_sparse (0 / 1), else by the LAST formed equations of this context — at least thres records per active pixel are live, and where
+        // 4 thres P is still below a quarter of the slots the stream is sparse (BASELINE: 5 x 68.6 k of 1 M slots = 0.34 -> dense; 10 M events on 2048 x 4096: 0.055)
+        const bool sparse = p.tag && (c->opt_gram_sparse == 1 || (c->opt_gram_sparse < 0 && c->P_prev > 0 && c->n_cand >= (2u << 20) && 16ull * (size_t)c->thres * c->P_prev < c->n_cand));
+        // (sparse form: up to four times the slots per wave — a wave's pipeline takes three stages to fill; option gram_sparse_chunk: 1 ... 8, no difference from 2 up)
+        const long chunk_cap = sparse ? (long)c->opt_gram_sparse_chunk * kGramChunk : kGramChunk;
         const long per_round = (long)c->n_cu * (kGramBlock / 64);
-        const long rounds = std::max<long>(1, ((long)c->n_cand + per_round * kGramChunk - 1) / (per_round * kGramChunk));
+        const long rounds = std::max<long>(1, ((long)c->n_cand + per_round * chunk_cap - 1) / (per_round * chunk_cap));
         long chunk = ((long)c->n_cand + per_round * rounds - 1) / (per_round * rounds);
         chunk = (chunk + 7) & ~7L;
-        chunk = std::min<long>(std::max<long>(chunk, kGramChunkMin), kGramChunk);
+        chunk = std::min<long>(std::max<long>(chunk, kGramChunkMin), chunk_cap);
         p.chunk = (int)chunk;
         const long waves = ((long)c->n_cand + chunk - 1) / chunk;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[2], s));
@@ -1487,7 +1495,10 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
             // 1288 vs 1047 at 40 M —, two are within noise of four or of the sweeping launch from 5 M events up: four wherever the lists are used)
             p.gather_waves = (gw_env == 1 || gw_env == 2 || gw_env == 4) ? gw_env : 4;
         }
-        if (p.tag) {
+        if (p.tag && sparse) {
+            if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_kernel<true, true, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
+            else hipLaunchKernelGGL((emba_gram_kernel<true, false, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
+        } else if (p.tag) {
             if (c->aw_in_gram) hipLaunchKernelGGL((emba_gram_kernel<true, true>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
             else hipLaunchKernelGGL((emba_gram_kernel<true, false>), dim3(grid), dim3(kGramBlock), 0, s, p, aw);
         } else {
@@ -1892,6 +1903,8 @@ const OptionRef kOptions[] = {
     {"solve_counts", &emba_ctx::opt_solve_counts, -1, 2},
     {"syrk_dense", &emba_ctx::opt_syrk_dense, 0, 1},
     {"syrk_lists", &emba_ctx::opt_syrk_lists, 0, 2},
+    {"gram_sparse", &emba_ctx::opt_gram_sparse, -1, 1},
+    {"gram_sparse_chunk", &emba_ctx::opt_gram_sparse_chunk, 1, 8},
     {"solve_debug", &emba_ctx::opt_solve_debug, 0, 1},
     {"poisson", &emba_ctx::opt_poisson, 0, 2},
     {"gemm64", &emba_ctx::opt_gemm64, 0, 1},

@@ -84,6 +84,9 @@ template <class T> __device__ __forceinline__ T stream_load(const T* p, bool nt)
 #ifndef GRAM_U
 #define GRAM_U 4
 #endif
+#ifndef GRAM_SPARSE_TS
+#define GRAM_SPARSE_TS 2         // sparse form: tag loads (64 slots each) per wave and stage.  10 M events on 2048 x 4096: 1: 97-102 us, 2: 77-79, 3: 79-81, 4: 93-110 (64 B of scratch), 8: 170
+#endif
 constexpr int kGramPad = 256;     // record slots allocated past the last one: the Gram kernel's stages read whole 8-record groups
 constexpr int kGramChunkMin = 64; // smallest share of record slots a wave of the Gram kernel is given
 constexpr int kGramChunk = 1024;   // most record slots a wave of the Gram (A11/b1) kernel is given (multiple of 8)
@@ -1667,7 +1670,7 @@ __device__ __forceinline__ uint32_t rec_elem15_hi(double2 v)
 // GATHER (the resident one-GPU step): every block first does its slice of the list-driven active-set write + A22 | b2 gather (active_gather_*): it
 // only depends on launch A of the post-warp pair, like the Gram sums, and as a prologue it costs three short round trips instead of a launch of
 // its own with a pass over the count map (round 4, 1 M events: 27.5 + 15 us -> 34.5 us).
-template <bool TAGS, int kGramBlock, bool GATHER>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order)
+template <bool TAGS, int kGramBlock, bool GATHER, bool SPARSE = false>   // TAGS: p.tag is the per-slot tag stream (pixel order); otherwise activity is decided from the records (tile order).  SPARSE (with TAGS): few slots live — stages of 128 tags, compacted
 __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_blk, const ActiveWriteParams& aw)
 {
     __shared__ uint32_t s_tag[kGramKeys];
@@ -1701,7 +1704,8 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     // separate streams 128 KB apart (4096 concurrent streams chip-wide cost DRAM page locality once the records exceed the
     // Infinity Cache).  Which wave sums which record is immaterial: everything of a pair meets in the block's LDS table.
     constexpr int U = TAGS ? GRAM_U : GRAM_U_NT;   // independent 1-KiB loads (8 records each) per wave and stage
-    constexpr int kStage = 8 * U;
+    constexpr int TS = GRAM_SPARSE_TS;             // SPARSE: tag loads (64 slots each) per wave and stage
+    constexpr int kStage = SPARSE ? 64 * TS : 8 * U;
     const int kStride = kSW * kStage;
     const long start = gram_blk * (kGramBlock / 64) * p.chunk;
     const long end = (start + (long)(kGramBlock / 64) * p.chunk < p.n_slots) ? start + (long)(kGramBlock / 64) * p.chunk : p.n_slots;
@@ -1813,6 +1817,131 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
             for (int v = 0; v + 1 < U; ++v) { y[v] = y[v + 1]; a_[v] = a_[v + 1]; }
         }
     };
+    if constexpr (TAGS && SPARSE) {
+        // SPARSE slot streams (10 M events on a 2048 x 4096 panorama in pixel order — 7 % of the slots live; the dense form gates ten million tags in
+        // stages of 32 to fetch two records per stage, one memory latency per stage: 177-181 us at 1.6 TB/s; this form: 77-79 us).  A stage is 64 TS = 128 slots: TS coalesced
+        // tag loads, TS activity gathers, TS ballots; the live slots' positions are compacted through a 128-byte LDS strip of the wave and only they are fetched — 8 U records
+        // per round, all of a stage's in one round while fewer than 1 slot in 4 is live (more: further rounds on the spot).  Per stage the dependent steps tags -> activity
+        // words -> records -> sums are spread over three iterations as in the dense form: while stage j-1 is summed, the records of stage j, the activity words of j+1 and
+        // the tags of j+2 are in flight.  The pair keys of a stage's first and last slot bound those of every record in it (slots are sorted by pair): same fast path.
+        __shared__ uint8_t s_pos[kGramBlock / 64][64 * TS];
+        uint8_t* pos = s_pos[threadIdx.x >> 6];
+        const double* tag0 = p.tag + start;
+        const int tag_lim = (int)((p.n_slots + kGramPad - 1 - start < (long)0x7FFFFFF0) ? (p.n_slots + kGramPad - 1 - start) : (long)0x7FFFFFF0);
+        typedef const uint32_t __attribute__((address_space(4))) * const_u32_ptr;
+        const_u32_ptr key_s = (const_u32_ptr)(uintptr_t)key0;
+        const double2* recm = reinterpret_cast<const double2*>(p.rec + (size_t)kRecStride * start) + m;      // + 8 s: piece m of the record in slot start + s
+        auto tags = [&](int off, double* T) {
+#pragma unroll
+            for (int t = 0; t < TS; ++t) { const int sidx = off + 64 * t + lane; T[t] = tag0[sidx < tag_lim ? sidx : tag_lim]; }
+        };
+        auto words = [&](int off, const double* T, uint32_t* S, uint32_t* W) {      // S: bit 5 = the tag is this evaluation's, bits 0-4 = its pixel's bit in the activity word
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                const uint32_t pi = (uint32_t)__double2loint(T[t]);
+                const bool valid = off + 64 * t + lane < len && (uint32_t)__double2hiint(T[t]) == p.stamp && pi != kInvalidPix;
+                S[t] = valid ? (32u | (pi & 31u)) : 0u;
+                W[t] = p.active_bits[valid ? (pi >> 5) : 0u];                       // (unconditional: a load under a lane mask is waited for at the end of its branch)
+            }
+        };
+        auto compact = [&](const uint32_t* S, const uint32_t* W) -> int {           // live slots of the stage -> pos[0 .. total)
+            int total = 0;
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                const bool live = (S[t] & 32u) && (((EMBA_ABL(p.ablate, 256) ? ~0u : W[t]) >> (S[t] & 31u)) & 1u);
+                const unsigned long long M = __ballot(live);
+                if (live) pos[total + __popcll(M & ((1ull << lane) - 1ull))] = (uint8_t)(64 * t + lane);
+                total += (int)__popcll(M);
+            }
+            return total;
+        };
+        auto fetch = [&](int off, int total, int round, double2* x, int* sidx) {    // records pos[8 U round ..) of the stage at off
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = 8 * U * round + 8 * u + R;
+                const bool v = q < total;
+                const int sl = off + (int)pos[v ? q : 0];
+                sidx[u] = v ? sl : -1;
+                x[u] = v ? recm[8 * (size_t)sl] : make_double2(0.0, 0.0);
+            }
+        };
+        auto consume_s = [&](double2* x, int* sidx) {
+            if ((k_first == cur_key) && (k_last == cur_key)) {             // fast path: the whole stage belongs to the current pair
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = sidx[u] >= 0;
+                    const double w = weight(x[u]);
+                    const double ax = ok ? w * x[u].x : 0.0, ay = ok ? w * x[u].y : 0.0, bx = ok ? x[u].x : 0.0, by = ok ? x[u].y : 0.0;
+                    if (__ballot(ok)) {
+                        dirty = true;
+                        if (!EMBA_ABL(p.ablate, 64)) {
+                            acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
+                            acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
+                            acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
+                        }
+                    }
+                }
+                return;
+            }
+            // the stage straddles a pair boundary: the records of each MFMA step grouped by pair (rolled loop, registers rotated; x and sidx are dead after this call)
+#pragma unroll 1
+            for (int u = 0; u < U; ++u) {
+                const bool in = sidx[0] >= 0;
+                const double w = weight(x[0]);
+                const uint32_t key = in ? key0[sidx[0]] : 0xFFFFFFFFu;
+                unsigned long long remaining = __ballot(in);
+                while (remaining) {
+                    const int first = __ffsll((long long)remaining) - 1;
+                    const uint32_t k0 = (uint32_t)__shfl((int)key, first);
+                    if (k0 != cur_key) {
+                        if (dirty) flush();
+                        cur_key = k0;
+                        dirty = false;
+                    }
+                    const bool mine = in && (key == k0);
+                    dirty = true;
+                    const double ax = mine ? w * x[0].x : 0.0, ay = mine ? w * x[0].y : 0.0, bx = mine ? x[0].x : 0.0, by = mine ? x[0].y : 0.0;
+                    if (!EMBA_ABL(p.ablate, 64)) {
+                        acc_ee = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc_ee, 0, 0, 0);
+                        acc_oe = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bx, acc_oe, 0, 0, 0);
+                        acc_oo = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, by, acc_oo, 0, 0, 0);
+                    }
+                    remaining &= ~__ballot(mine);
+                }
+#pragma unroll
+                for (int v = 0; v + 1 < U; ++v) { x[v] = x[v + 1]; sidx[v] = sidx[v + 1]; }
+            }
+        };
+        // iteration j (stage j at off): (a) the sums of stage j-1 — its first round is in xP, further rounds are fetched on the spot while its positions still stand —,
+        // (b) stage j's live slots compacted and its first round of records requested, (c) activity words of stage j+1, (d) tags of stage j+2
+        int totP = 0, offP = 0; uint32_t kfP = 0, klP = 0;
+        double T[TS];                                            // tags: of stage j+1 at the top of iteration j (one register set: read by words(), then reloaded)
+        auto iterate = [&](int off, double2* xP, int* sP, double2* xC, int* sC, const uint32_t* Sc, const uint32_t* Wc, uint32_t* Sn, uint32_t* Wn) {
+            if (totP > 0) {
+                k_first = kfP; k_last = klP;
+                consume_s(xP, sP);
+                for (int round = 1; 8 * U * round < totP; ++round) { fetch(offP, totP, round, xP, sP); consume_s(xP, sP); }
+            }
+            const int tot = (off < len) ? compact(Sc, Wc) : 0;
+            if (tot > 0) {
+                fetch(off, tot, 0, xC, sC);
+                kfP = key_s[off]; klP = key_s[(off + kStage < len ? off + kStage : len) - 1];
+            }
+            totP = tot; offP = off;
+            words(off + kStride, T, Sn, Wn);
+            tags(off + 2 * kStride, T);
+        };
+        uint32_t Sa[TS], Sb[TS], Wa[TS], Wb[TS];
+        double2 xA2[U], xB2[U]; int sA[U], sB[U];
+        tags(off0, T);
+        words(off0, T, Sa, Wa);
+        tags(off0 + kStride, T);
+        // stage j: S / W in (Sa, Wa) for even j, (Sb, Wb) for odd j; records of even stages in xA2, of odd stages in xB2.  One iteration past the last stage sums it.
+        for (int off = off0; off - kStride < len;) {
+            iterate(off, xB2, sB, xA2, sA, Sa, Wa, Sb, Wb); off += kStride; if (off - kStride >= len) break;
+            iterate(off, xA2, sA, xB2, sB, Sb, Wb, Sa, Wa); off += kStride;
+        }
+    } else
     if (TAGS) {
         // Tag stream: one 8-B word {panorama pixel, evaluation stamp} per slot, written by the warp kernels next to the record.  A stage
         // first reads its 32 tags (256 contiguous bytes), looks the activity bits up, and then fetches ONLY the records that take part
@@ -2040,11 +2169,11 @@ __device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
     for (int q = 0; q < 4; ++q) if (m & (1u << q)) p.ep_out[k++] = e[q];
 }
 
-template <bool TAGS, bool GATHER>
+template <bool TAGS, bool GATHER, bool SPARSE = false>
 __global__ __launch_bounds__(kGramBlock) void emba_gram_kernel(GramParams p, ActiveWriteParams aw)
 {
     if ((int)blockIdx.x >= p.n_gram_blocks) { ep_tail_block((long)blockIdx.x - p.n_gram_blocks, p); return; }      // (block-uniform)
-    gram_body<TAGS, kGramBlock, GATHER>(p, blockIdx.x, aw);
+    gram_body<TAGS, kGramBlock, GATHER, SPARSE>(p, blockIdx.x, aw);
 }
 
 // A22 / b2 from the records, for the weighted (IRLS) or caller-supplied-ep cases (model.cpp:599-636); the quadratic

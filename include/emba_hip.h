@@ -350,6 +350,8 @@ emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
  *   step_fast      1 emba_step zeroes the per-pixel sums behind their reader (no clearing pass) | 0 keeps the clearing pass
  *   step_gather    0 sweeping active-set write | 1 list-driven gather as a launch | 2 (default) inside the Gram kernel | 3 inside it at every size
  *   step_one_set   1 emba_step keeps one record set | 0 alternates between two like an LM loop
+ *   gram_sparse    -1 auto (by the active-pixel count of the window's last equations) | 0 | 1 the Gram kernel's form for slot streams with few live records (pixel
+ *                  order on a large panorama): stages of 128 tags, the live slots compacted, only their records fetched;  gram_sparse_chunk 1 ... 8 (4): its slots per wave, x 1024
  *   gather_waves   0 auto (4) | 1 | 2 | 4 waves of a Gram workgroup do its slice of the gather
  *   chunk_order_bin 0 tile-order chunks longest first | 1 in bin order
  *   solve_perm     -1 auto | 0 | 1 U's columns ordered by panorama column in the Schur solve

@@ -99,6 +99,36 @@ def test_normal_equations_parity(gpu, oracle_mod, cfg):
     print(cfg, errs)
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(n_events=20000),                                                                       # dense slots through the sparse form: several rounds of records per stage of 128 tags
+    dict(n_events=30000, pano_h=256, K=21, sensor=(64, 48), focal=60.0, dt_knots=0.01),         # many control-pose pairs: stages that straddle pair boundaries
+    dict(n_events=60000, pano_h=512, K=9, sensor=(64, 48), focal=120.0, thres_valid_pixel=6),   # a long focal length on a big panorama: few pixels reach the threshold — most slots dead
+    dict(n_events=8000, pano_h=64, K=4, sensor=(16, 12), focal=12.0),
+    "baseline",
+])
+@pytest.mark.parametrize("cost", [("quadratic", 0.0), ("huber", 0.1)])
+def test_gram_sums_from_a_sparse_slot_stream(gpu, oracle_mod, cfg, cost, monkeypatch):
+    """Round 5: the Gram kernel's form for slot streams with few live records (option gram_sparse = 1 forces it: stages of 128 tags, the live slots compacted
+    through LDS, only their records fetched) gives the A11 | b1 of the dense form's — against the oracle, through formNormalEq[IRLS] and through two resident steps (the
+    second chooses its form from the first one's active-pixel count when the option is left alone)."""
+    from emba_amd.synth import make_workload
+    monkeypatch.setitem(OPTIONS, "gram_sparse", 1)
+    monkeypatch.setitem(OPTIONS, "order", 1)                 # pixel order: the tag stream exists there
+    w = make_workload() if cfg == "baseline" else small_workload(**cfg)
+    irls = {"quadratic": 0, "huber": 1}[cost[0]]
+    g = gpu_run(w, cost_type=cost[0], a=cost[1])
+    o = oracle_run(oracle_mod, w, irls=irls, a=cost[1])
+    assert o["ne"]["P"] > 0
+    compare_normal_eq(g["ne"], o["ne"])
+    if irls == 0:
+        m = make_legm(w)
+        m.set_events(w.events); m.upload_map(w.Gx, w.Gy)
+        for it in range(2):
+            n_inl, P = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+            assert n_inl == o["ep"].size and P == o["ne"]["P"]
+            compare_normal_eq(m._finish(w.alpha, False), o["ne"])
+
+
 @pytest.mark.parametrize("cost_type,a,irls", [("huber", 0.1, 1), ("cauchy", 0.1, 2), ("cauchy", 5.0, 2), ("huber", 1e9, 1)])
 def test_irls_parity(gpu, oracle_mod, cost_type, a, irls):
     w = small_workload(n_events=20000)

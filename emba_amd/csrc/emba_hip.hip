@@ -1265,6 +1265,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         p.count = c->d_count; p.rec = c->d_rec; p.tag = (c->use_tags && !c->tile_order) ? c->d_tag : nullptr; p.e_sorted = c->d_e_sorted; p.flag = c->d_flag;
         p.err = c->d_err;
         p.ablate = c->ablate;
+        p.rec_nt = (c->tile_order || c->n_cand * (size_t)(kRecStride * 8) > ((size_t)144 << 20)) ? 1 : 0;      // (1 M slots = 128 MB: kept in the Infinity Cache for the Gram kernel)
         p.irls = c->cost_irls; p.eta = c->cost_eta;
         p.stamp = ++c->rec_stamp; c->set_stamp = p.stamp;
         p.marker = c->count_mark = count_marker(p.stamp);

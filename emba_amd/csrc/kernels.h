@@ -293,6 +293,7 @@ struct WarpParams {
     int32_t* count; double* pixacc; double* rec; double* tag; double* e_sorted; uint8_t* flag;   // tag: 8 B per record slot {pano pixel, stamp}, or nullptr
     int* err;   // the step's status word: bit 0 = a batch outside the knots; bits 1.. = inliers the tiled kernel found OUTSIDE their tile (drift of the trajectory since the order was built)
     double* d_pm; double* d_D; double* d_dp; double* d_Gpm; double* d_temp; int32_t* d_pm_int;  // DUMP only
+    int rec_nt;  // record stores non-temporal (windows whose records do not fit the Infinity Cache)
     int ablate;  // diagnostics only (EMBA_ABLATE): 1 no count marker, 2 no record store, 4 no texel gather, 8 no pixacc atomics
     int irls; double eta;   // robust cost the per-pixel sums are weighted with (0 quadratic: w = 1), model.cpp:599-636
     uint32_t stamp;         // evaluation number written into every record's tail word (see record_valid)
@@ -549,11 +550,10 @@ __device__ __forceinline__ void store_records(const WarpParams& p, int t, const 
                 typedef double v2d __attribute__((ext_vector_type(2)));
                 v2d* dst = reinterpret_cast<v2d*>(p.rec + (size_t)kRecStride * (EMBA_ABL(p.ablate, 32) ? (s_slot[rr] & 8191u) : s_slot[rr])) + c8;
                 const v2d val = reinterpret_cast<const v2d*>(s_tile + rr * kRecLds)[c8];
-#if REC_NT_STORE
-                __builtin_nontemporal_store(val, dst);
-#else
-                *dst = val;
-#endif
+                // (non-temporal where the window's records exceed the Infinity Cache; a small window's records — the BASELINE workload: 128 MB of slots, two sets — are
+                // the Gram kernel's cache hits a few microseconds later: 37.6-38.0 -> 35.3-35.8 us there)
+                if (REC_NT_STORE && p.rec_nt) __builtin_nontemporal_store(val, dst);
+                else *dst = val;
             }
         }
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the next stage overwrites it

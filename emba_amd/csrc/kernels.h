@@ -2350,6 +2350,55 @@ __global__ __launch_bounds__(256) void emba_reg_cost_kernel(const double* __rest
     if (threadIdx.x == 0) atomicAdd(out, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 
+// Both cost terms of a trial point in ONE launch, results straight to pinned host memory (round 5): blocks [0, nb_data) reduce the data term, the blocks behind them
+// the regulariser; every block adds its sum to acc[0 / 1] and takes a ticket; the block with the last ticket reads the two totals, writes {data, reg, error word} and then
+// the sequence number to the host (system-scope release: the host spins on it, as it does for a step's counts) and puts acc / ticket back to zero for the next call.
+// (Before: memset + two kernels + two 16-byte copies + a stream synchronise: ~60 us of a 570-us LM iteration at the BASELINE shape behind the evaluation it waits for.)
+struct CostsParams {
+    const double* e_sorted; const uint8_t* flag; long n_pm; int irls; double eta;
+    const double* Gx; const double* Gy; long npix; int nb_data, nb_reg;
+    double* acc; unsigned int* ticket; const int* err_dev;
+    double* host_out; int seq;       // host_out (pinned): [0] data sum, [1] reg sum, [2] error word (int), [3] sequence number (int)
+};
+__global__ __launch_bounds__(256) void emba_costs_kernel(CostsParams p)
+{
+    __shared__ double s_w[4];
+    __shared__ int s_last;
+    const bool reg = (int)blockIdx.x >= p.nb_data;
+    double acc = 0;
+    if (!reg) {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.n_pm; i += (long)p.nb_data * 256) {
+            if (!p.flag[i]) continue;
+            const double e = p.e_sorted[i];
+            if (p.irls == 0) acc += e * e;                                   // 0.5*ep.dot(ep), solver.cpp:88
+            else if (p.irls == 2) acc += log1p(p.eta * (e * e));               // model.cpp:283-290
+            else { const double a = fabs(e); acc += (a < p.eta) ? 0.5 * a * a : p.eta * a - 0.5 * p.eta * p.eta; }  // :294-312
+        }
+    } else {
+        for (long i = (long)((int)blockIdx.x - p.nb_data) * 256 + threadIdx.x; i < p.npix; i += (long)p.nb_reg * 256) {
+            const double a = p.Gx[i], b = p.Gy[i];
+            acc += a * a + b * b;                                          // model.cpp:260-277
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(p.acc + (reg ? 1 : 0), (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
+        __threadfence();
+        s_last = (atomicAdd(p.ticket, 1u) == gridDim.x - 1u) ? 1 : 0;
+        if (s_last) {
+            __threadfence();
+            const double d = atomicAdd(p.acc, 0.0), r = atomicAdd(p.acc + 1, 0.0);      // (read at the point of coherence: every other block's add precedes its ticket)
+            p.acc[0] = 0.0; p.acc[1] = 0.0; *p.ticket = 0u;                              // (the next call is ordered behind this kernel on the stream)
+            p.host_out[0] = d; p.host_out[1] = r;
+            reinterpret_cast<int*>(p.host_out + 2)[0] = p.err_dev[0];
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<int*>(p.host_out + 3), p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Measurement aids of bench.py: what an event bracket around NOTHING reads on this box, and the shader clock the chip
 // really runs at while it is busy.  Neither touches the product's data.

@@ -950,7 +950,7 @@ def test_costs_in_one_call(gpu, oracle_mod, cost):
     nem = np.zeros((w.pano_h, w.pano_w), dtype=np.int32)
     ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, w.events, True, nem)
     d, r = m.costs(cost[0], cost[1], w.alpha)
-    assert d == pytest.approx(m.dataCost(*cost), rel=1e-13) and r == pytest.approx(m.regCost(w.alpha), rel=1e-13)
+    assert d == pytest.approx(m.dataCost(*cost), rel=1e-12) and r == pytest.approx(m.regCost(w.alpha), rel=1e-12)      # (different reduction trees: the two forms use different grids)
     irls = {"quadratic": 0, "huber": 1, "cauchy": 2}[cost[0]]
     assert d == pytest.approx(oracle_mod.data_cost(ep, irls, cost[1]), rel=1e-10)
     assert r == pytest.approx(oracle_mod.reg_cost(w.Gx, w.Gy, w.alpha), rel=1e-12)

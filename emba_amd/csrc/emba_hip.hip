@@ -764,6 +764,7 @@ emba_status emba_create(const emba_cfg* cfg, emba_ctx** out)
     for (int i = 0; i < 2; ++i) CREATE_TRY(hipEventCreate(&c->cal_ev[i]));
     CREATE_TRY(hipMalloc((void**)&c->d_probe, 8 * sizeof(unsigned long long))); c->caps[reinterpret_cast<void**>(&c->d_probe)] = 8 * sizeof(unsigned long long);
     CREATE_TRY(hipEventCreateWithFlags(&c->knots_copied, hipEventDisableTiming));
+    CREATE_TRY(hipDeviceSynchronize());      // (the memsets above ran on the default stream, which does not order the context's non-blocking stream behind it)
 #undef CREATE_TRY
     *out = c;
     return EMBA_OK;

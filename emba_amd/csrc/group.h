@@ -313,6 +313,7 @@ emba_status group_ensure_buffers(emba_group* g, int K)
             G_HIP(g, hipMalloc((void**)&g->count[r], g->npix * sizeof(int32_t)));
             G_HIP(g, hipMalloc((void**)&g->count_u8[r], g->npix));
             G_HIP(g, hipMemset(g->count[r], 0, g->npix * sizeof(int32_t)));
+            G_HIP(g, hipDeviceSynchronize());      // (default stream: not ordered in front of the rank's non-blocking stream)
         }
         G_TRY(g, r, emba_bind_exchange_buffers(g->ctx[r], g->count[r], g->pack[r], need));
     }

@@ -141,7 +141,7 @@ struct emba_ctx {
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
     bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
-    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
+    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_syrk_min_cols = 512, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
@@ -1921,6 +1921,7 @@ const OptionRef kOptions[] = {
     {"syrk_lists", &emba_ctx::opt_syrk_lists, 0, 2},
     {"gram_sparse", &emba_ctx::opt_gram_sparse, -1, 1},
     {"gram_sparse_chunk", &emba_ctx::opt_gram_sparse_chunk, 1, 8},
+    {"syrk_min_cols", &emba_ctx::opt_syrk_min_cols, 64, 4096},
     {"solve_debug", &emba_ctx::opt_solve_debug, 0, 1},
     {"poisson", &emba_ctx::opt_poisson, 0, 2},
     {"gemm64", &emba_ctx::opt_gemm64, 0, 1},
@@ -2213,7 +2214,9 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         }
         bp.slice_mask = d_mask;
         hipLaunchKernelGGL(emba_schur_build_kernel, dim3((unsigned)std::min<size_t>((p1 - p0 + kBuildWaves - 1) / kBuildWaves, 4096)), dim3(64 * kBuildWaves), lds_bytes, s, bp);
-        int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / 512));   // ... but >= 512 columns each: a block pays a fixed LDS combine + 32-KB slab write
+        int nks = (int)std::max<long>(1, std::min<long>(nks_max, kc / c->opt_syrk_min_cols));   // ... but >= 512 columns each (option syrk_min_cols): a block pays a fixed LDS combine + 32-KB slab write
+        // ... and whole rounds of one block per CU: 268 blocks of 512 columns on 256 CUs (K = 21, 137 k columns) took 57 us, 255 blocks of 536 columns 44 us
+        if ((long)nbp * nks > c->n_cu) nks = (int)std::max<long>(1, ((long)nbp * nks / c->n_cu) * c->n_cu / nbp);
         SyrkParams sp{};
         sp.A = d_U; sp.lda = lds_; sp.n = n; sp.k = kc; sp.C = d_S; sp.ldc = lds_; sp.slab = d_slab; sp.nbp = nbp; sp.range = d_range;
         // Where it pays: a BANDED U — a pixel is in view for the fraction fov / (path of the optical axis over the window) of the control poses, and an operand block

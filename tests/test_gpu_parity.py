@@ -842,6 +842,13 @@ def test_randomised_soak(gpu, oracle_mod):
         tag = f"case {case}: {w.describe()} cost={cost} thres={thres} alpha={w.alpha}"
         if case < int(os.environ.get("EMBA_SOAK_FIRST", "0")):
             continue
+        # every third case in pixel order through the Gram kernel's sparse-stream form, every third in tile order (round 5; options change speed only)
+        OPTIONS.clear()
+        if case % 3 == 1:
+            OPTIONS.update(gram_sparse=1, order=1)
+        elif case % 3 == 2:
+            OPTIONS.update(order=2)
+        tag += f" options={dict(OPTIONS)}"
         try:
             o = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)
             g = gpu_run(w, cost_type=cost[0], a=cost[1])
@@ -892,6 +899,7 @@ def test_randomised_soak(gpu, oracle_mod):
             bad.append(f"{tag}: {e}")
         except Exception as e:   # noqa: BLE001 (a status from the library: reported with its case, the sweep goes on)
             bad.append(f"{tag}: {type(e).__name__}: {e}")
+    OPTIONS.clear()
     assert not bad, "\n".join(bad[:10])
 
 

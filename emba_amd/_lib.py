@@ -41,6 +41,7 @@ SIGNATURES = {
                                       C.c_size_t]),
     "emba_last_setup_ms": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _szp, _szp]),
     "emba_last_order_stats": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_last_tile_geometry": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "emba_last_tile_drift": (C.c_int, [C.c_void_p, _szp, _i32p]),
     "emba_event_counts": (C.c_int, [C.c_void_p, _szp, _szp]),
     "emba_eval_data_error": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, _dp, C.c_int32, _dp, _szp, _i32p]),

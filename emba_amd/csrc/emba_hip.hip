@@ -141,6 +141,8 @@ struct emba_ctx {
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
     bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
+    int opt_tile_reserve = 2, opt_tile_shape = -1, opt_tile_fine = -1, opt_tile_min_events = 1650000, opt_tile_chunk = 0;   // emba_set_option: the tile order's window rule (prepare_order)
+    int tile_shape = 0; bool tile_fine = false;   // ... and what the current order uses: index into kTileShapes, its finer pitch grid
     int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_syrk_min_cols = 512, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
@@ -240,6 +242,8 @@ void free_window(emba_ctx* c)
     c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
     c->have_events = false; c->keys_ready = false; c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0; c->P_prev = 0;
     c->eval_launched = c->eval_done = c->active_done = c->accum_done = false;
+    // (counters of the previous window that were never resolved must not be read as this window's)
+    c->inl_pending = c->P_pending = false; c->ep_deferred = false; c->ep_valid = false; c->inl_idx_valid = false; c->seq_armed = false;
 }
 
 void free_all_buffers(emba_ctx* c)
@@ -358,45 +362,97 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
 
     // ---- which order?  Tile order pays when many events share a panorama pixel (the per-pixel sums are then combined in LDS) and the
     // chains of a sensor pixel stay in a tile for a while (every tile entry costs one extra warp of the predecessor).
+    // Round 6: WHICH tile (order_kernels.h: the window rule).  The 1152-pixel LDS tile comes in four shapes (kernels.h: kTileShapes); every chain is cut into the
+    // longest segments that fit a tile of the shape on its pitch grid, and the shape with the fewest entries + chunks wins — a fast pan wants wide tiles, a
+    // trajectory that pitches wants tall ones (scripts/lead_in_sim.py: 5 M events over 4.8 s at 0.5 rad/s: 19.5 % lead-ins at 48 x 24, 11.5 % at 72 x 16).
     BinGeom g{};
-    g.W = c->W; g.H = c->H; g.bw = kTileW - 2 * kTileMargin; g.bh = kTileH - 2 * kTileMargin;
-    g.nbx = (c->W + g.bw - 1) / g.bw; g.nby = (c->H + g.bh - 1) / g.bh;
-    const size_t nbins = (size_t)g.nbx * g.nby + 1;
-    uint32_t *d_bin = nullptr, *d_emit = nullptr, *d_pos = nullptr; uint8_t* d_used = nullptr; unsigned long long* d_breaks = nullptr;
+    uint32_t *d_bin = nullptr, *d_emit = nullptr, *d_pos = nullptr, *d_pred = nullptr; uint8_t* d_used = nullptr; unsigned long long* d_breaks = nullptr;
     bool tile = false;
-    size_t n_break = 0, n_used_bins = 0;
+    size_t n_break = 0, n_used_bins = 0, nbins = 1;
     if (c->order_mode != 1 && ns && knots_host) {
+        const size_t max_bins = (size_t)((c->W + 7) / 8) * ((c->H + 1) / 2) + 1;      // (the finest pitch any candidate uses is 8 x 2)
         if ((st = ws_get(c, 20, ns * 4, (void**)&d_bin)) || (st = ws_get(c, 21, ns * 4, (void**)&d_emit)) || (st = ws_get(c, 22, ns * 4, (void**)&d_pos)) ||
-            (st = ws_get(c, 23, nbins + 8, (void**)&d_used)))
+            (st = ws_get(c, 23, max_bins + 8, (void**)&d_used)) || (st = ws_get(c, 29, ns * 4, (void**)&d_pred)))
             return st;
         d_breaks = reinterpret_cast<unsigned long long*>(d_err + 8);
-        HIP_TRY(c, hipMemsetAsync(d_used, 0, nbins, s));
-        HIP_TRY(c, hipMemsetAsync(d_breaks, 0, 8, s));
         // the poses the caller starts from (staged through the pinned buffer like every evaluation's)
         HIP_TRY(c, hipMemcpyAsync(c->d_knots, knots_host, (size_t)4 * K * sizeof(double), hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(emba_pose_kernel, dim3(nblocks(nbatch, 64)), dim3(64), 0, s, c->d_batch_t, (int)nbatch, c->d_knots, K, t0, dt, c->d_pose, c->d_err);
-        hipLaunchKernelGGL(emba_predict_bin_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, c->d_pm_batch, (long)ns, c->d_pose, kPoseStride, c->d_lut,
-                           c->fx, c->fy, c->cx, c->cy, g, d_bin, d_used);
-        hipLaunchKernelGGL(emba_expand_count_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, (long)ns, d_emit);
-        hipLaunchKernelGGL(emba_count_breaks_kernel, dim3((unsigned)std::min<size_t>(nblocks(ns), 1024)), dim3(256), 0, s, d_emit, (long)ns, d_breaks);
-        std::vector<uint8_t> h_used(nbins);
-        unsigned long long hb = 0;
-        HIP_TRY(c, hipMemcpyAsync(h_used.data(), d_used, nbins, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipMemcpyAsync(&hb, d_breaks, 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-        n_break = (size_t)hb;
-        for (size_t b = 0; b + 1 < nbins; ++b) n_used_bins += h_used[b];
-        const double per_px = n_used_bins ? (double)c->n_used / ((double)n_used_bins * g.bw * g.bh) : 0.0;     // events per panorama pixel of the occupied tiles
+        hipLaunchKernelGGL(emba_predict_pixel_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, c->d_pm_batch, (long)ns, c->d_pose, kPoseStride, c->d_lut,
+                           c->fx, c->fy, c->cx, c->cy, c->W, c->H, d_pred);
+        const int r = std::max(0, std::min(c->opt_tile_reserve, 5));
+        std::vector<uint8_t> h_used(max_bins);
+        auto geom = [&](int shape, bool fine) {
+            BinGeom q{};
+            const TileShape& ts = kTileShapes[shape];
+            q.W = c->W; q.H = c->H; q.tw = ts.tw; q.th = ts.th; q.r = r;
+            q.bw = fine ? ts.fine_pw : ts.pw; q.bh = fine ? ts.fine_ph : ts.ph;
+            q.bw = std::min(q.bw, ts.tw - 2 * r); q.bh = std::min(q.bh, ts.th - 2 * r);     // (a single pixel must fit wherever it lies in its pitch cell)
+            q.nbx = (c->W + q.bw - 1) / q.bw; q.nby = (c->H + q.bh - 1) / q.bh;
+            return q;
+        };
+        // lead-ins and occupied tiles of one candidate; leaves its assignment in d_bin / d_emit
+        auto evaluate = [&](const BinGeom& q, size_t* breaks, size_t* used) -> emba_status {
+            const size_t nb_ = (size_t)q.nbx * q.nby + 1;
+            HIP_TRY(c, hipMemsetAsync(d_used, 0, nb_, s));
+            HIP_TRY(c, hipMemsetAsync(d_breaks, 0, 8, s));
+            hipLaunchKernelGGL(emba_assign_tiles_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_pred, (long)ns, q, d_bin, d_used);
+            hipLaunchKernelGGL(emba_expand_count_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, (long)ns, d_emit);
+            hipLaunchKernelGGL(emba_count_breaks_kernel, dim3((unsigned)std::min<size_t>(nblocks(ns), 1024)), dim3(256), 0, s, d_emit, (long)ns, d_breaks);
+            unsigned long long hb = 0;
+            HIP_TRY(c, hipMemcpyAsync(h_used.data(), d_used, nb_, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipMemcpyAsync(&hb, d_breaks, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            *breaks = (size_t)hb; *used = 0;
+            for (size_t b = 0; b + 1 < nb_; ++b) *used += h_used[b];
+            return EMBA_OK;
+        };
+        // what a candidate costs the warp kernel, in entries: every lead-in is a full warp, every chunk zeroes and flushes an LDS tile (~ 256 entries' worth:
+        // 3 M events, round 3: 902 -> 2520 entries per chunk took the kernel from 191 to 174 us)
+        auto cost = [&](size_t breaks, size_t used) {
+            const double entries = (double)c->n_used + (double)breaks;
+            const double chunks = std::max((double)used, entries / (double)(kWarpNew * kTileWaves * 8));
+            return entries + 256.0 * chunks;
+        };
+        int best = -1; bool best_fine = false; double best_cost = 0; size_t best_breaks = 0, best_used = 0; int last = -1; bool last_fine = false;
+        // (the tall shape first, the others have to beat it by 2 %: at equal lead-ins 36 x 32 measured 3-5 % faster than 48 x 24 — 3 M events 155 vs 161 us, config 4's
+        // shard 245 vs 260, 2 M 111 vs 115, city 463 vs 465; profiles/r06_regime_sweep.txt)
+        static const int kShapeOrder[kNumTileShapes] = {3, 0, 1, 2};
+        for (int si = 0; si < kNumTileShapes; ++si) {
+            const int sh = kShapeOrder[si];
+            if (c->opt_tile_shape >= 0 && sh != c->opt_tile_shape) continue;
+            size_t br = 0, us = 0;
+            if ((st = evaluate(geom(sh, false), &br, &us))) return st;
+            last = sh; last_fine = false;
+            const double cc = cost(br, us);
+            if (best < 0 || cc < 0.98 * best_cost) { best = sh; best_fine = false; best_cost = cc; best_breaks = br; best_used = us; }
+        }
+        // dense tiles can afford a finer grid of tile origins (segments end closer to the tile's far edge, and a tile's entries spread over more chunks): config 4's
+        // shard (11.7 k entries per tile) 258 -> 229 us; at 3-5 k entries per tile it loses (3 M: 162 -> 173, 5 M: 236 -> 271)
+        if (best >= 0 && c->opt_tile_fine != 0 && (c->opt_tile_fine == 1 || (double)c->n_used / std::max<size_t>(best_used, 1) >= 2.0 * kWarpNew * kTileWaves * 8)) {
+            size_t br = 0, us = 0;
+            if ((st = evaluate(geom(best, true), &br, &us))) return st;
+            last_fine = true; last = best;
+            const double cc = cost(br, us);
+            if (cc < best_cost || c->opt_tile_fine == 1) { best_fine = true; best_cost = cc; best_breaks = br; best_used = us; }
+        }
+        if (best < 0) return fail(c, EMBA_ERR_INVALID_ARG, "option tile_shape %d: no such shape", c->opt_tile_shape);
+        g = geom(best, best_fine);
+        if (last != best || last_fine != best_fine) { size_t br = 0, us = 0; if ((st = evaluate(g, &br, &us))) return st; }   // d_bin / d_emit of the winner
+        c->tile_shape = best; c->tile_fine = best_fine;
+        nbins = (size_t)g.nbx * g.nby + 1;
+        n_break = best_breaks; n_used_bins = best_used;
+        const double per_px = n_used_bins ? (double)c->n_used / ((double)n_used_bins * g.bw * g.bh) : 0.0;     // events per panorama pixel of the occupied pitch cells
         const double lead_frac = c->n_used ? (double)n_break / (double)c->n_used : 1.0;
         // Measured (profiles/r02c_order_sweep.txt): the tile order wins once the working set has left the Infinity Cache (3 M events, 1024x2048:
         // 374 vs 394 us per step; 5 M / K=97: 558 vs 618; 100 M: 4.8 vs 8.7 ms warp) and loses below it (1 M events, 24 per pixel: 82 vs 52 us
         // — every entry of the tile order is a warp, lead-ins included, and a workgroup's LDS tile is zeroed and flushed for a handful of groups).
         // (round 3, with at least 5 groups per wave and chunk: 2 M events 220 vs 246 us per step, 1.5 M 188 vs 155 — the pixel order falls off a cliff
-        // between 1.5 M and 2 M events, where its 128-B records stop fitting the 256-MB Infinity Cache)
-        // (round 5: a slow pan over a big sensor — the city shape at 0.1 rad/s: 10 M events on 640x480, 50 events per panorama pixel, 40 % lead-ins — is
+        // between 1.5 M and 2 M events: twice the events on the same footprint are twice as close along a chain, nearly all of them inliers — 3 x the atomic requests)
+        // (round 5: a slow pan over a big sensor — the city shape at 0.1 rad/s: 10 M events on 640x480, 50 events per panorama pixel — is
         // atomic-request bound in pixel order (7.3 M requests on 155 k lines); the tile order's LDS sums win there in spite of the extra entries: step 867 vs
         // 946-995 us.  Hence the second clause: very dense tiles tolerate more lead-ins.)
-        tile = (c->order_mode == 2) || (c->n_used >= 2000000 && per_px >= 8.0 && (lead_frac <= 0.35 || (per_px >= 24.0 && lead_frac <= 0.5)));
+        tile = (c->order_mode == 2) || (c->n_used >= (size_t)c->opt_tile_min_events && per_px >= 8.0 && (lead_frac <= 0.35 || (per_px >= 24.0 && lead_frac <= 0.5)));
         c->order_per_px = per_px; c->order_lead_frac = lead_frac;
     }
 
@@ -435,8 +491,10 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         HIP_TRY(c, hipStreamSynchronize(s));
         std::vector<std::pair<uint32_t, uint32_t>> occ;   // (bin, start)
         for (size_t b = 0; b < nbins; ++b) if (h_start[b] != 0xFFFFFFFFu) occ.emplace_back((uint32_t)b, h_start[b]);
+        std::vector<ChunkDesc> h_chunks;
+        const size_t slots = (size_t)c->n_cu * 2;      // workgroups of the tiled kernel the chip holds at a time
+        {
         // chunk size: enough workgroups for ~8 rounds of the chip, at most 16 groups of 63 entries per wave
-        const size_t slots = (size_t)c->n_cu * 2;
         size_t chunk = (nd + slots * 8 - 1) / (slots * 8);
         // (at least 5 groups per wave: a workgroup zeroes and flushes its 55-KB LDS tile whatever it has to do — 3 M events: 902 -> 2520 entries per
         // chunk, warp kernel 191 -> 174 us; 5 M: 280 -> 271; from 10 M on the first rule gives more than that anyway)
@@ -444,15 +502,17 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // 5 M: 257 -> 242), 5 beyond (10 M: 8 groups 493 us, 5 groups 464 — there the first rule decides most chunks anyway)
         const size_t min_groups = nd < (size_t)8000000 ? 8 : 5;
         chunk = std::min<size_t>(std::max<size_t>(chunk, (size_t)kWarpNew * kTileWaves * min_groups), (size_t)kWarpNew * kTileWaves * 16);
-        std::vector<ChunkDesc> h_chunks;
+        if (c->opt_tile_chunk > 0) chunk = (size_t)c->opt_tile_chunk;
         for (size_t k = 0; k < occ.size(); ++k) {
             const uint32_t b = occ[k].first, b0 = occ[k].second, b1 = (k + 1 < occ.size()) ? occ[k + 1].second : (uint32_t)nd;
-            const size_t cnt = b1 - b0, nch = (cnt + chunk - 1) / chunk, per = (cnt + nch - 1) / nch;
+            // (pieces in whole ROUNDS of the workgroup's waves: a piece of G groups takes ceil(G / 8) rounds whatever it holds, so only a tile's last piece may be ragged)
+            constexpr size_t kRound = (size_t)kWarpNew * kTileWaves;
+            const size_t cnt = b1 - b0, nch = (cnt + chunk - 1) / chunk, per = ((cnt + nch - 1) / nch + kRound - 1) / kRound * kRound;
             const int bx = (int)(b % (uint32_t)g.nbx), by = (int)(b / (uint32_t)g.nbx);
             for (size_t q = 0; q < nch; ++q) {
                 ChunkDesc d;
                 d.begin = b0 + (uint32_t)(q * per); d.end = (uint32_t)std::min<size_t>(b0 + (q + 1) * per, b1);
-                d.x0 = bx * g.bw - kTileMargin; d.y0 = by * g.bh - kTileMargin;
+                d.x0 = bx * g.bw - g.r; d.y0 = by * g.bh - g.r;
                 if (d.begin < d.end) h_chunks.push_back(d);
             }
         }
@@ -461,6 +521,7 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // Option chunk_order_bin keeps the bins' order (neighbouring chunks on one XCD).
         c->chunks_lpt = !c->opt_chunk_order_bin;
         if (c->chunks_lpt) std::stable_sort(h_chunks.begin(), h_chunks.end(), [](const ChunkDesc& a, const ChunkDesc& b) { return a.end - a.begin > b.end - b.begin; });
+        }
         c->n_chunks = (long)h_chunks.size();
         if ((st = dev_alloc(c, &c->d_chunks, h_chunks.size()))) return st;
         HIP_TRY(c, hipMemcpyAsync(c->d_chunks, h_chunks.data(), h_chunks.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, s));
@@ -952,6 +1013,19 @@ emba_status emba_last_order_stats(const emba_ctx* c, double* events_per_pano_px,
     return EMBA_OK;
 }
 
+emba_status emba_last_tile_geometry(const emba_ctx* c, int32_t* tile_w, int32_t* tile_h, int32_t* pitch_x, int32_t* pitch_y, int32_t* reserve)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    const TileShape& ts = kTileShapes[c->tile_shape];
+    const int r = std::max(0, std::min(c->opt_tile_reserve, 5));
+    if (tile_w) *tile_w = ts.tw;
+    if (tile_h) *tile_h = ts.th;
+    if (pitch_x) *pitch_x = std::min(c->tile_fine ? ts.fine_pw : ts.pw, ts.tw - 2 * r);
+    if (pitch_y) *pitch_y = std::min(c->tile_fine ? ts.fine_ph : ts.ph, ts.th - 2 * r);
+    if (reserve) *reserve = r;
+    return EMBA_OK;
+}
+
 emba_status emba_event_counts(const emba_ctx* c, size_t* n_used, size_t* n_cand)
 {
     if (!c) return EMBA_ERR_INVALID_ARG;
@@ -1275,7 +1349,7 @@ emba_status emba_eval_launch(emba_ctx* c, const double* knots, int32_t K, int64_
         c->pixacc_clean = false; c->pixacc_consumed = false;
         p.chunks = c->d_chunks; p.n_chunks = c->n_chunks; p.chunks_linear = c->chunks_lpt ? 1 : 0;
         if (c->kernel_timing) HIP_TRY(c, hipEventRecord(c->kt[0], s));
-        if (c->tile_order) hipLaunchKernelGGL(emba_warp_tiled_kernel, dim3((unsigned)grid8(c->n_chunks)), dim3(kTileWaves * 64), 0, s, p);
+        if (c->tile_order) launch_warp_tiled(c->tile_shape, dim3((unsigned)grid8(c->n_chunks)), s, p);
         else if (c->segpose) hipLaunchKernelGGL((emba_warp_residual_kernel<false, false, true>), dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         else hipLaunchKernelGGL(emba_warp_residual_kernel<false>, dim3((unsigned)grid8(c->nblk)), dim3(kWarpBlock), 0, s, p);
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[1], s)); c->kt_warp_valid = true; c->kt_valid[c->kt_slot][0] = true; }
@@ -1633,7 +1707,7 @@ emba_status emba_compact_ep(emba_ctx* c)
 emba_status emba_get_ep(emba_ctx* c, double* ep_host, size_t cap, size_t* n_inliers)
 {
     if (!c || (!ep_host && cap)) return c ? fail(c, EMBA_ERR_INVALID_ARG, "ep_host NULL") : EMBA_ERR_INVALID_ARG;
-    if (!c->eval_done && !c->inl_pending && !c->ep_deferred) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    if (!c->eval_launched || (!c->eval_done && !c->inl_pending && !c->ep_deferred)) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
     HIP_TRY(c, hipSetDevice(c->device));
     emba_status st;
     if ((st = resolve_pending(c))) return st;
@@ -1916,6 +1990,11 @@ const OptionRef kOptions[] = {
     {"solve_perm", &emba_ctx::solve_perm_mode, -1, 1},
     {"gather_waves", &emba_ctx::opt_gather_waves, 0, 4},
     {"chunk_order_bin", &emba_ctx::opt_chunk_order_bin, 0, 1},
+    {"tile_reserve", &emba_ctx::opt_tile_reserve, 0, 5},
+    {"tile_shape", &emba_ctx::opt_tile_shape, -1, kNumTileShapes - 1},
+    {"tile_fine", &emba_ctx::opt_tile_fine, -1, 1},
+    {"tile_min_events", &emba_ctx::opt_tile_min_events, 0, 2000000000},
+    {"tile_chunk", &emba_ctx::opt_tile_chunk, 0, 1 << 20},
     {"solve_counts", &emba_ctx::opt_solve_counts, -1, 2},
     {"syrk_dense", &emba_ctx::opt_syrk_dense, 0, 1},
     {"syrk_lists", &emba_ctx::opt_syrk_lists, 0, 2},
@@ -1935,7 +2014,7 @@ emba_status emba_set_option(emba_ctx* c, const char* name, int32_t value)
         if (!strcmp(o.name, name)) {
             if (value < o.lo || value > o.hi) return fail(c, EMBA_ERR_INVALID_ARG, "option %s: %d outside [%d, %d]", name, (int)value, o.lo, o.hi);
             c->*(o.field) = (int)value;
-            if (!strcmp(name, "order") || !strcmp(name, "chunk_order_bin")) c->keys_ready = false;      // the device order is rebuilt at the next evaluation
+            if (!strcmp(name, "order") || !strcmp(name, "chunk_order_bin") || !strncmp(name, "tile_", 5)) c->keys_ready = false;      // the device order is rebuilt at the next evaluation
             return EMBA_OK;
         }
     return fail(c, EMBA_ERR_INVALID_ARG, "unknown option '%s'", name);

@@ -263,17 +263,17 @@ __global__ __launch_bounds__(256) void emba_texel_kernel(const double* __restric
 // ------------------------------------------------------------------------------------------------
 struct ChunkDesc { uint32_t begin, end; int32_t x0, y0; };   // entries [begin, end) of the device order; LDS tile origin (panorama px)
 
-#ifndef TILE_W
-#define TILE_W 48
-#define TILE_H 24
-#define TILE_MARGIN 8
-#endif
-constexpr int kTileW = TILE_W, kTileH = TILE_H;         // LDS accumulator tile: a 32 x 8 bin plus a margin of 8 px on every side.  Other shapes of the same 1152-px budget
-                                                        // (round 4, profiles/r04_tile_shape_sweep.txt): bins of 64x8, 48x12, 32x20 with a 4-px margin cut the lead-in copies at
-                                                        // 3 M events from 23 % to 21 / 16 / 14 % (the chains cross ROWS of bins more than columns) and change the warp kernel's
-                                                        // time by less than its run-to-run spread (153-158 us; 10 M: 459-502; 40 M: 1655-1717)
-constexpr int kTileMargin = TILE_MARGIN;
-constexpr int kTilePx = kTileW * kTileH;
+// LDS accumulator tile of the tiled kernel: 1152 panorama pixels x 6 doubles = 54 KB, two workgroups per CU.  Round 6: four shapes of that budget, one kernel
+// instantiation each; a window takes the shape that cuts its chains into the fewest segments (order_kernels.h: the window rule; emba_hip.hip: prepare_order).
+// {tile w, h, pitch of the tile-origin grid, its finer variant for very dense windows}
+struct TileShape { int tw, th, pw, ph, fine_pw, fine_ph; };
+constexpr int kNumTileShapes = 4;
+constexpr TileShape kTileShapes[kNumTileShapes] = {
+    {48, 24, 32, 8, 16, 4},      // the shape of rounds 2-5 (then: a 32 x 8 bin + 8 px of margin)
+    {72, 16, 48, 4, 24, 4},      // fast pans
+    {96, 12, 64, 4, 32, 2},
+    {36, 32, 24, 8, 12, 8},      // trajectories that pitch
+};
 #ifndef TILE_WAVES
 #define TILE_WAVES 8
 #endif
@@ -655,98 +655,115 @@ __global__ __launch_bounds__(kWarpBlock) WARP_OCC void emba_warp_residual_kernel
 }
 
 // Tile order: blockIdx -> chunk of one panorama bin's events (ChunkDesc).  The workgroup's waves take the chunk's 63-entry groups
-// round-robin; inlier measurements whose pixel lies inside the LDS tile (the bin plus kTileMargin pixels on every side: trial poses
+// round-robin; inlier measurements whose pixel lies inside the LDS tile (under the poses the order was built from: all of them, with a reserve of a few pixels on every side — trial poses
 // of an LM loop move events by a few pixels) add their six terms with LDS atomics, the few outside go to HBM directly; at the end
 // every touched pixel of the tile costs ONE atomic request to its 64-B accumulator line and one marker store.
+template <int kTileW, int kTileH>
 __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu(TILE_OCC, TILE_OCC))) void emba_warp_tiled_kernel(WarpParams p)
 {
+    constexpr int kTilePx = kTileW * kTileH;
     __shared__ double s_sum[6][kTilePx];                                                  // SoA: plane k = k-th term of every tile pixel
     __shared__ __attribute__((aligned(16))) double s_tile[kTileWaves][kTileRecStage * kRecLds];
     __shared__ uint32_t s_slot[kTileWaves][kTileRecStage];
     __shared__ uint16_t s_list[kTileWaves][64];
 
-    const long c = p.chunks_linear ? (long)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, t = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // One chunk per workgroup; the list is sorted longest first and walked in grid order (chunks_linear).  (Round 6 tried the other way round — the entry list, in
+    // tile order, cut into one EQUAL share per workgroup slot of the chip, a workgroup working through the pieces of tiles in its share: 2 M events 113 -> 145 us,
+    // 3 M 160 -> 194, city 495 -> 538: a piece of G groups takes ceil(G / 8) rounds of the workgroup's eight waves whatever its size, and with two or three pieces
+    // per share the slowest workgroup — the kernel's end — is the one whose pieces round worst; profiles/r06_share_form_sweep.txt.)
+    const long c = p.chunks_linear ? (long)blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if (c >= p.n_chunks) return;      // (block-uniform)
     for (int k = tid; k < 6 * kTilePx; k += kTileWaves * 64) (&s_sum[0][0])[k] = 0.0;
     __syncthreads();
-    if (c < p.n_chunks) {   // (block-uniform)
+    {
         const ChunkDesc ch = p.chunks[c];
-        const long begin = ch.begin, end = ch.end;
-        constexpr long kStep = (long)kWarpNew * kTileWaves;
-        // Software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter (vmcnt): waiting
-        // for a load means waiting for everything issued before it.  Each iteration therefore: (1) works on group g from registers
-        // — its waits are for its own bearing-vector / segment / texel gathers (cache hits), behind which nothing slow is queued;
-        // (2) once the texels are here issues the event words, spline parameters and record slots of group g+1 (HBM streams), which
-        // have the group's remaining arithmetic and LDS atomics to arrive; (3) waits for everything once and rotates the registers;
-        // (4) issues the record stores last.
-        // Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
-        LaneIn cur, nxt;
         {
-            const long g0 = begin + (long)kWarpNew * wv;
-            const long i0 = g0 + t - 1;
-            load_event_words<true>(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // (so that `cur` is known to be loaded on BOTH ways into the loop: see (3))
-        }
+            const long begin = ch.begin, end = ch.end;
+            constexpr long kStep = (long)kWarpNew * kTileWaves;
+            // Software pipeline over the wave's groups.  Loads, stores and atomics of a wave share ONE in-order counter (vmcnt): waiting
+            // for a load means waiting for everything issued before it.  Each iteration therefore: (1) works on group g from registers
+            // — its waits are for its own bearing-vector / segment / texel gathers (cache hits), behind which nothing slow is queued;
+            // (2) once the texels are here issues the event words, spline parameters and record slots of group g+1 (HBM streams), which
+            // have the group's remaining arithmetic and LDS atomics to arrive; (3) waits for everything once and rotates the registers;
+            // (4) issues the record stores last.
+            // Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
+            LaneIn cur, nxt;
+            {
+                const long g0 = begin + (long)kWarpNew * wv;
+                const long i0 = g0 + t - 1;
+                load_event_words<true>(p, i0, g0 < end && i0 >= 0 && i0 < end, cur);
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // (so that `cur` is known to be loaded on BOTH ways into the loop: see (3))
+            }
 #pragma unroll 1
-        for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += kStep) {   // wave-uniform
-            const long i = g0 + t - 1;
-            auto prefetch = [&]() { const long i1 = i + kStep; load_event_words<true>(p, i1, g0 + kStep < end && i1 < end, nxt); };
-            LaneOut o;
-            warp_lane<false, true>(p, i, cur, t, o, prefetch);
-            const unsigned long long inl_mask = __ballot(o.inl);
-            bool outside = false;
-            if (o.inl) {
-                const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
-                outside = !(lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH);
-                if (!outside) {
-                    const int q = ly * kTileW + lx;
-                    if (!EMBA_ABL(p.ablate, 8)) {
-                        atomicAdd(&s_sum[0][q], o.v0); atomicAdd(&s_sum[1][q], o.v1); atomicAdd(&s_sum[2][q], o.v2);
-                        atomicAdd(&s_sum[3][q], o.v3); atomicAdd(&s_sum[4][q], o.v4); atomicAdd(&s_sum[5][q], 1.0);
+            for (long g0 = begin + (long)kWarpNew * wv; g0 < end; g0 += kStep) {   // wave-uniform
+                const long i = g0 + t - 1;
+                auto prefetch = [&]() { const long i1 = i + kStep; load_event_words<true>(p, i1, g0 + kStep < end && i1 < end, nxt); };
+                LaneOut o;
+                warp_lane<false, true>(p, i, cur, t, o, prefetch);
+                const unsigned long long inl_mask = __ballot(o.inl);
+                bool outside = false;
+                if (o.inl) {
+                    const int lx = o.pmx - ch.x0, ly = o.pmy - ch.y0;
+                    outside = !(lx >= 0 && lx < kTileW && ly >= 0 && ly < kTileH);
+                    if (!outside) {
+                        const int q = ly * kTileW + lx;
+                        if (!EMBA_ABL(p.ablate, 8)) {
+                            atomicAdd(&s_sum[0][q], o.v0); atomicAdd(&s_sum[1][q], o.v1); atomicAdd(&s_sum[2][q], o.v2);
+                            atomicAdd(&s_sum[3][q], o.v3); atomicAdd(&s_sum[4][q], o.v4); atomicAdd(&s_sum[5][q], 1.0);
+                        }
+                    } else {   // moved out of the tile since the order was built: still correct, just not aggregated
+                        double* a = p.pixacc + (size_t)kPixAccStride * o.pi;
+                        p.count[o.pi] = p.marker;
+                        atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
                     }
-                } else {   // moved out of the tile since the order was built: still correct, just not aggregated
-                    double* a = p.pixacc + (size_t)kPixAccStride * o.pi;
-                    p.count[o.pi] = p.marker;
-                    atomicAdd(a + 0, o.v0); atomicAdd(a + 1, o.v1); atomicAdd(a + 2, o.v2); atomicAdd(a + 3, o.v3); atomicAdd(a + 4, o.v4); atomicAdd(a + 5, 1.0);
+                }
+                {   // how many: the host re-bins the window for the next evaluation when the trajectory has drifted away from the one the order was built for
+                    const unsigned long long om = __ballot(outside);
+                    if (om && t == 0 && p.err) atomicAdd(p.err, 2 * (int)__popcll(om));
+                }
+                const uint32_t slot = cur.slot;
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // (3) vmcnt(0): the prefetched words are in.  The builtin, not inline asm: the compiler's own wait-count bookkeeping must
+                                                      // know it, or it waits again at the next iteration's first use of `cur` — behind the record stores issued below
+                cur = nxt;
+                __builtin_amdgcn_sched_barrier(0);
+                store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)
+            }
+        }
+        __syncthreads();
+        // flush: wave by wave over the tile's pixels; touched ones are listed (LDS) and sent 10 pixels = 60 lanes per atomic instruction
+        for (int q0 = wv * 64; q0 < kTilePx; q0 += kTileWaves * 64) {
+            const int q = q0 + t;
+            const bool touched = q < kTilePx && s_sum[5][q] > 0.0;
+            const unsigned long long m = __ballot(touched);
+            if (!m) continue;
+            if (touched) s_list[wv][__popcll(m & ((1ull << t) - 1ull))] = (uint16_t)q;
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int n_emit = __popcll(m);
+            const int r10 = t / 6, comp = t - 6 * r10;
+            for (int g = 0; g < n_emit; g += 10) {
+                const int k = g + r10;
+                if (t < 60 && k < n_emit) {
+                    const int qq = s_list[wv][k];
+                    const int gy = ch.y0 + qq / kTileW, gx = ch.x0 + qq % kTileW;
+                    const size_t pi = (size_t)gy * p.W + gx;
+                    if (comp == 0 && !EMBA_ABL(p.ablate, 1)) p.count[pi] = p.marker;
+                    if (!EMBA_ABL(p.ablate, 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
                 }
             }
-            {   // how many: the host re-bins the window for the next evaluation when the trajectory has drifted away from the one the order was built for
-                const unsigned long long om = __ballot(outside);
-                if (om && t == 0 && p.err) atomicAdd(p.err, 2 * (int)__popcll(om));
-            }
-            const uint32_t slot = cur.slot;
-            __builtin_amdgcn_s_waitcnt(0x0F70);   // (3) vmcnt(0): the prefetched words are in.  The builtin, not inline asm: the compiler's own wait-count bookkeeping must
-                                                  // know it, or it waits again at the next iteration's first use of `cur` — behind the record stores issued below
-            cur = nxt;
-            __builtin_amdgcn_sched_barrier(0);
-            store_records<kTileRecStage>(p, t, o, slot, inl_mask, s_tile[wv], s_slot[wv]);   // (4)
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    __syncthreads();
-    if (c >= p.n_chunks) return;
-    const ChunkDesc ch = p.chunks[c];
-    // flush: wave by wave over the tile's pixels; touched ones are listed (LDS) and sent 10 pixels = 60 lanes per atomic instruction
-    for (int q0 = wv * 64; q0 < kTilePx; q0 += kTileWaves * 64) {
-        const int q = q0 + t;
-        const bool touched = q < kTilePx && s_sum[5][q] > 0.0;
-        const unsigned long long m = __ballot(touched);
-        if (!m) continue;
-        if (touched) s_list[wv][__popcll(m & ((1ull << t) - 1ull))] = (uint16_t)q;
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int n_emit = __popcll(m);
-        const int r10 = t / 6, comp = t - 6 * r10;
-        for (int g = 0; g < n_emit; g += 10) {
-            const int k = g + r10;
-            if (t < 60 && k < n_emit) {
-                const int qq = s_list[wv][k];
-                const int gy = ch.y0 + qq / kTileW, gx = ch.x0 + qq % kTileW;
-                const size_t pi = (size_t)gy * p.W + gx;
-                if (comp == 0 && !EMBA_ABL(p.ablate, 1)) p.count[pi] = p.marker;
-                if (!EMBA_ABL(p.ablate, 8)) atomicAdd(p.pixacc + (size_t)kPixAccStride * pi + comp, s_sum[comp][qq]);
-            }
-        }
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+inline void launch_warp_tiled(int shape, dim3 grid, hipStream_t s, const WarpParams& p)
+{
+    switch (shape) {
+    case 1: hipLaunchKernelGGL((emba_warp_tiled_kernel<kTileShapes[1].tw, kTileShapes[1].th>), grid, dim3(kTileWaves * 64), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((emba_warp_tiled_kernel<kTileShapes[2].tw, kTileShapes[2].th>), grid, dim3(kTileWaves * 64), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((emba_warp_tiled_kernel<kTileShapes[3].tw, kTileShapes[3].th>), grid, dim3(kTileWaves * 64), 0, s, p); break;
+    default: hipLaunchKernelGGL((emba_warp_tiled_kernel<kTileShapes[0].tw, kTileShapes[0].th>), grid, dim3(kTileWaves * 64), 0, s, p); break;
     }
 }
 

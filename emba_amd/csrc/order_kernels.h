@@ -226,12 +226,22 @@ __global__ void emba_batch_cp_kernel(const int64_t* __restrict__ batch_t, long n
 // ------------------------------------------------------------------------------------------------------------------------------
 // tile order: predicted panorama tile of every pm-order entry under the initial trajectory
 // ------------------------------------------------------------------------------------------------------------------------------
-struct BinGeom { int W, H, bw, bh, nbx, nby; };   // bins of bw x bh panorama pixels, nbx x nby of them
+// Round 6: the WINDOW rule.  Rounds 2-5 gave an entry to the (tile - 2 x margin) bin its predicted pixel fell in, so a chain of a sensor pixel paid a
+// lead-in copy every time it crossed a bin edge although the LDS tile around the bin reaches a margin further on every side (a 32 x 8 bin inside a 48 x 24
+// tile: a chain that moves vertically was cut every 8 px where the tile would have held it for 24).  Now a chain is cut GREEDILY into the longest segments
+// whose bounding box still fits one LDS tile (less a reserve of `r` pixels on every side for the drift of an LM loop's trial poses) whose origin lies on
+// the pitch grid: a segment with bounding box [xmin, xmax] x [ymin, ymax] belongs to the tile with origin (floor(xmin / px) px - r, floor(ymin / py) py - r),
+// and it may grow while xmax - floor(xmin / px) px < tw - 2 r (same in y).  Greedy longest segments are optimal for a sequence (feasibility is hereditary).
+// scripts/lead_in_sim.py: lead-in copies 31.5 -> 12.8 % at 2 M events, 23.1 -> 9.1 % at 3 M, 40.5 -> 17.3 % on the city shape, 16.1 -> 4.6 % on config 4's shard.
+// Speed only, as before: whatever the trial poses move out of a tile goes to HBM directly (and is counted: emba_last_tile_drift).
+struct BinGeom { int W, H, bw, bh, nbx, nby, tw, th, r; };   // pitch grid of tile origins: bw x bh panorama pixels, nbx x nby of them; LDS tile tw x th; reserve r
 
-__global__ __launch_bounds__(256) void emba_predict_bin_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pm_batch, long ns,
-                                                               const double* __restrict__ pose, int pose_stride, const double* __restrict__ lut,
-                                                               double fx, double fy, double cx, double cy, BinGeom g,
-                                                               uint32_t* __restrict__ bin, uint8_t* __restrict__ bin_used)
+constexpr uint32_t kNoPixel = 0xFFFFFFFFu;
+
+// predicted panorama pixel of every pm entry under the poses the window starts from, packed (y << 16 | x); kNoPixel outside the panorama (never an inlier)
+__global__ __launch_bounds__(256) void emba_predict_pixel_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pm_batch, long ns,
+                                                                 const double* __restrict__ pose, int pose_stride, const double* __restrict__ lut,
+                                                                 double fx, double fy, double cx, double cy, int W, int H, uint32_t* __restrict__ pred)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ns) return;
@@ -244,11 +254,52 @@ __global__ __launch_bounds__(256) void emba_predict_bin_kernel(const uint32_t* _
     const double b0 = bv[0], b1 = bv[1], b2 = bv[2];
     const double x = R[0] * b0 + R[1] * b1 + R[2] * b2, y = R[3] * b0 + R[4] * b1 + R[5] * b2, z = R[6] * b0 + R[7] * b1 + R[8] * b2;
     const double px = round(cx + atan2(x, z) * fx), py = round(cy + asin(y / sqrt(x * x + y * y + z * z)) * fy);
-    uint32_t b = kNoBin;
-    if (px >= 0.0 && px < (double)g.W && py >= 0.0 && py < (double)g.H) b = (uint32_t)((int)py / g.bh) * (uint32_t)g.nbx + (uint32_t)((int)px / g.bw);
-    else b = (uint32_t)g.nbx * (uint32_t)g.nby;        // one extra bin for whatever falls outside the panorama (never an inlier)
-    bin[i] = b;
-    bin_used[b] = 1;
+    pred[i] = (px >= 0.0 && px < (double)W && py >= 0.0 && py < (double)H) ? (((uint32_t)(int)py << 16) | (uint32_t)(int)px) : kNoPixel;
+}
+
+// One thread per CHAIN (the entries of one sensor pixel: a head without kEvHasPred and the entries behind it that have it) walks it once and gives every
+// entry its tile: bin[i] = oy * nbx + ox (nbx * nby: predicted outside the panorama).  Halo entries (kEvLead: the predecessor a rank inherits from the
+// shard in front of it) only ever appear as lead-in copies — warped for their pm and Jacobian, never summed — and do not constrain a segment.
+__global__ __launch_bounds__(256) void emba_assign_tiles_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pred, long ns, BinGeom g,
+                                                                uint32_t* __restrict__ bin, uint8_t* __restrict__ bin_used)
+{
+    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 >= ns || (pm_pix[i0] & kEvHasPred)) return;     // not the head of a chain
+    const uint32_t none = (uint32_t)g.nbx * (uint32_t)g.nby;
+    const int wx = g.tw - 2 * g.r, wy = g.th - 2 * g.r;
+    long seg = i0;                       // first entry of the open segment
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;   // its bounding box (x1 < x0: empty)
+    long i = i0;
+    for (;;) {
+        const bool more = i < ns && (i == i0 || (pm_pix[i] & kEvHasPred));
+        bool close = !more, fits = false;
+        int nx0 = x0, nx1 = x1, ny0 = y0, ny1 = y1;
+        uint32_t pp = kNoPixel;
+        bool free_entry = false;
+        if (more) {
+            pp = pred[i];
+            free_entry = (pm_pix[i] & kEvLead) != 0;          // a halo entry: any tile will do
+            if (!free_entry && pp != kNoPixel) {
+                const int px = (int)(pp & 0xFFFFu), py = (int)(pp >> 16);
+                if (x1 < x0) { nx0 = nx1 = px; ny0 = ny1 = py; }
+                else { nx0 = min(x0, px); nx1 = max(x1, px); ny0 = min(y0, py); ny1 = max(y1, py); }
+                fits = (nx1 - (nx0 / g.bw) * g.bw < wx) && (ny1 - (ny0 / g.bh) * g.bh < wy);
+                close = !fits;
+            } else if (!free_entry) close = true;             // predicted outside the panorama: ends the segment, takes the extra bin
+        }
+        if (close && seg < i) {                               // entries [seg, i) form a segment
+            const uint32_t b = (x1 < x0) ? none : (uint32_t)(y0 / g.bh) * (uint32_t)g.nbx + (uint32_t)(x0 / g.bw);
+            for (long k = seg; k < i; ++k) bin[k] = b;
+            bin_used[b] = 1;
+            seg = i; x1 = -1; x0 = 0;
+        }
+        if (!more) break;
+        if (free_entry) { /* joins whatever segment follows (or precedes) it */ }
+        else if (pp == kNoPixel) { bin[i] = none; bin_used[none] = 1; seg = i + 1; x1 = -1; x0 = 0; }
+        else if (fits) { x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; }
+        else { const int px = (int)(pp & 0xFFFFu), py = (int)(pp >> 16); x0 = x1 = px; y0 = y1 = py; }    // opens the next segment
+        ++i;
+    }
 }
 
 // how many entries the tile order needs for pm entry i: the event itself (halo entries appear only as lead-ins) plus a lead-in copy

@@ -109,9 +109,12 @@ emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint
 emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
                                size_t* n_entries, size_t* n_chunks);
 
-/* What the last pixel / tile order decision of a window saw (at its first evaluation): events per panorama pixel of the occupied 32 x 8-px tiles under the
- * first trajectory, and the fraction of lead-in copies the tile order would add.  Diagnostics; either pointer may be NULL. */
+/* What the last pixel / tile order decision of a window saw (at its first evaluation): events per panorama pixel of the occupied cells of the tile-origin grid
+ * under the first trajectory, and the fraction of lead-in copies the tile order would add.  Diagnostics; either pointer may be NULL. */
 emba_status emba_last_order_stats(const emba_ctx* ctx, double* events_per_pano_px, double* lead_in_frac);
+/* The LDS tile that decision chose for the window (round 6: one of four shapes of 1152 panorama pixels), the pitch of its origin grid and the reserve kept free
+ * on every side of a tile for the drift of trial poses (options tile_shape, tile_fine, tile_reserve).  Diagnostics; any pointer may be NULL. */
+emba_status emba_last_tile_geometry(const emba_ctx* ctx, int32_t* tile_w, int32_t* tile_h, int32_t* pitch_x, int32_t* pitch_y, int32_t* reserve);
 
 /* Tile order only: inliers of the last resolved evaluation that the tiled kernel found outside their tile (+ margin) — the
  * trajectory has moved them since the order was built; they are handled correctly, one HBM atomic each — and how many times this
@@ -354,6 +357,9 @@ emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
  *                  order on a large panorama): stages of 128 tags, the live slots compacted, only their records fetched;  gram_sparse_chunk 1 ... 8 (4): its slots per wave, x 1024
  *   gather_waves   0 auto (4) | 1 | 2 | 4 waves of a Gram workgroup do its slice of the gather
  *   chunk_order_bin 0 tile-order chunks longest first | 1 in bin order
+ *   tile_shape     -1 auto (fewest entries + chunks) | 0 48x24 | 1 72x16 | 2 96x12 | 3 36x32: the tiled kernel's LDS tile;  tile_fine -1 auto | 0 | 1 the finer grid of tile origins;
+ *                  tile_reserve 0 ... 5 (2): pixels kept free on every side of a tile when chains are cut into tile-sized segments;  tile_min_events (1650000): fewest
+ *                  events for which order = 0 considers the tile order;  tile_chunk 0 auto | entries per workgroup of the tiled kernel
  *   solve_perm     -1 auto | 0 | 1 U's columns ordered by panorama column in the Schur solve
  *   solve_counts   -1 auto | 0 list lengths counted from the records | 2 both, compared
  *   syrk_dense     1 dense instead of block-sparse SYRK;  syrk_lists 0 auto | 1 the block-sparse SYRK's per-pair slice lists always | 2 its (pair, chunk) items always;

@@ -148,6 +148,7 @@ struct emba_ctx {
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
     uint32_t* d_fblk_cnt = nullptr; uint32_t* d_fblk_off = nullptr; long n_fblk = 0;   // inlier-flag counts per kFlagBlk pm-order entries
+    uint32_t* d_fsup = nullptr; long n_fsup = 0; int fsup_half = 0;                    // ... summed per kFlagSup of those by launch A (two arrays used alternately; fsup_half: the one the last launch A filled)
     double* d_ep = nullptr;
     // order / key cache
     bool keys_ready = false; int64_t key_t0 = 0, key_dt = 0; int key_K = 0;
@@ -291,8 +292,8 @@ void ws_release(emba_ctx* c, int first, int last)
 inline unsigned nblocks(size_t n, unsigned per = 256) { return (unsigned)std::max<size_t>((n + per - 1) / per, 1); }
 
 // out[i] = sum_{j<i} in[j]; total_dev[0] = sum of all (may be nullptr).  Workspaces 16, 17.
-emba_status dev_scan(emba_ctx* c, const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_dev)
-{
+emba_status dev_scan(emba_ctx* c, const uint32_t* in, uint32_t* out, size_t n, uint32_t* total_dev, int* total_host = nullptr, const int* err_dev = nullptr, int* err_host = nullptr)
+{   // (total_host / err_host: pinned, device-visible words the middle launch writes the total and the evaluation's status word to — no copy node)
     hipStream_t s = c->stream;
     const size_t ntiles = (n + kScanTile - 1) / kScanTile;
     uint32_t *sums = nullptr, *offs = nullptr, *tot = nullptr;
@@ -301,7 +302,7 @@ emba_status dev_scan(emba_ctx* c, const uint32_t* in, uint32_t* out, size_t n, u
     tot = total_dev ? total_dev : offs + ntiles + 1;
     if (!n) { HIP_TRY(c, hipMemsetAsync(tot, 0, 4, s)); return EMBA_OK; }
     hipLaunchKernelGGL(emba_scan_tile_sums_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, in, (long)n, sums);
-    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, sums, offs, (long)ntiles, tot, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, sums, offs, (long)ntiles, tot, total_host, err_dev, err_host);
     hipLaunchKernelGGL(emba_scan_apply_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, in, (long)n, offs, out);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
@@ -636,8 +637,8 @@ emba_status launch_ep_compaction(emba_ctx* c)
     if (c->n_pm) {
         const uint32_t* perm = nullptr;    // (flags and residuals are stored in pm-order by both warp kernels)
         hipLaunchKernelGGL(emba_flag_count_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_flag, perm, (long)c->n_pm, c->d_fblk_cnt);
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total,
-                           c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1);
+        // (round 6: the block counts by the three-launch scan — one 256-thread block walked all of them before: 101 us for 97 k counts at 100 M events)
+        { emba_status st = dev_scan(c, c->d_fblk_cnt, c->d_fblk_off, (size_t)c->n_fblk, c->d_total, c->h_pinned_dev, c->d_err, c->h_pinned_dev + 1); if (st) return st; }
         hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, perm, c->d_fblk_off,
                            (long)c->n_pm, c->d_ep, c->d_inl_idx);
         c->inl_idx_valid = true; c->ep_valid = true;
@@ -657,8 +658,7 @@ emba_status ensure_inl_idx(emba_ctx* c)
     { emba_status st = launch_ep_compaction(c); if (st) return st; }
     if (c->inl_idx_valid || !c->n_pm) return EMBA_OK;
     // (the fused step leaves the per-block inlier counts of this evaluation in d_fblk_cnt, not their prefix)
-    hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, c->stream, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total, (int*)nullptr, (const int*)nullptr,
-                       (int*)nullptr);
+    { emba_status st = dev_scan(c, c->d_fblk_cnt, c->d_fblk_off, (size_t)c->n_fblk, c->d_total); if (st) return st; }
     hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, c->stream, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off,
                        (long)c->n_pm, c->d_ep, c->d_inl_idx);   // (ep is rewritten with the same values)
     HIP_TRY(c, hipGetLastError());
@@ -911,6 +911,9 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     }
     c->n_fblk = (long)std::max<size_t>((ns + kFlagBlk - 1) / kFlagBlk, 1);
     if ((st = dev_alloc(c, &c->d_fblk_cnt, (size_t)c->n_fblk)) || (st = dev_alloc(c, &c->d_fblk_off, (size_t)c->n_fblk))) return st;
+    c->n_fsup = (c->n_fblk + kFlagSup - 1) / kFlagSup;
+    if ((st = dev_alloc(c, &c->d_fsup, (size_t)2 * c->n_fsup))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_fsup, 0, (size_t)2 * c->n_fsup * sizeof(uint32_t), c->stream));      // (both halves: launch A adds into one and zeroes the other for the next step)
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
     // a record is valid iff it carries the current evaluation's stamp (record_valid): a reused buffer holds older stamps only, new memory is cleared
     if (rec_fresh) HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, c->caps[reinterpret_cast<void**>(&c->d_rec)], s));
@@ -1454,6 +1457,8 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // Tried and dropped (round 3, 1 M events): both launches as ONE kernel with the per-block counts published through flags (look-back,
         // and "sum every predecessor"): 38-270 us against 6.3 + 11.2 — the eight XCDs' L2s are not coherent with each other, so every flag is a
         // round trip to the memory side (and a release / acquire pair writes back / invalidates a whole L2); a kernel boundary is cheaper.
+        c->fsup_half ^= 1;
+        q.fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup; q.fsup_next = c->d_fsup + (size_t)(c->fsup_half ^ 1) * c->n_fsup; q.n_sup = c->n_fsup;
         q.active_bits = c->d_active_bits; q.pack_head = c->d_pack; q.head_len = head; aw.bits_head_done = 1;
         q.blk_rect = c->d_blk_rect; q.W = c->W; aw.blk_rect = c->d_blk_rect; aw.rect_out = c->d_rect;   // the texel rectangle of the NEXT evaluation
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
@@ -1466,7 +1471,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         c->aw_in_gram = false;
         // the residual vector ep of this evaluation: compacted by tail blocks of the Gram launch that follows (kernels.h: ep_tail_block) — launch A has just
         // left the per-block inlier-flag counts they need
-        c->ep_in_gram = c->step_wants_ep && c->step_ep != 2 && c->n_cand && c->n_fblk <= kEpTailMaxFblk;
+        c->ep_in_gram = c->step_wants_ep && c->step_ep != 2 && c->n_cand;
         c->ep_after_gram = c->step_wants_ep && !c->ep_in_gram;
         if (lists && c->step_gather >= 2) { c->aw_saved = aw; c->aw_in_gram = true; }
         else if (lists) hipLaunchKernelGGL(emba_active_gather_kernel, dim3(1024), dim3(256), 0, s, aw);
@@ -1563,6 +1568,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         const bool ep_tail = c->ep_in_gram && !ep_host && c->n_pm;
         if (ep_tail) {
             p.ep_flag = c->d_flag; p.ep_e = c->d_e_sorted; p.ep_out = c->d_ep; p.ep_fblk_cnt = c->d_fblk_cnt; p.ep_n_pm = (long)c->n_pm; p.ep_n_fblk = c->n_fblk;
+            p.ep_fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup;
             grid += (unsigned)((c->n_pm + kEpTailBlk - 1) / kEpTailBlk);
         }
         c->ep_in_gram = false;
@@ -1587,8 +1593,8 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         if (ep_tail) c->ep_valid = true;
         if (c->kernel_timing) { HIP_TRY(c, hipEventRecord(c->kt[3], s)); c->kt_accum_valid = true; c->kt_valid[c->kt_slot][1] = true; }
     }
-    if (c->ep_after_gram && !ep_host && c->n_pm) {      // the step's ep for a window too long for the tail form: launch A's per-block flag counts -> offsets -> compaction
-        hipLaunchKernelGGL(emba_scan_kernel, dim3(1), dim3(256), 0, s, c->d_fblk_cnt, c->d_fblk_off, c->n_fblk, c->d_total + 2, (int*)nullptr, (const int*)nullptr, (int*)nullptr);
+    if (c->ep_after_gram && !ep_host && c->n_pm) {      // option step_ep = 2 (A/B): the step's ep by launches of its own behind the Gram kernel: launch A's per-block flag counts -> offsets -> compaction
+        { emba_status st = dev_scan(c, c->d_fblk_cnt, c->d_fblk_off, (size_t)c->n_fblk, c->d_total + 2); if (st) return st; }
         hipLaunchKernelGGL(emba_compact_ep_kernel, dim3((unsigned)c->n_fblk), dim3(256), 0, s, c->d_e_sorted, c->d_flag, (const uint32_t*)nullptr, c->d_fblk_off, (long)c->n_pm,
                            c->d_ep, (int32_t*)nullptr);
         c->ep_valid = true;

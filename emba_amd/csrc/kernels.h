@@ -856,8 +856,11 @@ __device__ __forceinline__ uint32_t flag_quad(long i0, long n_pm, const uint8_t*
     return m;
 }
 
+// (round 6) fsup: the counts of kFlagSup consecutive blocks summed — 1 M pm entries per word —, so that a tail block of the Gram launch (ep_tail_block) finds the
+// inliers in front of it from <= 1023 block counts + one word per million entries whatever the window's length
+constexpr int kFlagSup = 1024;
 __device__ __forceinline__ void flag_count_block(long blk, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ perm, long n_pm,
-                                                 uint32_t* __restrict__ fblk_cnt)
+                                                 uint32_t* __restrict__ fblk_cnt, uint32_t* __restrict__ fsup = nullptr)
 {
     __shared__ uint32_t s_w[4];
     uint32_t j[4];
@@ -866,7 +869,11 @@ __device__ __forceinline__ void flag_count_block(long blk, const uint8_t* __rest
     for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x == 0) fblk_cnt[blk] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+    if (threadIdx.x == 0) {
+        const uint32_t n = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+        fblk_cnt[blk] = n;
+        if (fsup && n) atomicAdd(fsup + blk / kFlagSup, n);
+    }
 }
 
 __device__ __forceinline__ void compact_ep_block(long blk, const double* __restrict__ e_sorted, const uint8_t* __restrict__ flag,
@@ -1107,6 +1114,7 @@ struct PostWarpParams {
     int* blk_rect; int W;                                     // non-null: per-block bounding boxes of the touched pixels (-> the next evaluation's texel rectangle)
     uint16_t* seg; double* clear_inactive;                    // the resident one-GPU step (active_count_block): per-unit active lists; zero the lines of touched, inactive pixels
     const uint8_t* global_u8;                                 // a sharded window's rank: activity from the all-reduced saturated byte counts (active_count_block)
+    uint32_t* fsup; uint32_t* fsup_next; long n_sup;          // non-null: the flag-count blocks also sum into this step's super-counts (flag_count_block); block 0 zeroes the NEXT step's
 };
 
 struct ActiveWriteParams {
@@ -1130,7 +1138,8 @@ __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
     // A11 = Zero, b1 = Zero (model.cpp:357-361): the head of the pack
     if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
     if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W, p.marker, p.seg, p.clear_inactive, p.global_u8);
-    else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt);
+    else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt, p.fsup);
+    if (blockIdx.x == 0 && p.fsup_next) for (long i = threadIdx.x; i < p.n_sup; i += 256) p.fsup_next[i] = 0u;    // (two arrays, used alternately: nobody reads or adds to this one during this launch)
 }
 
 __device__ __forceinline__ void active_write_block(long blk, const ActiveWriteParams& a)
@@ -1584,7 +1593,7 @@ struct GramParams {
     int gather_waves;  // GATHER form: 1, 2 or 4 of the block's 16 waves do its slice of the active-set gather, the others stream (host: by size)
     int n_gram_blocks; // blocks [0, n_gram_blocks) of the grid form the Gram sums; the blocks behind them (the resident step, ep_out != nullptr) compact the
                        // residuals into the reference-order ep vector (ep_tail_block): no launch and no scan launch of their own
-    const uint8_t* ep_flag; const double* ep_e; double* ep_out; const uint32_t* ep_fblk_cnt; long ep_n_pm, ep_n_fblk;
+    const uint8_t* ep_flag; const double* ep_e; double* ep_out; const uint32_t* ep_fblk_cnt; long ep_n_pm, ep_n_fblk; const uint32_t* ep_fsup;
 };
 
 // Global flush of one 16x16 tile value owned by (row, col) for the pair `key`.
@@ -2143,17 +2152,21 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
 // ep = the inliers' residuals in the reference's order (model.cpp:221,256: sensor pixel major, then time = pm-order) — what evaluateDataError RETURNS.
 // Round 5: in the resident step the compaction rides at the END of the Gram launch instead of being a scan + a compaction launch of
 // its own (+ 10 us per step at 1 M events).  Launch A has left the inlier-flag count of every kFlagBlk pm entries; a tail block takes kEpTailBlk entries
-// (four of those), sums the counts in front of it itself (a few thousand L2-resident words: the host uses this form up to kEpTailMaxFblk of them) and
+// (four of those), sums the counts in front of it itself (L2-resident words) and
 // writes its inliers' residuals at their ranks.  The tail blocks start as Gram blocks retire (one 16-wave block per CU either way).
 constexpr int kEpTailBlk = 4 * kFlagBlk;
-constexpr long kEpTailMaxFblk = 8192;       // <= 8.4 M pm entries: every tail block sums at most that many per-block counts
+// Round 6: at every window length (round 5: up to 8.4 M entries, longer windows paid a one-block scan of all block counts — 101 us at 100 M events — and a compaction launch
+// of 1024-entry blocks behind the Gram kernel).  The inliers in front of a tail block = launch A's super-counts (one word per kFlagSup block counts = 1 M entries) in front of
+// it + the <= kFlagSup - 1 + 3 block counts of its own million.
 __device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
 {
     __shared__ uint32_t s_x[kGramBlock / 64], s_b[kGramBlock / 64];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const long nfront = cb * (kEpTailBlk / kFlagBlk);
+    const long nsup = nfront / kFlagSup;
     uint32_t part = 0;
-    for (long j0 = 0; j0 < nfront; j0 += kGramBlock) {
+    for (long s0 = 0; s0 < nsup; s0 += kGramBlock) { const long s = s0 + t; if (s < nsup) part += p.ep_fsup[s]; }
+    for (long j0 = nsup * kFlagSup; j0 < nfront; j0 += kGramBlock) {
         const long j = j0 + t;
         const uint32_t v = p.ep_fblk_cnt[j < p.ep_n_fblk ? j : p.ep_n_fblk - 1];
         if (j < nfront) part += v;

@@ -26,3 +26,21 @@ def hip_lib():
     from emba_amd import build, _lib
     build.build_hip()
     return _lib.load()
+
+
+def pytest_terminal_summary(terminalreporter):
+    """Worst ELEMENT-WISE errors per quantity over the session (tests/helpers.py: assert_close_elementwise), for the log and BASELINE.md."""
+    try:
+        import helpers
+    except Exception:   # noqa: BLE001
+        return
+    if not helpers.WORST:
+        return
+    terminalreporter.write_line("worst element-wise error per quantity, |a-b| / (|b| + 1e-7 max|b|)  [bound 1e-5]:")
+    for k in sorted(helpers.WORST):
+        terminalreporter.write_line(f"    {k:28s} {helpers.WORST[k]:.3e}")
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, "parity_elementwise.json"), "w") as f:
+            json.dump(helpers.WORST, f, indent=1, sort_keys=True)

@@ -52,15 +52,27 @@ def test_city_shape_10M_events_one_evaluation_and_form(gpu, oracle_mod):
     ep = m.evaluateDataError(w.traj, w.Gx, w.Gy, ev, True, nem)
     m.formNormalEq(ep, w.K, nem, w.thres_valid_pixel)
     ne = m.applyL2Reg(w.alpha)
-    d = m.dump_state(fields=("inlier_idx", "pm_int"))
+    d = m.dump_state(fields=("inlier_idx", "pm_int", "D", "dp", "temp"))
+    # round 6: a RESIDENT step on the same window — more than 8.4 M pm entries, where round 5 compacted ep by a one-block scan + a launch of its own; now the
+    # tail blocks of the Gram launch do it at every length (kernels.h: ep_tail_block, launch A's super-counts)
+    m.upload_map(w.Gx, w.Gy)
+    n_inl_step, P_step = m.step(w.traj, w.thres_valid_pixel, w.alpha)
+    assert m.get_option("ep_valid") == 1, "the step did not leave ep on the device"
+    ep_step = m.get_ep()
     m.close()
     o = O.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
     ep_o, nem_o, d_o = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns, dump=True)
     assert np.array_equal(nem, nem_o), "num_ev_map differs at 10 M events"
     assert ep_o.size > 5_000_000, "the workload is meant to be mostly inliers"
     assert np.array_equal(d["inlier_idx"], d_o["inlier_idx"]) and np.array_equal(d["pm_int"], d_o["pm_int"])
+    # per-event Jacobians / displacements / temp rows at config 3's size, value by value, on every 64th event
+    assert_close(d["D"][::64], d_o["D"][::64], "dpm_ddrot_cp", tight=1e-10)
+    assert_close(d["dp"][::64], d_o["dp"][::64], "dp", tight=1e-9)
+    assert_close(d["temp"][::64], d_o["temp"][::64], "temp", tight=1e-10)
     del d, d_o
     assert_close(ep, ep_o, "ep")
+    assert n_inl_step == ep_o.size
+    assert_close(ep_step, ep_o, "ep of the resident step (tail blocks, 10 M entries)")
     ne_o = o.apply_l2(o.form_normal_eq(ep_o, w.K, nem_o, w.thres_valid_pixel), w.alpha, w.Gx, w.Gy)
     _compare_blocks(ne, ne_o)
 

@@ -64,6 +64,14 @@ SIGNATURES = {
     "emba_solve_shard_size": (C.c_int, [C.c_void_p, _szp]),
     "emba_solve_shard_count": (C.c_int, [C.c_void_p, C.c_int32, _szp]),
     "emba_solve_shard_pack": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "emba_cg_shard_size": (C.c_int, [C.c_void_p, _szp]),
+    "emba_cg_shard_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_void_p]),
+    "emba_cg_shard_apply": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "emba_cg_shard_pt": (C.c_int, [C.c_void_p, C.c_void_p, _dp]),
+    "emba_cg_shard_update": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p]),
+    "emba_cg_shard_direction": (C.c_int, [C.c_void_p, C.c_double]),
+    "emba_cg_shard_end": (C.c_int, [C.c_void_p, _dp, C.c_void_p]),
+    "emba_solve_shard_cached": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _i32p, _szp]),
     "emba_solve_shard_partial": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]),
     "emba_solve_shard_finish": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_double, C.c_int32, C.c_void_p, _dp, C.c_void_p]),
     "emba_solve_normal_eq_cg": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _i32p, _dp]),
@@ -118,6 +126,7 @@ SIGNATURES = {
     "emba_group_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
     "emba_group_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_group_apply_l2": (C.c_int, [C.c_void_p, C.c_double]),
+    "emba_group_last_solve_exchanged": (C.c_int, [C.c_void_p, _i32p]),
     "emba_group_solve_cg": (C.c_int, [C.c_void_p, C.c_double, C.c_int32, C.c_int32, C.c_double, _dp, _dp, _i32p, _dp]),
     "emba_group_trial_reject": (C.c_int, [C.c_void_p]),
     "emba_group_download": (C.c_int, [C.c_void_p, _dp, _dp, _u32p, C.c_size_t, _dp, _dp]),

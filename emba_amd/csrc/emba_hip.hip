@@ -37,6 +37,8 @@ struct DevBuf {
 
 }  // namespace
 
+struct SolveLists { uint32_t* off = nullptr; emba::RecView sorted{}; };   // per-pixel record lists of a solve — sorted: the participating records in pixel order; off[i]: first record of pixel i
+
 struct emba_ctx {
     emba_cfg cfg{};
     int device = 0;
@@ -59,6 +61,11 @@ struct emba_ctx {
     // the per-pixel record lists + pixel-ordered records of the last LOCAL solve (workspaces 0, 33): a re-solve of the same equations with another
     // lambda (a rejected LM trial, solver.cpp:340-352) reuses them
     bool lists_valid = false; uint32_t lists_stamp = 0; size_t lists_P = 0, lists_nrec = 0;
+    // round 6: ... and so does the SHARDED solve — lists_packed: the workspaces hold the records this rank RECEIVED as the owner of the pixels
+    // [lists_lo, lists_lo + lists_P), keyed by its own working set's stamp (the ranks evaluate and form in lockstep); a re-solve skips count, pack and the all-to-all
+    bool lists_packed = false; long lists_lo = 0;
+    struct CgShard { bool active = false; int rank = 0, n_ranks = 1, n = 0, skip = 0; size_t lo = 0, npix = 0, Nl = 0; double lambda = 0;
+                     double *x = nullptr, *r = nullptr, *p = nullptr, *z = nullptr, *t = nullptr, *invd = nullptr, *sc = nullptr; SolveLists L; } cg;   // emba_cg_shard_*
     uint32_t count_stamp = 0;   // record stamp (set_stamp) of the evaluation whose materialised, LOCAL counts d_count_own holds; 0: none (build_lists)
     bool perm_valid = false; uint32_t* d_perm = nullptr;   // column order of U for the local Schur solve (solve_perm), valid with the lists
     int solve_perm_mode = -1;                               // option solve_perm (A/B): -1 auto, 0 off, 1 on
@@ -2203,7 +2210,6 @@ emba_status emba_device_pci_bus_id(emba_ctx* c, char* buf, size_t len)
 // ---- f1: the solvers (solve_kernels.h) ------------------------------------------------------------------------------------------
 namespace {
 
-struct SolveLists { uint32_t* off = nullptr; RecView sorted{}; };   // sorted: the participating records in pixel order; off[i]: first record of pixel i
 
 // per-pixel record lists over `n_pix` pixels of `view` (n_rec records): counts from the records themselves, exclusive scan, fill.
 // Workspaces 0 (off), 1 (cursor), 33 (the records in pixel order).
@@ -2212,12 +2218,15 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
     hipStream_t s = c->stream;
     uint32_t *d_off = nullptr, *d_cursor = nullptr; double* d_sorted = nullptr;
     emba_status st;
-    if (!view.packed && c->lists_valid && c->lists_stamp == view.stamp && c->lists_P == n_pix && c->lists_nrec == n_rec && c->ws[0].p && c->ws[33].p) {
+    const uint32_t key_stamp = view.packed ? c->set_stamp : view.stamp;
+    if (c->lists_valid && c->lists_packed == (view.packed != 0) && c->lists_stamp == key_stamp && c->lists_P == n_pix && c->lists_nrec == n_rec && c->ws[0].p && c->ws[33].p &&
+        (!view.packed || c->lists_lo == view.pix_base)) {
         out->off = (uint32_t*)c->ws[0].p;
         out->sorted = RecView{};
         out->sorted.rec = (const double*)c->ws[33].p; out->sorted.packed = 1; out->sorted.pix_base = 0;
         return EMBA_OK;
     }
+    if (view.packed && !view.rec) return fail(c, EMBA_ERR_STATE, "the received records of these equations are not cached on this rank: run the record exchange (emba_solve_shard_cached says when it can be skipped)");
     c->lists_valid = false; c->perm_valid = false;
     if ((st = ws_get(c, 0, (n_pix + 2) * 4, (void**)&d_off)) || (st = ws_get(c, 1, (n_pix + 1) * 4, (void**)&d_cursor)) ||
         (st = ws_get(c, 33, (n_rec + 1) * kRecStride * sizeof(double), (void**)&d_sorted)))
@@ -2252,7 +2261,7 @@ emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n
     out->off = d_off;
     out->sorted = RecView{};
     out->sorted.rec = d_sorted; out->sorted.packed = 1; out->sorted.pix_base = 0;
-    if (!view.packed) { c->lists_valid = true; c->lists_stamp = view.stamp; c->lists_P = n_pix; c->lists_nrec = n_rec; }
+    c->lists_valid = true; c->lists_packed = view.packed != 0; c->lists_stamp = key_stamp; c->lists_P = n_pix; c->lists_nrec = n_rec; c->lists_lo = view.pix_base;
     return EMBA_OK;
 }
 
@@ -2576,6 +2585,19 @@ namespace {
 void shard_range(size_t P, int rank, int n_ranks, size_t* lo, size_t* hi) { *lo = (P * (size_t)rank) / n_ranks; *hi = (P * ((size_t)rank + 1)) / n_ranks; }
 }
 
+// Does this rank still hold, in pixel order, the records it received as the owner of its pixel range for the CURRENT equations (a re-solve with another lambda after a
+// rejected trial, solver.cpp:340-352)?  Then emba_solve_shard_count / _pack and the all-to-all can be skipped and emba_solve_shard_partial / _finish take recv_dev = NULL.
+extern "C" emba_status emba_solve_shard_cached(emba_ctx* c, int32_t rank, int32_t n_ranks, int32_t* cached, size_t* n_recv)
+{
+    if (!c || !cached || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_cached: bad arguments") : EMBA_ERR_INVALID_ARG;
+    size_t lo, hi;
+    shard_range(c->P, rank, n_ranks, &lo, &hi);
+    *cached = (c->finish_done && !c->eq_in_alt && c->lists_valid && c->lists_packed && c->lists_stamp == c->set_stamp && c->lists_P == hi - lo && c->lists_lo == (long)lo &&
+               c->ws[0].p && c->ws[33].p && c->ws[9].p) ? 1 : 0;
+    if (n_recv) *n_recv = *cached ? c->lists_nrec : 0;
+    return EMBA_OK;
+}
+
 extern "C" emba_status emba_solve_shard_partial(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda, double* S_part_dev)
 {
     if (!c || !S_part_dev || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "solve_shard_partial: bad arguments") : EMBA_ERR_INVALID_ARG;
@@ -2719,6 +2741,141 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
     HIP_TRY(c, hipStreamSynchronize(s));
     if (iterations) *iterations = it;
     if (error) *error = err;
+    return EMBA_OK;
+}
+
+// ---- LEGM::solveNormalEqCG over a sharded window (round 6, VERDICT r5 missing #3: a launch file with use_CG = true on several GPUs, solver.cpp:190-202) --------------
+// The system [A11m A12; A12^T A22m] is applied matrix-free with the PIXELS sharded: rank r owns the active pixels [P r / n, P (r+1) / n) and — after the same
+// record exchange as the sharded Schur solve (cached across re-solves) — every record of those pixels.  A CG vector is [pose part, 3K, REPLICATED | this rank's
+// 2 x (its pixels) map entries]; the map part of M v is local, the pose part is a sum over the ranks' pixels: ONE all-reduce of 3K + 2 doubles per application
+// (the rank's share of t1 and of p.t), one of 2 doubles per iteration for r.r and r.z.  Every rank takes the same scalars from the reduced sums, so the
+// replicated pose parts stay bit-identical.  The loop itself (Eigen's ConjugateGradient.h:28-88) is driven by the host: emba_group_solve_cg, emba_amd/sharded.py.
+//   begin     lists of the owned pixels' records, x = 0, r = b, p = invd r;  red[n] = r.r, red[n+1] = r.p (partial)      -> all-reduce red (n + 2)
+//   apply     t = M p on this rank's pixels;  red[0..n) = its share of t1 (rank 0 adds A11m p1), red[n] = p2.t2          -> all-reduce red (n + 2)
+//   pt        t1 = red[0..n);  *pt = p1.t1 + red[n]
+//   update    x += alpha p, r -= alpha t, z = invd r;  red[n] = r.r, red[n+1] = r.z (partial)                             -> all-reduce red + n (2)
+//   direction p = z + beta p
+//   end       x1 -> host, this rank's x2 into x2_full_dev (zeros elsewhere)                                               -> all-reduce x2_full (2P)
+// Partial sums count the replicated pose part on rank 0 only.
+extern "C" emba_status emba_cg_shard_size(emba_ctx* c, size_t* red_doubles)
+{
+    if (!c || !red_doubles) return EMBA_ERR_INVALID_ARG;
+    *red_doubles = (size_t)3 * c->K + 2;
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_begin(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda, int32_t fix_first_pose,
+                                           double* red_dev)
+{
+    if (!c || !red_dev || rank < 0 || rank >= n_ranks) return c ? fail(c, EMBA_ERR_INVALID_ARG, "cg_shard_begin: bad arguments") : EMBA_ERR_INVALID_ARG;
+    if (!c->finish_done) return fail(c, EMBA_ERR_STATE, "solveNormalEqCG needs formNormalEq + applyL2Reg (emba_form_finish) first");
+    if (c->eq_in_alt) return fail(c, EMBA_ERR_STATE, "an evaluation has been written since these equations were formed: report the LM decision first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    auto& g = c->cg;
+    g.active = false;
+    g.rank = rank; g.n_ranks = n_ranks; g.n = 3 * c->K; g.skip = fix_first_pose ? 3 : 0; g.lambda = lambda;
+    size_t lo, hi;
+    shard_range(c->P, rank, n_ranks, &lo, &hi);
+    g.lo = lo; g.npix = hi - lo; g.Nl = (size_t)g.n + 2 * g.npix;
+    emba_status st;
+    if ((st = ws_get(c, 6, g.Nl * 8, (void**)&g.x)) || (st = ws_get(c, 7, g.Nl * 8, (void**)&g.r)) || (st = ws_get(c, 8, g.Nl * 8, (void**)&g.p)) ||
+        (st = ws_get(c, 9, g.Nl * 8, (void**)&g.z)) || (st = ws_get(c, 10, g.Nl * 8, (void**)&g.t)) || (st = ws_get(c, 11, g.Nl * 8, (void**)&g.invd)) ||
+        (st = ws_get(c, 13, 64, (void**)&g.sc)))
+        return st;
+    RecView view{};
+    view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
+    if ((st = build_lists(c, view, n_recv, g.npix, &g.L))) return st;
+    HIP_TRY(c, hipMemsetAsync(red_dev, 0, ((size_t)g.n + 2) * 8, s));
+    const unsigned grid = (unsigned)std::min<size_t>(nblocks(g.Nl), 1024);
+    hipLaunchKernelGGL(emba_cg_init_kernel, dim3(grid), dim3(256), 0, s, pack_A11(c), pack_b1(c), pack_A22b2(c) + 5 * lo, g.n, g.skip, (long)g.npix, lambda, g.x, g.r, g.p, g.invd,
+                       red_dev + g.n, (long)(rank == 0 ? 0 : g.n));
+    HIP_TRY(c, hipGetLastError());
+    g.active = true;
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_apply(emba_ctx* c, double* red_dev)
+{
+    if (!c || !red_dev) return EMBA_ERR_INVALID_ARG;
+    auto& g = c->cg;
+    if (!g.active) return fail(c, EMBA_ERR_STATE, "call emba_cg_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = g.n;
+    if (g.rank == 0) hipLaunchKernelGGL(emba_cg_a11_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pack_A11(c), n, g.lambda, g.skip, g.p, g.t);
+    else HIP_TRY(c, hipMemsetAsync(g.t, 0, (size_t)n * 8, s));
+    CgPixParams pp{};
+    pp.view = g.L.sorted; pp.off = g.L.off; pp.A22b2 = pack_A22b2(c) + 5 * g.lo; pp.lambda = g.lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = g.skip;
+    pp.P = (long)g.npix; pp.v = g.p; pp.y = g.t;
+    if (g.npix) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((g.npix + 3) / 4, (size_t)4 * c->n_cu)), dim3(256), (size_t)n * 8, s, pp);
+    HIP_TRY(c, hipMemcpyAsync(red_dev, g.t, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemsetAsync(red_dev + n, 0, 16, s));
+    if (g.npix) hipLaunchKernelGGL(emba_cg_dot_kernel, dim3((unsigned)std::min<size_t>(nblocks(2 * g.npix), 1024)), dim3(256), 0, s, g.p + n, g.t + n, (long)(2 * g.npix), red_dev + n);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_pt(emba_ctx* c, const double* red_dev, double* pt)
+{
+    if (!c || !red_dev || !pt) return EMBA_ERR_INVALID_ARG;
+    auto& g = c->cg;
+    if (!g.active) return fail(c, EMBA_ERR_STATE, "call emba_cg_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int n = g.n;
+    HIP_TRY(c, hipMemcpyAsync(g.t, red_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));      // the reduced t1, identical on every rank
+    HIP_TRY(c, hipMemsetAsync(g.sc, 0, 16, s));
+    hipLaunchKernelGGL(emba_cg_dot_kernel, dim3(1), dim3(256), 0, s, g.p, g.t, (long)n, g.sc);     // (one block: the same summation order on every rank)
+    double h[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(&h[0], g.sc, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(&h[1], red_dev + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    *pt = h[0] + h[1];
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_update(emba_ctx* c, double alpha, double* red_dev)
+{
+    if (!c || !red_dev) return EMBA_ERR_INVALID_ARG;
+    auto& g = c->cg;
+    if (!g.active) return fail(c, EMBA_ERR_STATE, "call emba_cg_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const long from = g.rank == 0 ? 0 : g.n;
+    const unsigned grid = (unsigned)std::min<size_t>(nblocks(g.Nl), 1024);
+    HIP_TRY(c, hipMemsetAsync(red_dev + g.n, 0, 16, s));
+    hipLaunchKernelGGL(emba_cg_xr_kernel, dim3(grid), dim3(256), 0, s, alpha, g.p, g.t, (long)g.Nl, g.x, g.r, red_dev + g.n, from);
+    hipLaunchKernelGGL(emba_cg_z_kernel, dim3(grid), dim3(256), 0, s, g.invd, g.r, (long)g.Nl, g.z, red_dev + g.n + 1, from);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_direction(emba_ctx* c, double beta)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    auto& g = c->cg;
+    if (!g.active) return fail(c, EMBA_ERR_STATE, "call emba_cg_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(emba_cg_p_kernel, dim3(nblocks(g.Nl)), dim3(256), 0, c->stream, beta, g.z, (long)g.Nl, g.p);
+    HIP_TRY(c, hipGetLastError());
+    return EMBA_OK;
+}
+
+extern "C" emba_status emba_cg_shard_end(emba_ctx* c, double* x1_host, double* x2_full_dev)
+{
+    if (!c) return EMBA_ERR_INVALID_ARG;
+    auto& g = c->cg;
+    if (!g.active) return fail(c, EMBA_ERR_STATE, "call emba_cg_shard_begin first");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (x2_full_dev) {
+        HIP_TRY(c, hipMemsetAsync(x2_full_dev, 0, 2 * c->P * sizeof(double), s));
+        if (g.npix) HIP_TRY(c, hipMemcpyAsync(x2_full_dev + 2 * g.lo, g.x + g.n, 2 * g.npix * 8, hipMemcpyDeviceToDevice, s));
+    }
+    if (x1_host) HIP_TRY(c, hipMemcpyAsync(x1_host, g.x, (size_t)g.n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    g.active = false;
     return EMBA_OK;
 }
 

@@ -171,6 +171,7 @@ struct emba_group {
     int decl_irls = 0; double decl_eta = 0.0;   // robust cost declared for the evaluations (emba_group_set_cost)
     // grow-only scratch of the sharded solve, per rank (an LM loop calls it every iteration)
     std::vector<double*> sv_send, sv_recv, sv_S, sv_x2; std::vector<size_t> cap_send, cap_recv, cap_S, cap_x2;
+    bool last_solve_exchanged = true;   // the last sharded solve ran the record exchange (false: every rank had its received records cached)
     bool x2_on_ranks = false;   // sv_x2[r] holds the all-reduced x2 of the last emba_group_solve (emba_group_update_map with x2_host == NULL)
     RankPool pool;
     int sw_ = 0;
@@ -699,6 +700,43 @@ emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alp
     return EMBA_OK;
 }
 
+// Records to the ranks that own their pixels (count, pack, all-to-all) — unless every rank still holds, in pixel order, what it received for the CURRENT equations
+// (round 6, VERDICT r5 #4: a re-solve with another lambda after a rejected trial, solver.cpp:340-352; two ranks on one device at config 2's shape: 20.5 ms per solve,
+// most of it this exchange).  n_recv[r]: records rank r owns; g->last_solve_exchanged says which way it went.
+}  // extern "C"
+static emba_status group_exchange_records(emba_group* g, std::vector<size_t>* n_recv_out, const std::function<void(const char*)>& stage)
+{
+    const int n = g->n;
+    std::vector<int32_t> have(n, 0);
+    std::vector<size_t> n_recv(n, 0);
+    for (int r = 0; r < n; ++r) G_TRY(g, r, emba_solve_shard_cached(g->ctx[r], r, n, &have[r], &n_recv[r]));
+    bool all = true;
+    for (int r = 0; r < n; ++r) all = all && have[r];
+    g->last_solve_exchanged = !all;
+    if (all) { *n_recv_out = n_recv; stage("records cached on their owners"); return EMBA_OK; }
+    std::vector<std::vector<size_t>> cnt(n, std::vector<size_t>(n, 0));
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_count(g->ctx[r], n, cnt[r].data()); }); if (st) return st; }
+    stage("shard_count");
+    std::vector<size_t> n_send(n, 0);
+    std::fill(n_recv.begin(), n_recv.end(), 0);
+    std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
+    for (int r = 0; r < n; ++r) for (int d = 0; d < n; ++d) { n_send[r] += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
+    // grow-only scratch (an LM loop solves every iteration: no hipMalloc / hipFree per call)
+    for (int r = 0; r < n; ++r) {
+        emba_status st;
+        if ((st = grow(g, r, &g->sv_send[r], &g->cap_send[r], std::max<size_t>(n_send[r], 1) * 16)) || (st = grow(g, r, &g->sv_recv[r], &g->cap_recv[r], std::max<size_t>(n_recv[r], 1) * 16)))
+            return st;
+    }
+    stage("grow");
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_pack(g->ctx[r], n, g->sv_send[r]); }); if (st) return st; }
+    stage("shard_pack");
+    { emba_status st = group_alltoall(g, g->sv_send.data(), g->sv_recv.data(), cnt16); if (st) return st; }
+    stage("alltoall (enqueue)");
+    *n_recv_out = n_recv;
+    return EMBA_OK;
+}
+extern "C" {
+
 // LEGM::solveNormalEq (model.cpp:721-792) over the group: records to their pixel owners, partial Schur sums, all-reduce, replicated
 // Cholesky, x2 exchanged.  x1_host: 3K, x2_host: 2P (either may be NULL).
 emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host)
@@ -714,27 +752,17 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
         fprintf(stderr, "[group solve] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_dbg).count());
         t_dbg = now;
     };
-    std::vector<std::vector<size_t>> cnt(n, std::vector<size_t>(n, 0));
-    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_count(g->ctx[r], n, cnt[r].data()); }); if (st) return st; }
-    stage("shard_count");
-    std::vector<size_t> n_recv(n, 0), n_send(n, 0);
-    std::vector<std::vector<size_t>> cnt16(n, std::vector<size_t>(n, 0));
-    for (int r = 0; r < n; ++r) for (int d = 0; d < n; ++d) { n_send[r] += cnt[r][d]; n_recv[d] += cnt[r][d]; cnt16[r][d] = 16 * cnt[r][d]; }
+    std::vector<size_t> n_recv(n, 0);
+    { emba_status st = group_exchange_records(g, &n_recv, stage); if (st) return st; }
+    const bool cached = !g->last_solve_exchanged;
     size_t s_doubles = 0;
     G_TRY(g, 0, emba_solve_shard_size(g->ctx[0], &s_doubles));
-    // grow-only scratch (an LM loop solves every iteration: no hipMalloc / hipFree per call)
     for (int r = 0; r < n; ++r) {
         emba_status st;
-        if ((st = grow(g, r, &g->sv_send[r], &g->cap_send[r], std::max<size_t>(n_send[r], 1) * 16)) || (st = grow(g, r, &g->sv_recv[r], &g->cap_recv[r], std::max<size_t>(n_recv[r], 1) * 16)) ||
-            (st = grow(g, r, &g->sv_S[r], &g->cap_S[r], s_doubles)) || (st = grow(g, r, &g->sv_x2[r], &g->cap_x2[r], std::max<size_t>(2 * g->P, 2))))
-            return st;
+        if ((st = grow(g, r, &g->sv_S[r], &g->cap_S[r], s_doubles)) || (st = grow(g, r, &g->sv_x2[r], &g->cap_x2[r], std::max<size_t>(2 * g->P, 2)))) return st;
     }
-    stage("grow");
-    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_pack(g->ctx[r], n, g->sv_send[r]); }); if (st) return st; }
-    stage("shard_pack");
-    { emba_status st = group_alltoall(g, g->sv_send.data(), g->sv_recv.data(), cnt16); if (st) return st; }
-    stage("alltoall (enqueue)");
-    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_partial(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, g->sv_S[r]); }); if (st) return st; }
+    stage("grow S, x2");
+    { emba_status st = gpool(g, [&](int r) { return emba_solve_shard_partial(g->ctx[r], r, n, cached ? nullptr : g->sv_recv[r], n_recv[r], lambda, g->sv_S[r]); }); if (st) return st; }
     stage("shard_partial");
     { emba_status st = group_allreduce(g, (void* const*)g->sv_S.data(), s_doubles, XType::F64); if (st) return st; }
     stage("allreduce S (enqueue)");
@@ -742,7 +770,7 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
     // failure is reported once, for the group
     std::vector<emba_status> fin(n, EMBA_OK);
     (void)g->pool.run([&](int r) {
-        fin[r] = emba_solve_shard_finish(g->ctx[r], r, n, g->sv_recv[r], n_recv[r], lambda, fix_first_pose, g->sv_S[r], r == 0 ? x1_host : nullptr, g->sv_x2[r]);
+        fin[r] = emba_solve_shard_finish(g->ctx[r], r, n, cached ? nullptr : g->sv_recv[r], n_recv[r], lambda, fix_first_pose, g->sv_S[r], r == 0 ? x1_host : nullptr, g->sv_x2[r]);
         return EMBA_OK; });
     stage("shard_finish");
     for (int r = 0; r < n; ++r) if (fin[r] && fin[r] != EMBA_ERR_NUMERIC) return gfail(g, fin[r], "rank %d: %s", r, emba_last_error(g->ctx[r]));
@@ -756,13 +784,88 @@ emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pos
     return EMBA_OK;
 }
 
-// LEGM::solveNormalEqCG (model.cpp:794-840): provided for a one-rank group (the sharded loop uses the Schur solve)
+// LEGM::solveNormalEqCG (model.cpp:794-840) over the group.  One rank: the single-context solver.  Several (round 6): the pixels are sharded as in the Schur
+// solve (same record exchange, cached across re-solves) and Eigen's loop (ConjugateGradient.h:28-88) runs here on scalars that every rank reads from the same
+// all-reduced sums — emba_cg_shard_* (emba_hip.hip) are the per-rank steps, the collectives are one all-reduce of 3K + 2 doubles per matrix application and one
+// of 2 doubles per iteration.
 emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host, double* x2_host,
                                 int32_t* iterations, double* error)
 {
     if (!g) return EMBA_ERR_INVALID_ARG;
-    if (g->n != 1 || g->use_rccl) return gfail(g, EMBA_ERR_STATE, "solveNormalEqCG is provided for one rank; a sharded window uses the Schur solve");
-    G_TRY(g, 0, emba_solve_normal_eq_cg(g->ctx[0], lambda, fix_first_pose, max_iter, tol, x1_host, x2_host, iterations, error));
+    g->x2_on_ranks = false;
+    if (g->n == 1 && !g->use_rccl) {
+        G_TRY(g, 0, emba_solve_normal_eq_cg(g->ctx[0], lambda, fix_first_pose, max_iter, tol, x1_host, x2_host, iterations, error));
+        return EMBA_OK;
+    }
+    const int n = g->n;
+    if (max_iter <= 0) max_iter = 100;     // model.cpp:823-824
+    if (!(tol > 0)) tol = 1e-6;
+    std::vector<size_t> n_recv(n, 0);
+    { emba_status st = group_exchange_records(g, &n_recv, [](const char*) {}); if (st) return st; }
+    const bool cached = !g->last_solve_exchanged;
+    size_t red_len = 0;
+    G_TRY(g, 0, emba_cg_shard_size(g->ctx[0], &red_len));
+    const size_t nn = red_len - 2;
+    for (int r = 0; r < n; ++r) {
+        emba_status st;      // (sv_S doubles as the reduce buffer: (3K+1)^2 doubles when the Schur solve has grown it, at least 3K + 2 here)
+        if ((st = grow(g, r, &g->sv_S[r], &g->cap_S[r], red_len)) || (st = grow(g, r, &g->sv_x2[r], &g->cap_x2[r], std::max<size_t>(2 * g->P, 2)))) return st;
+    }
+    // the two scalars behind the pose part of every rank's reduce buffer, read from rank 0's copy (identical everywhere)
+    auto read2 = [&](double* a, double* b) -> emba_status {
+        double h[2] = {0, 0};
+        G_HIP(g, hipSetDevice(g->dev[0]));
+        G_HIP(g, hipMemcpyAsync(h, g->sv_S[0] + nn, 16, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        G_HIP(g, hipStreamSynchronize(g->ctx[0]->stream));
+        if (a) *a = h[0];
+        if (b) *b = h[1];
+        return EMBA_OK;
+    };
+    { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_begin(g->ctx[r], r, n, cached ? nullptr : g->sv_recv[r], n_recv[r], lambda, fix_first_pose, g->sv_S[r]); }); if (st) return st; }
+    { emba_status st = group_allreduce(g, (void* const*)g->sv_S.data(), red_len, XType::F64); if (st) return st; }
+    double rhs2 = 0, absNew = 0;
+    { emba_status st = read2(&rhs2, &absNew); if (st) return st; }
+    int it = 0;
+    double err = 0;
+    if (rhs2 != 0) {
+        const double thr = std::max(tol * tol * rhs2, std::numeric_limits<double>::min());
+        double rn2 = rhs2;
+        if (rn2 >= thr) {
+            while (it < max_iter) {
+                { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_apply(g->ctx[r], g->sv_S[r]); }); if (st) return st; }
+                { emba_status st = group_allreduce(g, (void* const*)g->sv_S.data(), red_len, XType::F64); if (st) return st; }
+                std::vector<double> pt(n, 0.0);
+                { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_pt(g->ctx[r], g->sv_S[r], &pt[r]); }); if (st) return st; }
+                const double alpha = absNew / pt[0];      // (pt[r] are equal: the same reduced values, the same one-block dot)
+                { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_update(g->ctx[r], alpha, g->sv_S[r]); }); if (st) return st; }
+                std::vector<void*> tail(n);
+                for (int r = 0; r < n; ++r) tail[r] = g->sv_S[r] + nn;
+                { emba_status st = group_allreduce(g, tail.data(), 2, XType::F64); if (st) return st; }
+                double absNext = 0;
+                { emba_status st = read2(&rn2, &absNext); if (st) return st; }
+                if (rn2 < thr) break;
+                const double beta = absNext / absNew;
+                absNew = absNext;
+                { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_direction(g->ctx[r], beta); }); if (st) return st; }
+                ++it;
+            }
+        }
+        err = std::sqrt(rn2 / rhs2);
+    }
+    { emba_status st = gpool(g, [&](int r) { return emba_cg_shard_end(g->ctx[r], r == 0 ? x1_host : nullptr, g->sv_x2[r]); }); if (st) return st; }
+    { emba_status st = group_allreduce(g, (void* const*)g->sv_x2.data(), 2 * g->P, XType::F64); if (st) return st; }
+    G_HIP(g, hipSetDevice(g->dev[0]));
+    if (x2_host && g->P) G_HIP(g, hipMemcpyAsync(x2_host, g->sv_x2[0], 2 * g->P * 8, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    for (int r = 0; r < n; ++r) { G_HIP(g, hipSetDevice(g->dev[r])); G_HIP(g, hipStreamSynchronize(g->ctx[r]->stream)); }
+    g->x2_on_ranks = true;
+    if (iterations) *iterations = it;
+    if (error) *error = err;
+    return EMBA_OK;
+}
+
+emba_status emba_group_last_solve_exchanged(const emba_group* g, int32_t* exchanged)
+{
+    if (!g || !exchanged) return EMBA_ERR_INVALID_ARG;
+    *exchanged = g->last_solve_exchanged ? 1 : 0;
     return EMBA_OK;
 }
 
@@ -773,7 +876,7 @@ emba_status emba_group_update_map(emba_group* g, const double* x2_host, double d
     // x2_host == NULL: every rank applies the x2 the last emba_group_solve left in ITS device memory (the all-reduced vector) — nothing crosses
     // to the host and back, and not once per rank
     if (!x2_host && (g->n > 1 || g->use_rccl)) {
-        if (!g->x2_on_ranks) return gfail(g, EMBA_ERR_STATE, "x2 NULL: emba_group_solve has not left an x2 on the ranks (after emba_group_solve_cg pass the host vector)");
+        if (!g->x2_on_ranks) return gfail(g, EMBA_ERR_STATE, "x2 NULL: no emba_group_solve / emba_group_solve_cg has left an x2 on the ranks");
         for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_update_map_dev(g->ctx[r], g->sv_x2[r], damping));
         return EMBA_OK;
     }

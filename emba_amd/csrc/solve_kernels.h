@@ -1016,8 +1016,8 @@ __global__ __launch_bounds__(256) void emba_cg_pixel_kernel(CgPixParams p)
 // out[0] += r.r, out[1] += r.p
 __global__ __launch_bounds__(256) void emba_cg_init_kernel(const double* __restrict__ A11, const double* __restrict__ b1, const double* __restrict__ A22b2,
                                                            int n, int skip, long P, double lambda, double* __restrict__ x, double* __restrict__ r,
-                                                           double* __restrict__ pv, double* __restrict__ invd, double* __restrict__ out)
-{
+                                                           double* __restrict__ pv, double* __restrict__ invd, double* __restrict__ out, long sum_from = 0)
+{   // sum_from: first entry that counts in the two sums (the sharded solve: the pose part is replicated on every rank and must enter the all-reduced sums once)
     __shared__ double s_w[2][4];
     const long N = n + 2 * P;
     double rr = 0.0, rp = 0.0;
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(256) void emba_cg_init_kernel(const double* __restr
         else { const long i = (k - n) >> 1; const int h = (int)((k - n) & 1); const double* q = A22b2 + 5 * i; const double a = h ? q[2] : q[0]; d = a + lambda * a; b = q[3 + h]; }
         const double iv = (d != 0.0) ? 1.0 / d : 1.0;
         x[k] = 0.0; r[k] = b; invd[k] = iv; pv[k] = iv * b;
-        rr += b * b; rp += b * iv * b;
+        if (k >= sum_from) { rr += b * b; rp += b * iv * b; }
     }
     rr = wave_sum(rr); rp = wave_sum(rp);
     if ((threadIdx.x & 63) == 0) { s_w[0][threadIdx.x >> 6] = rr; s_w[1][threadIdx.x >> 6] = rp; }
@@ -1048,14 +1048,14 @@ __global__ __launch_bounds__(256) void emba_cg_dot_kernel(const double* __restri
 
 // x += alpha p; r -= alpha t; out += r.r
 __global__ __launch_bounds__(256) void emba_cg_xr_kernel(double alpha, const double* __restrict__ pv, const double* __restrict__ t, long N,
-                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ out)
+                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ out, long sum_from = 0)
 {
     __shared__ double s_w[4];
     double acc = 0.0;
     for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) {
         x[k] += alpha * pv[k];
         const double rv = r[k] - alpha * t[k];
-        r[k] = rv; acc += rv * rv;
+        r[k] = rv; if (k >= sum_from) acc += rv * rv;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
@@ -1065,11 +1065,11 @@ __global__ __launch_bounds__(256) void emba_cg_xr_kernel(double alpha, const dou
 
 // z = invd .* r ; out += r.z
 __global__ __launch_bounds__(256) void emba_cg_z_kernel(const double* __restrict__ invd, const double* __restrict__ r, long N, double* __restrict__ z,
-                                                        double* __restrict__ out)
+                                                        double* __restrict__ out, long sum_from = 0)
 {
     __shared__ double s_w[4];
     double acc = 0.0;
-    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) { const double zv = invd[k] * r[k]; z[k] = zv; acc += r[k] * zv; }
+    for (long k = (long)blockIdx.x * 256 + threadIdx.x; k < N; k += (long)gridDim.x * 256) { const double zv = invd[k] * r[k]; z[k] = zv; if (k >= sum_from) acc += r[k] * zv; }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
     __syncthreads();

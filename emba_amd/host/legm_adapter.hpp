@@ -311,7 +311,7 @@ std::pair<int, double> LEGM::solveNormalEqCG(const MatXd& A11, const MatXd& A12,
     std::vector<double> v1, v2;
     std::pair<int, double> res(0, 0.0);
     try { res = st.impl->solveNormalEqCG(lambda, fix_first_pose, v1, v2); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
-    st.x2_on_device = false;     // (the CG solve runs on rank 0 only: updateMap uploads x2 to every rank)
+    st.x2_on_device = false;     // (updateMap uploads the x2 the caller hands back: one rank keeps its CG solution in the solver's workspace, not where updateMap looks)
     const int skip = fix_first_pose ? 3 : 0;
     x1 = Eigen::Map<const VecXd>(v1.data() + skip, (Eigen::Index)v1.size() - skip);
     x2 = Eigen::Map<const VecXd>(v2.data(), (Eigen::Index)v2.size());

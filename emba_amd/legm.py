@@ -265,6 +265,40 @@ class LEGM:
     def solve_shard_pack(self, n_ranks, send_ptr):
         self._check(self._L.emba_solve_shard_pack(self._ctx, int(n_ranks), C.c_void_p(send_ptr)))
 
+    def solve_shard_cached(self, rank, n_ranks):
+        """n_recv if this rank still holds the records it received for the current equations (a re-solve may skip the exchange), else None."""
+        f, n = C.c_int32(0), C.c_size_t(0)
+        self._check(self._L.emba_solve_shard_cached(self._ctx, int(rank), int(n_ranks), C.byref(f), C.byref(n)))
+        return int(n.value) if f.value else None
+
+    # -- sharded solveNormalEqCG: the per-rank steps (emba_cg_shard_*), driven by emba_amd.sharded.ShardedLEGM.solveNormalEqCG
+    def cg_shard_size(self):
+        n = C.c_size_t(0)
+        self._check(self._L.emba_cg_shard_size(self._ctx, C.byref(n)))
+        return n.value
+
+    def cg_shard_begin(self, rank, n_ranks, recv_ptr, n_recv, lam, fix_first_pose, red_ptr):
+        self._check(self._L.emba_cg_shard_begin(self._ctx, int(rank), int(n_ranks), C.c_void_p(recv_ptr), int(n_recv), float(lam), 1 if fix_first_pose else 0, C.c_void_p(red_ptr)))
+
+    def cg_shard_apply(self, red_ptr):
+        self._check(self._L.emba_cg_shard_apply(self._ctx, C.c_void_p(red_ptr)))
+
+    def cg_shard_pt(self, red_ptr):
+        v = C.c_double(0)
+        self._check(self._L.emba_cg_shard_pt(self._ctx, C.c_void_p(red_ptr), C.byref(v)))
+        return v.value
+
+    def cg_shard_update(self, alpha, red_ptr):
+        self._check(self._L.emba_cg_shard_update(self._ctx, float(alpha), C.c_void_p(red_ptr)))
+
+    def cg_shard_direction(self, beta):
+        self._check(self._L.emba_cg_shard_direction(self._ctx, float(beta)))
+
+    def cg_shard_end(self, x2_full_ptr):
+        x1 = np.zeros(3 * self.K)
+        self._check(self._L.emba_cg_shard_end(self._ctx, _p(x1, _dp), C.c_void_p(x2_full_ptr)))
+        return x1
+
     def solve_shard_partial(self, rank, n_ranks, recv_ptr, n_recv, lam, S_ptr):
         self._check(self._L.emba_solve_shard_partial(self._ctx, int(rank), int(n_ranks), C.c_void_p(recv_ptr), int(n_recv), float(lam), C.c_void_p(S_ptr)))
 

@@ -189,16 +189,20 @@ class ShardedLEGM:
         n_inl, self.P = e.last_counts()
         return n_inl, out
 
-    def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
-        """LEGM::solveNormalEq (model.cpp:721-792) over all ranks, after iteration(): the sparse A12 factors are time-sharded, a pixel's
-        columns are sums over several ranks' records, so the records are first sent to the rank that owns their pixel (contiguous
-        ranges of the active set), each rank forms the Schur sums of ITS pixels, one all-reduce of the (3K+1)^2 block follows, the
-        Cholesky is replicated and the per-pixel x2 are exchanged.  Three collectives: all-to-all (records), all-reduce (S), all-reduce
-        (x2, disjoint supports).  Returns (x1 [3K], x2 [2P]) — identical on every rank.  resident_x2: x2 is returned as the DEVICE tensor
-        the all-reduce left on this rank (for ShardedModel.updateMap: no trip through the host)."""
+    def _exchange_records(self):
+        """Records to their pixels' owners (count, pack, all-to-all) -> (recv tensor or None, n_recv).  Round 6: a re-solve of the SAME
+        equations with another lambda (after a rejected trial, solver.cpp:340-352: 5 of 7 solves in an LM loop) finds the received records still on the
+        owners, in pixel order — one one-word all-reduce (every rank must take the same branch) instead of the exchange: (None, n_recv)."""
         import torch
         e, dist, w, r = self.engine, self.dist, self.world, self.rank
         dev = self.pack.device
+        cached = e.solve_shard_cached(r, w) if hasattr(e, "solve_shard_cached") else None
+        flag = torch.tensor([1.0 if cached is not None else 0.0], dtype=torch.float64, device=dev)
+        if w > 1:
+            dist.all_reduce(flag)
+        self.last_solve_exchanged = not (float(flag.item()) == float(w))
+        if not self.last_solve_exchanged:
+            return None, int(cached)
         counts = e.solve_shard_count(w)                                            # records this rank sends to every owner
         table = torch.zeros(w * w, dtype=torch.int64, device=dev)
         table[r * w:(r + 1) * w] = torch.from_numpy(counts).to(dev)
@@ -214,6 +218,19 @@ class ShardedLEGM:
             dist.all_to_all_single(recv[: n_recv * 16], send[: n_send * 16], [int(v) * 16 for v in recv_counts], [int(v) * 16 for v in counts])
         else:
             e.sync(); recv[: n_send * 16] = send[: n_send * 16]; _device_sync(dev)
+        return recv, n_recv
+
+    def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
+        """LEGM::solveNormalEq (model.cpp:721-792) over all ranks, after iteration(): the sparse A12 factors are time-sharded, a pixel's
+        columns are sums over several ranks' records, so the records are first sent to the rank that owns their pixel (contiguous
+        ranges of the active set), each rank forms the Schur sums of ITS pixels, one all-reduce of the (3K+1)^2 block follows, the
+        Cholesky is replicated and the per-pixel x2 are exchanged.  Three collectives: all-to-all (records), all-reduce (S), all-reduce
+        (x2, disjoint supports).  Returns (x1 [3K], x2 [2P]) — identical on every rank.  resident_x2: x2 is returned as the DEVICE tensor
+        the all-reduce left on this rank (for ShardedModel.updateMap: no trip through the host)."""
+        import torch
+        e, dist, w, r = self.engine, self.dist, self.world, self.rank
+        dev = self.pack.device
+        recv, n_recv = self._exchange_records()
         S = torch.zeros(e.solve_shard_size(), dtype=torch.float64, device=dev)
         e.solve_shard_partial(r, w, recv, n_recv, lam, S)
         if w > 1:
@@ -242,6 +259,59 @@ class ShardedLEGM:
             raise failure if failure is not None else EmbaError(_ERR_NUMERIC, "the damped normal equations are not positive definite on another rank")
         x1 = x2[n2 + 1:].cpu().numpy().copy()
         return x1, (x2[: 2 * self.P] if resident_x2 else x2[: 2 * self.P].cpu().numpy())
+
+
+    # (method of ShardedLEGM, defined below the class body's other solvers for readability)
+
+
+def _sharded_solve_cg(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6, resident_x2=False):
+    """LEGM::solveNormalEqCG (model.cpp:794-840; solver.cpp:190-202 selects it with use_CG) over all ranks — round 6.  The pixels are sharded by owner as in
+    solveNormalEq (same record exchange, skipped on a re-solve); Eigen's loop (ConjugateGradient.h:28-88: diagonal preconditioner, zero initial guess, 100
+    iterations, tolerance 1e-6 on |r| / |b|) runs on every rank on scalars read from the SAME all-reduced sums: one all-reduce of 3K + 2 doubles per
+    application of the matrix, one of 2 per iteration.  Returns (x1, x2, iterations, error) — identical on every rank."""
+    import torch
+    e, dist, w, r = self.engine, self.dist, self.world, self.rank
+    dev = self.pack.device
+    recv, n_recv = self._exchange_records()
+    n = 3 * int(e.K)
+    red = torch.zeros(e.cg_shard_size(), dtype=torch.float64, device=dev)
+    tiny = float(np.finfo(np.float64).tiny)
+
+    def reduce(t):
+        if w > 1:
+            dist.all_reduce(t)
+        _device_sync(dev)
+
+    e.cg_shard_begin(r, w, recv, n_recv, lam, fix_first_pose, red)
+    reduce(red)
+    rhs2, abs_new = (float(v) for v in red[n:n + 2].cpu())
+    it, err = 0, 0.0
+    if rhs2 != 0.0:
+        thr = max(tol * tol * rhs2, tiny)
+        rn2 = rhs2
+        if rn2 >= thr:
+            while it < max_iter:
+                e.cg_shard_apply(red)
+                reduce(red)
+                alpha = abs_new / e.cg_shard_pt(red)
+                e.cg_shard_update(alpha, red)
+                tail = red[n:n + 2]
+                reduce(tail)
+                rn2, abs_next = (float(v) for v in tail.cpu())
+                if rn2 < thr:
+                    break
+                beta = abs_next / abs_new
+                abs_new = abs_next
+                e.cg_shard_direction(beta)
+                it += 1
+        err = float(np.sqrt(rn2 / rhs2))
+    x2 = torch.zeros(2 * max(self.P, 1), dtype=torch.float64, device=dev)
+    x1 = e.cg_shard_end(x2)
+    reduce(x2)
+    return np.asarray(x1).copy(), (x2[: 2 * self.P] if resident_x2 else x2[: 2 * self.P].cpu().numpy()), it, err
+
+
+ShardedLEGM.solveNormalEqCG = _sharded_solve_cg
 
 
 class ShardedModel:
@@ -298,8 +368,9 @@ class ShardedModel:
     def solveNormalEq(self, lam, fix_first_pose=False, resident_x2=False):
         return self.sh.solveNormalEq(lam, fix_first_pose, resident_x2=resident_x2)
 
-    def solveNormalEqCG(self, lam, fix_first_pose=False):
-        raise NotImplementedError("solveNormalEqCG is single-GPU (emba_solve_normal_eq_cg); the sharded loop uses the Schur solve")
+    def solveNormalEqCG(self, lam, fix_first_pose=False, resident_x2=False):
+        x1, x2, _, _ = self.sh.solveNormalEqCG(lam, fix_first_pose, resident_x2=resident_x2)
+        return x1, x2
 
     def updateMap(self, x2, damping):
         if hasattr(x2, "data_ptr"):            # the tensor of solveNormalEq(resident_x2=True)
@@ -414,8 +485,33 @@ class HipEngine:
     def solve_shard_pack(self, n_ranks, send):
         self.m.solve_shard_pack(n_ranks, send.data_ptr())
 
-    def solve_shard_partial(self, rank, n_ranks, recv, n_recv, lam, S):
-        self.m.solve_shard_partial(rank, n_ranks, recv.data_ptr(), n_recv, lam, S.data_ptr())
+    def solve_shard_cached(self, rank, n_ranks):
+        return self.m.solve_shard_cached(rank, n_ranks)
+
+    # sharded solveNormalEqCG: the per-rank steps around ShardedLEGM.solveNormalEqCG's collectives
+    def cg_shard_size(self):
+        return self.m.cg_shard_size()
+
+    def cg_shard_begin(self, rank, n_ranks, recv, n_recv, lam, fix_first_pose, red):
+        self.m.cg_shard_begin(rank, n_ranks, recv.data_ptr() if recv is not None else None, n_recv, lam, fix_first_pose, red.data_ptr())
+
+    def cg_shard_apply(self, red):
+        self.m.cg_shard_apply(red.data_ptr())
+
+    def cg_shard_pt(self, red):
+        return self.m.cg_shard_pt(red.data_ptr())
+
+    def cg_shard_update(self, alpha, red):
+        self.m.cg_shard_update(alpha, red.data_ptr())
+
+    def cg_shard_direction(self, beta):
+        self.m.cg_shard_direction(beta)
+
+    def cg_shard_end(self, x2):
+        return self.m.cg_shard_end(x2.data_ptr())
+
+    def solve_shard_partial(self, rank, n_ranks, recv, n_recv, lam, S):      # recv None: the rank's cached records (solve_shard_cached)
+        self.m.solve_shard_partial(rank, n_ranks, recv.data_ptr() if recv is not None else None, n_recv, lam, S.data_ptr())
 
     def solve_shard_finish(self, rank, n_ranks, recv, n_recv, lam, fix_first_pose, S, x2):
-        return self.m.solve_shard_finish(rank, n_ranks, recv.data_ptr(), n_recv, lam, fix_first_pose, S.data_ptr(), x2.data_ptr())
+        return self.m.solve_shard_finish(rank, n_ranks, recv.data_ptr() if recv is not None else None, n_recv, lam, fix_first_pose, S.data_ptr(), x2.data_ptr())

@@ -260,14 +260,36 @@ emba_status emba_last_solve_info(const emba_ctx* ctx, int32_t* info);
  *   emba_solve_shard_finish  adds the replicated [A11m | b1], factors, x1 -> x1_host (identical on every rank); x2 of the owned pixels
  *                            into x2_full_dev (2P doubles, zero elsewhere: the caller all-reduces it to get every rank's full x2)
  * Call after emba_form_finish (A22/b2 all-reduced, L2 applied), all on the context's stream.  Tested as rank threads on one GPU
- * against the single-process oracle (tests/test_gpu_sharded.py). */
+ * against the single-process oracle (tests/test_gpu_sharded.py).
+ * Re-solves (round 6): solver.cpp:340-352 solves the SAME equations again with a larger lambda after every rejected trial.  A rank keeps the records it received
+ * for its pixels (in pixel order) until new equations are formed; emba_solve_shard_cached says whether it still holds them for the current equations — when every
+ * rank does, skip count / pack / all-to-all and pass recv_dev = NULL, n_recv = the cached count to _partial and _finish. */
 emba_status emba_solve_shard_size(emba_ctx* ctx, size_t* s_doubles);
 emba_status emba_solve_shard_count(emba_ctx* ctx, int32_t n_ranks, size_t* counts_host);
 emba_status emba_solve_shard_pack(emba_ctx* ctx, int32_t n_ranks, double* send_dev);
+emba_status emba_solve_shard_cached(emba_ctx* ctx, int32_t rank, int32_t n_ranks, int32_t* cached, size_t* n_recv);
 emba_status emba_solve_shard_partial(emba_ctx* ctx, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv,
                                      double lambda, double* S_part_dev);
 emba_status emba_solve_shard_finish(emba_ctx* ctx, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv,
                                     double lambda, int32_t fix_first_pose, double* S_dev, double* x1_host, double* x2_full_dev);
+
+/* LEGM::solveNormalEqCG for a sharded window (round 6; model.cpp:794-840 with the pixels sharded by owner as in the Schur solve): the per-rank steps around the
+ * caller's collectives.  A CG vector is [3K pose entries, replicated | this rank's pixels' map entries]; `red_dev` holds emba_cg_shard_size doubles = 3K + 2:
+ *   emba_cg_shard_begin      (after the record exchange, or with recv_dev = NULL where emba_solve_shard_cached allows) x = 0, r = b, p = invd r;
+ *                            red[3K] = r.r, red[3K+1] = r.p, partial                           -- caller: all-reduce(SUM) red_dev (3K + 2) --
+ *   emba_cg_shard_apply      t = M p on the rank's pixels; red[0..3K) = its share of the pose part of t, red[3K] = its p.t    -- all-reduce red_dev (3K + 2) --
+ *   emba_cg_shard_pt         takes the reduced pose part; *pt = p.t (host, identical on every rank)        [alpha = r.z / p.t]
+ *   emba_cg_shard_update     x += alpha p, r -= alpha t, z = invd r; red[3K] = r.r, red[3K+1] = r.z, partial         -- all-reduce red_dev + 3K (2) --
+ *   emba_cg_shard_direction  p = z + beta p                                                                [beta = r.z / previous r.z]
+ *   emba_cg_shard_end        x1 -> x1_host; the rank's x2 into x2_full_dev (2P doubles, zero elsewhere)               -- all-reduce x2_full_dev (2P) --
+ * The loop and its stopping rule are Eigen's (ConjugateGradient.h:28-88): emba_group_solve_cg, emba_amd/sharded.py: ShardedLEGM.solveNormalEqCG. */
+emba_status emba_cg_shard_size(emba_ctx* ctx, size_t* red_doubles);
+emba_status emba_cg_shard_begin(emba_ctx* ctx, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda, int32_t fix_first_pose, double* red_dev);
+emba_status emba_cg_shard_apply(emba_ctx* ctx, double* red_dev);
+emba_status emba_cg_shard_pt(emba_ctx* ctx, const double* red_dev, double* pt);
+emba_status emba_cg_shard_update(emba_ctx* ctx, double alpha, double* red_dev);
+emba_status emba_cg_shard_direction(emba_ctx* ctx, double beta);
+emba_status emba_cg_shard_end(emba_ctx* ctx, double* x1_host, double* x2_full_dev);
 
 /* LEGM::solveNormalEqCG (model.cpp:794-840; selected by BA_config.use_CG at solver.cpp:190-202): Eigen's ConjugateGradient (default
  * diagonal preconditioner, zero initial guess; max_iter <= 0 -> 100, tol <= 0 -> 1e-6 as in the reference) on the full system
@@ -450,10 +472,13 @@ emba_status emba_group_set_cost(emba_group* g, int32_t irls, double eta);
 emba_status emba_group_download(emba_group* g, double* A11, double* b1, uint32_t* active_idx, size_t cap_P, double* A22, double* b2);
 emba_status emba_group_costs(emba_group* g, int32_t irls, double eta, double alpha, double* data_cost, double* reg_cost);
 emba_status emba_group_solve(emba_group* g, double lambda, int32_t fix_first_pose, double* x1_host, double* x2_host);
-/* LEGM::solveNormalEqCG: one-rank groups only (EMBA_ERR_STATE otherwise: a sharded window uses the Schur solve) */
+/* LEGM::solveNormalEqCG over the group (round 6: any number of ranks — the pixels are sharded as in the Schur solve, one all-reduce of 3K + 2 doubles per
+ * application of the matrix and one of 2 doubles per iteration; emba_cg_shard_* below are the per-rank steps). */
 emba_status emba_group_solve_cg(emba_group* g, double lambda, int32_t fix_first_pose, int32_t max_iter, double tol, double* x1_host, double* x2_host,
                                 int32_t* iterations, double* error);
-/* x2_host == NULL: every rank applies the (all-reduced) x2 the last emba_group_solve left in its own device memory. */
+/* Did the last emba_group_solve / _solve_cg run the record exchange (1), or did every rank still hold the records it had received for these equations (0)? */
+emba_status emba_group_last_solve_exchanged(const emba_group* g, int32_t* exchanged);
+/* x2_host == NULL: every rank applies the (all-reduced) x2 the last emba_group_solve / _solve_cg left in its own device memory. */
 emba_status emba_group_update_map(emba_group* g, const double* x2_host, double damping);
 emba_status emba_group_map_accept(emba_group* g);
 emba_status emba_group_map_reject(emba_group* g);

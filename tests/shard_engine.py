@@ -93,6 +93,7 @@ class OracleShardEngine:
         self.ep_pix = np.array([m["pix"] for m in self.meas], dtype=np.int64)
 
     def form_active(self, thres, sync=True):
+        self._recv_cache = None             # new equations: the records an owner received for the previous ones are stale (emba_solve_shard_cached)
         self.meas_form = self.meas          # the measurements these equations consist of (a later, rejected, trial evaluation must not replace them:
                                             # the device keeps them in its second record set, the reference in its host copies of A and b)
         cnt = self.count.numpy()
@@ -183,12 +184,24 @@ class OracleShardEngine:
             out[i, 14] = m["dp"][0]; out[i, 15] = m["dp"][1]
         send[: out.size].copy_(torch.from_numpy(out.ravel()))
 
+    def solve_shard_cached(self, rank, n_ranks):
+        """like the device: n_recv while this owner still holds the records it received for the current equations, else None"""
+        c = getattr(self, "_recv_cache", None)
+        return c.shape[0] if c is not None else None
+
+    def _received(self, recv, n_recv):
+        if recv is None:
+            assert self._recv_cache is not None and self._recv_cache.shape[0] == n_recv, "no cached records for these equations"
+            return self._recv_cache
+        self._recv_cache = recv[: n_recv * 16].numpy().reshape(n_recv, 16).copy()
+        return self._recv_cache
+
     def _pixel_terms(self, recv, n_recv, lam):
         """per OWNED pixel: A12 columns (3K x 2) from the received records, C = A22m, b2 (global, from the reduced pack)."""
         K = self.K
         pk = self.pack[: self.pack_len].numpy()
         A22b2 = pk[9 * K * K + 3 * K:].reshape(self.P, 5)
-        R = recv[: n_recv * 16].numpy().reshape(n_recv, 16)
+        R = self._received(recv, n_recv)
         cols = {}
         for r in R:
             code = int(r[13]); ci = code % (1 << 24); pair = code >> 24; c, p = pair // 4096, pair % 4096
@@ -227,6 +240,83 @@ class OracleShardEngine:
             xx[2 * ci:2 * ci + 2] = np.linalg.solve(C, b2 - A.T @ x1)                    # :790-791
         x2[: xx.size].copy_(torch.from_numpy(xx))            # (the caller's buffer carries a status word behind the 2P entries)
         return x1
+
+    # ---- sharded solveNormalEqCG: the per-rank steps (the device's emba_cg_shard_*), dense per-pixel blocks on the CPU -------------------
+    def cg_shard_size(self):
+        return 3 * self.K + 2
+
+    def cg_shard_begin(self, rank, n_ranks, recv, n_recv, lam, fix_first_pose, red):
+        K = self.K; n = 3 * K
+        pk = self.pack[: self.pack_len].numpy()
+        A11 = pk[:9 * K * K].reshape(n, n, order="F"); b1 = pk[9 * K * K:9 * K * K + n]
+        sk = 3 if fix_first_pose else 0
+        terms = self._pixel_terms(recv, n_recv, lam)            # ci -> (A12 columns 3K x 2, C = A22m, b2)
+        own = sorted(terms)
+        lo, hi = (self.P * rank) // n_ranks, (self.P * (rank + 1)) // n_ranks
+        pix = list(range(lo, hi))
+        A22b2 = pk[9 * K * K + 3 * K:].reshape(self.P, 5)
+        A11m = A11 + lam * np.diag(np.diag(A11))
+        A11m[:sk, :] = 0; A11m[:, :sk] = 0
+        cols = {}
+        for ci in pix:
+            a = A22b2[ci]
+            C = np.array([[a[0] * (1 + lam), a[1]], [a[1], a[2] * (1 + lam)]])
+            A = terms[ci][0].copy() if ci in terms else np.zeros((n, 2))
+            A[:sk, :] = 0
+            cols[ci] = (A, C, a[3:5].copy())
+        assert set(own) <= set(pix)
+        d1 = np.diag(A11) * (1 + lam)
+        bb1 = b1.copy(); bb1[:sk] = 0
+        inv = lambda d: np.where(d != 0, 1.0 / np.where(d != 0, d, 1.0), 1.0)
+        x = np.zeros(n + 2 * len(pix)); r = np.concatenate([bb1] + [cols[ci][2] for ci in pix]) if pix else bb1.copy()
+        invd = np.concatenate([inv(d1)] + [inv(np.array([cols[ci][1][0, 0], cols[ci][1][1, 1]])) for ci in pix]) if pix else inv(d1)
+        p = invd * r
+        self._cg = dict(rank=rank, n=n, pix=pix, cols=cols, A11m=A11m, x=x, r=r, p=p, invd=invd, z=None, t=None)
+        frm = 0 if rank == 0 else n
+        out = np.zeros(n + 2)
+        out[n] = float(np.dot(r[frm:], r[frm:])); out[n + 1] = float(np.dot(r[frm:], p[frm:]))
+        red.copy_(torch.from_numpy(out))
+
+    def cg_shard_apply(self, red):
+        g = self._cg; n = g["n"]; p = g["p"]
+        t = np.zeros_like(p)
+        if g["rank"] == 0:
+            t[:n] = g["A11m"] @ p[:n]
+        for k, ci in enumerate(g["pix"]):
+            A, C, _ = g["cols"][ci]
+            v2 = p[n + 2 * k:n + 2 * k + 2]
+            t[:n] += A @ v2
+            t[n + 2 * k:n + 2 * k + 2] = A.T @ p[:n] + C @ v2
+        g["t"] = t
+        out = np.zeros(n + 2)
+        out[:n] = t[:n]; out[n] = float(np.dot(p[n:], t[n:]))
+        red.copy_(torch.from_numpy(out))
+
+    def cg_shard_pt(self, red):
+        g = self._cg; n = g["n"]
+        rr = red.numpy()
+        g["t"][:n] = rr[:n]
+        return float(np.dot(g["p"][:n], g["t"][:n]) + rr[n])
+
+    def cg_shard_update(self, alpha, red):
+        g = self._cg; n = g["n"]
+        g["x"] = g["x"] + alpha * g["p"]
+        g["r"] = g["r"] - alpha * g["t"]
+        g["z"] = g["invd"] * g["r"]
+        frm = 0 if g["rank"] == 0 else n
+        red[n] = float(np.dot(g["r"][frm:], g["r"][frm:])); red[n + 1] = float(np.dot(g["r"][frm:], g["z"][frm:]))
+
+    def cg_shard_direction(self, beta):
+        g = self._cg
+        g["p"] = g["z"] + beta * g["p"]
+
+    def cg_shard_end(self, x2):
+        g = self._cg; n = g["n"]
+        xx = np.zeros(2 * max(self.P, 1))
+        for k, ci in enumerate(g["pix"]):
+            xx[2 * ci:2 * ci + 2] = g["x"][n + 2 * k:n + 2 * k + 2]
+        x2[: xx.size].copy_(torch.from_numpy(xx))
+        return g["x"][:n].copy()
 
     # ---- what ShardedModel asks of "this rank's LEGM" in the LM loop (emba_amd.solver.solve_time_window over ranks) -------------
     @property

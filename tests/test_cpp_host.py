@@ -97,7 +97,7 @@ def test_adapter_binary_builds_where_the_reference_is_present(hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0,0", False, False), ("0,0", True, False)])
+@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0,0", False, False), ("0,0", True, False), ("0,0", False, True)])
 def test_adapter_runs_the_reference_call_order(tmp_path, hip_lib, oracle_mod, devices, use_irls, use_cg):
     """solveTimeWindow's call order (solver.cpp:63-353) through the EMBA::LEGM adapter — evaluateDataError, formNormalEq[IRLS], applyL2Reg,
     the first-window trim, solveNormalEq[CG], updateMap, evaluateDataError on the trial Mats, accept / reject inferred from the calls — on one
@@ -155,7 +155,7 @@ def test_cpp_resident_host_compiles_and_links(tmp_path, hip_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0", False, False), ("0,0,0", True, False)])
+@pytest.mark.parametrize("devices,use_irls,use_cg", [("0", False, False), ("0", True, False), ("0", False, True), ("0,0", False, False), ("0,0,0", True, False), ("0,0,0", False, True)])
 def test_cpp_resident_solve_time_window(tmp_path, hip_lib, oracle_mod, devices, use_irls, use_cg):
     """EMBA::solveTimeWindow (solver.cpp:11-368) as a C++ host with everything of an iteration resident in HBM
     (emba_amd/host/solve_time_window.hpp on emba_host::ShardedLEGM; 1, 2 and 3 ranks on one GPU; Schur, Huber IRLS, CG) — against the same loop in

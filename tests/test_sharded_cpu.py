@@ -93,7 +93,11 @@ def _solve_worker(rank, world, port, cfg, out_dir, lam, fix):
         eng.upload_map(w.Gx, w.Gy)
         sh.iteration(w.traj, w.thres_valid_pixel, w.alpha, download=True)
         x1, x2 = sh.solveNormalEq(lam, fix)
-        np.savez(os.path.join(out_dir, f"sol{rank}.npz"), x1=x1, x2=x2)
+        first = sh.last_solve_exchanged
+        y1, y2 = sh.solveNormalEq(10 * lam, fix)              # the re-solve after a rejected trial: same equations, larger lambda (solver.cpp:340-352)
+        second = sh.last_solve_exchanged
+        c1, c2, cit, cerr = sh.solveNormalEqCG(lam, fix)       # LEGM::solveNormalEqCG over the ranks (round 6)
+        np.savez(os.path.join(out_dir, f"sol{rank}.npz"), x1=x1, x2=x2, y1=y1, y2=y2, exchanged=np.array([first, second, sh.last_solve_exchanged]), c1=c1, c2=c2, cit=cit, cerr=cerr)
     finally:
         dist.destroy_process_group()
 
@@ -107,11 +111,19 @@ def test_sharded_solve_protocol_over_gloo(oracle_mod, tmp_path, world, lam, fix)
     w = small_workload(**cfg)
     o = oracle_run(oracle_mod, w, dense_A12=True)
     ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, fix)
+    oy1, oy2 = oracle_mod.solve_normal_eq(o["ne"], 10 * lam, fix)
+    oc1, oc2, ocit, ocerr = o["oracle"].solve_cg_sparse(o["ne"], o["ep"], w.K, o["num_ev_map"], w.thres_valid_pixel, 0, 0.0, lam, fix)
     for r in range(world):
         s = np.load(tmp_path / f"sol{r}.npz")
         assert s["x1"].shape == ox1.shape and s["x2"].shape == ox2.shape
         assert np.allclose(s["x1"], ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()), f"rank {r} x1"
         assert np.allclose(s["x2"], ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max()), f"rank {r} x2"
+        # round 6: the re-solve skipped count / pack / all-to-all (every owner still held its records) and is the oracle's solve for the new lambda;
+        # the sharded CG ran on the cached records too and stops like the oracle's restatement of Eigen's loop
+        assert s["exchanged"].tolist() == [True, False, False], s["exchanged"]
+        assert np.allclose(s["y1"], oy1, rtol=1e-7, atol=1e-9 * np.abs(oy1).max()) and np.allclose(s["y2"], oy2, rtol=1e-7, atol=1e-9 * np.abs(oy2).max()), f"rank {r} re-solve"
+        assert abs(int(s["cit"]) - ocit) <= 2 and float(s["cerr"]) < 1e-6 and ocerr < 1e-6
+        assert np.abs(s["c1"] - oc1).max() <= 1e-4 * np.abs(oc1).max() and np.abs(s["c2"] - oc2).max() <= 1e-4 * np.abs(oc2).max(), f"rank {r} CG"
 
 
 def _lm_worker(rank, world, port, cfg, out_dir, ba_kw, n_iter):
@@ -139,7 +151,7 @@ def _lm_worker(rank, world, port, cfg, out_dir, ba_kw, n_iter):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ba_kw", [(8, dict(alpha=5.0)), (3, dict(use_IRLS=True, cost_type="huber", eta=0.1, alpha=1.0))])
+@pytest.mark.parametrize("world,ba_kw", [(8, dict(alpha=5.0)), (3, dict(use_IRLS=True, cost_type="huber", eta=0.1, alpha=1.0)), (2, dict(alpha=5.0, use_CG=True))])
 def test_sharded_lm_loop_over_gloo(oracle_mod, tmp_path, world, ba_kw):
     """EMBA::solveTimeWindow (solver.cpp:63-353) over `world` ranks with real collectives (gloo): every rank runs the LM loop on a ShardedModel
     (data cost summed, sharded normal equations — X1 as saturated bytes — and sharded Schur solve, replicated map) and must take the
@@ -151,7 +163,7 @@ def test_sharded_lm_loop_over_gloo(oracle_mod, tmp_path, world, ba_kw):
     n_iter = 4
     mp.spawn(_lm_worker, args=(world, _free_port(), cfg, str(tmp_path), ba_kw, n_iter), nprocs=world, join=True)
     w = small_workload(**cfg)
-    om = OracleModel(oracle_mod, w)
+    om = OracleModel(oracle_mod, w, use_cg=bool(ba_kw.get("use_CG")))
     ro = solve_time_window(om, perturbed(w, 0.003), w.events, w.Gx, w.Gy, BASettings(**ba_kw), LMSettings(max_num_iter=n_iter))
     ref_log = np.array([[e[1], e[2], e[3], float(e[4])] for e in ro.log])
     for k in range(world):

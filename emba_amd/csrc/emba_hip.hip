@@ -388,6 +388,16 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         hipLaunchKernelGGL(emba_pose_kernel, dim3(nblocks(nbatch, 64)), dim3(64), 0, s, c->d_batch_t, (int)nbatch, c->d_knots, K, t0, dt, c->d_pose, c->d_err);
         hipLaunchKernelGGL(emba_predict_pixel_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, c->d_pm_batch, (long)ns, c->d_pose, kPoseStride, c->d_lut,
                            c->fx, c->fy, c->cx, c->cy, c->W, c->H, d_pred);
+        // the chains of the pm-order: heads -> list (one wave of the assignment kernel per chain)
+        uint32_t *d_hflag = d_emit, *d_hpos = d_pos, *d_heads = nullptr, *d_nheads = d_err + 6;
+        if ((st = ws_get(c, 30, ns * 4, (void**)&d_heads))) return st;
+        hipLaunchKernelGGL(emba_head_flag_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, (long)ns, d_hflag);
+        if ((st = dev_scan(c, d_hflag, d_hpos, ns, d_nheads))) return st;
+        hipLaunchKernelGGL(emba_head_list_kernel, dim3(nblocks(ns)), dim3(256), 0, s, d_hflag, d_hpos, (long)ns, d_heads);
+        uint32_t h_nheads = 0;
+        HIP_TRY(c, hipMemcpyAsync(&h_nheads, d_nheads, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        const long n_heads = (long)h_nheads;
         const int r = std::max(0, std::min(c->opt_tile_reserve, 5));
         std::vector<uint8_t> h_used(max_bins);
         auto geom = [&](int shape, bool fine) {
@@ -404,7 +414,7 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
             const size_t nb_ = (size_t)q.nbx * q.nby + 1;
             HIP_TRY(c, hipMemsetAsync(d_used, 0, nb_, s));
             HIP_TRY(c, hipMemsetAsync(d_breaks, 0, 8, s));
-            hipLaunchKernelGGL(emba_assign_tiles_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_pred, (long)ns, q, d_bin, d_used);
+            hipLaunchKernelGGL(emba_assign_tiles_kernel, dim3((unsigned)((n_heads + 3) / 4)), dim3(256), 0, s, c->d_pm_pix, d_pred, d_heads, n_heads, (long)ns, q, d_bin, d_used);
             hipLaunchKernelGGL(emba_expand_count_kernel, dim3(nblocks(ns)), dim3(256), 0, s, c->d_pm_pix, d_bin, (long)ns, d_emit);
             hipLaunchKernelGGL(emba_count_breaks_kernel, dim3((unsigned)std::min<size_t>(nblocks(ns), 1024)), dim3(256), 0, s, d_emit, (long)ns, d_breaks);
             unsigned long long hb = 0;

@@ -257,49 +257,86 @@ __global__ __launch_bounds__(256) void emba_predict_pixel_kernel(const uint32_t*
     pred[i] = (px >= 0.0 && px < (double)W && py >= 0.0 && py < (double)H) ? (((uint32_t)(int)py << 16) | (uint32_t)(int)px) : kNoPixel;
 }
 
-// One thread per CHAIN (the entries of one sensor pixel: a head without kEvHasPred and the entries behind it that have it) walks it once and gives every
-// entry its tile: bin[i] = oy * nbx + ox (nbx * nby: predicted outside the panorama).  Halo entries (kEvLead: the predecessor a rank inherits from the
-// shard in front of it) only ever appear as lead-in copies — warped for their pm and Jacobian, never summed — and do not constrain a segment.
-__global__ __launch_bounds__(256) void emba_assign_tiles_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pred, long ns, BinGeom g,
-                                                                uint32_t* __restrict__ bin, uint8_t* __restrict__ bin_used)
+// Chain heads (an entry without kEvHasPred: the first entry of a sensor pixel, or the halo entry in front of it): flags -> scan -> list.  Pose-independent.
+__global__ void emba_head_flag_kernel(const uint32_t* __restrict__ pm_pix, long ns, uint32_t* __restrict__ flag)
 {
-    const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i0 >= ns || (pm_pix[i0] & kEvHasPred)) return;     // not the head of a chain
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ns) flag[i] = (pm_pix[i] & kEvHasPred) ? 0u : 1u;
+}
+__global__ void emba_head_list_kernel(const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pos, long ns, uint32_t* __restrict__ heads)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ns && flag[i]) heads[pos[i]] = (uint32_t)i;
+}
+
+__device__ __forceinline__ int wave_prefix_min(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d); if (lane >= d) v = min(v, u); }
+    return v;
+}
+__device__ __forceinline__ int wave_prefix_max(int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(v, d); if (lane >= d) v = max(v, u); }
+    return v;
+}
+
+// One WAVE per CHAIN (the entries of one sensor pixel: a head and the entries behind it), 64 entries at a time from coalesced loads: the bounding box of the open
+// segment is a wave prefix min / max over the entries since its start, the first entry that no longer fits is a ballot away, and a closed segment's entries
+// get their tile — bin[i] = oy * nbx + ox (nbx * nby: predicted outside the panorama) — by coalesced stores.  (The first form walked a chain with ONE thread, two
+// dependent loads per entry: 2 ms per candidate geometry at 10 M events, 10-12 ms of a window's first evaluation for the four shapes.)  Halo entries
+// (kEvLead: the predecessor a rank inherits from the shard in front of it) only ever appear as lead-in copies — warped for their pm and Jacobian, never summed —
+// and do not constrain a segment.
+__global__ __launch_bounds__(256) void emba_assign_tiles_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pred, const uint32_t* __restrict__ heads,
+                                                                long n_heads, long ns, BinGeom g, uint32_t* __restrict__ bin, uint8_t* __restrict__ bin_used)
+{
+    const int lane = threadIdx.x & 63;
+    const long k = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n_heads) return;      // (wave-uniform)
+    const long c0 = heads[k], c1 = (k + 1 < n_heads) ? (long)heads[k + 1] : ns;
     const uint32_t none = (uint32_t)g.nbx * (uint32_t)g.nby;
     const int wx = g.tw - 2 * g.r, wy = g.th - 2 * g.r;
-    long seg = i0;                       // first entry of the open segment
-    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;   // its bounding box (x1 < x0: empty)
-    long i = i0;
-    for (;;) {
-        const bool more = i < ns && (i == i0 || (pm_pix[i] & kEvHasPred));
-        bool close = !more, fits = false;
-        int nx0 = x0, nx1 = x1, ny0 = y0, ny1 = y1;
-        uint32_t pp = kNoPixel;
-        bool free_entry = false;
-        if (more) {
-            pp = pred[i];
-            free_entry = (pm_pix[i] & kEvLead) != 0;          // a halo entry: any tile will do
-            if (!free_entry && pp != kNoPixel) {
-                const int px = (int)(pp & 0xFFFFu), py = (int)(pp >> 16);
-                if (x1 < x0) { nx0 = nx1 = px; ny0 = ny1 = py; }
-                else { nx0 = min(x0, px); nx1 = max(x1, px); ny0 = min(y0, py); ny1 = max(y1, py); }
-                fits = (nx1 - (nx0 / g.bw) * g.bw < wx) && (ny1 - (ny0 / g.bh) * g.bh < wy);
-                close = !fits;
-            } else if (!free_entry) close = true;             // predicted outside the panorama: ends the segment, takes the extra bin
+    constexpr int kBig = 0x7FFFFFFF;
+    long seg = c0;                                      // first entry of the open segment
+    int X0 = kBig, X1 = -1, Y0 = kBig, Y1 = -1;         // its bounding box (X1 < X0: empty) — wave-uniform
+    auto close = [&](long end, int x0, int x1, int y0) {   // entries [seg, end) are a segment with this bounding box
+        if (seg >= end) return;
+        const uint32_t b = (x1 < x0) ? none : (uint32_t)(y0 / g.bh) * (uint32_t)g.nbx + (uint32_t)(x0 / g.bw);
+        for (long j = seg + lane; j < end; j += 64) bin[j] = b;
+        if (lane == 0) bin_used[b] = 1;
+    };
+    for (long base = c0; base < c1; base += 64) {
+        const long i = base + lane;
+        const bool in = i < c1;
+        const uint32_t pw = in ? pm_pix[i] : 0u, pp = in ? pred[i] : kNoPixel;
+        const bool free_entry = in && (pw & kEvLead) != 0;              // a halo entry: any tile will do
+        const bool nopix = in && !free_entry && pp == kNoPixel;         // predicted outside the panorama: ends the segment, takes the extra bin
+        const bool real = in && !free_entry && !nopix;
+        const int px = (int)(pp & 0xFFFFu), py = (int)(pp >> 16);
+        int cur = 0;                                                    // first lane of this block that has not been given to a segment yet
+        while (cur < 64 && base + cur < c1) {                           // (wave-uniform)
+            const bool mine = real && lane >= cur;
+            int a0 = wave_prefix_min(mine ? px : kBig, lane), a1 = wave_prefix_max(mine ? px : -1, lane);
+            int b0 = wave_prefix_min(mine ? py : kBig, lane), b1 = wave_prefix_max(mine ? py : -1, lane);
+            a0 = min(a0, X0); a1 = max(a1, X1); b0 = min(b0, Y0); b1 = max(b1, Y1);         // ... since the segment's start
+            const bool fits = (a1 < a0) || ((a1 - (a0 / g.bw) * g.bw < wx) && (b1 - (b0 / g.bh) * g.bh < wy));
+            const unsigned long long stop = __ballot(in && lane >= cur && ((real && !fits) || nopix));
+            if (!stop) {                                                // the rest of the block joins the open segment
+                X0 = __shfl(a0, 63); X1 = __shfl(a1, 63); Y0 = __shfl(b0, 63); Y1 = __shfl(b1, 63);
+                break;
+            }
+            const int b = __ffsll((long long)stop) - 1;                 // the first entry that ends it
+            const int q = b > cur ? b - 1 : 0;
+            const int cx0 = b > cur ? __shfl(a0, q) : X0, cx1 = b > cur ? __shfl(a1, q) : X1, cy0 = b > cur ? __shfl(b0, q) : Y0;
+            close(base + b, cx0, cx1, cy0);
+            const bool b_nopix = (__ballot(nopix) >> b) & 1ull;
+            if (b_nopix) { if (lane == 0) { bin[base + b] = none; bin_used[none] = 1; } seg = base + b + 1; X0 = kBig; X1 = -1; Y0 = kBig; Y1 = -1; }
+            else { seg = base + b; X0 = X1 = __shfl(px, b); Y0 = Y1 = __shfl(py, b); }      // opens the next segment (a single pixel always fits: wx >= bw, wy >= bh)
+            cur = b + 1;
         }
-        if (close && seg < i) {                               // entries [seg, i) form a segment
-            const uint32_t b = (x1 < x0) ? none : (uint32_t)(y0 / g.bh) * (uint32_t)g.nbx + (uint32_t)(x0 / g.bw);
-            for (long k = seg; k < i; ++k) bin[k] = b;
-            bin_used[b] = 1;
-            seg = i; x1 = -1; x0 = 0;
-        }
-        if (!more) break;
-        if (free_entry) { /* joins whatever segment follows (or precedes) it */ }
-        else if (pp == kNoPixel) { bin[i] = none; bin_used[none] = 1; seg = i + 1; x1 = -1; x0 = 0; }
-        else if (fits) { x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1; }
-        else { const int px = (int)(pp & 0xFFFFu), py = (int)(pp >> 16); x0 = x1 = px; y0 = y1 = py; }    // opens the next segment
-        ++i;
     }
+    close(c1, X0, X1, Y0);
 }
 
 // how many entries the tile order needs for pm entry i: the event itself (halo entries appear only as lead-ins) plus a lead-in copy

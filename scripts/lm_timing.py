@@ -12,6 +12,9 @@ n, ph, K, dt = (int(a[0]), int(a[1]), int(a[2]), float(a[3])) if len(a) >= 4 els
 max_iter = int(a[4]) if len(a) >= 5 else 6
 w = make_workload(n_events=n, pano_h=ph, K=K, dt_knots=dt)
 m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h)
+for kv in filter(None, os.environ.get("EMBA_OPTS", "").split(",")):      # A/B: EMBA_OPTS=order=1,tile_reserve=4 python scripts/lm_timing.py
+    name, _, val = kv.partition("=")
+    m.set_option(name.strip(), int(val))
 # a perturbed start (left-multiplied small rotations on every control pose but the first), so that the loop has something to do
 rng = np.random.default_rng(3)
 init = type(w.traj)(w.traj.knots_xyzw.copy(), w.traj.t0_ns, w.traj.dt_ns)
@@ -52,6 +55,7 @@ for window in (1, 2):
     once = max(0.0, el[0] - float(np.median(el[1:]))) if len(el) > 2 else 0.0
     print(f"   once per window: set_events + first upload {setup*1e3:.1f} ms, event ordering inside the first evaluation {once*1e3:.1f} ms"
           f" -> {(wall-setup-once)/max(r.iterations,1)*1e3:.2f} ms per iteration without them")
+    print(f"   order: {m.setup_info()}; inliers outside their tile in the last evaluation, re-binnings of the window: {m.tile_drift()}")
     print("   ms inside the model calls: " + ", ".join(f"{k} {v*1e3:.2f}" for k, v in T.items()))
     inside = sum(v for k, v in T.items())
     print(f"   per iteration: " + ", ".join(f"{k} {v/max(r.iterations,1)*1e3:.3f}" for k, v in T.items() if k not in ("set_events", "upload_map")) +

@@ -150,7 +150,7 @@ struct emba_ctx {
     bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
     int opt_tile_reserve = 2, opt_tile_shape = -1, opt_tile_fine = -1, opt_tile_min_events = 1650000, opt_tile_chunk = 0;   // emba_set_option: the tile order's window rule (prepare_order)
     int tile_shape = 0; bool tile_fine = false;   // ... and what the current order uses: index into kTileShapes, its finer pitch grid
-    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_syrk_min_cols = 512, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
+    int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_syrk_min_cols = 512, opt_syrk_item_cap = 4096, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
     int step_ep = 1;              // emba_step produces ep (what evaluateDataError returns, model.cpp:256) in every step; 0: on demand only (A/B, bench.py's no_ep block)
     bool step_wants_ep = false;   // set by emba_step around its emba_form_active
     const uint8_t* global_u8 = nullptr;   // set by emba_step_form_active around its emba_form_active: the all-reduced saturated byte counts activity is decided from
@@ -2024,6 +2024,7 @@ const OptionRef kOptions[] = {
     {"gram_sparse", &emba_ctx::opt_gram_sparse, -1, 1},
     {"gram_sparse_chunk", &emba_ctx::opt_gram_sparse_chunk, 1, 8},
     {"syrk_min_cols", &emba_ctx::opt_syrk_min_cols, 64, 4096},
+    {"syrk_item_cap", &emba_ctx::opt_syrk_item_cap, 1, 65536},
     {"solve_debug", &emba_ctx::opt_solve_debug, 0, 1},
     {"poisson", &emba_ctx::opt_poisson, 0, 2},
     {"gemm64", &emba_ctx::opt_gemm64, 0, 1},
@@ -2221,6 +2222,15 @@ emba_status emba_device_pci_bus_id(emba_ctx* c, char* buf, size_t len)
 namespace {
 
 
+// A kernel that keeps the 3K-vector x1 (or the pose part of a CG vector) in dynamic LDS: above 64 KB (K > 2730) the launch needs the attribute raised, above the
+// CU's 160 KB there is no such launch — say so instead of a generic launch failure
+emba_status pose_vector_lds(emba_ctx* c, const void* kernel, size_t bytes, const char* what)
+{
+    if (bytes > (size_t)160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "%s: K = %zu control poses need %zu bytes of LDS for the pose vector (limit 160 KB: K <= 6826)", what, bytes / 24, bytes);
+    if (bytes > (size_t)64 * 1024) HIP_TRY(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return EMBA_OK;
+}
+
 // per-pixel record lists over `n_pix` pixels of `view` (n_rec records): counts from the records themselves, exclusive scan, fill.
 // Workspaces 0 (off), 1 (cursor), 33 (the records in pixel order).
 emba_status build_lists(emba_ctx* c, const RecView& view, size_t n_rec, size_t n_pix, SolveLists* out)
@@ -2340,7 +2350,7 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
         // keeps the round-3/4 form (a workgroup per (pair, part) walking every nks-th slice of the pair's list).
         int item_chunk = 0, n_item_chunks = 0;
         uint32_t* d_pair_items = nullptr; uint32_t* d_items = nullptr;
-        const uint32_t item_cap = 4096;
+        const uint32_t item_cap = (uint32_t)c->opt_syrk_item_cap;      // slabs of the item form: items beyond them add to S by global atomics (option syrk_item_cap: 4096; tests force the overflow branch with 8)
         if (items_form) {
             const long pairs_est = (long)band_blocks * (band_blocks + 1) / 2;
             item_chunk = (int)std::min<long>(64, std::max<long>(4, ((long)n_slices * pairs_est * 3 / 2 + 2999) / 3000));
@@ -2516,6 +2526,7 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
     if (P)
+        if ((st = pose_vector_lds(c, (const void*)emba_schur_x2_kernel, (size_t)n * sizeof(double), "solveNormalEq (x2)"))) return st;
         hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), (size_t)n * sizeof(double), s, L.sorted, L.off, d_y,
                            d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2, n);
     HIP_TRY(c, hipGetLastError());
@@ -2655,6 +2666,7 @@ extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_
         HIP_TRY(c, hipMemsetAsync(x2_full_dev, 0, 2 * c->P * sizeof(double), s));
         RecView view{};       // the received records in pixel order, as emba_solve_shard_partial's build_lists left them
         view.rec = (const double*)c->ws[33].p; view.packed = 1; view.pix_base = 0;
+        if ((st = pose_vector_lds(c, (const void*)emba_schur_x2_kernel, (size_t)n * sizeof(double), "solveNormalEq (x2)"))) return st;
         if (n_pix)
             hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((n_pix + 3) / 4, 8192)), dim3(256), (size_t)n * sizeof(double), s, view, (const uint32_t*)c->ws[0].p,
                                d_y, d_cf, d_rhs, c->irls, c->eta, (long)n_pix, x2_full_dev + 2 * lo, n);
@@ -2704,6 +2716,7 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
         if (b) *b = h[1];
         return EMBA_OK;
     };
+    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)n * 8, "solveNormalEqCG"))) return st;
     CgPixParams pp{};
     pp.view = L.sorted; pp.off = L.off; pp.A22b2 = pack_A22b2(c); pp.lambda = lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = skip;
     pp.P = (long)P;
@@ -2796,6 +2809,7 @@ extern "C" emba_status emba_cg_shard_begin(emba_ctx* c, int32_t rank, int32_t n_
     RecView view{};
     view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
     if ((st = build_lists(c, view, n_recv, g.npix, &g.L))) return st;
+    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)g.n * 8, "solveNormalEqCG"))) return st;
     HIP_TRY(c, hipMemsetAsync(red_dev, 0, ((size_t)g.n + 2) * 8, s));
     const unsigned grid = (unsigned)std::min<size_t>(nblocks(g.Nl), 1024);
     hipLaunchKernelGGL(emba_cg_init_kernel, dim3(grid), dim3(256), 0, s, pack_A11(c), pack_b1(c), pack_A22b2(c) + 5 * lo, g.n, g.skip, (long)g.npix, lambda, g.x, g.r, g.p, g.invd,

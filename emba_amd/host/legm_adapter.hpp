@@ -58,7 +58,6 @@ struct LegmHipState {
     bool map_is_trial = false;           // the device holds a trial map nobody has decided about
     // the caller's CURRENT map is zero outside these pixels (the active set of the accepted trial it came from): the next updateMap zeroes
     // just them instead of two whole planes.  Invalid until a trial of this object has been accepted, and after any map it did not produce.
-    std::vector<uint32_t> cur_nonzero; bool cur_nonzero_valid = false;
     // the x2 of the last Schur solve stays on the ranks' devices: updateMap recognises it (size + a strided sample) and skips the upload
     std::vector<double> x2_sample; size_t x2_size = 0; bool x2_on_device = false;
     bool numeric_failure = false;        // the last solve met a 2x2 block that is not positive definite: x1 / x2 are NaN like the reference's (model.cpp:750)
@@ -125,8 +124,7 @@ inline void settle_trial(LegmHipState& st, bool accepted)
     try { if (accepted) st.impl->acceptMap(); else st.impl->rejectMap(); }
     catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     st.map_is_trial = false; st.trial_pending = false;
-    if (accepted) { st.cur_nonzero = st.trial_active; st.cur_nonzero_valid = true; }     // solver.cpp:304-305: Gx_new.copyTo(Gx)
-    else { st.trial_gx = st.trial_gy = nullptr; }
+    if (!accepted) { st.trial_gx = st.trial_gy = nullptr; }
 }
 
 inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2,
@@ -220,7 +218,6 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
             resident = (smp.size() == st.trial_sample.size()) && std::memcmp(smp.data(), st.trial_sample.data(), smp.size() * sizeof(double)) == 0;
         }
     }
-    if (!resident) st.cur_nonzero_valid = false;    // a map this object did not produce: nothing is known about where it is zero
     if (!resident && st.map_is_trial) legm_hip_detail::settle_trial(st, false);   // some other map: the pending trial is void
     try {
         std::vector<double> ep = st.impl->evaluateDataError(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
@@ -338,19 +335,10 @@ void LEGM::updateMap(cv::Mat& Gx_new, cv::Mat& Gy_new, const VecXd& x2, const do
     }
     double* gx = Gx_new.ptr<double>(); double* gy = Gy_new.ptr<double>();
     const size_t npix = (size_t)Gx_new.rows * Gx_new.cols;
-    // zero the planes: everything (two memsets of H x W doubles), or — when the clones are known to be the map an accepted trial of this
-    // object produced — just that trial's active pixels, the only places where they are not zero already
-    bool zeroed = false;
-    if (st.cur_nonzero_valid) {
-        for (uint32_t p : st.cur_nonzero) { gx[p] = 0.0; gy[p] = 0.0; }
-        //  ... which holds for solver.cpp's call order (Gx.clone() of the accepted map, :237-238) but is an assumption about the caller:
-        // a strided sample of both planes must now read zero, else these are other Mats and everything is cleared as the reference does (model.cpp:892-901)
-        std::vector<double> smp;
-        legm_hip_detail::sample_plane(gx, npix, smp); legm_hip_detail::sample_plane(gy, npix, smp);
-        zeroed = true;
-        for (double v : smp) if (v != 0.0 || v != v) { zeroed = false; break; }
-    }
-    if (!zeroed) { std::memset(gx, 0, npix * sizeof(double)); std::memset(gy, 0, npix * sizeof(double)); }
+    // zero the planes, all of them, as the reference does (model.cpp:892-901).  (Rounds 4-5 cleared only the previous trial's active pixels when the clones looked
+    // like the map an accepted trial of this object had produced, and verified that with a strided sample: a caller's other Mats with non-zeros between the sample
+    // points would have kept stale values — ADVICE r5; a full scan costs what the two memsets cost.)
+    std::memset(gx, 0, npix * sizeof(double)); std::memset(gy, 0, npix * sizeof(double));
     if (st.numeric_failure) {
         // x2 is NaN (see solveNormalEq): the reference's loop writes Gx + damping * NaN into the active pixels and zero elsewhere
         // (model.cpp:863-903); the device is not touched, the trial evaluation that follows is short-circuited

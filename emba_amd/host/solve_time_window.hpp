@@ -21,7 +21,11 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <stdexcept>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "legm_sharded.hpp"
@@ -65,8 +69,9 @@ class RuntimeLog {
 public:
     explicit RuntimeLog(const std::string& result_dir) : dir_(result_dir + "/final_results")
     {
-        const std::string cmd = "mkdir -p '" + dir_ + "'";
-        if (std::system(cmd.c_str()) != 0) throw std::runtime_error("cannot create " + dir_);
+        std::error_code ec;      // (no shell: a result_dir with a quote in it is a directory name, not a command — ADVICE r5; and no fork of a process that holds the GPU)
+        std::filesystem::create_directories(dir_, ec);
+        if (ec) throw std::runtime_error("cannot create " + dir_ + ": " + ec.message());
         FILE* f = std::fopen((dir_ + "/iterations.txt").c_str(), "w");       // emba.cpp:223 opens it afresh
         if (f) std::fclose(f);
     }
@@ -193,7 +198,7 @@ inline LMResult solveTimeWindow(ShardedLEGM& model, const TrajectoryView& traj0,
                     const std::pair<int, double> r = model.solveNormalEqCG(lambda, ba.first_time_window, x1, x2);
                     cg_it = r.first;
                     if (rl) rl->cg(iter, r.first, r.second);
-                    model.updateMap(x2, ba.damping_factor);                                                     // (the CG solve runs on rank 0: x2 goes to every rank)
+                    model.updateMap(x2, ba.damping_factor);                                                     // (x2 of the CG solve goes through the host, as in the reference)
                 } else {
                     model.solveNormalEqResident(lambda, ba.first_time_window, x1);                              // :190-194; x2 stays on the device
                 }
@@ -209,6 +214,8 @@ inline LMResult solveTimeWindow(ShardedLEGM& model, const TrajectoryView& traj0,
         }
         if (numeric_failure) {
             iter += 1;
+            // (the reference evaluates the NaN trial point and records that evaluation too, solver.cpp:271-291: a record of zero duration keeps the file's line count)
+            if (rl) rl->add(RuntimeLog::ObjFunc, iter, 0.0, (long)model.numActivePixels());
             res.log.push_back({iter, std::log10(lambda), cost_min, INFINITY, false, model.numActivePixels(), cg_it});
             cost_has_decreased = false; lambda *= 10; count_tol = 0;
             continue;

@@ -385,7 +385,8 @@ emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
  *   solve_perm     -1 auto | 0 | 1 U's columns ordered by panorama column in the Schur solve
  *   solve_counts   -1 auto | 0 list lengths counted from the records | 2 both, compared
  *   syrk_dense     1 dense instead of block-sparse SYRK;  syrk_lists 0 auto | 1 the block-sparse SYRK's per-pair slice lists always | 2 its (pair, chunk) items always;
- *                  syrk_min_cols 64 ... 4096 (512): fewest columns of U a workgroup of the dense split-K SYRK takes
+ *                  syrk_min_cols 64 ... 4096 (512): fewest columns of U a workgroup of the dense split-K SYRK takes;  syrk_item_cap 1 ... 65536 (4096): slabs of the item
+ *                  form (an item beyond them adds its tile to S by global atomics)
  *   solve_debug    1 prints the band statistics of a solve
  *   poisson        0 folded Fourier form | 1 dense sine transforms | 2 no folding;  gemm64 1 forces the 64-wide GEMM tiles */
 emba_status emba_set_option(emba_ctx* ctx, const char* name, int32_t value);

@@ -554,6 +554,26 @@ def test_schur_solve_with_the_columns_of_U_in_panorama_column_order(gpu, oracle_
         assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max())
 
 
+@pytest.mark.parametrize("opts", [dict(syrk_lists=1), dict(syrk_lists=2), dict(syrk_lists=2, syrk_item_cap=8), dict(syrk_dense=1), dict(syrk_dense=1, syrk_min_cols=64),
+                                  dict(syrk_lists=2, solve_perm=1), dict(syrk_lists=1, solve_perm=0)])
+def test_schur_solve_under_every_form_of_the_syrk(gpu, oracle_mod, opts, monkeypatch):
+    """the block-sparse SYRK has three forms — per-pair slice LISTS, (pair, slice chunk) ITEMS (three list kernels, the slab reduce, and the
+    overflow branch where an item beyond the slabs adds to S by global atomics) — and the dense split-K form; which one runs is decided from the band of U, so a
+    long window is the only thing that reaches the item form by itself.  Every form forced (options syrk_lists / syrk_dense / syrk_min_cols / syrk_item_cap:
+    8 slabs for hundreds of items) at K = 100 (five row blocks) against the oracle, with a re-solve on the cached lists."""
+    for k, v in opts.items():
+        monkeypatch.setitem(OPTIONS, k, v)
+    w = small_workload(n_events=120000, pano_h=256, K=100, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3)
+    g = gpu_run(w)
+    assert g["ne"]["P"] >= 512
+    o = oracle_run(oracle_mod, w, dense_A12=True)
+    for lam in (1e-2, 1.0):
+        x1, x2 = g["legm"].solveNormalEq(lam, fix_first_pose=True)
+        ox1, ox2 = oracle_mod.solve_normal_eq(o["ne"], lam, True)
+        assert np.allclose(x1, ox1, rtol=1e-7, atol=1e-9 * np.abs(ox1).max()), opts
+        assert np.allclose(x2, ox2, rtol=1e-7, atol=1e-9 * np.abs(ox2).max()), opts
+
+
 @pytest.mark.parametrize("K,kw", [(8, {}), (90, dict(n_events=60000, pano_h=256, sensor=(64, 48), focal=60.0, dt_knots=0.004, thres_valid_pixel=3))])
 def test_schur_solve_with_an_unobserved_control_pose(gpu, oracle_mod, K, kw):
     """model.cpp:789 is Eigen's PIVOTED ldlt: for a semi-definite S (a control pose no event constrains) it returns, with a ZERO update in
@@ -1131,6 +1151,8 @@ def test_call_order_pairs_never_give_a_wrong_number(gpu, oracle_mod):
         "map_reject": lambda m: m.rejectMap(),
         "trial_reject": lambda m: m.rejectTrial(),
         "step": lambda m: m.step(w.traj, w.thres_valid_pixel, w.alpha),
+        "get_ep": lambda m: dict(ep=m.get_ep()),         # (must be this window's current evaluation's vector, or EMBA_ERR_STATE — never an earlier one's)
+        "set_events": lambda m: m.set_events(w.events),  # ... a new window: whatever was pending belongs to the old one
     }
     n_ok = n_state = 0
     for start in ("fresh", "formed"):
@@ -1156,6 +1178,8 @@ def test_call_order_pairs_never_give_a_wrong_number(gpu, oracle_mod):
                     if isinstance(r, dict) and not trial_map:
                         if "ne" in r:
                             compare_normal_eq(r["ne"], o["ne"])
+                        elif "ep" in r:
+                            assert_close(r["ep"], o["ep"], "ep")
                         else:
                             check_solve(*r["x"])
                 # the canonical sequence on the same context afterwards

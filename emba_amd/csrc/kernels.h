@@ -1621,9 +1621,16 @@ __device__ __forceinline__ void gram_atomic_out(double v, int row, int col, uint
 // per block) so that the 16 waves of a block cost ONE set of global atomics per pair instead of 16 — the global fp64 atomics
 // all land on the few A11 blocks of the current pairs and serialise at the memory side otherwise.  Called once or twice per
 // wave: a real function (arguments by value, in registers), so that its index arithmetic stays out of the streaming loop.
+// (a real call: 31 argument registers — the two LDS tables travel as 16-bit LDS addresses in one word and dim | ablate in another, or the last arguments would go
+// through the stack: 16 B of scratch per lane in every Gram kernel until round 6)
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) double lds_f64_t;
 __device__ __attribute__((noinline)) void gram_flush(double4_t ee, double4_t oe, double4_t oo, uint32_t key, double* A11, double* b1,
-                                                     int dim, int ablate, uint32_t* s_tag, double* s_tile)
+                                                     uint32_t dim_ablate, uint32_t lds_tag_tile)
 {
+    const int dim = (int)(dim_ablate & 0x3FFFFu), ablate = (int)(dim_ablate >> 18);      // (dim = 3K <= 196 605; the diagnostics mask fits 14 bits)
+    uint32_t* const s_tag = (uint32_t*)(lds_u32_t*)(uintptr_t)(lds_tag_tile & 0xFFFFu);
+    double* const s_tile = (double*)(lds_f64_t*)(uintptr_t)(lds_tag_tile >> 16);
     const int lane = threadIdx.x & 63;
     int slot = -1;
     if (lane == 0) {
@@ -1745,7 +1752,8 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     bool dirty = false;
     double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
     auto flush = [&]() {
-        gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, p.dim, p.ablate, s_tag, s_tile);
+        gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, (uint32_t)p.dim | ((uint32_t)p.ablate << 18),
+                   ((uint32_t)(uintptr_t)(lds_u32_t*)s_tag & 0xFFFFu) | ((uint32_t)(uintptr_t)(lds_f64_t*)s_tile << 16));      // (the kernel's LDS is < 64 KB)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
     };

@@ -689,6 +689,11 @@ __global__ __launch_bounds__(kTileWaves * 64) __attribute__((amdgpu_waves_per_eu
             // have the group's remaining arithmetic and LDS atomics to arrive; (3) waits for everything once and rotates the registers;
             // (4) issues the record stores last.
             // Before: a vmcnt(0) per staging round and one at the loop head = ~15 us per group, 67 % of wave time waiting.
+            // (Round 6, measured and dropped: the NEXT group's bearing-vector / segment gathers issued in front of this group's record stores, the stores in a
+            // static number — lanes without a record writing to a trash line — so that the next group's first wait is vmcnt(8) and does not include the stores'
+            // acknowledgements: the ISA did what was intended and the kernel got SLOWER, city 490 -> 537 us, 10 M 461 -> 469, 40 M 1784 -> 1832, 3 M equal
+            // (profiles/r06_early_gather_ab.txt; 112 instead of 101 VGPRs).  The acknowledgement wait is not what the wave loses: by ablation the record stores
+            // cost 14-21 % of the kernel, a third to a half of that with the stores going to a cache-resident window — issue and drain, not the wait.)
             LaneIn cur, nxt;
             {
                 const long g0 = begin + (long)kWarpNew * wv;

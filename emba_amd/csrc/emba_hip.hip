@@ -929,8 +929,8 @@ emba_status set_events_core(emba_ctx* c, const uint16_t* x, const uint16_t* y, c
     c->n_fblk = (long)std::max<size_t>((ns + kFlagBlk - 1) / kFlagBlk, 1);
     if ((st = dev_alloc(c, &c->d_fblk_cnt, (size_t)c->n_fblk)) || (st = dev_alloc(c, &c->d_fblk_off, (size_t)c->n_fblk))) return st;
     c->n_fsup = (c->n_fblk + kFlagSup - 1) / kFlagSup;
-    if ((st = dev_alloc(c, &c->d_fsup, (size_t)2 * c->n_fsup))) return st;
-    HIP_TRY(c, hipMemsetAsync(c->d_fsup, 0, (size_t)2 * c->n_fsup * sizeof(uint32_t), c->stream));      // (both halves: launch A adds into one and zeroes the other for the next step)
+    if ((st = dev_alloc(c, &c->d_fsup, (size_t)2 * c->n_fsup * kFlagSupStride))) return st;
+    HIP_TRY(c, hipMemsetAsync(c->d_fsup, 0, (size_t)2 * c->n_fsup * kFlagSupStride * sizeof(uint32_t), c->stream));      // (both halves: launch A adds into one and zeroes the other for the next step)
     if ((st = dev_alloc(c, &c->d_ep, ns))) return st;
     // a record is valid iff it carries the current evaluation's stamp (record_valid): a reused buffer holds older stamps only, new memory is cleared
     if (rec_fresh) HIP_TRY(c, hipMemsetAsync(c->d_rec, 0, c->caps[reinterpret_cast<void**>(&c->d_rec)], s));
@@ -1475,7 +1475,7 @@ emba_status emba_form_active(emba_ctx* c, int32_t thres, size_t* P, size_t* pack
         // and "sum every predecessor"): 38-270 us against 6.3 + 11.2 — the eight XCDs' L2s are not coherent with each other, so every flag is a
         // round trip to the memory side (and a release / acquire pair writes back / invalidates a whole L2); a kernel boundary is cheaper.
         c->fsup_half ^= 1;
-        q.fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup; q.fsup_next = c->d_fsup + (size_t)(c->fsup_half ^ 1) * c->n_fsup; q.n_sup = c->n_fsup;
+        q.fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup * kFlagSupStride; q.fsup_next = c->d_fsup + (size_t)(c->fsup_half ^ 1) * c->n_fsup * kFlagSupStride; q.n_sup = c->n_fsup;
         q.active_bits = c->d_active_bits; q.pack_head = c->d_pack; q.head_len = head; aw.bits_head_done = 1;
         q.blk_rect = c->d_blk_rect; q.W = c->W; aw.blk_rect = c->d_blk_rect; aw.rect_out = c->d_rect;   // the texel rectangle of the NEXT evaluation
         hipLaunchKernelGGL(emba_post_warp_a_kernel, dim3((unsigned)(c->n_ablk + c->n_fblk)), dim3(256), 0, s, q);
@@ -1585,7 +1585,7 @@ emba_status emba_form_accumulate(emba_ctx* c, const double* ep_host, int32_t irl
         const bool ep_tail = c->ep_in_gram && !ep_host && c->n_pm;
         if (ep_tail) {
             p.ep_flag = c->d_flag; p.ep_e = c->d_e_sorted; p.ep_out = c->d_ep; p.ep_fblk_cnt = c->d_fblk_cnt; p.ep_n_pm = (long)c->n_pm; p.ep_n_fblk = c->n_fblk;
-            p.ep_fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup;
+            p.ep_fsup = c->d_fsup + (size_t)c->fsup_half * c->n_fsup * kFlagSupStride;
             grid += (unsigned)((c->n_pm + kEpTailBlk - 1) / kEpTailBlk);
         }
         c->ep_in_gram = false;

@@ -861,9 +861,12 @@ __device__ __forceinline__ uint32_t flag_quad(long i0, long n_pm, const uint8_t*
     return m;
 }
 
-// (round 6) fsup: the counts of kFlagSup consecutive blocks summed — 1 M pm entries per word —, so that a tail block of the Gram launch (ep_tail_block) finds the
-// inliers in front of it from <= 1023 block counts + one word per million entries whatever the window's length
-constexpr int kFlagSup = 1024;
+// (round 6) fsup: the counts of kFlagSup consecutive blocks summed — 64 K pm entries per word —, so that a tail block of the Gram launch (ep_tail_block) finds the
+// inliers in front of it from <= 63 block counts + one word per 64 K entries in front of those (1526 words at 100 M events) whatever the window's length.
+// Every super-count has a 64-B line of its own (kFlagSupStride words apart) and 64 adders: atomics on one LINE are served one after the other at the memory side —
+// with the super-counts packed (977 adds to one line at 1 M events, whether into one word or sixteen) launch A took 18.0 instead of 8.5 us.
+constexpr int kFlagSup = 64;
+constexpr int kFlagSupStride = 16;
 __device__ __forceinline__ void flag_count_block(long blk, const uint8_t* __restrict__ flag, const uint32_t* __restrict__ perm, long n_pm,
                                                  uint32_t* __restrict__ fblk_cnt, uint32_t* __restrict__ fsup = nullptr)
 {
@@ -877,7 +880,7 @@ __device__ __forceinline__ void flag_count_block(long blk, const uint8_t* __rest
     if (threadIdx.x == 0) {
         const uint32_t n = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
         fblk_cnt[blk] = n;
-        if (fsup && n) atomicAdd(fsup + blk / kFlagSup, n);
+        if (fsup && n) atomicAdd(fsup + (blk / kFlagSup) * kFlagSupStride, n);
     }
 }
 
@@ -1144,7 +1147,7 @@ __global__ __launch_bounds__(256) void emba_post_warp_a_kernel(PostWarpParams p)
     if (p.pack_head) for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.head_len; i += (long)gridDim.x * 256) p.pack_head[i] = 0.0;
     if ((long)blockIdx.x < p.n_ablk) active_count_block(blockIdx.x, p.count, p.npix, p.thres, p.ablk_cnt, p.raw_count, p.pixacc, p.active_bits, p.blk_rect, p.W, p.marker, p.seg, p.clear_inactive, p.global_u8);
     else flag_count_block((long)blockIdx.x - p.n_ablk, p.flag, p.perm, p.n_pm, p.fblk_cnt, p.fsup);
-    if (blockIdx.x == 0 && p.fsup_next) for (long i = threadIdx.x; i < p.n_sup; i += 256) p.fsup_next[i] = 0u;    // (two arrays, used alternately: nobody reads or adds to this one during this launch)
+    if (blockIdx.x == 0 && p.fsup_next) for (long i = threadIdx.x; i < p.n_sup; i += 256) p.fsup_next[i * kFlagSupStride] = 0u;    // (two arrays, used alternately: nobody reads or adds to this one during this launch)
 }
 
 __device__ __forceinline__ void active_write_block(long blk, const ActiveWriteParams& a)
@@ -1634,8 +1637,8 @@ __device__ __attribute__((noinline)) void gram_flush(double4_t ee, double4_t oe,
                                                      uint32_t dim_ablate, uint32_t lds_tag_tile)
 {
     const int dim = (int)(dim_ablate & 0x3FFFFu), ablate = (int)(dim_ablate >> 18);      // (dim = 3K <= 196 605; the diagnostics mask fits 14 bits)
-    uint32_t* const s_tag = (uint32_t*)(lds_u32_t*)(uintptr_t)(lds_tag_tile & 0xFFFFu);
-    double* const s_tile = (double*)(lds_f64_t*)(uintptr_t)(lds_tag_tile >> 16);
+    uint32_t* const s_tag = (uint32_t*)(lds_u32_t*)(uintptr_t)((lds_tag_tile & 0xFFFFu) << 2);      // (LDS addresses in units of the tables' element sizes: 160 KB fit)
+    double* const s_tile = (double*)(lds_f64_t*)(uintptr_t)((lds_tag_tile >> 16) << 3);
     const int lane = threadIdx.x & 63;
     int slot = -1;
     if (lane == 0) {
@@ -1758,7 +1761,7 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
     double4_t acc_ee = {0.0, 0.0, 0.0, 0.0}, acc_oe = acc_ee, acc_oo = acc_ee;
     auto flush = [&]() {
         gram_flush(acc_ee, acc_oe, acc_oo, cur_key, p.A11, p.b1, (uint32_t)p.dim | ((uint32_t)p.ablate << 18),
-                   ((uint32_t)(uintptr_t)(lds_u32_t*)s_tag & 0xFFFFu) | ((uint32_t)(uintptr_t)(lds_f64_t*)s_tile << 16));      // (the kernel's LDS is < 64 KB)
+                   (((uint32_t)(uintptr_t)(lds_u32_t*)s_tag >> 2) & 0xFFFFu) | (((uint32_t)(uintptr_t)(lds_f64_t*)s_tile >> 3) << 16));
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc_ee[r] = 0.0; acc_oe[r] = 0.0; acc_oo[r] = 0.0; }
     };
@@ -2169,8 +2172,8 @@ __device__ __forceinline__ void gram_body(const GramParams& p, const long gram_b
 // writes its inliers' residuals at their ranks.  The tail blocks start as Gram blocks retire (one 16-wave block per CU either way).
 constexpr int kEpTailBlk = 4 * kFlagBlk;
 // Round 6: at every window length (round 5: up to 8.4 M entries, longer windows paid a one-block scan of all block counts — 101 us at 100 M events — and a compaction launch
-// of 1024-entry blocks behind the Gram kernel).  The inliers in front of a tail block = launch A's super-counts (one word per kFlagSup block counts = 1 M entries) in front of
-// it + the <= kFlagSup - 1 + 3 block counts of its own million.
+// of 1024-entry blocks behind the Gram kernel).  The inliers in front of a tail block = launch A's super-counts (one word per kFlagSup block counts = 64 K entries) in front of
+// it + the <= kFlagSup - 1 block counts behind the last whole super-count.
 __device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
 {
     __shared__ uint32_t s_x[kGramBlock / 64], s_b[kGramBlock / 64];
@@ -2178,7 +2181,7 @@ __device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
     const long nfront = cb * (kEpTailBlk / kFlagBlk);
     const long nsup = nfront / kFlagSup;
     uint32_t part = 0;
-    for (long s0 = 0; s0 < nsup; s0 += kGramBlock) { const long s = s0 + t; if (s < nsup) part += p.ep_fsup[s]; }
+    for (long s0 = 0; s0 < nsup; s0 += kGramBlock) { const long s = s0 + t; if (s < nsup) part += p.ep_fsup[s * kFlagSupStride]; }
     for (long j0 = nsup * kFlagSup; j0 < nfront; j0 += kGramBlock) {
         const long j = j0 + t;
         const uint32_t v = p.ep_fblk_cnt[j < p.ep_n_fblk ? j : p.ep_n_fblk - 1];
@@ -2210,6 +2213,8 @@ __device__ __forceinline__ void ep_tail_block(long cb, const GramParams& p)
     for (int w = 0; w < kGramBlock / 64; ++w) { k += s_b[w]; if (w < wv) k += s_x[w]; }
 #pragma unroll
     for (int q = 0; q < 4; ++q) if (m & (1u << q)) p.ep_out[k++] = e[q];
+    // (round 6, measured and dropped: the block's inliers through 32 KB of LDS at their ranks and out in one coalesced sweep — city + 28 vs + 35 us, 40 M + 169 vs + 180,
+    // 100 M + 453 vs + 460: the compaction moves 17 B per event at 3.7-4 TB/s either way, next to a Gram kernel that is itself bandwidth-bound)
 }
 
 template <bool TAGS, bool GATHER, bool SPARSE = false>

@@ -123,6 +123,7 @@ SIGNATURES = {
     "emba_group_upload_map": (C.c_int, [C.c_void_p, _dp, _dp]),
     "emba_group_step": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
     "emba_group_eval": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int64, C.c_int64, _dp, _dp, _dp, _szp, _i32p]),
+    "emba_group_get_ep": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _szp]),
     "emba_group_form": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, _szp, _szp]),
     "emba_group_set_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "emba_group_apply_l2": (C.c_int, [C.c_void_p, C.c_double]),

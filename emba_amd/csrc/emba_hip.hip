@@ -67,6 +67,7 @@ struct emba_ctx {
     struct CgShard { bool active = false; int rank = 0, n_ranks = 1, n = 0, skip = 0; size_t lo = 0, npix = 0, Nl = 0; double lambda = 0;
                      double *x = nullptr, *r = nullptr, *p = nullptr, *z = nullptr, *t = nullptr, *invd = nullptr, *sc = nullptr; SolveLists L; } cg;   // emba_cg_shard_*
     uint32_t count_stamp = 0;   // record stamp (set_stamp) of the evaluation whose materialised, LOCAL counts d_count_own holds; 0: none (build_lists)
+    size_t perm_lo = 0, perm_n = 0;   // ... of the pixels [perm_lo, perm_lo + perm_n) of the active set (a rank's owned range in the sharded solve)
     bool perm_valid = false; uint32_t* d_perm = nullptr;   // column order of U for the local Schur solve (solve_perm), valid with the lists
     int solve_perm_mode = -1;                               // option solve_perm (A/B): -1 auto, 0 off, 1 on
     double* h_cost = nullptr;           // pinned: {data cost sum, reg cost sum, error word, sequence number} of emba_costs, written by the kernel itself
@@ -95,6 +96,7 @@ struct emba_ctx {
     uint32_t eval_seq = 0;
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
+    void* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2]{};   // two pinned 4-MB buffers: device -> PAGEABLE host memory in pipelined chunks (d2h_pageable)
     int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P [3] step sequence number
     int seq = 0;                    // sequence number of the last step whose post-warp kernels publish [3]
     bool seq_armed = false;         // the pending counts come from kernels that publish the sequence number
@@ -736,6 +738,32 @@ emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
     return EMBA_OK;
 }
 
+// Device -> host into memory the CALLER owns (pageable: an Eigen vector, a cv::Mat, a numpy array).  hipMemcpy stages such a copy through the runtime's own bounce
+// buffers one chunk after the other; here the DMA of chunk i + 1 into one pinned buffer runs while the CPU copies chunk i out of the other — the two halves of the
+// drop-in's largest transfer (ep: 56 MB per evaluateDataError at 10 M events) overlap instead of adding up.  The stream must have been drained up to `src`'s producer.
+emba_status d2h_pageable(emba_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return EMBA_OK;
+    constexpr size_t kChunk = (size_t)4 << 20;
+    if (bytes <= kChunk / 4) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return EMBA_OK; }
+    for (int k = 0; k < 2; ++k)
+        if (!c->h_stage[k]) { HIP_TRY(c, hipHostMalloc(&c->h_stage[k], kChunk, hipHostMallocDefault)); HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); }
+    hipStream_t s = c->stream;
+    const size_t n = (bytes + kChunk - 1) / kChunk;
+    auto len = [&](size_t i) { return std::min(kChunk, bytes - i * kChunk); };
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage[0], src, len(0), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipEventRecord(c->stage_ev[0], s));
+    for (size_t i = 0; i < n; ++i) {
+        if (i + 1 < n) {
+            HIP_TRY(c, hipMemcpyAsync(c->h_stage[(i + 1) & 1], (const char*)src + (i + 1) * kChunk, len(i + 1), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipEventRecord(c->stage_ev[(i + 1) & 1], s));
+        }
+        HIP_TRY(c, hipEventSynchronize(c->stage_ev[i & 1]));
+        std::memcpy((char*)dst + i * kChunk, c->h_stage[i & 1], len(i));
+    }
+    return EMBA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -859,6 +887,7 @@ void emba_destroy(emba_ctx* c)
     if (c->h_cost) (void)hipHostFree(c->h_cost);
     if (c->d_cost_acc) (void)hipFree(c->d_cost_acc);
     if (c->h_knots) (void)hipHostFree(c->h_knots);
+    for (int k = 0; k < 2; ++k) { if (c->h_stage[k]) (void)hipHostFree(c->h_stage[k]); if (c->stage_ev[k]) (void)hipEventDestroy(c->stage_ev[k]); }
     if (c->knots_copied) (void)hipEventDestroy(c->knots_copied);
     for (int i = 0; i < 8; ++i) { if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]); if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]); }
     for (int k = 0; k < 16; ++k) for (int i = 0; i < 5; ++i) if (c->kt_sets[k][i]) (void)hipEventDestroy(c->kt_sets[k][i]);
@@ -1393,11 +1422,11 @@ emba_status emba_eval_finish(emba_ctx* c, double* ep_out, size_t* n_inliers, int
     emba_status st = resolve_pending(c);
     if (st) return st;
     if (n_inliers) *n_inliers = c->n_inliers;
-    if (ep_out && c->n_inliers) HIP_TRY(c, hipMemcpy(ep_out, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
+    if (ep_out && c->n_inliers) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if ((st = d2h_pageable(c, ep_out, c->d_ep, c->n_inliers * sizeof(double)))) return st; }
     if (num_ev_map_out) {
         { emba_status st0 = ensure_counts(c); if (st0) return st0; }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        HIP_TRY(c, hipMemcpy(num_ev_map_out, c->d_count, c->npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if ((st = d2h_pageable(c, num_ev_map_out, c->d_count, c->npix * sizeof(int32_t)))) return st;
     }
     return EMBA_OK;
 }
@@ -1738,7 +1767,7 @@ emba_status emba_get_ep(emba_ctx* c, double* ep_host, size_t cap, size_t* n_inli
     if (n_inliers) *n_inliers = c->n_inliers;
     if (cap < c->n_inliers) return fail(c, EMBA_ERR_CAPACITY, "cap=%zu < inliers=%zu", cap, c->n_inliers);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->n_inliers) HIP_TRY(c, hipMemcpy(ep_host, c->d_ep, c->n_inliers * sizeof(double), hipMemcpyDeviceToHost));
+    if (c->n_inliers && (st = d2h_pageable(c, ep_host, c->d_ep, c->n_inliers * sizeof(double)))) return st;
     return EMBA_OK;
 }
 
@@ -2456,14 +2485,15 @@ bool axis_path(const emba_ctx* c, double* path_az_out, double* path_el_out)
     return true;
 }
 
-emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
-{
+emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm, size_t lo = 0)
+{   // the pixels [lo, lo + P) of the active set (round 6: a rank's owned range in the sharded solve too — without the order its half of the product took 1.45 ms where
+    // the whole single-rank product takes 0.96); perm[j] is relative to lo
     *perm = nullptr;
     // Measured (device time of one solve, with / without; the U build reads its pixels' records out of sequence and pays 5 % for it): config 2's shape (K = 201,
     // 10 M events over 10 s) 3.96 / 4.16 ms — SYRK 1.25 / 1.52, 5.8 / 7.9 products per slice —; 10 M events at K = 97: 2.81 / 2.79; 1 M events over 1 s at
     // K = 201 (every pixel sees the whole window: nothing to gain) 2.27 / 2.24.  From six row blocks (K >= 128) up, unless option solve_perm forces it.
     if (c->solve_perm_mode == 0 || P < 4 * (size_t)kSyrkSlicePix || (c->solve_perm_mode < 0 && 3 * c->K < 384) || 3 * c->K < 256) return EMBA_OK;
-    if (c->perm_valid) { *perm = c->d_perm; return EMBA_OK; }
+    if (c->perm_valid && c->perm_lo == lo && c->perm_n == P) { *perm = c->d_perm; return EMBA_OK; }
     if (c->solve_perm_mode < 0) {
         double path_az = 0.0, path_el = 0.0;
         if (!axis_path(c, &path_az, &path_el)) return EMBA_OK;
@@ -2474,12 +2504,12 @@ emba_status solve_perm(emba_ctx* c, size_t P, const uint32_t** perm)
     emba_status st;
     if ((st = ws_get(c, 34, ((size_t)c->W + 2) * 4, (void**)&d_cnt)) || (st = ws_get(c, 35, P * 4, (void**)&d_tick)) || (st = ws_get(c, 36, P * 4, (void**)&d_pm))) return st;
     HIP_TRY(c, hipMemsetAsync(d_cnt, 0, ((size_t)c->W + 1) * 4, s));
-    hipLaunchKernelGGL(emba_perm_ticket_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active, (long)P, c->W, d_cnt, d_tick);
+    hipLaunchKernelGGL(emba_perm_ticket_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active + lo, (long)P, c->W, d_cnt, d_tick);
     if ((st = dev_scan(c, d_cnt, d_cnt, (size_t)c->W, nullptr))) return st;
-    hipLaunchKernelGGL(emba_perm_place_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active, (long)P, c->W, d_cnt, d_tick, d_pm);
+    hipLaunchKernelGGL(emba_perm_place_kernel, dim3(nblocks(P)), dim3(256), 0, s, c->d_active + lo, (long)P, c->W, d_cnt, d_tick, d_pm);
     HIP_TRY(c, hipGetLastError());
     uint32_t* v0 = d_pm;
-    c->d_perm = v0; c->perm_valid = true;
+    c->d_perm = v0; c->perm_valid = true; c->perm_lo = lo; c->perm_n = P;
     *perm = v0;
     return EMBA_OK;
 }
@@ -2525,10 +2555,11 @@ extern "C" emba_status emba_solve_normal_eq(emba_ctx* c, double lambda, int32_t 
     if ((st = schur_accumulate(c, L.sorted, L, P, pack_A22b2(c), lambda, n, d_S, lds_, d_y, d_cf, d_info, perm))) return st;
     if ((st = schur_factor_solve(c, d_S, lds_, n, skip, d_rhs, d_info))) return st;
     // x2 = A22m^-1 (b2 - A12^T x1), straight from the records of each pixel
-    if (P)
+    if (P) {
         if ((st = pose_vector_lds(c, (const void*)emba_schur_x2_kernel, (size_t)n * sizeof(double), "solveNormalEq (x2)"))) return st;
         hipLaunchKernelGGL(emba_schur_x2_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, 8192)), dim3(256), (size_t)n * sizeof(double), s, L.sorted, L.off, d_y,
                            d_cf, d_rhs, c->irls, c->eta, (long)P, d_x2, n);
+    }
     HIP_TRY(c, hipGetLastError());
     int info = 0;
     HIP_TRY(c, hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -2575,7 +2606,7 @@ extern "C" emba_status emba_solve_shard_count(emba_ctx* c, int32_t n_ranks, size
     unsigned long long* d_cnt = nullptr;
     if ((st = ws_get(c, 14, (size_t)3 * n_ranks * 8 + 8, (void**)&d_cnt))) return st;
     HIP_TRY(c, hipMemsetAsync(d_cnt, 0, (size_t)3 * n_ranks * 8 + 8, s));
-    if (c->n_cand) hipLaunchKernelGGL(emba_shard_count_kernel, dim3(nblocks(c->n_cand)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt);
+    if (c->n_cand) hipLaunchKernelGGL(emba_shard_count_kernel, dim3((unsigned)std::min<size_t>(nblocks(c->n_cand), (size_t)4 * c->n_cu)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt);
     std::vector<unsigned long long> h(n_ranks);
     HIP_TRY(c, hipMemcpyAsync(h.data(), d_cnt, (size_t)n_ranks * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -2589,14 +2620,14 @@ extern "C" emba_status emba_solve_shard_count(emba_ctx* c, int32_t n_ranks, size
 
 extern "C" emba_status emba_solve_shard_pack(emba_ctx* c, int32_t n_ranks, double* send_dev)
 {
-    if (!c || n_ranks < 1) return EMBA_ERR_INVALID_ARG;
+    if (!c || n_ranks < 1 || n_ranks > kShardMaxRanks) return EMBA_ERR_INVALID_ARG;
     if (!c->ws[14].p) return fail(c, EMBA_ERR_STATE, "call emba_solve_shard_count first");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     unsigned long long* d_cnt = (unsigned long long*)c->ws[14].p;
     HIP_TRY(c, hipMemsetAsync(d_cnt + 2 * n_ranks, 0, (size_t)n_ranks * 8, s));
     if (c->n_cand && send_dev)
-        hipLaunchKernelGGL(emba_shard_pack_kernel, dim3(nblocks(c->n_cand, 32)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt + n_ranks,
+        hipLaunchKernelGGL(emba_shard_pack_kernel, dim3(nblocks(c->n_cand, kShardPackRec)), dim3(256), 0, s, local_view(c), (long)c->n_cand, (long)c->P, (int)n_ranks, d_cnt + n_ranks,
                            d_cnt + 2 * n_ranks, send_dev);
     HIP_TRY(c, hipGetLastError());
     return EMBA_OK;
@@ -2640,7 +2671,9 @@ extern "C" emba_status emba_solve_shard_partial(emba_ctx* c, int32_t rank, int32
     view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
     SolveLists L;
     if ((st = build_lists(c, view, n_recv, n_pix, &L))) return st;
-    return schur_accumulate(c, L.sorted, L, n_pix, pack_A22b2(c) + 5 * lo, lambda, n, S_part_dev, lds_, d_y, d_cf, d_info);
+    const uint32_t* perm = nullptr;
+    if ((st = solve_perm(c, n_pix, &perm, lo))) return st;
+    return schur_accumulate(c, L.sorted, L, n_pix, pack_A22b2(c) + 5 * lo, lambda, n, S_part_dev, lds_, d_y, d_cf, d_info, perm);
 }
 
 extern "C" emba_status emba_solve_shard_finish(emba_ctx* c, int32_t rank, int32_t n_ranks, const double* recv_dev, size_t n_recv, double lambda,

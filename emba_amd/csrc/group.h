@@ -486,6 +486,7 @@ emba_status group_exchange_counts(emba_group* g, int thres, bool exact, const st
 // ep_out (capacity >= events used) = the residuals of ALL ranks merged into the reference's order (sensor pixel major, then time:
 // ranks are time-ordered, so inside a pixel rank r's measurements precede rank r+1's); *n_inliers their number; num_ev_map_out the
 // GLOBAL count map (exact int32 exchange).
+emba_status emba_group_get_ep(emba_group* g, double* ep_out, size_t cap, size_t* n_inliers);
 emba_status emba_group_eval(emba_group* g, const double* knots, int32_t K, int64_t t0_ns, int64_t dt_ns, const double* Gx, const double* Gy,
                             double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out)
 {
@@ -512,28 +513,47 @@ emba_status emba_group_eval(emba_group* g, const double* knots, int32_t K, int64
     if (!ep_out && !n_inliers)      // nothing asked for: E2 is enqueued only (the costs / formNormalEq that follow find an evaluation to work on)
         for (int r = 0; r < g->n; ++r) G_TRY(g, r, emba_eval_finish(g->ctx[r], nullptr, nullptr, nullptr));
     if (ep_out || n_inliers) {
-        // per rank: residuals in the rank's own reference order + the sensor pixel of each; merged by (pixel, rank)
-        std::vector<std::vector<double>> ep(g->n); std::vector<std::vector<uint32_t>> px(g->n);
         size_t total = 0;
-        for (int r = 0; r < g->n; ++r) {
-            ep[r].resize(std::max<size_t>(g->n_local[r], 1));
-            size_t m = 0;
-            G_TRY(g, r, emba_eval_finish(g->ctx[r], ep_out ? ep[r].data() : nullptr, &m, nullptr));
-            ep[r].resize(m); total += m;
-            if (ep_out) { px[r].resize(std::max<size_t>(m, 1)); G_TRY(g, r, emba_get_inlier_pixels(g->ctx[r], px[r].data())); px[r].resize(m); }
-        }
+        for (int r = 0; r < g->n; ++r) { size_t m = 0; G_TRY(g, r, emba_eval_finish(g->ctx[r], nullptr, &m, nullptr)); total += m; }
         g->n_inliers = total;
         if (n_inliers) *n_inliers = total;
-        if (ep_out) {
-            const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
-            std::vector<size_t> start(S + 1, 0);                              // global offset of every sensor pixel's block
-            for (int r = 0; r < g->n; ++r) for (uint32_t p : px[r]) ++start[p + 1];
-            for (size_t p = 0; p < S; ++p) start[p + 1] += start[p];
-            std::vector<size_t> cur(start.begin(), start.end() - 1);
-            for (int r = 0; r < g->n; ++r)                                    // rank-major inside a pixel: earlier ranks first
-                for (size_t i = 0; i < ep[r].size(); ++i) ep_out[cur[px[r][i]]++] = ep[r][i];
-        }
+        if (ep_out) return emba_group_get_ep(g, ep_out, total, nullptr);
     }
+    return EMBA_OK;
+}
+
+// The residual vector of the last emba_group_eval in the reference's order (model.cpp:221,256: sensor pixel major, then time), into memory the caller owns — apart
+// from the evaluation (round 6), so that a host that must RETURN it by value (the EMBA::LEGM adapter: VecXd evaluateDataError) can size its vector from the inlier
+// count first and have the residuals land in it directly.  Several ranks: each rank's vector + the sensor pixel of each entry, merged by (pixel, rank).
+emba_status emba_group_get_ep(emba_group* g, double* ep_out, size_t cap, size_t* n_inliers)
+{
+    if (!g || (!ep_out && cap)) return EMBA_ERR_INVALID_ARG;
+    if (g->n == 1 && !g->use_rccl) {
+        size_t m = 0;
+        G_TRY(g, 0, emba_get_ep(g->ctx[0], ep_out, cap, &m));
+        g->n_inliers = m;
+        if (n_inliers) *n_inliers = m;
+        return EMBA_OK;
+    }
+    std::vector<std::vector<double>> ep(g->n); std::vector<std::vector<uint32_t>> px(g->n);
+    size_t total = 0;
+    for (int r = 0; r < g->n; ++r) {
+        ep[r].resize(std::max<size_t>(g->n_local[r], 1));
+        size_t m = 0;
+        G_TRY(g, r, emba_get_ep(g->ctx[r], ep[r].data(), ep[r].size(), &m));
+        ep[r].resize(m); total += m;
+        px[r].resize(std::max<size_t>(m, 1)); G_TRY(g, r, emba_get_inlier_pixels(g->ctx[r], px[r].data())); px[r].resize(m);
+    }
+    g->n_inliers = total;
+    if (n_inliers) *n_inliers = total;
+    if (cap < total) return gfail(g, EMBA_ERR_CAPACITY, "cap=%zu < inliers=%zu", cap, total);
+    const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
+    std::vector<size_t> start(S + 1, 0);                              // global offset of every sensor pixel's block
+    for (int r = 0; r < g->n; ++r) for (uint32_t p : px[r]) ++start[p + 1];
+    for (size_t p = 0; p < S; ++p) start[p + 1] += start[p];
+    std::vector<size_t> cur(start.begin(), start.end() - 1);
+    for (int r = 0; r < g->n; ++r)                                    // rank-major inside a pixel: earlier ranks first
+        for (size_t i = 0; i < ep[r].size(); ++i) ep_out[cur[px[r][i]]++] = ep[r][i];
     return EMBA_OK;
 }
 

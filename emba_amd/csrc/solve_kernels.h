@@ -1096,61 +1096,74 @@ __device__ __forceinline__ int pixel_owner(long k, long P, int n_ranks)
     return r;
 }
 
-// Wave-aggregated tickets: the lanes of a wave that want a slot in the same owner's list take them with ONE atomic (the leader adds the group's size and
-// hands out consecutive positions).  Round 5: with one atomic per record the ~1 M records of the BASELINE window queued on n_ranks addresses — 5.9 ms for the
-// count kernel and as much again for the pack kernel on two ranks (11.6 of a 12-ms LM iteration), against 0.3 ms for the whole single-rank solve.
-__device__ __forceinline__ unsigned long long wave_owner_ticket(bool active, int owner, unsigned long long* __restrict__ cursor)
+// (Round 5 had wave-aggregated tickets here — one atomic per owner and wave instead of one per record: 2-rank solve 11.6 -> 2.0 ms at the BASELINE shape.)
+// Round 6: BLOCK-aggregated.  Tickets per wave still meant one RETURNING atomic per owner for every 8 records of the pack kernel (eight lanes per record), on
+// n_ranks addresses of one line: 440 k of them at config 2's shape = 14.2 ms per launch (profiles/r06_two_rank_kernel_stats.txt) — returning atomics on one line are
+// served one after the other, ~30 ns each.  Now a block counts its records per owner in LDS and takes ONE global ticket per owner (count kernel: one plain add).
+constexpr int kShardMaxRanks = 1024;      // (emba_solve_shard_count refuses more)
+constexpr int kShardPackRec = 2048;       // records per block of the pack kernel
+
+__global__ __launch_bounds__(256) void emba_shard_count_kernel(RecView v, long n_rec, long P, int n_ranks, unsigned long long* __restrict__ cnt)
 {
-    const int lane = threadIdx.x & 63;
-    unsigned long long pos = 0, remaining = __ballot(active);
-    while (remaining) {                                                    // (wave-uniform: at most n_ranks trips)
-        const int leader = __ffsll((long long)remaining) - 1;
-        const int o = __shfl(owner, leader);
-        const bool mine = active && owner == o;
-        const unsigned long long same = __ballot(mine);
-        unsigned long long base = 0;
-        if (lane == leader) base = atomicAdd(cursor + o, (unsigned long long)__popcll(same));
-        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), leader) << 32) | (uint32_t)__shfl((int)(base & 0xFFFFFFFFull), leader);
-        if (mine) pos = base + (unsigned long long)__popcll(same & ((1ull << lane) - 1ull));
-        remaining &= ~same;
+    __shared__ uint32_t s_cnt[kShardMaxRanks];
+    for (int r = threadIdx.x; r < n_ranks; r += 256) s_cnt[r] = 0u;
+    __syncthreads();
+    for (long s = (long)blockIdx.x * 256 + threadIdx.x; s < n_rec; s += (long)gridDim.x * 256) {
+        int32_t k = 0;
+        if (rec_pixel(v, s, k)) atomicAdd(&s_cnt[pixel_owner(k, P, n_ranks)], 1u);
     }
-    return pos;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_ranks; r += 256) if (s_cnt[r]) atomicAdd(cnt + r, (unsigned long long)s_cnt[r]);
 }
 
-__global__ void emba_shard_count_kernel(RecView v, long n_rec, long P, int n_ranks, unsigned long long* __restrict__ cnt)
-{
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int32_t k = 0;
-    const bool ok = s < n_rec && rec_pixel(v, s, k);
-    (void)wave_owner_ticket(ok, ok ? pixel_owner(k, P, n_ranks) : 0, cnt);
-}
-
-// packed record = the record with its tail word rewritten to {compact pixel index, control-pose pair key}.  Eight lanes per 128-B record (coalesced reads in
-// slot order, one full line written per record), like emba_csr_fill_sorted_kernel; launch with 32 records per 256-thread block.
+// packed record = the record with its tail word rewritten to {compact pixel index, control-pose pair key}.  A block takes kShardPackRec consecutive slots: a first
+// sweep over their tail words counts per owner (LDS), one ticket per owner gives the block its places in every owner's segment, a second sweep copies the records
+// there — eight lanes per 128-B record (coalesced reads in slot order, one full line written per record), the place inside the block's run from an LDS cursor.
 __global__ __launch_bounds__(256) void emba_shard_pack_kernel(RecView v, long n_rec, long P, int n_ranks, const unsigned long long* __restrict__ off,
                                                               unsigned long long* __restrict__ cursor, double* __restrict__ out)
 {
-    const long s = (long)blockIdx.x * 32 + (threadIdx.x >> 3);
-    const int lane = threadIdx.x & 63, c8 = threadIdx.x & 7;
-    const long sc = s < n_rec ? s : n_rec - 1;                       // (n_rec >= 1 whenever this is launched; every lane stays for the shuffles)
-    const double2 val = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * sc)[c8];
-    int32_t k = -1; int owner = 0; uint32_t key = 0;
-    bool ok = false;
-    if (c8 == 7 && s < n_rec) {                                      // the lane that holds the tail word
-        if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(val.y) - v.pix_base); ok = true; }
-        else { uint32_t pi; ok = record_valid(val.y, v.stamp, pi); if (ok) { k = v.compact[pi]; ok = k >= 0; } }
-        if (ok) { owner = pixel_owner(k, P, n_ranks); key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s]; }
+    __shared__ uint32_t s_cnt[kShardMaxRanks];
+    __shared__ unsigned long long s_base[kShardMaxRanks];
+    const long s0 = (long)blockIdx.x * kShardPackRec, s1 = s0 + kShardPackRec < n_rec ? s0 + kShardPackRec : n_rec;
+    for (int r = threadIdx.x; r < n_ranks; r += 256) s_cnt[r] = 0u;
+    __syncthreads();
+    for (long s = s0 + threadIdx.x; s < s1; s += 256) {
+        int32_t k = 0;
+        if (rec_pixel(v, s, k)) atomicAdd(&s_cnt[pixel_owner(k, P, n_ranks)], 1u);
     }
-    unsigned long long pos = wave_owner_ticket(ok, owner, cursor);
-    if (ok) pos += off[owner];
-    const int src = lane | 7;
-    const int okb = __shfl(ok ? 1 : 0, src);
-    k = __shfl(k, src); key = (uint32_t)__shfl((int)key, src);
-    pos = ((unsigned long long)(uint32_t)__shfl((int)(pos >> 32), src) << 32) | (uint32_t)__shfl((int)(pos & 0xFFFFFFFFull), src);
-    if (!okb) return;
-    double2 o = val;
-    if (c8 == 7) o.y = __hiloint2double((int)key, (int)k);
-    reinterpret_cast<double2*>(out + (size_t)kRecStride * pos)[c8] = o;
+    __syncthreads();
+    for (int r = threadIdx.x; r < n_ranks; r += 256) {
+        const uint32_t n = s_cnt[r];
+        s_base[r] = off[r] + (n ? atomicAdd(cursor + r, (unsigned long long)n) : 0ull);
+        s_cnt[r] = 0u;                                               // ... becomes the cursor inside the block's run
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, c8 = threadIdx.x & 7;
+    for (long sb = s0; sb < s1; sb += 32) {                          // (block-uniform trip count; every lane stays for the shuffles)
+        const long s = sb + (threadIdx.x >> 3);
+        const long sc = s < s1 ? s : s1 - 1;
+        const double2 val = reinterpret_cast<const double2*>(v.rec + (size_t)kRecStride * sc)[c8];
+        int32_t k = -1; uint32_t key = 0;
+        unsigned long long pos = 0;
+        bool ok = false;
+        if (c8 == 7 && s < s1) {                                     // the lane that holds the tail word
+            if (v.packed) { k = (int32_t)((long)(uint32_t)__double2loint(val.y) - v.pix_base); ok = true; }
+            else { uint32_t pi; ok = record_valid(val.y, v.stamp, pi); if (ok) { k = v.compact[pi]; ok = k >= 0; } }
+            if (ok) {
+                const int owner = pixel_owner(k, P, n_ranks);
+                key = v.packed ? (uint32_t)__double2hiint(val.y) : v.slot_key[s];
+                pos = s_base[owner] + atomicAdd(&s_cnt[owner], 1u);
+            }
+        }
+        const int src = lane | 7;
+        const int okb = __shfl(ok ? 1 : 0, src);
+        k = __shfl(k, src); key = (uint32_t)__shfl((int)key, src);
+        pos = ((unsigned long long)(uint32_t)__shfl((int)(pos >> 32), src) << 32) | (uint32_t)__shfl((int)(pos & 0xFFFFFFFFull), src);
+        if (!okb) continue;
+        double2 o = val;
+        if (c8 == 7) o.y = __hiloint2double((int)key, (int)k);
+        reinterpret_cast<double2*>(out + (size_t)kRecStride * pos)[c8] = o;
+    }
 }
 
 // S_aug += [A11m, . ; b1^T, 0] (the replicated part, added once after the all-reduce of the partial Schur sums)

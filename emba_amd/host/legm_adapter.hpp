@@ -220,10 +220,14 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
     }
     if (!resident && st.map_is_trial) legm_hip_detail::settle_trial(st, false);   // some other map: the pending trial is void
     try {
-        std::vector<double> ep = st.impl->evaluateDataError(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
+        // (round 6) the evaluation with the inlier count first, then the residuals straight into the vector this call returns: one pass over its (fresh) pages,
+        // fed from pinned staging buffers — before: an 8 B x events vector zero-filled per call, a pageable copy into it and a second copy into the VecXd
+        const size_t n_ep = st.impl->evaluateDataErrorCount(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
                                                             eval_deriv, num_ev_map.ptr<int32_t>());
-        st.K = K; st.n_ep = ep.size(); st.trial_pending = resident;
-        return Eigen::Map<VecXd>(ep.data(), (Eigen::Index)ep.size());
+        VecXd ep((Eigen::Index)n_ep);
+        if (n_ep) st.impl->fetchEp(ep.data(), n_ep);
+        st.K = K; st.n_ep = n_ep; st.trial_pending = resident;
+        return ep;
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     return VecXd();
 }

@@ -67,6 +67,19 @@ public:
         n_inliers_ = n_inl;
         return ep;
     }
+    // The same in two steps (round 6), for a caller that must RETURN ep by value: the evaluation with the inlier count (and num_ev_map) only, then the residuals
+    // straight into the caller's vector — no 8 B x events staging vector, no second copy (the adapter: 35 -> see profiles/r06_adapter_timing.txt).
+    size_t evaluateDataErrorCount(const TrajectoryView& traj, const double* Gx, const double* Gy, const EventPacket& events, bool eval_deriv, int32_t* num_ev_map)
+    {
+        if (!eval_deriv) throw std::runtime_error("eval_deriv=false is never used by the reference (solver.cpp:75,251) and is not provided");
+        ensureEvents(events);
+        K_ = traj.num_ctrl_poses;
+        size_t n_inl = 0;
+        check(emba_group_eval(g_, traj.knots_xyzw, traj.num_ctrl_poses, traj.t0_ns, traj.dt_ns, Gx, Gy, nullptr, &n_inl, num_ev_map));
+        n_inliers_ = n_inl;
+        return n_inl;
+    }
+    void fetchEp(double* dst, size_t n) { size_t m = 0; check(emba_group_get_ep(g_, dst, n, &m)); if (m != n) throw std::runtime_error("fetchEp: the inlier count changed"); }
     // formNormalEq / formNormalEqIRLS (model.cpp:316-687) on the device-resident residuals of the last evaluateDataError; applyL2Reg apart
     void formNormalEq(NormalEquations& ne, int num_ctrl_poses, int thres_valid_pixel, const std::string& cost_type = "quadratic", double a = 0.0)
     {

@@ -464,6 +464,10 @@ emba_status emba_group_step(emba_group* g, const double* knots_xyzw, int32_t K, 
  * send saturated bytes). */
 emba_status emba_group_eval(emba_group* g, const double* knots_xyzw, int32_t K, int64_t t0_ns, int64_t dt_ns, const double* Gx, const double* Gy,
                             double* ep_out, size_t* n_inliers, int32_t* num_ev_map_out);
+/* The residual vector of the last emba_group_eval (ep_out NULL there, n_inliers asked for) in the reference's order, into memory the caller owns: lets a host
+ * that returns it by value (VecXd LEGM::evaluateDataError) size its vector from the count and receive the residuals in it directly.  Host copies of this size go
+ * through two pinned 4-MB buffers in pipelined chunks (also for emba_eval_finish / emba_get_ep). */
+emba_status emba_group_get_ep(emba_group* g, double* ep_out, size_t cap, size_t* n_inliers);
 /* LEGM::formNormalEq[IRLS] + applyL2Reg over all ranks on the state of the last emba_group_eval (device-resident residuals). */
 emba_status emba_group_form(emba_group* g, int32_t thres_valid_pixel, int32_t irls, double eta, double alpha, size_t* n_inliers, size_t* P);
 /* LEGM::applyL2Reg as a call of its own (after emba_group_form with alpha = 0): once per set of equations, on every rank's replica. */

@@ -34,6 +34,13 @@ with tempfile.TemporaryDirectory() as d:
         # (the first iteration includes the window's registration, order preparation and first full upload: reported apart)
         print(f"drop-in (EMBA::LEGM adapter, solver.cpp's call order), N={n} K={K} pano {ph}x{2*ph}, devices {devs}: first iteration {ts[0]:.1f} ms, "
               f"following {len(ts)-1} iterations mean {np.mean(ts[1:]):.2f} ms (min {np.min(ts[1:]):.2f}, max {np.max(ts[1:]):.2f}); accepted {sum(acc)} of {len(acc)}")
+        for l in r.stdout.splitlines():
+            if l.startswith("PHASES "):
+                print("      " + l)
+        if "solve_debug" in os.environ.get("EMBA_HIP_OPTIONS", ""):      # EMBA_HIP_OPTIONS=solve_debug=1: the stages of every sharded solve (stderr of the library)
+            for l in r.stderr.splitlines():
+                if l.startswith("[group solve]"):
+                    print("      " + l)
 m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h)
 t0 = time.perf_counter(); m.set_events(w.events); m.upload_map(w.Gx, w.Gy); t_set = time.perf_counter() - t0
 t0 = time.perf_counter()

@@ -27,6 +27,17 @@ with tempfile.TemporaryDirectory() as d:
         f.write(struct.pack("<2d", w.C_th, w.alpha))
         for arr, ty in ((w.lut, "<f8"), (init.knots_xyzw, "<f8"), (w.Gx, "<f8"), (w.Gy, "<f8"), (w.events.x, "<u2"), (w.events.y, "<u2"), (w.events.polarity, "u1"), (w.events.t_ns, "<i8")):
             f.write(np.ascontiguousarray(arr).astype(ty).tobytes())
+    if os.environ.get("PROF_DEVICES"):      # PROF_DEVICES=0,0: rocprofv3 kernel stats of one window on those ranks instead of the timing runs (what do two ranks on one device spend?)
+        import glob
+        out = os.path.join(ROOT, "gpurun_out", "prof_resident_" + os.environ["PROF_DEVICES"].replace(",", "_"))
+        subprocess.run(["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", exe, p, os.environ["PROF_DEVICES"], str(max_iter), "0", "0", "", "1"],
+                       capture_output=True, text=True, timeout=900, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        for f in glob.glob(out + "/*/*_kernel_stats.csv"):
+            print(f"kernel stats of one window, devices {os.environ['PROF_DEVICES']}, {max_iter} LM iterations:")
+            for l in open(f).read().splitlines()[:28]:
+                c = l.split('","')
+                print("   " + " | ".join(x.strip('"')[:70] for x in c[:4]))
+        sys.exit(0)
     for devs in ("0", "0,0"):
         r = subprocess.run([exe, p, devs, str(max_iter), "0", "0", "", "3"], capture_output=True, text=True, timeout=900)
         win = [l for l in r.stdout.splitlines() if l.startswith("WINDOW ")]

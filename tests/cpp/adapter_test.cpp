@@ -125,6 +125,9 @@ int main(int argc, char** argv)
     const bool timing = getenv("ADAPTER_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_iter = now();
+    // ADAPTER_TIMING: wall time inside each of the model's calls and in the loop's own host work, per LM iteration (scripts/adapter_timing.py)
+    double tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // eval, form + L2, trim, solve, clones, updateMap, costs, accept copies
+    auto lap = [&](int k, const std::chrono::steady_clock::time_point& t0) { if (timing) tp[k] += std::chrono::duration<double, std::milli>(now() - t0).count(); };
 
     // ---- solveTimeWindow's state (solver.cpp:15-61)
     double lambda = 1e-3; const double lambda_max = 1e3, lambda_min = 1e-300;
@@ -142,9 +145,12 @@ int main(int argc, char** argv)
             } else {
                 ep = ep_new; num_ev_map_new.copyTo(num_ev_map);                                             // :99-102
             }
+            auto tf = now();
             if (use_irls) model.formNormalEqIRLS(A11, A12, A22_blocks, b1, b2, ep, K, num_ev_map, thres, active, inactive, cost_type, eta);   // :114-119
             else model.formNormalEq(A11, A12, A22_blocks, b1, b2, ep, K, num_ev_map, thres, active, inactive);                                  // :122-126
             model.applyL2Reg(A22_blocks, b2, active, alpha, Gx, Gy);                                        // :130
+            lap(1, tf);
+            auto tt = now();
             if (first_time_window) {                                                                         // :156-165
                 const size_t left = 3 * (K - 1);
                 EMBA::MatXd A11_1st = A11.block(3, 3, left, left);
@@ -152,20 +158,37 @@ int main(int argc, char** argv)
                 EMBA::VecXd b1_1st = b1.tail(left);
                 A11 = A11_1st; A12 = A12_1st; b1 = b1_1st;
             }
+            lap(2, tt);
         }
         int cg_it = -1;
+        auto ts = now();
         if (!use_cg) model.solveNormalEq(A11, A12, A22_blocks, b1, b2, lambda, x1, x2);                      // :190-194
         else cg_it = model.solveNormalEqCG(A11, A12, A22_blocks, b1, b2, lambda, x1, x2).first;             // :196-202
+        lap(3, ts);
         LinTraj* traj_new = traj->clone();                                                                   // :226-234
         update_traj(traj_new, x1, first_time_window ? 1 : 0);
+        auto tc = now();
         cv::Mat Gx_new = Gx.clone(), Gy_new = Gy.clone();                                                    // :237-240
+        lap(4, tc);
+        auto tu = now();
         model.updateMap(Gx_new, Gy_new, x2, damping, active, inactive);
+        lap(5, tu);
+        auto te = now();
         ep_new = model.evaluateDataError(traj_new, Gx_new, Gy_new, events, true, num_ev_map_new);            // :251
+        lap(0, te);
+        auto tk = now();
         cost_new = robust_cost(ep_new, irls, eta) + reg_cost(Gx_new, Gy_new, alpha);                         // :257-268
+        lap(6, tk);
         iter += 1;
         const bool accepted = cost_new < cost_min;
         printf("LM %d %.1f %.17g %.17g %d %zu %d\n", iter, std::log10(lambda), cost_min, cost_new, accepted ? 1 : 0, active.size(), cg_it);
-        if (timing) { const auto t1 = now(); printf("TIME %d %.3f ms (whole LM iteration through the adapter, incl. the loop's own Mat clones / copies)\n", iter, std::chrono::duration<double, std::milli>(t1 - t_iter).count()); }
+        if (timing) {
+            const auto t1 = now();
+            printf("TIME %d %.3f ms (whole LM iteration through the adapter, incl. the loop's own Mat clones / copies)\n", iter, std::chrono::duration<double, std::milli>(t1 - t_iter).count());
+            printf("PHASES %d evaluateDataError %.2f  formNormalEq+applyL2Reg %.2f  first-window trim %.2f  solve %.2f  Gx.clone x2 %.2f  updateMap %.2f  host cost sums %.2f  (ms)\n",
+                   iter, tp[0], tp[1], tp[2], tp[3], tp[4], tp[5], tp[6]);
+            for (double& v : tp) v = 0;
+        }
         if (accepted) {                                                                                      // :299-339
             cost_has_decreased = true;
             delete traj; traj = traj_new;

@@ -449,7 +449,10 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         }
         // dense tiles can afford a finer grid of tile origins (segments end closer to the tile's far edge, and a tile's entries spread over more chunks): config 4's
         // shard (11.7 k entries per tile) 258 -> 229 us; at 3-5 k entries per tile it loses (3 M: 162 -> 173, 5 M: 236 -> 271)
-        if (best >= 0 && c->opt_tile_fine != 0 && (c->opt_tile_fine == 1 || (double)c->n_used / std::max<size_t>(best_used, 1) >= 2.0 * kWarpNew * kTileWaves * 8)) {
+        // (... and only below 16 M events: the finer grid doubles the chunks — 40 M events 1749 -> 1879 us, config 5's shard 566 -> 655, 100 M + 2 % per step;
+        // profiles/r06_large_window_ab.txt)
+        if (best >= 0 && c->opt_tile_fine != 0 &&
+            (c->opt_tile_fine == 1 || (c->n_used < (size_t)16000000 && (double)c->n_used / std::max<size_t>(best_used, 1) >= 2.0 * kWarpNew * kTileWaves * 8))) {
             size_t br = 0, us = 0;
             if ((st = evaluate(geom(best, true), &br, &us))) return st;
             last_fine = true; last = best;

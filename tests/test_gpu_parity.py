@@ -882,7 +882,8 @@ def test_randomised_soak(gpu, oracle_mod):
         if case % 3 == 1:
             OPTIONS.update(gram_sparse=1, order=1)
         elif case % 3 == 2:
-            OPTIONS.update(order=2)
+            # (round 6) ... with every LDS tile shape, both origin grids and reserves 0 ... 4 of the window rule (each shape is a kernel instantiation of its own)
+            OPTIONS.update(order=2, tile_shape=int(rng.integers(-1, 4)), tile_fine=int(rng.integers(-1, 2)), tile_reserve=int(rng.integers(0, 5)))
         tag += f" options={dict(OPTIONS)}"
         try:
             o = oracle_run(oracle_mod, w, irls=irls, a=cost[1], dense_A12=True)

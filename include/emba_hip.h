@@ -103,8 +103,8 @@ emba_status emba_set_events_dev(emba_ctx* ctx, const uint16_t* x_dev, const uint
                                 const int64_t* halo_batch_t_ns_dev, size_t n_halo);
 
 /* Diagnostics of the once-per-window work: wall time of the last emba_set_events[_dev] and of the order preparation done by
- * the first evaluation (control-pose pairs, record slots, optional tile order), whether the tile order is in use (events binned
- * by the panorama tile the first trajectory sends them to: option "order"), entries of the device order (events +
+ * the first evaluation (control-pose pairs, record slots, optional tile order), whether the tile order is in use (events grouped
+ * by the panorama tile the first trajectory sends their chain segment to: option "order"), entries of the device order (events +
  * halo / lead-in copies) and workgroup chunks of the tiled kernel.  Any pointer may be NULL. */
 emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, double* prepare_ms, int32_t* tile_order,
                                size_t* n_entries, size_t* n_chunks);
@@ -116,7 +116,7 @@ emba_status emba_last_order_stats(const emba_ctx* ctx, double* events_per_pano_p
  * on every side of a tile for the drift of trial poses (options tile_shape, tile_fine, tile_reserve).  Diagnostics; any pointer may be NULL. */
 emba_status emba_last_tile_geometry(const emba_ctx* ctx, int32_t* tile_w, int32_t* tile_h, int32_t* pitch_x, int32_t* pitch_y, int32_t* reserve);
 
-/* Tile order only: inliers of the last resolved evaluation that the tiled kernel found outside their tile (+ margin) — the
+/* Tile order only: inliers of the last resolved evaluation that the tiled kernel found outside their LDS tile — the
  * trajectory has moved them since the order was built; they are handled correctly, one HBM atomic each — and how many times this
  * context has rebuilt the order of a window for that reason (done at the next evaluation once a fifth of the inliers are outside).
  * No reference counterpart (the reference has no device order).  Either pointer may be NULL. */

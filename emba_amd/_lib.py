@@ -41,6 +41,7 @@ SIGNATURES = {
                                       C.c_size_t]),
     "emba_last_setup_ms": (C.c_int, [C.c_void_p, _dp, _dp, _i32p, _szp, _szp]),
     "emba_last_order_stats": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "emba_last_order_inlier_estimate": (C.c_int, [C.c_void_p, _dp]),
     "emba_last_tile_geometry": (C.c_int, [C.c_void_p, _i32p, _i32p, _i32p, _i32p, _i32p]),
     "emba_last_tile_drift": (C.c_int, [C.c_void_p, _szp, _i32p]),
     "emba_event_counts": (C.c_int, [C.c_void_p, _szp, _szp]),

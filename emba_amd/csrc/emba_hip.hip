@@ -120,6 +120,7 @@ struct emba_ctx {
     int segpose_mode = 0;      // option segpose (A/B; 0 auto = yes, 1 no, 2 yes): pixel order evaluates the pose per event from segment records (default: yes)
     bool segpose = false;      // ... in the current evaluation
     bool chunks_lpt = false;   // the chunk list is sorted longest first and walked in grid order (no XCD-contiguous remapping)
+    double order_inl_pred = 0.0;   // ... and the inlier fraction the predicted pixels give (the rule's estimate of what the pixel order pays per event)
     double order_per_px = 0.0, order_lead_frac = 0.0;   // what the last order decision saw (diagnostics: emba_last_order_stats)
     bool tile_order = false; int order_mode = 0;   // option order: 0 auto, 1 pixel, 2 tile
     size_t n_lead = 0;                             // lead-in copies the tile order added
@@ -379,7 +380,8 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     uint32_t *d_bin = nullptr, *d_emit = nullptr, *d_pos = nullptr, *d_pred = nullptr; uint8_t* d_used = nullptr; unsigned long long* d_breaks = nullptr;
     bool tile = false;
     size_t n_break = 0, n_used_bins = 0, nbins = 1;
-    if (c->order_mode != 1 && ns && knots_host) {
+    // (auto on a window below tile_min_events never takes the tile order: nothing to analyse — 1.2 -> 0.3 ms of a 1 M-event window's first evaluation)
+    if (c->order_mode != 1 && ns && knots_host && (c->order_mode == 2 || c->n_used >= (size_t)c->opt_tile_min_events)) {
         const size_t max_bins = (size_t)((c->W + 7) / 8) * ((c->H + 1) / 2) + 1;      // (the finest pitch any candidate uses is 8 x 2)
         if ((st = ws_get(c, 20, ns * 4, (void**)&d_bin)) || (st = ws_get(c, 21, ns * 4, (void**)&d_emit)) || (st = ws_get(c, 22, ns * 4, (void**)&d_pos)) ||
             (st = ws_get(c, 23, max_bins + 8, (void**)&d_used)) || (st = ws_get(c, 29, ns * 4, (void**)&d_pred)))
@@ -400,6 +402,17 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         HIP_TRY(c, hipMemcpyAsync(&h_nheads, d_nheads, 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         const long n_heads = (long)h_nheads;
+        double f_pred = 1.0;
+        {
+            HIP_TRY(c, hipMemsetAsync(d_breaks, 0, 8, s));
+            hipLaunchKernelGGL(emba_count_pred_inliers_kernel, dim3((unsigned)std::min<size_t>(nblocks(ns), 1024)), dim3(256), 0, s, c->d_pm_pix, d_pred, (long)ns, c->outlier_px, d_breaks);
+            unsigned long long hi = 0;
+            HIP_TRY(c, hipMemcpyAsync(&hi, d_breaks, 8, hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipStreamSynchronize(s));
+            f_pred = c->n_used ? (double)hi / (double)c->n_used : 0.0;
+        }
+        c->order_inl_pred = f_pred;
+        const bool hopeless = c->order_mode == 0 && 83.0 * f_pred <= 41.0;      // the rule below cannot hold even without a single lead-in: skip the search for a tile
         const int r = std::max(0, std::min(c->opt_tile_reserve, 5));
         std::vector<uint8_t> h_used(max_bins);
         auto geom = [&](int shape, bool fine) {
@@ -434,6 +447,7 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
             const double chunks = std::max((double)used, entries / (double)(kWarpNew * kTileWaves * 8));
             return entries + 256.0 * chunks;
         };
+        if (!hopeless) {
         int best = -1; bool best_fine = false; double best_cost = 0; size_t best_breaks = 0, best_used = 0; int last = -1; bool last_fine = false;
         // (the tall shape first, the others have to beat it by 2 %: at equal lead-ins 36 x 32 measured 3-5 % faster than 48 x 24 — 3 M events 155 vs 161 us, config 4's
         // shard 245 vs 260, 2 M 111 vs 115, city 463 vs 465; profiles/r06_regime_sweep.txt)
@@ -475,8 +489,14 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
         // (round 5: a slow pan over a big sensor — the city shape at 0.1 rad/s: 10 M events on 640x480, 50 events per panorama pixel — is
         // atomic-request bound in pixel order (7.3 M requests on 155 k lines); the tile order's LDS sums win there in spite of the extra entries: step 867 vs
         // 946-995 us.  Hence the second clause: very dense tiles tolerate more lead-ins.)
-        tile = (c->order_mode == 2) || (c->n_used >= (size_t)c->opt_tile_min_events && per_px >= 8.0 && (lead_frac <= 0.35 || (per_px >= 24.0 && lead_frac <= 0.5)));
+        // Round 6: the rule prices both orders.  Per million events, fitted to profiles/r06_regime_sweep.txt and r06_sparse_order_ab.txt (warp + Gram kernels, us):
+        // pixel order 20 + 93 f (it pays per INLIER: an atomic request, a record, a live slot of the Gram kernel's tag stream; f = inlier fraction), tile order
+        // 31 (1 + lead) + 10 f + 30 (it pays per ENTRY, lead-in copies included, and its Gram kernel reads every candidate's slot).  The tile order wins where
+        // 83 f > 41 + 31 lead.  f is estimated from the predicted pixels (emba_count_pred_inliers_kernel).  (Rounds 2-5 asked for lead <= 0.35 only: with the window
+        // rule's fewer lead-ins that sent a 34 %-inlier stream — 10 M events on 640x480 at 0.5 rad/s — to the tile order: 850 us per step against 636 in pixel order.)
+        tile = (c->order_mode == 2) || (c->n_used >= (size_t)c->opt_tile_min_events && per_px >= 8.0 && 83.0 * f_pred > 41.0 + 31.0 * lead_frac);
         c->order_per_px = per_px; c->order_lead_frac = lead_frac;
+        }
     }
 
     if (!tile) {
@@ -1062,6 +1082,13 @@ emba_status emba_last_order_stats(const emba_ctx* c, double* events_per_pano_px,
     if (!c) return EMBA_ERR_INVALID_ARG;
     if (events_per_pano_px) *events_per_pano_px = c->order_per_px;
     if (lead_in_frac) *lead_in_frac = c->order_lead_frac;
+    return EMBA_OK;
+}
+
+emba_status emba_last_order_inlier_estimate(const emba_ctx* c, double* inlier_frac)
+{
+    if (!c || !inlier_frac) return EMBA_ERR_INVALID_ARG;
+    *inlier_frac = c->order_inl_pred;
     return EMBA_OK;
 }
 

@@ -451,6 +451,28 @@ __global__ void emba_iota_kernel(uint32_t* __restrict__ p, long n)
     if (i < n) p[i] = (uint32_t)i;
 }
 
+// statistics the host decides the order with: how many measurements the predicted pixels make INLIERS (consecutive entries of a chain no more than outlier_px apart,
+// model.cpp:199-200, on the rounded predictions: an estimate) — the pixel order pays per inlier (an atomic request, a record), the tile order per entry
+__global__ __launch_bounds__(256) void emba_count_pred_inliers_kernel(const uint32_t* __restrict__ pm_pix, const uint32_t* __restrict__ pred, long ns, double outlier_px,
+                                                                      unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t acc = 0;
+    const double lim2 = outlier_px * outlier_px;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < ns; i += (long)gridDim.x * 256) {
+        if (i == 0 || !(pm_pix[i] & kEvHasPred) || (pm_pix[i] & kEvLead)) continue;
+        const uint32_t a = pred[i], b = pred[i - 1];
+        if (a == kNoPixel || b == kNoPixel) continue;
+        const double dx = (double)(int)(a & 0xFFFFu) - (double)(int)(b & 0xFFFFu), dy = (double)(int)(a >> 16) - (double)(int)(b >> 16);
+        acc += (dx * dx + dy * dy <= lim2) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)((s_w[0] + s_w[1]) + (s_w[2] + s_w[3])));
+}
+
 // statistics the host decides the order with: chain breaks (lead-ins the tile order would need)
 __global__ __launch_bounds__(256) void emba_count_breaks_kernel(const uint32_t* __restrict__ emit, long ns, unsigned long long* __restrict__ out)
 {

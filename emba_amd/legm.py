@@ -134,10 +134,12 @@ class LEGM:
         self._check(self._L.emba_last_setup_ms(self._ctx, C.byref(a), C.byref(b), C.byref(t), C.byref(ne), C.byref(nc)))
         pp, lf = C.c_double(0), C.c_double(0)
         self._check(self._L.emba_last_order_stats(self._ctx, C.byref(pp), C.byref(lf)))
+        fi = C.c_double(0)
+        self._check(self._L.emba_last_order_inlier_estimate(self._ctx, C.byref(fi)))
         g = [C.c_int32(0) for _ in range(5)]
         self._check(self._L.emba_last_tile_geometry(self._ctx, *[C.byref(v) for v in g]))
         return dict(set_events_ms=a.value, prepare_ms=b.value, tile_order=bool(t.value), entries=ne.value, chunks=nc.value,
-                    events_per_pano_px=round(pp.value, 2), lead_in_frac=round(lf.value, 3),
+                    events_per_pano_px=round(pp.value, 2), lead_in_frac=round(lf.value, 3), inlier_frac_predicted=round(fi.value, 3),
                     tile=dict(w=g[0].value, h=g[1].value, pitch_x=g[2].value, pitch_y=g[3].value, reserve=g[4].value) if t.value else None)
 
     def tile_drift(self):

@@ -112,6 +112,8 @@ emba_status emba_last_setup_ms(const emba_ctx* ctx, double* set_events_ms, doubl
 /* What the last pixel / tile order decision of a window saw (at its first evaluation): events per panorama pixel of the occupied cells of the tile-origin grid
  * under the first trajectory, and the fraction of lead-in copies the tile order would add.  Diagnostics; either pointer may be NULL. */
 emba_status emba_last_order_stats(const emba_ctx* ctx, double* events_per_pano_px, double* lead_in_frac);
+/* ... and the inlier fraction it estimated from the predicted pixels (round 6: the rule prices the pixel order per inlier and the tile order per entry). */
+emba_status emba_last_order_inlier_estimate(const emba_ctx* ctx, double* inlier_frac);
 /* The LDS tile that decision chose for the window (round 6: one of four shapes of 1152 panorama pixels), the pitch of its origin grid and the reserve kept free
  * on every side of a tile for the drift of trial poses (options tile_shape, tile_fine, tile_reserve).  Diagnostics; any pointer may be NULL. */
 emba_status emba_last_tile_geometry(const emba_ctx* ctx, int32_t* tile_w, int32_t* tile_h, int32_t* pitch_x, int32_t* pitch_y, int32_t* reserve);

@@ -48,7 +48,7 @@ def run(tag, work, opts, steps):
     tl = su.get("tile")
     print(f"{work:9s} {tag:28s} {d['value'] / 1e9:7.3f} G ev/s  step {d['ms_per_step'] * 1e3:8.1f} us  warp {rf['kernel_ms_raw'] * 1e3:7.1f} us (frac {rf['algorithmic_bytes_per_launch'] / (rf['kernel_ms_raw'] * 1e-3) / 8e12:5.3f})"
           f"  gram {rf['accumulate_kernel_ms'] * 1e3:7.1f} us  | {'tile' if su['tile_order'] else 'pixel'} entries {su['entries']} chunks {su['chunks']} lead {su['lead_in_frac']:.3f} "
-          f"per_px {su['events_per_pano_px']:.1f} {('%dx%d@%dx%d r%d' % (tl['w'], tl['h'], tl['pitch_x'], tl['pitch_y'], tl['reserve'])) if tl else ''} inl {cfg['inlier_frac']:.3f} prep {su['prepare_ms']:.1f} ms  [{time.time() - t0:.0f} s]",
+          f"per_px {su['events_per_pano_px']:.1f} {('%dx%d@%dx%d r%d' % (tl['w'], tl['h'], tl['pitch_x'], tl['pitch_y'], tl['reserve'])) if tl else ''} inl {cfg['inlier_frac']:.3f} (predicted {su.get('inlier_frac_predicted', 0):.3f}) prep {su['prepare_ms']:.1f} ms  [{time.time() - t0:.0f} s]",
           flush=True)
     return d
 
@@ -84,6 +84,12 @@ def main():
     if S in ("lib",):      # EMBA_LIB=build_variants/x.so python scripts/regime_sweep.py --set lib
         for wk, steps in (("2M", 40), ("3M", 40), ("5M_K97", 30), ("city", 20), ("shard5M", 20), ("10M_K97", 20), ("40M", 6)):
             run("tile " + os.path.basename(os.environ.get("EMBA_LIB", "default")), wk, ["order=2"], steps)
+    if S in ("rule", "all"):      # does `auto` pick the faster order?  (every workload under auto, pixel and tile)
+        WORK.update({"10M_fast": "--events-per-gpu 10000000 --knots 97 --sensor 640x480", "20M_2048": "--events-per-gpu 20000000 --knots 256 --pano-h 2048",
+                     "5M_fast": "--events-per-gpu 5000000 --knots 97 --sensor 640x480", "4M_2048": "--events-per-gpu 4000000 --knots 256 --pano-h 2048"})
+        for wk, steps in (("1.5M", 40), ("2M", 40), ("3M", 30), ("5M_K97", 20), ("city", 12), ("shard5M", 12), ("10M_K97", 12), ("10M_2048", 10), ("10M_fast", 10), ("20M_2048", 8), ("5M_fast", 12), ("4M_2048", 12), ("shard12M", 8)):
+            for tag, o in (("auto", []), ("pixel", ["order=1"]), ("tile", ["order=2"])):
+                run(tag, wk, o, steps)
     if S in ("large", "all"):
         for wk, steps in (("shard12M", 10), ("10M_2048", 10), ("40M", 6)):
             run("auto", wk, [], steps)

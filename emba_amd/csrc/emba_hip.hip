@@ -354,6 +354,7 @@ emba_status prepare_order(emba_ctx* c, const double* knots_host, int64_t t0, int
     // (a previous order of this window goes away; its buffers are reused)
     c->d_ev_pix = nullptr; c->d_ev_batch = nullptr;
     c->tile_order = false; c->have_ev_pm = false; c->n_chunks = 0; c->n_lead = 0;
+    c->order_per_px = 0.0; c->order_lead_frac = 0.0; c->order_inl_pred = 0.0;
 
     // control-pose index per batch; a batch outside the knots is an error (BASALT_ASSERT_STREAM at so3_spline.h:221-229)
     uint32_t* d_err = nullptr;

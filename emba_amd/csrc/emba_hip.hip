@@ -151,6 +151,7 @@ struct emba_ctx {
     bool ep_valid = false;        // d_ep holds the current evaluation's residuals in the reference's order (the resident step's Gram launch compacts them in its tail blocks)
     bool ep_in_gram = false;      // ... the Gram launch of the equations being formed will do that (set by emba_form_active's fused branch)
     bool ep_after_gram = false;   // ... or, for windows too long for the tail form, the scan + compaction launches behind it
+    int opt_poison = 0;          // option poison = 1 (tests): every NEW device allocation of the context is filled with 0xFF bytes
     int opt_tile_reserve = 2, opt_tile_shape = -1, opt_tile_fine = -1, opt_tile_min_events = 1650000, opt_tile_chunk = 0;   // emba_set_option: the tile order's window rule (prepare_order)
     int tile_shape = 0; bool tile_fine = false;   // ... and what the current order uses: index into kTileShapes, its finer pitch grid
     int opt_gather_waves = 0, opt_chunk_order_bin = 0, opt_solve_counts = -1, opt_syrk_dense = 0, opt_syrk_lists = 0, opt_gram_sparse = -1, opt_gram_sparse_chunk = 4, opt_syrk_min_cols = 512, opt_syrk_item_cap = 4096, opt_solve_debug = 0, opt_poisson = 0, opt_gemm64 = 0;   // emba_set_option
@@ -235,6 +236,7 @@ emba_status dev_alloc(emba_ctx* c, T** p, size_t count, bool* fresh = nullptr)
     *p = nullptr;
     c->caps.erase(key);
     HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(p), bytes));
+    if (c->opt_poison) HIP_TRY(c, hipMemsetAsync(*p, 0xFF, bytes, c->stream));
     c->caps[key] = bytes;
     if (fresh) *fresh = true;
     return EMBA_OK;
@@ -289,6 +291,7 @@ emba_status ws_get(emba_ctx* c, int slot, size_t bytes, void** out)
         w.p = nullptr; w.bytes = 0;
         if (hipMalloc(&w.p, std::max<size_t>(bytes, 8)) != hipSuccess) return fail(c, EMBA_ERR_HIP, "hipMalloc of %zu bytes failed (workspace %d)", bytes, slot);
         w.bytes = std::max<size_t>(bytes, 8);
+        if (c->opt_poison) { (void)hipMemsetAsync(w.p, 0xFF, w.bytes, c->stream); }      // option poison (tests): new memory reads as NaN / 0xFFFFFFFF, so that a read of never-written workspace shows
     }
     *out = w.p;
     return EMBA_OK;
@@ -2073,6 +2076,7 @@ const OptionRef kOptions[] = {
     {"solve_perm", &emba_ctx::solve_perm_mode, -1, 1},
     {"gather_waves", &emba_ctx::opt_gather_waves, 0, 4},
     {"chunk_order_bin", &emba_ctx::opt_chunk_order_bin, 0, 1},
+    {"poison", &emba_ctx::opt_poison, 0, 1},
     {"tile_reserve", &emba_ctx::opt_tile_reserve, 0, 5},
     {"tile_shape", &emba_ctx::opt_tile_shape, -1, kNumTileShapes - 1},
     {"tile_fine", &emba_ctx::opt_tile_fine, -1, 1},

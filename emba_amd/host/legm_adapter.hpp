@@ -140,9 +140,21 @@ inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatX
     // bound to the device solvers below, which work from the sparse factors.  An empty matrix with the right row count keeps the
     // first-window trim of solver.cpp:156-165 (A12.block(3, 0, dim - 3, A12.cols())) well-formed.
     A12 = MatXd(dim, 0);
-    active.clear(); inactive.clear();
-    auto hint = active.end();
-    for (uint32_t p : ne.active_pix_idxes) hint = active.insert(hint, p);          // already ascending: O(P)
+    // The caller's set becomes exactly the (ascending) active list — by an in-order MERGE with what it holds, not clear() + P insertions: between two accepted steps
+    // of an LM loop the active set hardly changes, and freeing and allocating 488 k tree nodes (config 2's shape) was ~20 ms of every formNormalEq.  Correct whatever
+    // the set held before (an empty set takes the P insertions).
+    inactive.clear();
+    {
+        auto it = active.begin();
+        size_t a = 0;
+        const std::vector<uint32_t>& idx = ne.active_pix_idxes;
+        while (it != active.end() || a < P) {
+            if (it == active.end()) { active.insert(active.end(), (size_t)idx[a]); ++a; }
+            else if (a == P || *it < (size_t)idx[a]) it = active.erase(it);
+            else if (*it == (size_t)idx[a]) { ++it; ++a; }
+            else { active.insert(it, (size_t)idx[a]); ++a; }                       // (hint: right in front of `it`)
+        }
+    }
 #ifdef EMBA_HIP_FILL_INACTIVE
     // (the reference's updateMap walks this set, model.cpp:889-901; the device updateMap below does not — 2 M tree nodes per call saved)
     size_t a = 0; auto ih = inactive.end();

@@ -84,6 +84,16 @@ def merge_ep(ep_parts, pix_parts):
     return ep[order]
 
 
+def _fill_done(dev):
+    """A tensor torch has just zero-filled is about to be WRITTEN by the engine's kernels.  In production the engine runs on torch's current stream (HipEngine checks
+    it) and the fill is ordered in front of them; where it runs on a stream of its own (the rank-thread tests: check_stream=False) nothing orders torch's fill kernel
+    against the engine's first writes — with eight ranks saturating one device the fill was seen to run AFTER them once (round 6: the Schur sums of a rank zeroed, a
+    wrong x1).  Draining torch's stream here costs microseconds in either case."""
+    if dev.type == "cuda":
+        import torch
+        torch.cuda.current_stream(dev).synchronize()
+
+
 def _device_sync(dev):
     """(the CPU stand-in engine of the gloo tests keeps its tensors on the host)"""
     if dev.type == "cuda":
@@ -232,6 +242,7 @@ class ShardedLEGM:
         dev = self.pack.device
         recv, n_recv = self._exchange_records()
         S = torch.zeros(e.solve_shard_size(), dtype=torch.float64, device=dev)
+        _fill_done(dev)
         e.solve_shard_partial(r, w, recv, n_recv, lam, S)
         if w > 1:
             dist.all_reduce(S)
@@ -242,6 +253,7 @@ class ShardedLEGM:
         # so its result is equal across ranks only to rounding — every rank must apply the SAME pose update or the replicas drift apart.
         n2, n1 = 2 * max(self.P, 1), 3 * int(e.K)
         x2 = torch.zeros(n2 + 1 + n1, dtype=torch.float64, device=dev)      # [x2 (2P) | status | x1 (3K)]
+        _fill_done(dev)
         x1, failure = None, None
         try:
             x1 = e.solve_shard_finish(r, w, recv, n_recv, lam, fix_first_pose, S, x2)
@@ -275,6 +287,7 @@ def _sharded_solve_cg(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6, r
     recv, n_recv = self._exchange_records()
     n = 3 * int(e.K)
     red = torch.zeros(e.cg_shard_size(), dtype=torch.float64, device=dev)
+    _fill_done(dev)
     tiny = float(np.finfo(np.float64).tiny)
 
     def reduce(t):
@@ -306,6 +319,7 @@ def _sharded_solve_cg(self, lam, fix_first_pose=False, max_iter=100, tol=1e-6, r
                 it += 1
         err = float(np.sqrt(rn2 / rhs2))
     x2 = torch.zeros(2 * max(self.P, 1), dtype=torch.float64, device=dev)
+    _fill_done(dev)
     x1 = e.cg_shard_end(x2)
     reduce(x2)
     return np.asarray(x1).copy(), (x2[: 2 * self.P] if resident_x2 else x2[: 2 * self.P].cpu().numpy()), it, err

@@ -389,6 +389,7 @@ emba_status emba_set_cost(emba_ctx* ctx, int32_t irls, double eta);
  *   syrk_dense     1 dense instead of block-sparse SYRK;  syrk_lists 0 auto | 1 the block-sparse SYRK's per-pair slice lists always | 2 its (pair, chunk) items always;
  *                  syrk_min_cols 64 ... 4096 (512): fewest columns of U a workgroup of the dense split-K SYRK takes;  syrk_item_cap 1 ... 65536 (4096): slabs of the item
  *                  form (an item beyond them adds its tile to S by global atomics)
+ *   poison         1 (tests) fills every NEW device allocation of the context with 0xFF bytes: a read of never-written workspace then shows as NaN / 0xFFFFFFFF
  *   solve_debug    1 prints the band statistics of a solve
  *   poisson        0 folded Fourier form | 1 dense sine transforms | 2 no folding;  gemm64 1 forces the 64-wide GEMM tiles */
 emba_status emba_set_option(emba_ctx* ctx, const char* name, int32_t value);

@@ -1,3 +1,4 @@
+# evidence (round 6): what producing the reference-order ep vector costs a step — tail blocks of the Gram launch (step_ep=1) vs launches of their own (step_ep=2) vs none (profiles/r06_ep_in_step.txt)
 mkdir -p gpurun_out
 for cfg in "city|--events-per-gpu 10000000 --knots 97 --sensor 640x480 --yaw-rate 0.1 --steps 10" "40M|--events-per-gpu 40000000 --knots 97 --pano-h 2048 --steps 5" "100M|--events-per-gpu 100000000 --knots 256 --pano-h 2048 --steps 4"; do
   tag=${cfg%%|*}; args=${cfg#*|}

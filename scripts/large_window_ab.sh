@@ -1,3 +1,4 @@
+# evidence (round 6): tile shape / origin grid options at 12.5 M - 100 M events on one box (profiles/r06_large_window_ab.txt)
 mkdir -p gpurun_out
 for cfg in "100M|--events-per-gpu 100000000 --knots 256 --pano-h 2048 --steps 4" "40M|--events-per-gpu 40000000 --knots 97 --pano-h 2048 --steps 5" "shard12M|--events-per-gpu 12500000 --knots 256 --pano-h 2048 --shard-of 8 --shard-rank 3 --steps 8"; do
   tag=${cfg%%|*}; args=${cfg#*|}

@@ -1,3 +1,4 @@
+# development (round 6): the default library against build_variants/*.so of the same ABI on ONE box, interleaved (profiles/r06_early_gather_ab.txt)
 mkdir -p gpurun_out
 for rep in 1 2; do
 for lib in default noearly; do

@@ -1,3 +1,4 @@
+# evidence (round 6): pixel vs tile order and the tile reserve inside an LM loop at config 2 shape, plus the steady step under both orders (profiles/r06_lm_order_ab.txt)
 mkdir -p gpurun_out
 for o in "" "order=1" "order=2,tile_reserve=4" "order=2,tile_reserve=5,tile_shape=0"; do
   echo "=== EMBA_OPTS=$o"

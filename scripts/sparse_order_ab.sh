@@ -1,3 +1,4 @@
+# evidence (round 6): pixel vs tile order on low-inlier / sparse large windows (profiles/r06_sparse_order_ab.txt); the full table: scripts/regime_sweep.py --set rule
 for cfg in "10M_2048|--events-per-gpu 10000000 --knots 256 --pano-h 2048 --steps 10" "20M_2048|--events-per-gpu 20000000 --knots 256 --pano-h 2048 --steps 8" "10M_K97_fast|--events-per-gpu 10000000 --knots 97 --sensor 640x480 --steps 10"; do
   tag=${cfg%%|*}; args=${cfg#*|}
   for opts in "--opt order=1" "--opt order=2" ""; do

@@ -2358,6 +2358,8 @@ emba_status schur_accumulate(emba_ctx* c, const RecView& view, const SolveLists&
 {
     hipStream_t s = c->stream;
     // (the SYRK covers the n rows of S; row n of the augmented matrix, the right-hand side b1 - U y, is accumulated by the build kernel itself)
+    // (round 6, measured and dropped: chunk i + 1's U build on this stream beside chunk i's product on a second one — every chunk count was slower than one after
+    // the other, 3.87 -> 4.2 / 4.6 / 5.3 ms for 2 / 4 / 8 chunks at config 2's shape: profiles/r06_schur_pipe_ab.txt)
     const size_t chunk = std::max<size_t>(1, std::min<size_t>(std::max<size_t>(n_pix, 1), (size_t)(6ull << 30) / (16ull * (size_t)lds_)));   // <= 6 GB of U
     const int nb64 = (n + 63) / 64, nbp = nb64 * (nb64 + 1) / 2;
     const int nks_max = std::max(1, (4 * c->n_cu + nbp - 1) / nbp);   // enough (tile pair, K slab) blocks to fill the chip ...

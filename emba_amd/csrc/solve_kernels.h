@@ -86,6 +86,8 @@ __global__ void emba_csr_count_from_map_kernel(const uint32_t* __restrict__ acti
 // reads in slot order, one full line written per record), with the tail rewritten to the packed form {pixel of the list, pair key}.  The
 // U build, the x2 kernel and every iteration of the CG solver then stream a pixel's records from consecutive lines instead of gathering
 // random 128-B lines through an index list (config 2's shape: 7.5 M records, each pass ran at the ~2 TB/s of that gather).
+// (round 6, measured and dropped: one ticket per RUN of same-pixel records — a wave reads 64 tail words, the head lane of a run adds its length — instead of a
+// returning atomic per record: 457 -> 556 us at config 2's shape; the kernel is bound by its copy, not by the tickets.  profiles/r06_schur_pipe_ab.txt)
 __global__ __launch_bounds__(256) void emba_csr_fill_sorted_kernel(RecView v, long n_rec, const uint32_t* __restrict__ off, uint32_t* __restrict__ cursor,
                                                                    double* __restrict__ out)
 {

@@ -52,6 +52,8 @@ SIGNATURES = {
     "emba_compact_ep": (C.c_int, [C.c_void_p]),
     "emba_get_ep": (C.c_int, [C.c_void_p, _dp, C.c_size_t, _szp]),
     "emba_get_inlier_pixels": (C.c_int, [C.c_void_p, _u32p]),
+    "emba_get_inlier_pixel_starts": (C.c_int, [C.c_void_p, _u32p]),
+    "emba_get_ep_by_pixel": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_uint64)]),
     "emba_data_cost": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _dp]),
     "emba_reg_cost": (C.c_int, [C.c_void_p, C.c_double, _dp]),
     "emba_costs": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, _dp, _dp]),

@@ -5,10 +5,15 @@
 #include "../../include/emba_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -96,7 +101,8 @@ struct emba_ctx {
     uint32_t eval_seq = 0;
     uint32_t* d_total = nullptr;    // [0] inliers, [1] active pixels
     double* d_scalar = nullptr;     // cost reductions
-    void* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2]{};   // two pinned 4-MB buffers: device -> PAGEABLE host memory in pipelined chunks (d2h_pageable)
+    std::vector<uint32_t> h_pix_starts; uint32_t pix_starts_seq = 0;   // emba_get_inlier_pixel_starts of evaluation number pix_starts_seq (eval_seq), for emba_get_ep_by_pixel
+    void* h_stage[2] = {nullptr, nullptr}; hipEvent_t stage_ev[2]{};   // two pinned 8-MB buffers: device -> PAGEABLE host memory in pipelined chunks (d2h_chunks)
     int* h_pinned = nullptr;        // pinned, device-visible status words the kernels write: [0] inliers [1] err [2] P [3] step sequence number
     int seq = 0;                    // sequence number of the last step whose post-warp kernels publish [3]
     bool seq_armed = false;         // the pending counts come from kernels that publish the sequence number
@@ -193,7 +199,7 @@ struct emba_ctx {
     bool finish_done = false;   // emba_form_finish ran (L2 applied): the state emba_solve_normal_eq works on
     int solve_info = 0;         // last Schur solve: bit 0 a 2x2 block not positive definite (error), bit 1 a pivot of S vanished (zero update, like Eigen's ldlt)
     // grow-only workspaces of the Schur solve (an LM loop calls it every iteration)
-    struct { void* p = nullptr; size_t bytes = 0; } ws[40];   // 0-15 and 32-39 Schur solve, 16-31 sort / order preparation
+    struct { void* p = nullptr; size_t bytes = 0; } ws[44];   // 0-15 and 32-39 Schur solve, 16-31 sort / order preparation, 42 pixel starts of ep, 43 unpacked A22 | b2 of a download
     // f3 (Poisson reconstruction): sine matrices and eigenvalues of the two transform lengths, scratch planes
     double *d_SH = nullptr, *d_SW = nullptr, *d_lamH = nullptr, *d_lamW = nullptr, *d_pF = nullptr, *d_pT = nullptr, *d_pGx = nullptr, *d_pGy = nullptr;
     double* d_thomas = nullptr;   // Thomas factors of T_W + lambda1[i] I (W x H)
@@ -768,11 +774,72 @@ emba_status resolve_pending(emba_ctx* c, bool counts_only = false)
 // Device -> host into memory the CALLER owns (pageable: an Eigen vector, a cv::Mat, a numpy array).  hipMemcpy stages such a copy through the runtime's own bounce
 // buffers one chunk after the other; here the DMA of chunk i + 1 into one pinned buffer runs while the CPU copies chunk i out of the other — the two halves of the
 // drop-in's largest transfer (ep: 56 MB per evaluateDataError at 10 M events) overlap instead of adding up.  The stream must have been drained up to `src`'s producer.
-emba_status d2h_pageable(emba_ctx* c, void* dst, const void* src, size_t bytes)
+// A few helper threads for the CPU half of a large device -> pageable copy (round 6): memcpy into FRESH pages is bound by the page faults of the one thread that touches
+// them (ep into the vector evaluateDataError returns, 60 MB at config 2's shape: 8.8 ms = 6.8 GB/s).  The pool is process-wide, created at the first large copy and never
+// torn down (its threads sleep on a condition variable; a caller that arrives while another copy runs copies alone).
+struct CopyPool {
+    static constexpr int kHelpers = 3;
+    std::mutex m, use; std::condition_variable go, done;
+    uint64_t gen = 0; int pending = 0; bool started = false;
+    const std::function<void(int)>* job = nullptr;      // job(h), h = 0 (the caller) .. kHelpers
+    static void piece(int h, size_t n, size_t& lo, size_t& hi)
+    {
+        const size_t per = ((n / (kHelpers + 1)) + 4095) & ~(size_t)4095;      // whole pages to every thread
+        lo = std::min(n, per * (size_t)h); hi = (h == kHelpers) ? n : std::min(n, per * (size_t)(h + 1));
+    }
+    void worker(int h)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            { std::unique_lock<std::mutex> l(m); go.wait(l, [&] { return gen != seen; }); seen = gen; f = job; }
+            (*f)(h + 1);
+            { std::lock_guard<std::mutex> l(m); if (--pending == 0) done.notify_one(); }
+        }
+    }
+    // f(0) on the caller, f(1 .. kHelpers) on the helpers; alone (f(0 .. kHelpers) in turn) when another caller holds the pool
+    void run(const std::function<void(int)>& f)
+    {
+        std::unique_lock<std::mutex> u(use, std::try_to_lock);
+        if (!u.owns_lock()) { for (int h = 0; h <= kHelpers; ++h) f(h); return; }
+        if (!started) { for (int h = 0; h < kHelpers; ++h) std::thread([this, h] { worker(h); }).detach(); started = true; }
+        { std::lock_guard<std::mutex> l(m); job = &f; pending = kHelpers; ++gen; }
+        go.notify_all();
+        f(0);
+        { std::unique_lock<std::mutex> l(m); done.wait(l, [&] { return pending == 0; }); }
+    }
+    void copy(void* d, const void* sp, size_t nn)
+    {
+        if (nn < ((size_t)1 << 20)) { std::memcpy(d, sp, nn); return; }
+        run([&](int h) { size_t lo, hi; piece(h, nn, lo, hi); if (hi > lo) std::memcpy((char*)d + lo, (const char*)sp + lo, hi - lo); });
+    }
+};
+CopyPool* copy_pool() { static CopyPool* p = new CopyPool; return p; }      // (never destroyed: its detached threads may outlive every context)
+
+// Have the pages of [p, p + bytes) mapped before they are written: memory a caller has just allocated (the vector evaluateDataError returns) has no pages yet, and
+// a first write per page is a trap each (60 MB: 15 k of them on the copying thread).  One MADV_POPULATE_WRITE per piece does the same inside the kernel, without
+// changing what the pages hold; where the kernel does not know it (< 5.14) the pages are simply faulted in by the copy that follows.
+void populate_pages(void* p, size_t bytes)
+{
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+    const uintptr_t lo = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);
+}
+void populate_pages_parallel(void* p, size_t bytes)
+{
+    if (bytes < ((size_t)4 << 20)) return;
+    copy_pool()->run([&](int h) { size_t lo, hi; CopyPool::piece(h, bytes, lo, hi); if (hi > lo) populate_pages((char*)p + lo, hi - lo); });
+}
+
+// device -> host in pipelined chunks through the context's two pinned buffers: the DMA of chunk i + 1 runs while `consume(chunk, byte offset, bytes)` works on chunk i.
+// The stream must have been drained up to `src`'s producer.
+emba_status d2h_chunks(emba_ctx* c, const void* src, size_t bytes, const std::function<void(const void*, size_t, size_t)>& consume,
+                       const std::function<void()>& while_first_chunk_travels = nullptr)
 {
     if (!bytes) return EMBA_OK;
-    constexpr size_t kChunk = (size_t)4 << 20;
-    if (bytes <= kChunk / 4) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return EMBA_OK; }
+    constexpr size_t kChunk = (size_t)8 << 20;
     for (int k = 0; k < 2; ++k)
         if (!c->h_stage[k]) { HIP_TRY(c, hipHostMalloc(&c->h_stage[k], kChunk, hipHostMallocDefault)); HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[k], hipEventDisableTiming)); }
     hipStream_t s = c->stream;
@@ -780,15 +847,26 @@ emba_status d2h_pageable(emba_ctx* c, void* dst, const void* src, size_t bytes)
     auto len = [&](size_t i) { return std::min(kChunk, bytes - i * kChunk); };
     HIP_TRY(c, hipMemcpyAsync(c->h_stage[0], src, len(0), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipEventRecord(c->stage_ev[0], s));
+    if (while_first_chunk_travels) while_first_chunk_travels();
     for (size_t i = 0; i < n; ++i) {
         if (i + 1 < n) {
             HIP_TRY(c, hipMemcpyAsync(c->h_stage[(i + 1) & 1], (const char*)src + (i + 1) * kChunk, len(i + 1), hipMemcpyDeviceToHost, s));
             HIP_TRY(c, hipEventRecord(c->stage_ev[(i + 1) & 1], s));
         }
         HIP_TRY(c, hipEventSynchronize(c->stage_ev[i & 1]));
-        std::memcpy((char*)dst + i * kChunk, c->h_stage[i & 1], len(i));
+        consume(c->h_stage[i & 1], i * kChunk, len(i));
     }
     return EMBA_OK;
+}
+
+emba_status d2h_pageable(emba_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return EMBA_OK;
+    if (bytes <= ((size_t)1 << 20)) { HIP_TRY(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return EMBA_OK; }
+    // (the first chunk's DMA is queued before the destination's pages are populated: the two run side by side)
+    bool populated = false;
+    return d2h_chunks(c, src, bytes, [&](const void* chunk, size_t off, size_t len) { copy_pool()->copy((char*)dst + off, chunk, len); },
+                      [&]() { if (!populated) { populate_pages_parallel(dst, bytes); populated = true; } });
 }
 
 }  // namespace
@@ -1713,15 +1791,20 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     if (active_idx && P) HIP_TRY(c, hipMemcpyAsync(active_idx, c->d_active, P * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     double* d_A22 = nullptr; double* d_b2 = nullptr; double* d_A12 = nullptr;
     if ((A22 || b2) && P) {
-        if ((st = dev_alloc(c, &d_A22, 4 * P)) || (st = dev_alloc(c, &d_b2, 2 * P))) { dev_free(c, d_A22); return st; }
+        // (round 6) the unpacked blocks sit in a workspace (a hipMalloc / hipFree pair per call until then) and travel through the pinned pipeline + the copy helpers
+        // like ep: the drop-in downloads them twice per accepted step (formNormalEq, applyL2Reg), 23 MB each at config 2's shape
+        if ((st = ws_get(c, 43, 6 * P * sizeof(double), (void**)&d_A22))) return st;
+        d_b2 = d_A22 + 4 * P;
         hipLaunchKernelGGL(emba_unpack_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, s, pack_A22b2(c), (long)P, d_A22, d_b2);
-        if (A22) (void)hipMemcpyAsync(A22, d_A22, 4 * P * sizeof(double), hipMemcpyDeviceToHost, s);
-        if (b2) (void)hipMemcpyAsync(b2, d_b2, 2 * P * sizeof(double), hipMemcpyDeviceToHost, s);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (A22 && (st = d2h_pageable(c, A22, d_A22, 4 * P * sizeof(double)))) return st;
+        if (b2 && (st = d2h_pageable(c, b2, d_b2, 2 * P * sizeof(double)))) return st;
     }
     if (A12_dense && P) {
-        if ((st = ensure_compact(c))) { dev_free(c, d_A22); dev_free(c, d_b2); return st; }
+        if ((st = ensure_compact(c))) return st;
         const size_t n12 = (size_t)dim * 2 * P;
-        if ((st = dev_alloc(c, &d_A12, n12))) { dev_free(c, d_A22); dev_free(c, d_b2); return st; }
+        if ((st = dev_alloc(c, &d_A12, n12))) return st;
         (void)hipMemsetAsync(d_A12, 0, n12 * sizeof(double), s);
         if (c->n_cand)
             hipLaunchKernelGGL(emba_dense_a12_kernel, dim3((unsigned)((c->n_cand + 255) / 256)), dim3(256), 0, s, c->d_rec, c->d_slot_key,
@@ -1730,7 +1813,7 @@ emba_status emba_form_finish(emba_ctx* c, double alpha, double* A11, double* b1,
     }
     hipError_t e = hipStreamSynchronize(s);
     c->knots_in_flight = false;
-    dev_free(c, d_A22); dev_free(c, d_b2); dev_free(c, d_A12);
+    dev_free(c, d_A12);
     if (e != hipSuccess) return fail(c, EMBA_ERR_HIP, "form_finish: %s", hipGetErrorString(e));
     HIP_TRY(c, hipGetLastError());
     c->finish_done = true;
@@ -1820,6 +1903,53 @@ emba_status emba_get_inlier_pixels(emba_ctx* c, uint32_t* pix_host)
     HIP_TRY(c, hipMemcpyAsync(pix_host, d_out, c->n_inliers * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return EMBA_OK;
+}
+
+emba_status emba_get_inlier_pixel_starts(emba_ctx* c, uint32_t* starts_host)
+{
+    if (!c || !starts_host) return c ? fail(c, EMBA_ERR_INVALID_ARG, "starts_host NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched || (!c->eval_done && !c->inl_pending && !c->ep_deferred)) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st;
+    if ((st = resolve_pending(c)) || (st = ensure_inl_idx(c))) return st;
+    const uint32_t S = (uint32_t)((size_t)c->sw * c->sh);
+    uint32_t *d_px = nullptr, *d_starts = nullptr;
+    if ((st = ws_get(c, 15, std::max<size_t>(c->n_inliers, 1) * 4, (void**)&d_px)) || (st = ws_get(c, 42, ((size_t)S + 1) * 4, (void**)&d_starts))) return st;
+    if (c->n_inliers) hipLaunchKernelGGL(emba_inlier_pix_kernel, dim3(nblocks(c->n_pm)), dim3(256), 0, c->stream, c->d_pm_pix, c->d_flag, c->d_inl_idx, (long)c->n_pm, d_px);
+    hipLaunchKernelGGL(emba_pix_starts_kernel, dim3(nblocks(c->n_inliers + 1)), dim3(256), 0, c->stream, d_px, (long)c->n_inliers, S, d_starts);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(starts_host, d_starts, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->h_pix_starts.assign(starts_host, starts_host + S + 1);
+    c->pix_starts_seq = c->eval_seq;
+    return EMBA_OK;
+}
+
+emba_status emba_get_ep_by_pixel(emba_ctx* c, double* ep_out, const uint64_t* dst)
+{
+    if (!c || !ep_out || !dst) return c ? fail(c, EMBA_ERR_INVALID_ARG, "ep_out / dst NULL") : EMBA_ERR_INVALID_ARG;
+    if (!c->eval_launched || (!c->eval_done && !c->inl_pending && !c->ep_deferred)) return fail(c, EMBA_ERR_STATE, "no evaluateDataError state");
+    HIP_TRY(c, hipSetDevice(c->device));
+    emba_status st;
+    if ((st = resolve_pending(c))) return st;
+    const size_t S = (size_t)c->sw * c->sh;
+    if (c->pix_starts_seq != c->eval_seq || c->h_pix_starts.size() != S + 1) {
+        std::vector<uint32_t> tmp(S + 1);
+        if ((st = emba_get_inlier_pixel_starts(c, tmp.data()))) return st;
+    }
+    if (!c->ep_valid && (st = ensure_inl_idx(c))) return st;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const uint32_t* starts = c->h_pix_starts.data();
+    if ((size_t)starts[S] != c->n_inliers) return fail(c, EMBA_ERR_STATE, "the pixel starts do not belong to this evaluation (%u residuals there, %zu here)", starts[S], c->n_inliers);
+    size_t p = 0;      // the pixel cursor only moves forward: the chunks arrive in ep order
+    return d2h_chunks(c, c->d_ep, c->n_inliers * sizeof(double), [&](const void* chunk, size_t off, size_t len) {
+        const size_t a = off / sizeof(double), b = (off + len) / sizeof(double);
+        while (p < S && (size_t)starts[p + 1] <= a) ++p;
+        for (size_t q = p; q < S && (size_t)starts[q] < b; ++q) {
+            const size_t lo = std::max<size_t>(starts[q], a), hi = std::min<size_t>(starts[q + 1], b);
+            if (hi > lo) std::memcpy(ep_out + dst[q] + (lo - starts[q]), (const double*)chunk + (lo - a), (hi - lo) * sizeof(double));
+        }
+    });
 }
 
 emba_status emba_data_cost(emba_ctx* c, int32_t irls, double eta, double* cost)

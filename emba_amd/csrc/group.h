@@ -535,26 +535,39 @@ emba_status emba_group_get_ep(emba_group* g, double* ep_out, size_t cap, size_t*
         if (n_inliers) *n_inliers = m;
         return EMBA_OK;
     }
-    std::vector<std::vector<double>> ep(g->n); std::vector<std::vector<uint32_t>> px(g->n);
+    // (round 6) Every rank's residuals are in (sensor pixel, time) order, so a pixel's are one contiguous run per rank: S + 1 start offsets per rank say where, and
+    // every rank streams its vector through its pinned buffers and copies its runs to their places in ep_out from its own thread.  Until then: a copy of every
+    // rank's vector AND of one pixel word per residual to the host, then an element-by-element scatter — 47-56 ms per evaluateDataError on two ranks at config 2's
+    // shape (7.5 M residuals), the largest item of the multi-GPU drop-in's iteration.
+    const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
+    static const bool trace = std::getenv("EMBA_GROUP_TRACE") != nullptr;      // stage times on stderr
+    const auto t0 = std::chrono::steady_clock::now();
+    auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    std::vector<std::vector<uint32_t>> starts(g->n, std::vector<uint32_t>(S + 1));
+    { emba_status st = gpool(g, [&](int r) { return emba_get_inlier_pixel_starts(g->ctx[r], starts[r].data()); }); if (st) return st; }
+    const double t_starts = ms();
     size_t total = 0;
-    for (int r = 0; r < g->n; ++r) {
-        ep[r].resize(std::max<size_t>(g->n_local[r], 1));
-        size_t m = 0;
-        G_TRY(g, r, emba_get_ep(g->ctx[r], ep[r].data(), ep[r].size(), &m));
-        ep[r].resize(m); total += m;
-        px[r].resize(std::max<size_t>(m, 1)); G_TRY(g, r, emba_get_inlier_pixels(g->ctx[r], px[r].data())); px[r].resize(m);
-    }
+    for (int r = 0; r < g->n; ++r) total += starts[r][S];
     g->n_inliers = total;
     if (n_inliers) *n_inliers = total;
     if (cap < total) return gfail(g, EMBA_ERR_CAPACITY, "cap=%zu < inliers=%zu", cap, total);
-    const size_t S = (size_t)g->ctx[0]->sw * g->ctx[0]->sh;
-    std::vector<size_t> start(S + 1, 0);                              // global offset of every sensor pixel's block
-    for (int r = 0; r < g->n; ++r) for (uint32_t p : px[r]) ++start[p + 1];
-    for (size_t p = 0; p < S; ++p) start[p + 1] += start[p];
-    std::vector<size_t> cur(start.begin(), start.end() - 1);
-    for (int r = 0; r < g->n; ++r)                                    // rank-major inside a pixel: earlier ranks first
-        for (size_t i = 0; i < ep[r].size(); ++i) ep_out[cur[px[r][i]]++] = ep[r][i];
-    return EMBA_OK;
+    std::vector<std::vector<uint64_t>> dst(g->n, std::vector<uint64_t>(S));
+    for (size_t p = 0; p < S; ++p) {
+        uint64_t at = 0;
+        for (int r = 0; r < g->n; ++r) at += starts[r][p];              // everything of the pixels in front
+        for (int r = 0; r < g->n; ++r) { dst[r][p] = at; at += (uint64_t)starts[r][p + 1] - starts[r][p]; }   // rank-major inside a pixel: earlier ranks first
+    }
+    // The ranks' runs alternate inside every page of ep_out: left to the placement, two threads trap on the same fresh pages at the same time (measured: 16-17 ms for
+    // 60 MB on two ranks, slower than ONE thread's 8.8).  Every rank first has its own n-th of the vector's pages mapped, then places.
+    { emba_status st = gpool(g, [&](int r) { const size_t per = (total * sizeof(double) / g->n + 4095) & ~(size_t)4095, lo = std::min(total * sizeof(double), per * r),
+                                                  hi = (r == g->n - 1) ? total * sizeof(double) : std::min(total * sizeof(double), per * (r + 1));
+                                             if (hi > lo) populate_pages((char*)ep_out + lo, hi - lo);
+                                             return EMBA_OK; });
+      if (st) return st; }
+    const double t_dst = ms();
+    const emba_status st = gpool(g, [&](int r) { return starts[r][S] ? emba_get_ep_by_pixel(g->ctx[r], ep_out, dst[r].data()) : EMBA_OK; });
+    if (trace) fprintf(stderr, "[group ep] %d ranks, %zu residuals: pixel starts %.2f ms, offsets + pages %.2f, placement %.2f\n", g->n, total, t_starts, t_dst - t_starts, ms() - t_dst);
+    return st;
 }
 
 // LEGM::formNormalEq[IRLS] + applyL2Reg (model.cpp:316-719) over all ranks on the state of the last emba_group_eval:

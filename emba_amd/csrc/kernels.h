@@ -931,6 +931,18 @@ __global__ void emba_inlier_pix_kernel(const uint32_t* __restrict__ pm_pix, cons
     out[inl_idx[i]] = pm_pix[i] & 0x1FFFFFFFu;
 }
 
+// ... and where every sensor pixel's residuals begin in the rank's ep: starts[p] = number of inliers at sensor pixels < p (starts[S] = all), from the list above
+// (ascending).  Thread i <= m fills the pixels (px[i-1], px[i]] — the pixels without inliers in between take the same start.  A multi-GPU host places a rank's
+// residuals pixel block by pixel block from these S + 1 words instead of one word per residual (round 6).
+__global__ void emba_pix_starts_kernel(const uint32_t* __restrict__ px, long m, uint32_t S, uint32_t* __restrict__ starts)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > m) return;
+    const uint32_t lo = (i == 0) ? 0u : px[i - 1] + 1u;
+    const uint32_t hi = (i == m) ? S : (px[i] < S ? px[i] : S);
+    for (uint32_t q = lo; q <= hi && q <= S; ++q) starts[q] = (uint32_t)i;
+}
+
 // Caller-supplied residuals (the `ep` argument of formNormalEq, model.cpp:421): scatter into the records.
 __global__ void emba_override_ep_kernel(const double* __restrict__ ep_ext, const uint8_t* __restrict__ flag,
                                         const int32_t* __restrict__ inl_idx, const uint32_t* __restrict__ ev_slot, const uint32_t* __restrict__ ev_pix,

@@ -28,6 +28,8 @@
 #include <glog/logging.h>
 #include <opencv2/core.hpp>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -197,6 +199,11 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
         num_ev_map.setTo(0);
         return VecXd::Constant(1, std::numeric_limits<double>::quiet_NaN());
     }
+    // EMBA_ADAPTER_TRACE=1: where this call's time goes, on stderr (scripts/adapter_timing.py)
+    static const bool trace = std::getenv("EMBA_ADAPTER_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
+    double tr_key = 0, tr_res = 0, tr_eval = 0;
     // the sliding window hands the same packet to every LM trial; a new window may reuse the allocation: keyed on content
     const uint64_t key = legm_hip_detail::packet_key(events);
     if (st.src != events.data() || st.n != events.size() || st.src_key != key) {
@@ -213,6 +220,7 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
         knots[4 * i] = q.x(); knots[4 * i + 1] = q.y(); knots[4 * i + 2] = q.z(); knots[4 * i + 3] = q.w();
     }
     emba_host::TrajectoryView tv{knots.data(), K, traj_ptr->startTimeNs(), traj_ptr->knotIntervalNs()};  // t_beg_ns_, dt_knots_ns_
+    tr_key = since();
     // Are these the Mats updateMap has just filled?  Then the device already holds this map (the trial): no upload.
     const size_t npix = (size_t)Gx.rows * Gx.cols;
     bool resident = false;
@@ -231,14 +239,18 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
         }
     }
     if (!resident && st.map_is_trial) legm_hip_detail::settle_trial(st, false);   // some other map: the pending trial is void
+    tr_res = since();
     try {
         // (round 6) the evaluation with the inlier count first, then the residuals straight into the vector this call returns: one pass over its (fresh) pages,
         // fed from pinned staging buffers — before: an 8 B x events vector zero-filled per call, a pageable copy into it and a second copy into the VecXd
         const size_t n_ep = st.impl->evaluateDataErrorCount(tv, resident ? nullptr : Gx.ptr<double>(), resident ? nullptr : Gy.ptr<double>(), st.packet,
                                                             eval_deriv, num_ev_map.ptr<int32_t>());
+        tr_eval = since();
         VecXd ep((Eigen::Index)n_ep);
         if (n_ep) st.impl->fetchEp(ep.data(), n_ep);
         st.K = K; st.n_ep = n_ep; st.trial_pending = resident;
+        if (trace) fprintf(stderr, "[adapter] evaluateDataError: packet key + knots %.2f ms, is-it-the-trial-map check %.2f (resident %d), evaluation + count map %.2f, ep (%zu) into a new vector %.2f\n",
+                           tr_key, tr_res - tr_key, (int)resident, tr_eval - tr_res, n_ep, since() - tr_eval);
         return ep;
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     return VecXd();

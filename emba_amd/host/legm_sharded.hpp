@@ -146,7 +146,7 @@ public:
     {
         const size_t P = P_, dim = 3 * (size_t)K_;
         ne.dim_ctrl_poses = (int)dim; ne.num_active_pixels = P;
-        ne.A11.assign(dim * dim, 0.0); ne.b1.assign(dim, 0.0); ne.A22_blocks.assign(4 * P, 0.0); ne.b2.assign(2 * P, 0.0); ne.active_pix_idxes.assign(P, 0);
+        ne.A11.resize(dim * dim); ne.b1.resize(dim); ne.A22_blocks.resize(4 * P); ne.b2.resize(2 * P); ne.active_pix_idxes.resize(P);      // (all of it overwritten: no zero fill)
         check(emba_group_download(g_, ne.A11.data(), ne.b1.data(), P ? ne.active_pix_idxes.data() : nullptr, P, P ? ne.A22_blocks.data() : nullptr,
                                   P ? ne.b2.data() : nullptr));
     }

@@ -176,6 +176,13 @@ emba_status emba_get_ep(emba_ctx* ctx, double* ep_host, size_t cap, size_t* n_in
 /* Sensor pixel (y * sensor_w + x) of every inlier measurement of the last evaluation, in the order of ep (sensor pixel major, then time;
  * model.cpp:179-186): pix_host has capacity n_inliers.  What a multi-GPU host merges the ranks' residual vectors by (emba_group_eval). */
 emba_status emba_get_inlier_pixels(emba_ctx* ctx, uint32_t* pix_host);
+/* The same in S + 1 words (S = sensor_w * sensor_h): starts_host[p] = number of inlier measurements at sensor pixels < p, i.e. where pixel p's residuals begin in this
+ * context's ep; starts_host[S] = the inlier count.  Kept by the context for emba_get_ep_by_pixel.  Synchronizes. */
+emba_status emba_get_inlier_pixel_starts(emba_ctx* ctx, uint32_t* starts_host);
+/* The last evaluation's ep placed pixel block by pixel block: the residuals of sensor pixel p go to ep_out[dst[p] ...] (dst: S element offsets).  What a multi-GPU host
+ * merges time-sharded ranks' residual vectors with (model.cpp:179-186 orders them by sensor pixel, then time: inside a pixel, earlier ranks first): every rank writes
+ * its own pieces of ONE output vector, streamed through pinned buffers, and ranks may do so concurrently from their own threads.  Synchronizes. */
+emba_status emba_get_ep_by_pixel(emba_ctx* ctx, double* ep_out, const uint64_t* dst);
 
 /* Cost terms of the caller (solver.cpp:88-91,257-268), reduced on the device from the resident
  * residuals / map: data = 0.5*ep.ep (irls 0) or evaluateRobustDataCost (model.cpp:279-314);

@@ -37,6 +37,10 @@ with tempfile.TemporaryDirectory() as d:
         for l in r.stdout.splitlines():
             if l.startswith("PHASES "):
                 print("      " + l)
+        if os.environ.get("EMBA_ADAPTER_TRACE"):
+            for l in r.stderr.splitlines():
+                if l.startswith("[adapter]") or l.startswith("[group ep]"):
+                    print("      " + l)
         if "solve_debug" in os.environ.get("EMBA_HIP_OPTIONS", ""):      # EMBA_HIP_OPTIONS=solve_debug=1: the stages of every sharded solve (stderr of the library)
             for l in r.stderr.splitlines():
                 if l.startswith("[group solve]"):

@@ -439,3 +439,60 @@ def test_group_of_eight_on_one_device_step_rate(oracle_mod):
     print(f"group step {t_group * 1e6:.0f} us  vs  8 x single-context shard step {8 * t_single * 1e6:.0f} us  (ratio {t_group / (8 * t_single):.2f})")
     # measured 1.35; the bound leaves room for a loaded host — the rate is a report, the counts above are the test
     assert t_group <= 2.0 * 8 * t_single, (t_group, t_single)
+
+
+@pytest.mark.gpu
+def test_group_ep_is_merged_pixel_block_by_pixel_block(oracle_mod):
+    """emba_group_eval / emba_group_get_ep on several ranks (round 6): every rank's residuals are placed in the ONE output vector by sensor-pixel runs
+    (emba_get_inlier_pixel_starts, emba_get_ep_by_pixel) from the ranks' own threads — the result must be the oracle's ep, element for element in its order
+    (model.cpp:179-186, 221, 256), and the count map the all-reduced one.  Also the two entry points on a single context: the starts are the running counts of
+    emba_get_inlier_pixels, and the identity placement reproduces emba_get_ep."""
+    import ctypes as C
+    import torch
+    assert torch.cuda.is_available()
+    from emba_amd import LEGM, _lib
+    from emba_amd.synth import make_workload
+    L = _lib.load()
+    w = make_workload(n_events=600_000, pano_h=512, K=21)
+    ev = w.events
+    o = oracle_mod.OracleLEGM(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, w.lut, w.C_th)
+    ep_o, nem_o = o.evaluate_data_error(w.traj.knots_xyzw, w.traj.t0_ns, w.traj.dt_ns, w.Gx, w.Gy, ev.x, ev.y, ev.polarity, ev.t_ns)
+    lut = np.ascontiguousarray(w.lut, dtype=np.float64)
+    knots = np.ascontiguousarray(w.traj.knots_xyzw, np.float64)
+    x = np.ascontiguousarray(ev.x, np.uint16); y = np.ascontiguousarray(ev.y, np.uint16); pol = np.ascontiguousarray(ev.polarity, np.uint8)
+    t = np.ascontiguousarray(ev.t_ns, np.int64)
+    Gx = np.ascontiguousarray(w.Gx); Gy = np.ascontiguousarray(w.Gy)
+    for world in (3, 1):
+        cfg = _lib.EmbaCfg(w.sensor_w, w.sensor_h, w.pano_w, w.pano_h, lut.ctypes.data_as(_lib._dp), float(w.C_th), 100, 10.0, 0, None)
+        g = C.c_void_p()
+        dev = (C.c_int32 * world)(*([0] * world))
+        assert L.emba_group_create(C.byref(cfg), dev, world, C.byref(g)) == 0, L.emba_group_last_error(None)
+        try:
+            assert L.emba_group_set_events(g, x.ctypes.data_as(_lib._u16p), y.ctypes.data_as(_lib._u16p), pol.ctypes.data_as(_lib._u8p), t.ctypes.data_as(_lib._i64p), x.size) == 0
+            ep = np.full(x.size, np.nan); nem = np.zeros((w.pano_h, w.pano_w), np.int32); n_inl = C.c_size_t(0)
+            st = L.emba_group_eval(g, knots.ctypes.data_as(_lib._dp), w.K, int(w.traj.t0_ns), int(w.traj.dt_ns), Gx.ctypes.data_as(_lib._dp), Gy.ctypes.data_as(_lib._dp),
+                                   ep.ctypes.data_as(_lib._dp), C.byref(n_inl), nem.ctypes.data_as(_lib._i32p))
+            assert st == 0, L.emba_group_last_error(g)
+            assert n_inl.value == ep_o.size and np.array_equal(nem, nem_o)
+            assert_close(ep[: n_inl.value], ep_o, f"group ep, {world} ranks")
+            assert np.isnan(ep[n_inl.value:]).all()
+            # ... and fetched again on its own (the adapter's order: count first, then the vector it returns)
+            ep2 = np.full(n_inl.value, np.nan); n2 = C.c_size_t(0)
+            assert L.emba_group_get_ep(g, ep2.ctypes.data_as(_lib._dp), ep2.size, C.byref(n2)) == 0, L.emba_group_last_error(g)
+            assert n2.value == n_inl.value and np.array_equal(ep2, ep[: n_inl.value])
+        finally:
+            L.emba_group_destroy(g)
+    m = LEGM(w.sensor_w, w.sensor_h, w.lut, w.C_th, w.pano_w, w.pano_h, device=0)
+    try:
+        m.set_events(w.events); m.upload_map(w.Gx, w.Gy)
+        m.eval_launch(w.traj); n, ep, _ = m.eval_finish(want_ep=True)
+        S = w.sensor_w * w.sensor_h
+        px = np.zeros(n, np.uint32); starts = np.zeros(S + 1, np.uint32)
+        assert L.emba_get_inlier_pixels(m._ctx, px.ctypes.data_as(_lib._u32p)) == 0
+        assert L.emba_get_inlier_pixel_starts(m._ctx, starts.ctypes.data_as(_lib._u32p)) == 0
+        assert np.array_equal(starts, np.concatenate([[0], np.cumsum(np.bincount(px, minlength=S))]).astype(np.uint32))
+        out = np.full(n, np.nan); dst = starts[:S].astype(np.uint64)
+        assert L.emba_get_ep_by_pixel(m._ctx, out.ctypes.data_as(_lib._dp), dst.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        assert np.array_equal(out, ep)
+    finally:
+        m.close()

@@ -28,6 +28,8 @@
 #include <glog/logging.h>
 #include <opencv2/core.hpp>
 
+#include <malloc.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -176,6 +178,15 @@ LEGM::LEGM(const sensor_msgs::CameraInfo& camera_info_msg, double C_th, int pano
     const auto& bv = event_warper_ptr_->bearingVectors();
     std::vector<double> lut(3 * bv.size());
     for (size_t i = 0; i < bv.size(); ++i) { lut[3 * i] = bv[i].x; lut[3 * i + 1] = bv[i].y; lut[3 * i + 2] = bv[i].z; }
+    // The LM loop allocates and frees the same few large objects every iteration — the residual vector evaluateDataError returns (60 MB at 10 M events), two map
+    // clones, the 2x2 blocks — and glibc serves anything above 32 MB by mmap / munmap: fresh zeroed pages, a trap per page on first write and a teardown per free,
+    // a third of the drop-in's iteration at config 2's shape (measured: 32 -> 22 ms per iteration, first iteration 176 -> 99).  With mmap off and no trimming the
+    // heap keeps those pages and hands them out again.  This is a policy of the PROCESS's allocator, set by the node's model object because the node exists to run
+    // this loop; EMBA_HIP_MALLOC_KEEP=0 leaves the allocator alone.
+    {
+        const char* keep = std::getenv("EMBA_HIP_MALLOC_KEEP");
+        if (!keep || std::atoi(keep) != 0) { mallopt(M_MMAP_MAX, 0); mallopt(M_TRIM_THRESHOLD, 0x7FFFFFFF); mallopt(M_TOP_PAD, 64 << 20); }
+    }
     try {
         // ~LEGM is inline in the reference header (model.h:80): the adapter cannot hook it, so an object at a reused address finds the
         // previous one's entry — every field of it is reset here, not only the engine
@@ -262,10 +273,16 @@ void LEGM::formNormalEq(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, 
 {
     auto& st = g_state[this];
     CHECK((size_t)ep.size() == st.n_ep) << "formNormalEq expects the residual vector evaluateDataError returned (solver.cpp:99-102: the model state is that call's)";
+    static const bool trace = std::getenv("EMBA_ADAPTER_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
     legm_hip_detail::settle_trial(st, true); st.x2_on_device = false;        // formNormalEq after a trial evaluation: the step was accepted (solver.cpp:93-131)
+    const double t_settle = since();
     try { st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel); }
     catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    const double t_form = since();
     legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
+    if (trace) fprintf(stderr, "[adapter] formNormalEq: accept the trial %.2f ms, form + download %.2f, blocks and sets to the caller %.2f\n", t_settle, t_form - t_settle, since() - t_form);
 }
 
 void LEGM::formNormalEqIRLS(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, VecXd& b1, VecXd& b2, const VecXd& ep,
@@ -288,10 +305,15 @@ void LEGM::applyL2Reg(std::vector<Mat2d>& A22_blocks, VecXd& b2, const std::set<
 {
     auto& st = g_state[this];
     (void)Gx; (void)Gy; (void)active_pix_idxes;     // the device holds the same map and active set (evaluateDataError uploaded them)
+    static const bool trace = std::getenv("EMBA_ADAPTER_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
     try { st.impl->applyL2Reg(st.ne, alpha); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    const double t_dev = since();
     const size_t P = st.ne.num_active_pixels;
     for (size_t i = 0; i < P; ++i) A22_blocks[i] << st.ne.A22_blocks[4 * i], st.ne.A22_blocks[4 * i + 1], st.ne.A22_blocks[4 * i + 2], st.ne.A22_blocks[4 * i + 3];
     b2 = Eigen::Map<const VecXd>(st.ne.b2.data(), 2 * P);
+    if (trace) fprintf(stderr, "[adapter] applyL2Reg: device + download %.2f ms, blocks to the caller %.2f\n", t_dev, since() - t_dev);
 }
 
 // The blocks the caller passes are the ones formNormalEq + applyL2Reg exported (minus the first-window trim, detected from A11.rows()):

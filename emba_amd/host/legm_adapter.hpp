@@ -219,8 +219,9 @@ VecXd LEGM::evaluateDataError(Trajectory* traj_ptr, const cv::Mat& Gx, const cv:
     const uint64_t key = legm_hip_detail::packet_key(events);
     if (st.src != events.data() || st.n != events.size() || st.src_key != key) {
         st.packet.resize(events.size());
-        for (size_t k = 0; k < events.size(); ++k)
-            st.packet[k] = {events[k].x, events[k].y, (int64_t)events[k].ts.toNSec(), (bool)events[k].polarity};
+        emba_host::parallel_chunks(events.size(), [&](size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) st.packet[k] = {events[k].x, events[k].y, (int64_t)events[k].ts.toNSec(), (bool)events[k].polarity};
+        });
         st.src = events.data(); st.n = events.size(); st.src_key = key;
     }
     // control poses as quaternions (x,y,z,w) + spline timing exactly as LinearTrajectory stores them (trajectory.cpp:59-64)

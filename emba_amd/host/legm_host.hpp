@@ -8,10 +8,12 @@
 // All computation happens on the GPU behind the C ABI; this header only converts containers and caches the event packet
 // (the per-pixel event lists are pose-independent, so they are uploaded once per packet, not once per call).
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/emba_hip.h"
@@ -24,6 +26,20 @@ struct StatusError : std::runtime_error {
     emba_status status;
     StatusError(emba_status st, const std::string& msg) : std::runtime_error("emba_hip status " + std::to_string((int)st) + ": " + msg), status(st) {}
 };
+
+// fn(lo, hi) over [0, n) in up to four pieces on as many threads (the calling one included): the once-per-window container conversions of a 10 M-event packet
+// (array of structs -> the C ABI's struct of arrays) are memory passes of 150-300 MB, 25-50 ms on one thread
+template <class F> inline void parallel_chunks(size_t n, F&& fn)
+{
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t T = (n < ((size_t)1 << 20)) ? 1 : (hw >= 4 ? 4 : (hw >= 2 ? 2 : 1));
+    if (T == 1) { fn((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + T - 1) / T;
+    for (size_t t = 1; t < T; ++t) th.emplace_back([&fn, per, n, t] { const size_t lo = std::min(n, per * t), hi = std::min(n, per * (t + 1)); if (hi > lo) fn(lo, hi); });
+    fn((size_t)0, std::min(n, per));
+    for (auto& t : th) t.join();
+}
 
 struct Event {              // dvs_msgs::Event: uint16 x, uint16 y, time ts, bool polarity
     uint16_t x, y;
@@ -126,7 +142,7 @@ private:
         std::vector<uint16_t> x(ev.size()), y(ev.size());
         std::vector<uint8_t> pol(ev.size());
         std::vector<int64_t> t(ev.size());
-        for (size_t k = 0; k < ev.size(); ++k) { x[k] = ev[k].x; y[k] = ev[k].y; pol[k] = ev[k].polarity ? 1 : 0; t[k] = ev[k].t_ns; }
+        parallel_chunks(ev.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { x[k] = ev[k].x; y[k] = ev[k].y; pol[k] = ev[k].polarity ? 1 : 0; t[k] = ev[k].t_ns; } });
         check(emba_set_events(ctx_, x.data(), y.data(), pol.data(), t.data(), ev.size(), nullptr, nullptr, nullptr, 0));
         have_ev_ = true; ev_ptr_ = d; ev_n_ = ev.size(); ev_t0_ = tf; ev_t1_ = tl;
     }

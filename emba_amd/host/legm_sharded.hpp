@@ -45,7 +45,7 @@ public:
         // struct of arrays for the C ABI; the staging vectors are kept (a sliding-window run registers a window of about the same size again and
         // again: 13 B per event of freshly mapped pages each time cost more than the conversion itself — 10 M events: ~25 ms)
         sx_.resize(ev.size()); sy_.resize(ev.size()); sp_.resize(ev.size()); st_.resize(ev.size());
-        for (size_t k = 0; k < ev.size(); ++k) { sx_[k] = ev[k].x; sy_[k] = ev[k].y; sp_[k] = ev[k].polarity ? 1 : 0; st_[k] = ev[k].t_ns; }
+        parallel_chunks(ev.size(), [&](size_t lo, size_t hi) { for (size_t k = lo; k < hi; ++k) { sx_[k] = ev[k].x; sy_[k] = ev[k].y; sp_[k] = ev[k].polarity ? 1 : 0; st_[k] = ev[k].t_ns; } });
         check(emba_group_set_events(g_, sx_.data(), sy_.data(), sp_.data(), st_.data(), ev.size()));
     }
     void uploadMap(const double* Gx, const double* Gy) { check(emba_group_upload_map(g_, Gx, Gy)); }

@@ -24,7 +24,7 @@ with tempfile.TemporaryDirectory() as d:
         f.write(struct.pack("<2d", w.C_th, w.alpha))
         for arr, ty in ((w.lut, "<f8"), (init.knots_xyzw, "<f8"), (w.Gx, "<f8"), (w.Gy, "<f8"), (w.events.x, "<u2"), (w.events.y, "<u2"), (w.events.polarity, "u1"), (w.events.t_ns, "<i8")):
             f.write(np.ascontiguousarray(arr).astype(ty).tobytes())
-    for devs in ("0", "0,0"):
+    for devs in os.environ.get("ADAPTER_DEVICES", "0;0,0").split(";"):      # e.g. ADAPTER_DEVICES="0,0,0,0,0,0,0,0" (eight ranks on one device)
         env = dict(os.environ); env["EMBA_HIP_DEVICES"] = devs; env["ADAPTER_TIMING"] = "1"
         r = subprocess.run([exe, p, str(max_iter), "0", "0"], capture_output=True, text=True, timeout=600, env=env)
         ts = [float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith("TIME ")]

@@ -494,5 +494,10 @@ def test_group_ep_is_merged_pixel_block_by_pixel_block(oracle_mod):
         out = np.full(n, np.nan); dst = starts[:S].astype(np.uint64)
         assert L.emba_get_ep_by_pixel(m._ctx, out.ctypes.data_as(_lib._dp), dst.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
         assert np.array_equal(out, ep)
+        # a new evaluation of the same point: the placement finds the kept starts stale and takes them again by itself
+        m.eval_launch(w.traj); m.eval_finish(sync=False)
+        out2 = np.full(n, np.nan)
+        assert L.emba_get_ep_by_pixel(m._ctx, out2.ctypes.data_as(_lib._dp), dst.ctypes.data_as(C.POINTER(C.c_uint64))) == 0
+        assert np.array_equal(out2, ep)
     finally:
         m.close()

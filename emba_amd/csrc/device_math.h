@@ -45,6 +45,9 @@ __device__ __forceinline__ void hat3(const double* p, double* M)
 }
 
 // SO3Base::normalize (sophus/so3.hpp:297-303); (x,y,z,w) storage.
+// (round 6, measured and dropped: the four quotients by the same n with the reciprocal's refinement shared — the compiler's own fdiv expansion written out once,
+// bit-identical in every parity test — saves ~35 of the tiled kernel's ~1100 VALU instructions per event: warp kernel -1.4 % at config 3, -1 % at 3 M, +1 us at 1 M;
+// profiles/r06_shared_rcp_ab.txt.  Not worth a second path to the rounded pixel.)
 __device__ __forceinline__ void quat_normalize(double* q)
 {
     const double n2 = (q[0] * q[0] + q[2] * q[2]) + (q[1] * q[1] + q[3] * q[3]);

@@ -137,9 +137,7 @@ inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatX
     const int dim = ne.dim_ctrl_poses; const size_t P = ne.num_active_pixels;
     A11 = Eigen::Map<const MatXd>(ne.A11.data(), dim, dim);
     b1 = Eigen::Map<const VecXd>(ne.b1.data(), dim);
-    b2 = Eigen::Map<const VecXd>(ne.b2.data(), 2 * P);
-    A22_blocks.resize(P);
-    for (size_t i = 0; i < P; ++i) A22_blocks[i] << ne.A22_blocks[4 * i], ne.A22_blocks[4 * i + 1], ne.A22_blocks[4 * i + 2], ne.A22_blocks[4 * i + 3];
+    (void)A22_blocks; (void)b2;      // (already filled: form_and_download wrote the caller's containers directly)
     // The dense 3K x 2P matrix of model.cpp:358 (0.7 GB at K = 201, P = 68 k) is NOT produced: its only consumers, solveNormalEq[CG], are
     // bound to the device solvers below, which work from the sparse factors.  An empty matrix with the right row count keeps the
     // first-window trim of solver.cpp:156-165 (A12.block(3, 0, dim - 3, A12.cols())) well-formed.
@@ -166,6 +164,16 @@ inline void export_blocks(const emba_host::NormalEquations& ne, MatXd& A11, MatX
 #else
     (void)num_pix;
 #endif
+}
+
+// formNormalEq[IRLS] on the device, then the blocks straight into the caller's containers: a Mat2d is four doubles {m00, m10, m01, m11} and the device's block is
+// {xx, xy, xy, yy} — symmetric, the same bytes — so std::vector<Mat2d> and VecXd are download targets as they stand
+static_assert(sizeof(Mat2d) == 4 * sizeof(double), "Mat2d is expected to be four packed doubles");
+inline void form_and_download(LegmHipState& st, int num_ctrl_poses, int thres, const std::string& cost_type, double a, std::vector<Mat2d>& A22_blocks, VecXd& b2)
+{
+    const size_t P = st.impl->formNormalEqOnDevice(num_ctrl_poses, thres, cost_type, a);
+    A22_blocks.resize(P); b2.resize((Eigen::Index)(2 * P));
+    st.impl->downloadInto(st.ne, P ? reinterpret_cast<double*>(A22_blocks.data()) : nullptr, P ? b2.data() : nullptr);
 }
 
 }  // namespace legm_hip_detail
@@ -279,7 +287,7 @@ void LEGM::formNormalEq(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_blocks, 
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
     legm_hip_detail::settle_trial(st, true); st.x2_on_device = false;        // formNormalEq after a trial evaluation: the step was accepted (solver.cpp:93-131)
     const double t_settle = since();
-    try { st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel); }
+    try { legm_hip_detail::form_and_download(st, num_ctrl_poses, thres_valid_pixel, "quadratic", 0.0, A22_blocks, b2); }
     catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     const double t_form = since();
     legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
@@ -296,7 +304,7 @@ void LEGM::formNormalEqIRLS(MatXd& A11, MatXd& A12, std::vector<Mat2d>& A22_bloc
     legm_hip_detail::settle_trial(st, true); st.x2_on_device = false;
     try {
         st.impl->setCost(cost_type, a);             // later evaluations accumulate the weighted per-pixel sums directly (speed only)
-        st.impl->formNormalEq(st.ne, num_ctrl_poses, thres_valid_pixel, cost_type, a);
+        legm_hip_detail::form_and_download(st, num_ctrl_poses, thres_valid_pixel, cost_type, a, A22_blocks, b2);
     } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
     legm_hip_detail::export_blocks(st.ne, A11, A12, A22_blocks, b1, b2, (size_t)num_ev_map.rows * num_ev_map.cols, active_pix_idxes, inactive_pix_idxes);
 }
@@ -309,12 +317,11 @@ void LEGM::applyL2Reg(std::vector<Mat2d>& A22_blocks, VecXd& b2, const std::set<
     static const bool trace = std::getenv("EMBA_ADAPTER_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(); };
-    try { st.impl->applyL2Reg(st.ne, alpha); } catch (const std::exception& e) { LOG(FATAL) << e.what(); }
-    const double t_dev = since();
     const size_t P = st.ne.num_active_pixels;
-    for (size_t i = 0; i < P; ++i) A22_blocks[i] << st.ne.A22_blocks[4 * i], st.ne.A22_blocks[4 * i + 1], st.ne.A22_blocks[4 * i + 2], st.ne.A22_blocks[4 * i + 3];
-    b2 = Eigen::Map<const VecXd>(st.ne.b2.data(), 2 * P);
-    if (trace) fprintf(stderr, "[adapter] applyL2Reg: device + download %.2f ms, blocks to the caller %.2f\n", t_dev, since() - t_dev);
+    CHECK(A22_blocks.size() == P && (size_t)b2.size() == 2 * P) << "applyL2Reg expects the blocks formNormalEq exported (solver.cpp:114-130)";
+    try { st.impl->applyL2RegInto(alpha, P ? reinterpret_cast<double*>(A22_blocks.data()) : nullptr, P ? b2.data() : nullptr); }
+    catch (const std::exception& e) { LOG(FATAL) << e.what(); }
+    if (trace) fprintf(stderr, "[adapter] applyL2Reg: device + blocks into the caller's containers %.2f ms\n", since());
 }
 
 // The blocks the caller passes are the ones formNormalEq + applyL2Reg exported (minus the first-window trim, detected from A11.rows()):

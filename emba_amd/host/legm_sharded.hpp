@@ -89,6 +89,28 @@ public:
         download(ne);
     }
     void applyL2Reg(NormalEquations& ne, double alpha) { check(emba_group_apply_l2(g_, alpha)); download(ne); }
+    // The same two calls for a host that owns the block storage (the EMBA::LEGM adapter: std::vector<Mat2d> and VecXd of the caller): the equations are formed,
+    // P is known, the caller sizes its containers, and the 2x2 blocks {xx, xy, xy, yy} / b2 land in them directly — no second copy of 23 MB per call at
+    // config 2's shape.  ne receives A11, b1 and the active list; its block vectors stay empty.
+    size_t formNormalEqOnDevice(int num_ctrl_poses, int thres_valid_pixel, const std::string& cost_type = "quadratic", double a = 0.0)
+    {
+        if (num_ctrl_poses != K_) throw std::runtime_error("num_ctrl_poses differs from the trajectory used in evaluateDataError");
+        size_t n_inl = 0;
+        check(emba_group_form(g_, thres_valid_pixel, irls_code(cost_type), a, 0.0, &n_inl, &P_));
+        return P_;
+    }
+    void downloadInto(NormalEquations& ne, double* A22 /* 4 P */, double* b2 /* 2 P */)
+    {
+        const size_t P = P_, dim = 3 * (size_t)K_;
+        ne.dim_ctrl_poses = (int)dim; ne.num_active_pixels = P;
+        ne.A11.resize(dim * dim); ne.b1.resize(dim); ne.active_pix_idxes.resize(P); ne.A22_blocks.clear(); ne.b2.clear();
+        check(emba_group_download(g_, ne.A11.data(), ne.b1.data(), P ? ne.active_pix_idxes.data() : nullptr, P, P ? A22 : nullptr, P ? b2 : nullptr));
+    }
+    void applyL2RegInto(double alpha, double* A22, double* b2)
+    {
+        check(emba_group_apply_l2(g_, alpha));
+        if (P_) check(emba_group_download(g_, nullptr, nullptr, nullptr, P_, A22, b2));
+    }
     // declare the robust cost of the formNormalEq calls to come (speed only: emba_group_set_cost)
     void setCost(const std::string& cost_type, double a) { check(emba_group_set_cost(g_, irls_code(cost_type), a)); }
     // solveNormalEqCG (model.cpp:794-840): returns (cg.iterations(), cg.error())

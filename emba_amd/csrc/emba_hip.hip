@@ -5,6 +5,7 @@
 #include "../../include/emba_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -814,7 +815,17 @@ struct CopyPool {
         run([&](int h) { size_t lo, hi; piece(h, nn, lo, hi); if (hi > lo) std::memcpy((char*)d + lo, (const char*)sp + lo, hi - lo); });
     }
 };
-CopyPool* copy_pool() { static CopyPool* p = new CopyPool; return p; }      // (never destroyed: its detached threads may outlive every context)
+CopyPool* copy_pool()      // (never destroyed: its detached threads may outlive every context)
+{
+    static CopyPool* p = [] {
+        CopyPool* q = new CopyPool;
+        // a fork()ed child has none of the helper threads and possibly a mutex that a thread of the parent held: it starts from a fresh pool
+        static CopyPool* self = q;
+        (void)pthread_atfork(nullptr, nullptr, [] { new (self) CopyPool; });
+        return q;
+    }();
+    return p;
+}
 
 // Have the pages of [p, p + bytes) mapped before they are written: memory a caller has just allocated (the vector evaluateDataError returns) has no pages yet, and
 // a first write per page is a trap each (60 MB: 15 k of them on the copying thread).  One MADV_POPULATE_WRITE per piece does the same inside the kernel, without

@@ -2429,9 +2429,10 @@ namespace {
 
 // A kernel that keeps the 3K-vector x1 (or the pose part of a CG vector) in dynamic LDS: above 64 KB (K > 2730) the launch needs the attribute raised, above the
 // CU's 160 KB there is no such launch — say so instead of a generic launch failure
-emba_status pose_vector_lds(emba_ctx* c, const void* kernel, size_t bytes, const char* what)
+emba_status pose_vector_lds(emba_ctx* c, const void* kernel, size_t bytes, const char* what, size_t per_pose = 24)
 {
-    if (bytes > (size_t)160 * 1024) return fail(c, EMBA_ERR_CAPACITY, "%s: K = %zu control poses need %zu bytes of LDS for the pose vector (limit 160 KB: K <= 6826)", what, bytes / 24, bytes);
+    if (bytes > (size_t)160 * 1024)
+        return fail(c, EMBA_ERR_CAPACITY, "%s: K = %zu control poses need %zu bytes of LDS for the pose vector (limit 160 KB: K <= %zu)", what, bytes / per_pose, bytes, (size_t)160 * 1024 / per_pose);
     if (bytes > (size_t)64 * 1024) HIP_TRY(c, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return EMBA_OK;
 }
@@ -2927,14 +2928,14 @@ extern "C" emba_status emba_solve_normal_eq_cg(emba_ctx* c, double lambda, int32
         if (b) *b = h[1];
         return EMBA_OK;
     };
-    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)n * 8, "solveNormalEqCG"))) return st;
+    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)n * 16, "solveNormalEqCG", 48))) return st;
     CgPixParams pp{};
     pp.view = L.sorted; pp.off = L.off; pp.A22b2 = pack_A22b2(c); pp.lambda = lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = skip;
     pp.P = (long)P;
     auto apply = [&](const double* v, double* y) {   // y = [A11m A12; A12^T A22m] v
         hipLaunchKernelGGL(emba_cg_a11_kernel, dim3((n + 3) / 4), dim3(256), 0, s, pack_A11(c), n, lambda, skip, v, y);
         pp.v = v; pp.y = y;
-        if (P) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, (size_t)4 * c->n_cu)), dim3(256), (size_t)n * 8, s, pp);
+        if (P) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((P + 3) / 4, (size_t)8 * c->n_cu)), dim3(256), (size_t)n * 16, s, pp);
     };
     // Eigen/src/IterativeLinearSolvers/ConjugateGradient.h:28-88 (zero initial guess: residual = rhs)
     HIP_TRY(c, hipMemsetAsync(d_sc, 0, 64, s));
@@ -3020,7 +3021,7 @@ extern "C" emba_status emba_cg_shard_begin(emba_ctx* c, int32_t rank, int32_t n_
     RecView view{};
     view.rec = recv_dev; view.packed = 1; view.pix_base = (long)lo;
     if ((st = build_lists(c, view, n_recv, g.npix, &g.L))) return st;
-    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)g.n * 8, "solveNormalEqCG"))) return st;
+    if ((st = pose_vector_lds(c, (const void*)emba_cg_pixel_kernel, (size_t)g.n * 16, "solveNormalEqCG", 48))) return st;
     HIP_TRY(c, hipMemsetAsync(red_dev, 0, ((size_t)g.n + 2) * 8, s));
     const unsigned grid = (unsigned)std::min<size_t>(nblocks(g.Nl), 1024);
     hipLaunchKernelGGL(emba_cg_init_kernel, dim3(grid), dim3(256), 0, s, pack_A11(c), pack_b1(c), pack_A22b2(c) + 5 * lo, g.n, g.skip, (long)g.npix, lambda, g.x, g.r, g.p, g.invd,
@@ -3043,7 +3044,7 @@ extern "C" emba_status emba_cg_shard_apply(emba_ctx* c, double* red_dev)
     CgPixParams pp{};
     pp.view = g.L.sorted; pp.off = g.L.off; pp.A22b2 = pack_A22b2(c) + 5 * g.lo; pp.lambda = g.lambda; pp.irls = c->irls; pp.eta = c->eta; pp.n = n; pp.skip = g.skip;
     pp.P = (long)g.npix; pp.v = g.p; pp.y = g.t;
-    if (g.npix) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((g.npix + 3) / 4, (size_t)4 * c->n_cu)), dim3(256), (size_t)n * 8, s, pp);
+    if (g.npix) hipLaunchKernelGGL(emba_cg_pixel_kernel, dim3((unsigned)std::min<size_t>((g.npix + 3) / 4, (size_t)8 * c->n_cu)), dim3(256), (size_t)n * 16, s, pp);
     HIP_TRY(c, hipMemcpyAsync(red_dev, g.t, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
     HIP_TRY(c, hipMemsetAsync(red_dev + n, 0, 16, s));
     if (g.npix) hipLaunchKernelGGL(emba_cg_dot_kernel, dim3((unsigned)std::min<size_t>(nblocks(2 * g.npix), 1024)), dim3(256), 0, s, g.p + n, g.t + n, (long)(2 * g.npix), red_dev + n);

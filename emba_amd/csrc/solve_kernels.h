@@ -973,42 +973,64 @@ struct CgPixParams {
     const double* v; double* y;
 };
 
+// (round 6) In the x2 kernel's form: sixteen records of a pixel in flight per wave (lane l: element l & 15 of record l >> 4 of each group of four), the pose part of
+// the vector in LDS, the 12-term dot product of a record summed by DPP row rotations, dp / e / the pair key of a record straight from its line (one cached request per
+// 16-lane row).  Until then: four records per trip, v1[row] gathered from global memory behind the key, five ds_bpermute per group — 0.80 ms per application at
+// config 2's shape (1.2 TB/s over the 0.96 GB of records), 80 % of every CG iteration.
 __global__ __launch_bounds__(256) void emba_cg_pixel_kernel(CgPixParams p)
 {
-    extern __shared__ double s_y[];      // pose part contributed by this block
-    for (int r = threadIdx.x; r < p.n; r += 256) s_y[r] = 0.0;
+    extern __shared__ double s_cg[];     // [0, n): pose part contributed by this block; [n, 2n): the pose part of v
+    double* s_y = s_cg; double* s_v1 = s_cg + p.n;
+    for (int r = threadIdx.x; r < p.n; r += 256) { s_y[r] = 0.0; s_v1[r] = p.v[r]; }
     __syncthreads();
-    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4, g = lane & 48;
+    const int lane = threadIdx.x & 63, el = lane & 15, kk = lane >> 4;
     const long nwaves = (long)gridDim.x * 4;
-    const double* v1 = p.v; const double* v2 = p.v + p.n;
-    for (long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6); i < p.P; i += nwaves) {
+    const double* v2 = p.v + p.n;
+    const long i_first = (long)blockIdx.x * 4 + (threadIdx.x >> 6), i_last = p.P - 1;
+    auto load_b = [&](long i, uint32_t& b0, uint32_t& b1) { const long ic = i < i_last ? i : i_last; b0 = p.off[ic]; b1 = p.off[ic + 1]; };
+    uint32_t cb0, cb1, nb0, nb1;
+    load_b(i_first, cb0, cb1);
+    for (long i = i_first; i < p.P; i += nwaves) {
+        load_b(i + nwaves, nb0, nb1);                                  // (the next pixel's list bounds: in flight during this one)
         const double vx = v2[2 * i], vy = v2[2 * i + 1];
+        const double* q = p.A22b2 + 5 * i;
+        const double q0 = q[0], q1 = q[1], q2 = q[2];                  // (requested in front of the records, answered with them)
         double a0 = 0.0, a1 = 0.0;
-        const uint32_t b0 = p.off[i], b1 = p.off[i + 1];
-        for (uint32_t b = b0; b < b1; b += 4) {
-            const uint32_t bb = b + kk;
-            const bool in = bb < b1;
-            const uint32_t s = in ? bb : 0u;                           // (the records are in pixel order)
-            const double x = in ? p.view.rec[(size_t)kRecStride * s + el] : 0.0;
-            const uint32_t key = in ? rec_key(p.view, s) : 0u;
-            const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
-            const bool live = in && el < 12 && row >= p.skip;
-            double d = live ? x * v1[row] : 0.0;
-            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4); d += __shfl_xor(d, 8);
-            const double dx = __shfl(x, g | 12), dy = __shfl(x, g | 13), e = __shfl(x, g | 14);
-            double w = 1.0;
-            if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
-            else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
-            if (in) { a0 += w * d * dx; a1 += w * d * dy; }      // identical in the 16 lanes of a record
-            if (live) atomicAdd(&s_y[row], w * (dx * vx + dy * vy) * x);     // A12 v2
+        const uint32_t b0 = cb0, b1 = cb1;
+        for (uint32_t base = b0; base < b1; base += 16) {
+            double xv[4]; double2 dxy[4], et[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t r = base + 4 * u + kk;
+                const double* rp = p.view.rec + (size_t)kRecStride * (r < b1 ? r : b0);
+                xv[u] = rp[el];
+                dxy[u] = reinterpret_cast<const double2*>(rp)[6];
+                et[u] = reinterpret_cast<const double2*>(rp)[7];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + 4 * u >= b1) break;                             // (uniform)
+                const bool in = base + 4 * u + kk < b1;
+                const double x = xv[u], dx = dxy[u].x, dy = dxy[u].y, e = et[u].x;
+                const uint32_t key = (uint32_t)__double2hiint(et[u].y);   // (the records are in pixel order: tail = {pixel, pair key})
+                const int row = (el < 6) ? 3 * (int)(key >> 16) + el : 3 * (int)(key & 0xFFFFu) + el - 6;
+                const bool live = in && el < 12 && row >= p.skip;
+                double d = live ? x * s_v1[row] : 0.0;
+                d += dpp_row_ror<1>(d); d += dpp_row_ror<2>(d); d += dpp_row_ror<4>(d); d += dpp_row_ror<8>(d);      // every lane of the row: the record's dot product
+                double w = 1.0;
+                if (p.irls == 2) w = 1.0 / (1.0 + p.eta * e * e);
+                else if (p.irls == 1) { const double a = fabs(e); w = (a < p.eta) ? 1.0 : p.eta / a; }
+                if (in) { a0 += w * d * dx; a1 += w * d * dy; }            // identical in the 16 lanes of a record
+                if (live) atomicAdd(&s_y[row], w * (dx * vx + dy * vy) * x);     // A12 v2
+            }
         }
         a0 += __shfl_xor(a0, 16); a0 += __shfl_xor(a0, 32);
         a1 += __shfl_xor(a1, 16); a1 += __shfl_xor(a1, 32);
         if (lane == 0) {
-            const double* q = p.A22b2 + 5 * i;
-            p.y[p.n + 2 * i] = a0 + (q[0] + p.lambda * q[0]) * vx + q[1] * vy;
-            p.y[p.n + 2 * i + 1] = a1 + q[1] * vx + (q[2] + p.lambda * q[2]) * vy;
+            p.y[p.n + 2 * i] = a0 + (q0 + p.lambda * q0) * vx + q1 * vy;
+            p.y[p.n + 2 * i + 1] = a1 + q1 * vx + (q2 + p.lambda * q2) * vy;
         }
+        cb0 = nb0; cb1 = nb1;
     }
     __syncthreads();
     for (int r = threadIdx.x; r < p.n; r += 256) { const double a = s_y[r]; if (a != 0.0) atomicAdd(p.y + r, a); }
